@@ -1,0 +1,147 @@
+"""ctypes binding of libbgs.so (the C ABI in include/bgs.h).
+
+The shared library is built in-tree by `__graft_entry__.build()` (or `make -C
+bevy_gaussian_splatting_amd/csrc`). There is no CPU fallback: if the library is missing,
+or no HIP device is usable, every entry point of the package raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+from .camera import BgsView
+from .settings import BgsSettings
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbgs.so")
+
+BGS_OK = 0
+BGS_EINVAL = -1
+BGS_ENOMEM = -2
+BGS_EHIP = -3
+BGS_ECAPACITY = -4
+BGS_EINTERNAL = -5
+
+STAGE_NAMES = ("keygen", "depth_sort", "project", "tile_sort", "ranges", "raster")
+
+# every symbol include/bgs.h declares (tests check the library exports each one)
+EXPORTED_SYMBOLS = (
+    "bgs_create",
+    "bgs_destroy",
+    "bgs_last_error",
+    "bgs_version",
+    "bgs_settings_default",
+    "bgs_view_perspective",
+    "bgs_cloud_upload_f32",
+    "bgs_cloud_upload_f16",
+    "bgs_cloud_free",
+    "bgs_cloud_len",
+    "bgs_sort",
+    "bgs_render",
+    "bgs_framebuffer_device_ptr",
+    "bgs_sorted_entries_device_ptr",
+    "bgs_synchronize",
+    "bgs_stream",
+    "bgs_set_profiling",
+    "bgs_get_stats",
+    "bgs_radix_sort_pairs",
+)
+
+
+class BgsSortEntry(ctypes.Structure):
+    _fields_ = [("key", ctypes.c_uint32), ("index", ctypes.c_uint32)]
+
+
+class BgsStats(ctypes.Structure):
+    _fields_ = [
+        ("stage_ms", ctypes.c_float * 6),
+        ("total_ms", ctypes.c_float),
+        ("splat_count", ctypes.c_uint32),
+        ("visible_count", ctypes.c_uint32),
+        ("instance_count", ctypes.c_uint64),
+        ("instance_capacity", ctypes.c_uint64),
+        ("tiles_x", ctypes.c_uint32),
+        ("tiles_y", ctypes.c_uint32),
+        ("depth_passes", ctypes.c_uint32),
+        ("tile_passes", ctypes.c_uint32),
+        ("algorithmic_bytes", ctypes.c_uint64),
+        ("regrow_count", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+    ]
+
+
+class BgsError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libbgs error {status}: {message}")
+        self.status = status
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libbgs.so once and declare prototypes. Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+        )
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    vp = ctypes.c_void_p
+    u32 = ctypes.c_uint32
+    fp = ctypes.POINTER(ctypes.c_float)
+    up = ctypes.POINTER(ctypes.c_uint32)
+
+    lib.bgs_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    lib.bgs_create.restype = ctypes.c_int
+    lib.bgs_destroy.argtypes = [vp]
+    lib.bgs_destroy.restype = None
+    lib.bgs_last_error.argtypes = [vp]
+    lib.bgs_last_error.restype = ctypes.c_char_p
+    lib.bgs_version.argtypes = []
+    lib.bgs_version.restype = u32
+    lib.bgs_settings_default.argtypes = [ctypes.POINTER(BgsSettings)]
+    lib.bgs_settings_default.restype = None
+    lib.bgs_view_perspective.argtypes = [
+        fp, ctypes.c_float, ctypes.c_float, u32, u32, ctypes.POINTER(BgsView)]
+    lib.bgs_view_perspective.restype = None
+    lib.bgs_cloud_upload_f32.argtypes = [vp, u32, fp, fp, fp, fp, ctypes.POINTER(vp)]
+    lib.bgs_cloud_upload_f32.restype = ctypes.c_int
+    lib.bgs_cloud_upload_f16.argtypes = [vp, u32, fp, up, up, ctypes.POINTER(vp)]
+    lib.bgs_cloud_upload_f16.restype = ctypes.c_int
+    lib.bgs_cloud_free.argtypes = [vp, vp]
+    lib.bgs_cloud_free.restype = None
+    lib.bgs_cloud_len.argtypes = [vp]
+    lib.bgs_cloud_len.restype = u32
+    lib.bgs_sort.argtypes = [
+        vp, vp, ctypes.POINTER(BgsView), ctypes.POINTER(BgsSettings), ctypes.POINTER(BgsSortEntry)]
+    lib.bgs_sort.restype = ctypes.c_int
+    lib.bgs_render.argtypes = [
+        vp, vp, ctypes.POINTER(BgsView), ctypes.POINTER(BgsSettings), fp]
+    lib.bgs_render.restype = ctypes.c_int
+    lib.bgs_framebuffer_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
+    lib.bgs_framebuffer_device_ptr.restype = ctypes.c_int
+    lib.bgs_sorted_entries_device_ptr.argtypes = [vp, ctypes.POINTER(vp), up]
+    lib.bgs_sorted_entries_device_ptr.restype = ctypes.c_int
+    lib.bgs_synchronize.argtypes = [vp]
+    lib.bgs_synchronize.restype = ctypes.c_int
+    lib.bgs_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.bgs_stream.restype = ctypes.c_int
+    lib.bgs_set_profiling.argtypes = [vp, ctypes.c_int]
+    lib.bgs_set_profiling.restype = ctypes.c_int
+    lib.bgs_get_stats.argtypes = [vp, ctypes.POINTER(BgsStats)]
+    lib.bgs_get_stats.restype = ctypes.c_int
+    lib.bgs_radix_sort_pairs.argtypes = [vp, ctypes.POINTER(BgsSortEntry), u32, u32]
+    lib.bgs_radix_sort_pairs.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(lib: ctypes.CDLL, ctx, status: int) -> None:
+    if status != BGS_OK:
+        msg = lib.bgs_last_error(ctx)
+        raise BgsError(status, msg.decode("utf-8", "replace") if msg else "")

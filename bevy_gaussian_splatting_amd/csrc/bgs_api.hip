@@ -1,0 +1,653 @@
+// bgs_api.hip — libbgs host side: context, device buffers, per-frame orchestration, C ABI.
+//
+// One frame (bgs_render) is 11 enqueues on the context's stream, no host round trip in
+// between; every size that depends on the data (draw-list length V', instance count I) stays
+// on the device in the Control block and is consumed by persistent, ticket-driven kernels:
+//
+//   memset(zeroed scratch: Control | look-back words | tile ranges)
+//   keygen                        N x (16 B read, 8 B write) + 4 digit histograms
+//   onesweep x places             depth keys, 16 B/pair/pass
+//   project_emit                  V' splats -> records (front-to-back) + I instances
+//   onesweep x 2                  instances by tile x, then tile y (stable)
+//   tile_ranges, raster
+//   copy Control -> pinned host, sync, check overflow/watchdog (regrow + re-run on overflow)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/bgs.h"
+#include "bgs_device.h"
+#include "frame_params.h"
+#include "kernels.h"
+
+using namespace bgs;
+
+struct bgs_cloud {
+    CloudPtrs ptrs{};
+    void* allocs[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t bytes = 0;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+constexpr uint64_t MIN_INSTANCE_CAPACITY = 1ull << 22;  // 4M instances (32 MB per buffer)
+constexpr uint64_t MAX_INSTANCE_CAPACITY = 1ull << 30;  // look-back words carry 30-bit values
+constexpr uint32_t MAX_SPLATS = (1u << 30) - 1u;
+constexpr int EV_COUNT = BGS_STAGE_COUNT + 1;
+
+template <class T>
+T* dev_alloc(size_t count) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    return (T*)p;
+}
+
+}  // namespace
+
+struct bgs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    std::string error;
+
+    // zeroed-every-frame scratch: [Control | depth status | scan status | tile status | ranges]
+    uint8_t* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    size_t off_depth_status = 0, off_scan_status = 0, off_tile_status = 0, off_ranges = 0;
+    uint32_t scratch_n = 0;          // splat capacity the scratch was laid out for
+    uint64_t scratch_inst_cap = 0;   // instance capacity the scratch was laid out for
+
+    uint2* entries[2] = {nullptr, nullptr};
+    uint32_t entries_cap = 0;
+    void* records = nullptr;
+    size_t records_bytes = 0;
+    uint2* inst[2] = {nullptr, nullptr};
+    uint64_t inst_cap = 0;
+    float4* fb = nullptr;
+    size_t fb_pixels = 0;
+    uint32_t fb_w = 0, fb_h = 0;
+
+    Control* h_ctl = nullptr;  // pinned
+    hipEvent_t ev[EV_COUNT] = {};
+    bool profiling = true;
+    bool have_stats = false;
+    bgs_stats stats{};
+
+    const uint2* last_sorted = nullptr;
+    uint32_t last_sorted_n = 0;
+};
+
+namespace {
+
+int fail(bgs_ctx* ctx, int status, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    g_error = msg;
+    return status;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, BGS_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// (Re)build the zeroed scratch region for n splats and inst_cap instances.
+int ensure_scratch(bgs_ctx* ctx, uint32_t n, uint64_t inst_cap) {
+    if (ctx->scratch && n <= ctx->scratch_n && inst_cap <= ctx->scratch_inst_cap) return BGS_OK;
+    n = std::max(n, ctx->scratch_n);
+    inst_cap = std::max(inst_cap, ctx->scratch_inst_cap);
+    // depth sort may use either tile size; size for the smaller one
+    const size_t depth_tiles = ((size_t)n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
+    const size_t scan_tiles = ((size_t)n + 255) / 256 + 1;
+    const size_t inst_tiles = (inst_cap + sort_tile_size(true) - 1) / sort_tile_size(true) + 1;
+    size_t off = align_up(sizeof(Control), 256);
+    const size_t off_depth = off;
+    off += align_up(4 * depth_tiles * RADIX_BASE * sizeof(uint32_t), 256);
+    const size_t off_scan = off;
+    off += align_up(scan_tiles * sizeof(unsigned long long), 256);
+    const size_t off_tile = off;
+    off += align_up(2 * inst_tiles * RADIX_BASE * sizeof(uint32_t), 256);
+    const size_t off_ranges = off;
+    off += align_up((size_t)RADIX_BASE * RADIX_BASE * sizeof(uint2), 256);
+    if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; }
+    void* p = nullptr;
+    if (hipMalloc(&p, off) != hipSuccess) return fail(ctx, BGS_ENOMEM, "hipMalloc(scratch) failed");
+    ctx->scratch = (uint8_t*)p;
+    ctx->scratch_bytes = off;
+    ctx->off_depth_status = off_depth;
+    ctx->off_scan_status = off_scan;
+    ctx->off_tile_status = off_tile;
+    ctx->off_ranges = off_ranges;
+    ctx->scratch_n = n;
+    ctx->scratch_inst_cap = inst_cap;
+    return BGS_OK;
+}
+
+int ensure_entries(bgs_ctx* ctx, uint32_t n) {
+    if (n <= ctx->entries_cap && ctx->entries[0]) return BGS_OK;
+    for (auto& e : ctx->entries) { if (e) (void)hipFree(e); e = nullptr; }
+    for (auto& e : ctx->entries) {
+        e = dev_alloc<uint2>(n);
+        if (!e) return fail(ctx, BGS_ENOMEM, "hipMalloc(sort entries) failed");
+    }
+    ctx->entries_cap = n;
+    return BGS_OK;
+}
+
+int ensure_instances(bgs_ctx* ctx, uint64_t cap) {
+    if (cap <= ctx->inst_cap && ctx->inst[0]) return BGS_OK;
+    for (auto& e : ctx->inst) { if (e) (void)hipFree(e); e = nullptr; }
+    ctx->inst_cap = 0;
+    for (auto& e : ctx->inst) {
+        e = dev_alloc<uint2>(cap);
+        if (!e) return fail(ctx, BGS_ENOMEM, "hipMalloc(tile instances) failed");
+    }
+    ctx->inst_cap = cap;
+    return BGS_OK;
+}
+
+int ensure_records(bgs_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->records_bytes && ctx->records) return BGS_OK;
+    if (ctx->records) (void)hipFree(ctx->records);
+    ctx->records = nullptr;
+    ctx->records_bytes = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess)
+        return fail(ctx, BGS_ENOMEM, "hipMalloc(records) failed");
+    ctx->records = p;
+    ctx->records_bytes = bytes;
+    return BGS_OK;
+}
+
+int ensure_framebuffer(bgs_ctx* ctx, uint32_t w, uint32_t h) {
+    const size_t px = (size_t)w * h;
+    if (px > ctx->fb_pixels || !ctx->fb) {
+        if (ctx->fb) (void)hipFree(ctx->fb);
+        ctx->fb = dev_alloc<float4>(px);
+        if (!ctx->fb) return fail(ctx, BGS_ENOMEM, "hipMalloc(framebuffer) failed");
+        ctx->fb_pixels = px;
+    }
+    ctx->fb_w = w;
+    ctx->fb_h = h;
+    return BGS_OK;
+}
+
+int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s,
+             bool render) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (!cloud || !view || !s) return fail(ctx, BGS_EINVAL, "cloud, view and settings must be non-NULL");
+    if (s->radix_depth_bits != 16 && s->radix_depth_bits != 24 && s->radix_depth_bits != 32)
+        return fail(ctx, BGS_EINVAL, "radix_depth_bits must be 16, 24 or 32");
+    if (s->gaussian_mode > BGS_GAUSSIAN_3D) return fail(ctx, BGS_EINVAL, "gaussian_mode must be 2D or 3D");
+    if (s->sh_degree > 3) return fail(ctx, BGS_EINVAL, "sh_degree must be 0..3");
+    if (s->sort_mode > BGS_SORT_STD) return fail(ctx, BGS_EINVAL, "unknown sort_mode");
+    if (s->color_space > BGS_COLOR_LINEAR) return fail(ctx, BGS_EINVAL, "unknown color_space");
+    if (render) {
+        const float w = view->viewport[2], h = view->viewport[3];
+        if (!(w >= 1.0f) || !(h >= 1.0f) || w > 4096.0f || h > 4096.0f || w != std::floor(w) ||
+            h != std::floor(h))
+            return fail(ctx, BGS_EINVAL, "viewport width/height must be integers in [1, 4096]");
+    }
+    return BGS_OK;
+}
+
+// Enqueue + complete one frame. Returns BGS_OK, or BGS_ECAPACITY-internal signal via *need_cap.
+int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s,
+              bool render, uint64_t* need_cap) {
+    *need_cap = 0;
+    FrameParams fp{};
+    fill_frame_params(cloud->ptrs.n, view, s, fp);
+    const uint32_t n = fp.n;
+    const uint32_t places = depth_places(s);
+    const bool surfel = render && fp.gaussian_mode == 0u && fp.aabb != 0u;
+    const size_t rec_bytes = surfel ? sizeof(RecordSurfel) : sizeof(Record);
+
+    int rc;
+    if ((rc = ensure_entries(ctx, n)) != BGS_OK) return rc;
+    if (render) {
+        if ((rc = ensure_instances(ctx, std::max<uint64_t>(ctx->inst_cap, MIN_INSTANCE_CAPACITY))) != BGS_OK) return rc;
+        if ((rc = ensure_records(ctx, (size_t)n * rec_bytes)) != BGS_OK) return rc;
+        if ((rc = ensure_framebuffer(ctx, (uint32_t)fp.width, (uint32_t)fp.height)) != BGS_OK) return rc;
+    }
+    if ((rc = ensure_scratch(ctx, n, ctx->inst_cap)) != BGS_OK) return rc;
+
+    hipStream_t st = ctx->stream;
+    Control* ctl = (Control*)ctx->scratch;
+    uint32_t* depth_status = (uint32_t*)(ctx->scratch + ctx->off_depth_status);
+    unsigned long long* scan_status = (unsigned long long*)(ctx->scratch + ctx->off_scan_status);
+    uint32_t* tile_status = (uint32_t*)(ctx->scratch + ctx->off_tile_status);
+    uint2* ranges = (uint2*)(ctx->scratch + ctx->off_ranges);
+    const bool prof = ctx->profiling;
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(ctx->ev[i], st); };
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, st));
+    mark(0);
+    launch_keygen(st, fp, cloud->ptrs.position_visibility, ctx->entries[0], ctl, places);
+    mark(1);
+    const bool large = n > (4u << 20);
+    const uint32_t dtile = sort_tile_size(large);
+    const size_t depth_tiles = ((size_t)ctx->scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
+    (void)dtile;
+    const int sort_blocks = ctx->num_cus * 4;
+    int cur = 0;
+    for (uint32_t p = 0; p < places; ++p) {
+        const uint32_t key_xor =
+            (p + 1 == places && (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD)) ? 0xFFFFFFFFu : 0u;
+        launch_onesweep_pass(st, ctx->entries[cur], ctx->entries[cur ^ 1], &ctl->splat_count, n,
+                             ctl->hist_depth[p], depth_status + (size_t)p * depth_tiles * RADIX_BASE,
+                             &ctl->ticket[p], &ctl->error, p * RADIX_BITS, key_xor, large, sort_blocks);
+        cur ^= 1;
+    }
+    mark(2);
+    const uint2* draw_list = ctx->entries[cur];
+    ctx->last_sorted = draw_list;
+    ctx->last_sorted_n = n;
+
+    if (render) {
+        const uint32_t capacity = (uint32_t)std::min<uint64_t>(ctx->inst_cap, MAX_INSTANCE_CAPACITY);
+        CloudPtrs cp = cloud->ptrs;
+        launch_project_emit(st, fp, cp, draw_list, ctl, scan_status, ctx->records, ctx->inst[0], capacity,
+                            /*ticket_slot=*/4, ctx->num_cus * 3);
+        mark(3);
+        const size_t inst_tiles = (ctx->scratch_inst_cap + sort_tile_size(true) - 1) / sort_tile_size(true) + 1;
+        for (uint32_t p = 0; p < 2; ++p)
+            launch_onesweep_pass(st, ctx->inst[p], ctx->inst[p ^ 1], &ctl->instance_count, capacity,
+                                 ctl->hist_tile[p], tile_status + (size_t)p * inst_tiles * RADIX_BASE,
+                                 &ctl->ticket[5 + p], &ctl->error, p * RADIX_BITS, 0u, true, sort_blocks);
+        mark(4);
+        launch_tile_ranges(st, ctx->inst[0], ctl, ranges);
+        mark(5);
+        launch_raster(st, fp, ctx->records, ctx->inst[0], ranges, ctx->fb, view->clear_color);
+        mark(6);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+
+    const Control& h = *ctx->h_ctl;
+    if (h.error) return fail(ctx, BGS_EINTERNAL, "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
+    const uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
+    if (render && h.overflow) {
+        *need_cap = total;
+        return BGS_OK;
+    }
+
+    // stats
+    bgs_stats& stt = ctx->stats;
+    const uint32_t regrow = stt.regrow_count;
+    std::memset(&stt, 0, sizeof stt);
+    stt.regrow_count = regrow;
+    stt.splat_count = n;
+    stt.visible_count = render ? h.visible_count : h.draw_count;
+    stt.instance_count = render ? total : 0;
+    stt.instance_capacity = ctx->inst_cap;
+    stt.tiles_x = render ? (uint32_t)fp.tiles_x : 0;
+    stt.tiles_y = render ? (uint32_t)fp.tiles_y : 0;
+    stt.depth_passes = places;
+    stt.tile_passes = render ? 2 : 0;
+    {
+        // SURVEY 8(d) algorithmic bytes
+        const uint64_t N = n, k = places;
+        uint64_t bytes = N * 16 + N * 8 + k * N * 16;  // bytes_sort
+        if (render) {
+            const uint64_t B = cloud->ptrs.is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
+            const uint64_t P = (uint64_t)fp.width * fp.height;
+            bytes += V * (B - 16) + V * R + I * 8 + 2 * I * 16 + I * (4 + R) + P * 16;
+        }
+        stt.algorithmic_bytes = bytes;
+    }
+    if (prof) {
+        const int last = render ? 6 : 2;
+        auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ctx->ev[a], ctx->ev[b]); return t; };
+        stt.stage_ms[BGS_STAGE_KEYGEN] = ms(0, 1);
+        stt.stage_ms[BGS_STAGE_DEPTH_SORT] = ms(1, 2);
+        if (render) {
+            stt.stage_ms[BGS_STAGE_PROJECT] = ms(2, 3);
+            stt.stage_ms[BGS_STAGE_TILE_SORT] = ms(3, 4);
+            stt.stage_ms[BGS_STAGE_RANGES] = ms(4, 5);
+            stt.stage_ms[BGS_STAGE_RASTER] = ms(5, 6);
+        }
+        stt.total_ms = ms(0, last);
+    }
+    ctx->have_stats = true;
+    return BGS_OK;
+}
+
+int run(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s, bool render) {
+    int rc = validate(ctx, cloud, view, s, render);
+    if (rc != BGS_OK) return rc;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    ctx->stats.regrow_count = 0;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        uint64_t need = 0;
+        rc = run_frame(ctx, cloud, view, s, render, &need);
+        if (rc != BGS_OK) return rc;
+        if (!need) return BGS_OK;
+        // grow to the next power of two with 25 % headroom and re-run the frame
+        uint64_t cap = MIN_INSTANCE_CAPACITY;
+        while (cap < need + need / 4) cap <<= 1;
+        if (need > MAX_INSTANCE_CAPACITY)
+            return fail(ctx, BGS_ECAPACITY, "frame needs " + std::to_string(need) +
+                                                " tile instances, above the 2^30 limit");
+        cap = std::min(cap, MAX_INSTANCE_CAPACITY);
+        if ((rc = ensure_instances(ctx, cap)) != BGS_OK) return rc;
+        ctx->stats.regrow_count += 1;
+    }
+    return fail(ctx, BGS_ECAPACITY, "instance buffer kept overflowing");
+}
+
+void mat4_mul(const float* a, const float* b, float* out) {  // column-major out = a * b
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc += a[4 * k + r] * b[4 * c + k];
+            out[4 * c + r] = acc;
+        }
+}
+
+bool mat4_inverse(const float* m, float* out) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            a[r][c] = m[4 * c + r];
+            a[r][4 + c] = r == c ? 1.0 : 0.0;
+        }
+    for (int i = 0; i < 4; ++i) {
+        int piv = i;
+        for (int r = i + 1; r < 4; ++r)
+            if (std::fabs(a[r][i]) > std::fabs(a[piv][i])) piv = r;
+        if (a[piv][i] == 0.0) return false;
+        if (piv != i)
+            for (int c = 0; c < 8; ++c) std::swap(a[i][c], a[piv][c]);
+        const double d = a[i][i];
+        for (int c = 0; c < 8; ++c) a[i][c] /= d;
+        for (int r = 0; r < 4; ++r)
+            if (r != i) {
+                const double f = a[r][i];
+                for (int c = 0; c < 8; ++c) a[r][c] -= f * a[i][c];
+            }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) out[4 * c + r] = (float)a[r][4 + c];
+    return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+uint32_t bgs_version(void) { return (BGS_VERSION_MAJOR << 16) | BGS_VERSION_MINOR; }
+
+const char* bgs_last_error(const bgs_ctx* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+int bgs_create(int hip_device, bgs_ctx** out) {
+    if (!out) return fail(nullptr, BGS_EINVAL, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, BGS_EHIP, std::string("no usable HIP device (there is no CPU fallback): ") +
+                                           hipGetErrorString(e));
+    if (hip_device < 0 || hip_device >= count) return fail(nullptr, BGS_EINVAL, "hip_device out of range");
+    bgs_ctx* ctx = new (std::nothrow) bgs_ctx();
+    if (!ctx) return fail(nullptr, BGS_ENOMEM, "out of host memory");
+    ctx->device = hip_device;
+    auto bail = [&](const char* what, hipError_t err) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+        bgs_destroy(ctx);
+        return fail(nullptr, BGS_EHIP, msg);
+    };
+    if ((e = hipSetDevice(hip_device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, hip_device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    for (auto& ev : ctx->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    void* h = nullptr;
+    if ((e = hipHostMalloc(&h, sizeof(Control), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    ctx->h_ctl = (Control*)h;
+    *out = ctx;
+    return BGS_OK;
+}
+
+void bgs_destroy(bgs_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (auto e : ctx->entries) if (e) (void)hipFree(e);
+    for (auto e : ctx->inst) if (e) (void)hipFree(e);
+    if (ctx->records) (void)hipFree(ctx->records);
+    if (ctx->fb) (void)hipFree(ctx->fb);
+    if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
+    for (auto ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void bgs_settings_default(bgs_settings* out) {
+    if (!out) return;
+    std::memset(out, 0, sizeof *out);
+    for (int i = 0; i < 4; ++i) out->transform[5 * i] = 1.0f;
+    out->global_opacity = 1.0f;             // src/gaussian/settings.rs:114
+    out->global_scale = 1.0f;               // :115
+    out->gaussian_mode = BGS_GAUSSIAN_3D;   // :17-22 default
+    out->aabb = 0;                          // :113
+    out->opacity_adaptive_radius = 1;       // :116
+    out->color_space = BGS_COLOR_SRGB;      // :79-84 default
+    out->radix_depth_bits = 32;             // :52-57 default
+    out->sh_degree = 3;                     // Cargo.toml default feature sh3
+    out->sort_mode = BGS_SORT_RADIX;        // src/sort/mod.rs:60-74
+}
+
+void bgs_view_perspective(const float world_from_view[16], float fov_y_radians, float near_plane,
+                          uint32_t width, uint32_t height, bgs_view* out) {
+    if (!out || !world_from_view) return;
+    std::memset(out, 0, sizeof *out);
+    std::memcpy(out->world_from_view, world_from_view, 16 * sizeof(float));
+    if (!mat4_inverse(world_from_view, out->view_from_world))
+        for (int i = 0; i < 4; ++i) out->view_from_world[5 * i] = 1.0f;
+    // glam Mat4::perspective_infinite_reverse_rh (bevy PerspectiveProjection)
+    const float f = 1.0f / std::tan(0.5f * fov_y_radians);
+    const float aspect = (float)width / (float)height;
+    out->clip_from_view[0] = f / aspect;
+    out->clip_from_view[5] = f;
+    out->clip_from_view[11] = -1.0f;
+    out->clip_from_view[14] = near_plane;
+    mat4_mul(out->clip_from_view, out->view_from_world, out->clip_from_world);
+    out->viewport[0] = 0.0f;
+    out->viewport[1] = 0.0f;
+    out->viewport[2] = (float)width;
+    out->viewport[3] = (float)height;
+    out->clear_color[3] = 1.0f;  // opaque black, examples/headless.rs:70
+}
+
+static int upload_plane(bgs_ctx* ctx, const void* host, size_t bytes, void** dev) {
+    *dev = nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess)
+        return fail(ctx, BGS_ENOMEM, "hipMalloc(cloud plane) failed");
+    if (bytes && hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(p);
+        return fail(ctx, BGS_EHIP, "hipMemcpy(cloud plane) failed");
+    }
+    *dev = p;
+    return BGS_OK;
+}
+
+int bgs_cloud_upload_f32(bgs_ctx* ctx, uint32_t n, const float* pv, const float* sh, const float* rot,
+                         const float* so, bgs_cloud** out) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (!out) return fail(ctx, BGS_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n > MAX_SPLATS) return fail(ctx, BGS_EINVAL, "too many splats");
+    if (n && (!pv || !sh || !rot || !so)) return fail(ctx, BGS_EINVAL, "NULL plane pointer");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    bgs_cloud* c = new (std::nothrow) bgs_cloud();
+    if (!c) return fail(ctx, BGS_ENOMEM, "out of host memory");
+    const void* src[4] = {pv, sh, rot, so};
+    const size_t bytes[4] = {(size_t)n * 16, (size_t)n * 192, (size_t)n * 16, (size_t)n * 16};
+    for (int i = 0; i < 4; ++i) {
+        int rc = upload_plane(ctx, src[i], bytes[i], &c->allocs[i]);
+        if (rc != BGS_OK) { bgs_cloud_free(ctx, c); return rc; }
+        c->bytes += bytes[i];
+    }
+    c->ptrs.position_visibility = (const float4*)c->allocs[0];
+    c->ptrs.sh_f32 = (const float*)c->allocs[1];
+    c->ptrs.rotation = (const float4*)c->allocs[2];
+    c->ptrs.scale_opacity = (const float4*)c->allocs[3];
+    c->ptrs.n = n;
+    c->ptrs.is_f16 = 0;
+    *out = c;
+    return BGS_OK;
+}
+
+int bgs_cloud_upload_f16(bgs_ctx* ctx, uint32_t n, const float* pv, const uint32_t* sh_h2,
+                         const uint32_t* rso, bgs_cloud** out) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (!out) return fail(ctx, BGS_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n > MAX_SPLATS) return fail(ctx, BGS_EINVAL, "too many splats");
+    if (n && (!pv || !sh_h2 || !rso)) return fail(ctx, BGS_EINVAL, "NULL plane pointer");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    bgs_cloud* c = new (std::nothrow) bgs_cloud();
+    if (!c) return fail(ctx, BGS_ENOMEM, "out of host memory");
+    const void* src[3] = {pv, sh_h2, rso};
+    const size_t bytes[3] = {(size_t)n * 16, (size_t)n * 96, (size_t)n * 16};
+    for (int i = 0; i < 3; ++i) {
+        int rc = upload_plane(ctx, src[i], bytes[i], &c->allocs[i]);
+        if (rc != BGS_OK) { bgs_cloud_free(ctx, c); return rc; }
+        c->bytes += bytes[i];
+    }
+    c->ptrs.position_visibility = (const float4*)c->allocs[0];
+    c->ptrs.sh_f16 = (const uint32_t*)c->allocs[1];
+    c->ptrs.rot_scale_opacity_f16 = (const uint4*)c->allocs[2];
+    c->ptrs.n = n;
+    c->ptrs.is_f16 = 1;
+    *out = c;
+    return BGS_OK;
+}
+
+void bgs_cloud_free(bgs_ctx* ctx, bgs_cloud* cloud) {
+    if (!cloud) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    }
+    for (auto p : cloud->allocs) if (p) (void)hipFree(p);
+    delete cloud;
+}
+
+uint32_t bgs_cloud_len(const bgs_cloud* cloud) { return cloud ? cloud->ptrs.n : 0; }
+
+int bgs_sort(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* settings,
+             bgs_sort_entry* host_out) {
+    int rc = run(ctx, cloud, view, settings, /*render=*/false);
+    if (rc != BGS_OK) return rc;
+    if (host_out && ctx->last_sorted_n)
+        HIP_TRY(ctx, hipMemcpy(host_out, ctx->last_sorted, (size_t)ctx->last_sorted_n * sizeof(uint2),
+                               hipMemcpyDeviceToHost));
+    return BGS_OK;
+}
+
+int bgs_render(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* settings,
+               float* rgba_host_out) {
+    int rc = run(ctx, cloud, view, settings, /*render=*/true);
+    if (rc != BGS_OK) return rc;
+    if (rgba_host_out)
+        HIP_TRY(ctx, hipMemcpy(rgba_host_out, ctx->fb, (size_t)ctx->fb_w * ctx->fb_h * sizeof(float4),
+                               hipMemcpyDeviceToHost));
+    return BGS_OK;
+}
+
+int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes) {
+    if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
+    if (!ctx->fb) return fail(ctx, BGS_EINVAL, "no frame has been rendered yet");
+    *dptr = ctx->fb;
+    if (bytes) *bytes = (uint64_t)ctx->fb_w * ctx->fb_h * sizeof(float4);
+    return BGS_OK;
+}
+
+int bgs_sorted_entries_device_ptr(bgs_ctx* ctx, void** dptr, uint32_t* n) {
+    if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
+    if (!ctx->last_sorted) return fail(ctx, BGS_EINVAL, "no sort has been run yet");
+    *dptr = (void*)ctx->last_sorted;
+    if (n) *n = ctx->last_sorted_n;
+    return BGS_OK;
+}
+
+int bgs_synchronize(bgs_ctx* ctx) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BGS_OK;
+}
+
+int bgs_stream(bgs_ctx* ctx, void** hip_stream) {
+    if (!ctx || !hip_stream) return fail(ctx, BGS_EINVAL, "NULL argument");
+    *hip_stream = (void*)ctx->stream;
+    return BGS_OK;
+}
+
+int bgs_set_profiling(bgs_ctx* ctx, int enabled) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    ctx->profiling = enabled != 0;
+    return BGS_OK;
+}
+
+int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out) {
+    if (!ctx || !out) return fail(ctx, BGS_EINVAL, "NULL argument");
+    if (!ctx->have_stats) return fail(ctx, BGS_EINVAL, "no frame has been run yet");
+    *out = ctx->stats;
+    return BGS_OK;
+}
+
+int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries, uint32_t n, uint32_t passes) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (passes < 1 || passes > 4) return fail(ctx, BGS_EINVAL, "passes must be 1..4");
+    if (n > MAX_SPLATS) return fail(ctx, BGS_EINVAL, "too many pairs");
+    if (n == 0) return BGS_OK;
+    if (!entries) return fail(ctx, BGS_EINVAL, "entries is NULL");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    int rc;
+    if ((rc = ensure_entries(ctx, n)) != BGS_OK) return rc;
+    if ((rc = ensure_scratch(ctx, n, ctx->inst_cap)) != BGS_OK) return rc;
+    hipStream_t st = ctx->stream;
+    Control* ctl = (Control*)ctx->scratch;
+    uint32_t* depth_status = (uint32_t*)(ctx->scratch + ctx->off_depth_status);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->entries[0], entries, (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)&ctl->splat_count, (int)n, 1, st));
+    launch_histogram(st, ctx->entries[0], n, &ctl->hist_depth[0][0], passes);
+    const bool large = n > (4u << 20);
+    const size_t depth_tiles = ((size_t)ctx->scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
+    int cur = 0;
+    for (uint32_t p = 0; p < passes; ++p) {
+        launch_onesweep_pass(st, ctx->entries[cur], ctx->entries[cur ^ 1], &ctl->splat_count, n, ctl->hist_depth[p],
+                             depth_status + (size_t)p * depth_tiles * RADIX_BASE, &ctl->ticket[p], &ctl->error,
+                             p * RADIX_BITS, 0u, large, ctx->num_cus * 4);
+        cur ^= 1;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(entries, ctx->entries[cur], (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->h_ctl->error) return fail(ctx, BGS_EINTERNAL, "device watchdog tripped in radix sort");
+    return BGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// bgs_device.h — structs shared by the HIP kernels and the host orchestration (libbgs).
+// Plain C++ (no HIP types) so the host-side pre-flight test can compile it with g++.
+#pragma once
+#include <stdint.h>
+
+namespace bgs {
+
+constexpr int TILE_PX = 16;              // 16x16-pixel raster tiles
+constexpr uint32_t RADIX_BITS = 8;       // src/render/mod.rs:716
+constexpr uint32_t RADIX_BASE = 256;     // src/render/mod.rs:720
+constexpr uint32_t KEY_CULLED = 0xFFFFFFFFu;
+
+// sort_mode values (include/bgs.h)
+constexpr uint32_t SORT_NONE = 0, SORT_RADIX = 1, SORT_RAYON = 2, SORT_STD = 3;
+
+// Everything the per-splat stages read that is constant over a frame: the used parts of
+// Bevy's View uniform (src/render/bindings.wgsl:3-9) and CloudUniform
+// (src/render/mod.rs:995-1009). Passed to kernels by value.
+struct FrameParams {
+    float transform[16];        // gaussian_uniforms.transform, column-major
+    float view_from_world[16];
+    float clip_from_world[16];  // = unjittered_clip_from_world
+    float cam[3];               // view.world_position
+    float focal_x, focal_y;     // clip_from_view[0].x * W, clip_from_view[1].y * H (helpers.wgsl:20-23)
+    float viewport_w, viewport_h;
+    float global_opacity, global_scale;
+    uint32_t n;                 // gaussian_uniforms.count
+    uint32_t key_shift;         // RADIX_KEY_SHIFT
+    uint32_t gaussian_mode;     // 0 = 2D, 1 = 3D
+    uint32_t aabb;
+    uint32_t adaptive_radius;
+    uint32_t color_space;       // 0 = sRGB-encoded SH, 1 = linear
+    uint32_t sh_degree;
+    uint32_t sort_mode;
+    int32_t width, height;      // render target size in pixels
+    int32_t tiles_x, tiles_y;
+};
+
+// Projected record, one per draw-list rank, stored in front-to-back order.
+// 12 dwords = 48 B (R = 48). Meaning of p[] by pipeline variant:
+//   OBB (3D or 2D): p = {m00, m01, m10, m11, -}:  uv = M * (pixel_centre - centre)
+//   AABB 3D:        p = {m00, m11, A, B, C}: uv = (m00*dx, m11*dy) and
+//                   power = -0.5*(A*u*u + C*v*v) + B*u*v with (A,B,C) = conic * radius_px^2
+//                   (fs_main uses d = -major_minor = -radius_px * uv, gaussian.wgsl:456-458)
+// rect = inclusive tile bounds x0 | x1 << 8 | y0 << 16 | y1 << 24 (tiles_x, tiles_y <= 256).
+struct Record {
+    float cx, cy;       // quad centre in pixels (viewport origin at 0,0, y down)
+    float p[5];
+    float r, g, b, a;   // colour (linear, unclamped) and opacity * global_opacity
+    uint32_t rect;
+};
+static_assert(sizeof(Record) == 48, "Record must be 48 bytes");
+
+// 2DGS surfel record for the AABB path (src/render/gaussian_2d.wgsl:134-156): 24 dwords = 96 B.
+struct RecordSurfel {
+    float cx, cy;       // quad centre in pixels
+    float m00, m11;     // uv = (m00*dx, m11*dy) (axis-aligned square quad)
+    float radius;       // input.radius (both components equal), half-pixel units
+    float mean_x, mean_y;
+    float T[9];         // local_to_pixel columns u, v, w
+    float r, g, b, a;
+    uint32_t rect;
+    uint32_t pad[3];
+};
+static_assert(sizeof(RecordSurfel) == 96, "RecordSurfel must be 96 bytes");
+
+// Device-resident control block, zeroed at the start of every frame by one memset.
+struct Control {
+    uint32_t draw_count;      // entries of the draw list that reach the vertex stage (V' or N)
+    uint32_t instance_count;  // (tile, rank) instances emitted (clamped to capacity)
+    uint32_t instance_total_lo, instance_total_hi;  // unclamped 64-bit total
+    uint32_t overflow;        // 1 if instance_total > capacity
+    uint32_t error;           // device watchdog (bounded spins)
+    uint32_t visible_count;   // splats that pass the vertex-stage cull (stats)
+    uint32_t splat_count;     // N, parked on the device so the sort kernels read every size the same way
+    uint32_t ticket[16];      // dynamic tile ids: one word per kernel launch of the frame
+    uint32_t hist_depth[4][RADIX_BASE];  // global digit histograms of the depth keys
+    uint32_t hist_tile[2][RADIX_BASE];   // digit 0 = tile x, digit 1 = tile y
+};
+
+// look-back status word: flag in the top 2 bits, 30-bit value
+constexpr uint32_t STATUS_FLAG_SHIFT = 30;
+constexpr uint32_t STATUS_VALUE_MASK = (1u << STATUS_FLAG_SHIFT) - 1u;
+constexpr uint32_t STATUS_AGGREGATE = 1u << STATUS_FLAG_SHIFT;
+constexpr uint32_t STATUS_PREFIX = 2u << STATUS_FLAG_SHIFT;
+
+}  // namespace bgs

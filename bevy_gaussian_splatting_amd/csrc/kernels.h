@@ -1,0 +1,64 @@
+// kernels.h — host-callable launchers of the HIP kernels (one per stage of the hot path).
+// Every launcher only enqueues work on `stream`; none synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bgs_device.h"
+
+namespace bgs {
+
+// Device pointers of an uploaded planar cloud (src/gaussian/formats/planar_3d.rs:45-54).
+struct CloudPtrs {
+    const float4* position_visibility;  // n
+    const float* sh_f32;                // n*48      (f32 format)
+    const float4* rotation;             // n         (f32 format) [w,x,y,z]
+    const float4* scale_opacity;        // n         (f32 format)
+    const uint32_t* sh_f16;             // n*24      (f16 format)
+    const uint4* rot_scale_opacity_f16; // n         (f16 format)
+    uint32_t n;
+    uint32_t is_f16;
+};
+
+// Onesweep geometry: 256 threads x KPT keys per tile.
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_KPT_SMALL = 8;   // 2048-pair tiles: more tiles for <= ~4M keys
+constexpr int SORT_KPT_LARGE = 16;  // 4096-pair tiles
+inline uint32_t sort_tile_size(bool large) { return SORT_THREADS * (large ? SORT_KPT_LARGE : SORT_KPT_SMALL); }
+
+// keygen + fused global digit histograms (radix_sort_a, src/sort/radix.wgsl:71-107).
+void launch_keygen(hipStream_t stream, const FrameParams& fp, const float4* position_visibility,
+                   uint2* entries, Control* ctl, uint32_t places);
+
+// Standalone digit histograms of existing pairs (used by bgs_radix_sort_pairs).
+void launch_histogram(hipStream_t stream, const uint2* pairs, uint32_t n, uint32_t* hist /*[4][256]*/,
+                      uint32_t passes);
+
+// One stable 8-bit LSD pass (Onesweep: chained-scan look-back, LDS-ranked scatter).
+//   n_ptr      device word holding the pair count
+//   hist       256 global digit counts for this pass (un-scanned)
+//   status     zeroed look-back words [ceil(max_n / tile)][256]
+//   ticket     zeroed dynamic tile counter
+//   key_xor    XOR-ed into the key on output (un-inverts SORT_RAYON keys in the final pass)
+void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const uint32_t* n_ptr,
+                          uint32_t max_n, const uint32_t* hist, uint32_t* status, uint32_t* ticket,
+                          uint32_t* error_flag, uint32_t shift, uint32_t key_xor, bool large_tiles,
+                          int max_blocks);
+
+// Vertex stage in front-to-back order + ordered tile-instance emission
+// (vs_points once per splat, src/render/gaussian.wgsl:184-436).
+void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
+                         const uint2* draw_list, Control* ctl, unsigned long long* scan_status,
+                         void* records, uint2* instances, uint32_t capacity, uint32_t ticket_slot,
+                         int max_blocks);
+
+// Per-tile [start, end) over the tile-sorted instances; ranges indexed by (ty << 8 | tx).
+void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Control* ctl, uint2* ranges);
+
+// Per-16x16-tile front-to-back blend (fs_main + blend, src/render/gaussian.wgsl:438-505,
+// src/render/mod.rs:944-948).
+void launch_raster(hipStream_t stream, const FrameParams& fp, const void* records,
+                   const uint2* instances, const uint2* ranges, float4* framebuffer,
+                   const float clear_color[4]);
+
+}  // namespace bgs

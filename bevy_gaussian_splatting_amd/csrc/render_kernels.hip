@@ -1,0 +1,425 @@
+// render_kernels.hip — projection + tile binning + tile rasteriser (gfx950, wave64).
+//
+// The reference rasterises one instanced quad per splat through the fixed-function pipeline
+// with premultiplied-alpha blending in back-to-front draw order
+// (src/render/mod.rs:925-983, src/render/gaussian.wgsl:184-505). This file produces the same
+// image with a compute pipeline:
+//
+//   project_emit_kernel  vs_points ONCE per splat (the reference runs it per quad vertex, 4x),
+//                        walking the sorted draw list from its END, i.e. front-to-back, so
+//                        projected records land in HBM in traversal order; then an ordered
+//                        (chained-scan) expansion into (tile, rank) instances. Because instances
+//                        are emitted in rank order, a STABLE sort on the tile id alone yields
+//                        per-tile lists that are already front-to-back (== sorting on
+//                        tile-major|depth keys, with 2 instead of 6 digit passes).
+//   tile_ranges_kernel   [start, end) of every tile in the tile-sorted instance list.
+//   raster_kernel        one 256-thread workgroup per 16x16 tile; batches of 256 records are
+//                        staged in LDS (coalesced index read, 16-byte gathers), every thread
+//                        owns one pixel and composites front-to-back:
+//                            C += T*alpha*c, T *= 1-alpha        (fs_main + blend, reordered)
+//                        and stops when every pixel of the tile has T < 2^-16.
+//
+// Front-to-back vs the reference's back-to-front "over" is the same polynomial evaluated in
+// the opposite association order; the difference is f32 rounding (<< 1e-3).
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "splat_math.h"
+
+namespace bgs {
+
+namespace {
+
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr unsigned long long S64_FLAG_SHIFT = 62;
+constexpr unsigned long long S64_VALUE_MASK = (1ull << S64_FLAG_SHIFT) - 1ull;
+constexpr unsigned long long S64_AGGREGATE = 1ull << S64_FLAG_SHIFT;
+constexpr unsigned long long S64_PREFIX = 2ull << S64_FLAG_SHIFT;
+constexpr uint32_t SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// IEEE binary16 -> binary32 (exact; v_cvt_f32_f16 keeps subnormals), like unpack2x16float
+__device__ __forceinline__ float half_bits_to_float(unsigned short h) {
+    _Float16 x;
+    __builtin_memcpy(&x, &h, 2);
+    return (float)x;
+}
+__device__ __forceinline__ float half_lo(uint32_t v) { return half_bits_to_float((unsigned short)(v & 0xFFFFu)); }
+__device__ __forceinline__ float half_hi(uint32_t v) { return half_bits_to_float((unsigned short)(v >> 16)); }
+
+// SH coefficient fetchers: coefficient triple k = floats 3k..3k+2 of the splat's 48.
+struct ShF32 {
+    const float* base;
+    __device__ __forceinline__ V3 operator()(int k) const {
+        return V3{base[3 * k], base[3 * k + 1], base[3 * k + 2]};
+    }
+};
+// f16 plane: u32 word i holds coefficient 2i in the low half, 2i+1 in the high half
+// (src/render/planar.wgsl:117-130).
+struct ShF16 {
+    const uint32_t* base;
+    __device__ __forceinline__ float coef(int i) const {
+        const uint32_t w = base[i >> 1];
+        return (i & 1) ? half_hi(w) : half_lo(w);
+    }
+    __device__ __forceinline__ V3 operator()(int k) const {
+        return V3{coef(3 * k), coef(3 * k + 1), coef(3 * k + 2)};
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// project + ordered instance emission
+// ---------------------------------------------------------------------------------------
+template <bool F16, bool SURFEL>
+__global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, CloudPtrs cloud,
+                                                           const uint2* __restrict__ draw_list,
+                                                           Control* ctl,
+                                                           unsigned long long* scan_status,
+                                                           float4* __restrict__ records,
+                                                           uint2* __restrict__ instances,
+                                                           uint32_t capacity, uint32_t ticket_slot) {
+    __shared__ uint32_t s_prefix[256];  // exclusive tile-count prefix of the block's splats
+    __shared__ uint32_t s_rect[256];
+    __shared__ uint32_t s_histx[RADIX_BASE];
+    __shared__ uint32_t s_histy[RADIX_BASE];
+    __shared__ uint32_t s_tot[4];
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_tile;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t count = ctl->draw_count;
+    const uint32_t num_tiles = (count + 255u) / 256u;
+    if (num_tiles == 0u) return;
+    s_histx[tid] = 0u;
+    s_histy[tid] = 0u;
+    uint32_t visible_acc = 0u;
+
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= num_tiles) break;
+        const uint32_t j = tile * 256u + (uint32_t)tid;  // front-to-back rank
+        uint32_t ntiles = 0u, rect = 0u;
+        if (j < count) {
+            // the LAST entry of the draw list is drawn on top => it is the front-most
+            const uint2 entry = draw_list[count - 1u - j];
+            const uint32_t si = entry.y;
+            const float4 pv = cloud.position_visibility[si];
+            float rot[4], so[4];
+            if constexpr (F16) {
+                // src/render/planar.wgsl:154-176: first value of each pair in the HIGH half
+                const uint4 raw = cloud.rot_scale_opacity_f16[si];
+                rot[0] = half_hi(raw.x); rot[1] = half_lo(raw.x);
+                rot[2] = half_hi(raw.y); rot[3] = half_lo(raw.y);
+                so[0] = half_hi(raw.z); so[1] = half_lo(raw.z);
+                so[2] = half_hi(raw.w); so[3] = half_lo(raw.w);
+            } else {
+                const float4 r4 = cloud.rotation[si];
+                const float4 s4 = cloud.scale_opacity[si];
+                rot[0] = r4.x; rot[1] = r4.y; rot[2] = r4.z; rot[3] = r4.w;
+                so[0] = s4.x; so[1] = s4.y; so[2] = s4.z; so[3] = s4.w;
+            }
+            Projected pr;
+            if constexpr (F16)
+                project_splat(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so,
+                              ShF16{cloud.sh_f16 + (size_t)si * 24u}, pr);
+            else
+                project_splat(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so,
+                              ShF32{cloud.sh_f32 + (size_t)si * 48u}, pr);
+            visible_acc += pr.visible ? 1u : 0u;
+            if (pr.draw) {
+                ntiles = (uint32_t)(pr.tx1 - pr.tx0 + 1) * (uint32_t)(pr.ty1 - pr.ty0 + 1);
+                rect = (uint32_t)pr.tx0 | ((uint32_t)pr.tx1 << 8) | ((uint32_t)pr.ty0 << 16) |
+                       ((uint32_t)pr.ty1 << 24);
+                if constexpr (SURFEL) {
+                    float4* dst = records + (size_t)j * 6u;
+                    dst[0] = make_float4(pr.quad.cx, pr.quad.cy, pr.p[0], pr.p[1]);
+                    dst[1] = make_float4(pr.radius, pr.surfel.mean_x, pr.surfel.mean_y, pr.surfel.T[0]);
+                    dst[2] = make_float4(pr.surfel.T[1], pr.surfel.T[2], pr.surfel.T[3], pr.surfel.T[4]);
+                    dst[3] = make_float4(pr.surfel.T[5], pr.surfel.T[6], pr.surfel.T[7], pr.surfel.T[8]);
+                    dst[4] = make_float4(pr.color[0], pr.color[1], pr.color[2], pr.color[3]);
+                    dst[5] = make_float4(__uint_as_float(rect), 0.0f, 0.0f, 0.0f);
+                } else {
+                    float4* dst = records + (size_t)j * 3u;
+                    dst[0] = make_float4(pr.quad.cx, pr.quad.cy, pr.p[0], pr.p[1]);
+                    dst[1] = make_float4(pr.p[2], pr.p[3], pr.p[4], pr.color[0]);
+                    dst[2] = make_float4(pr.color[1], pr.color[2], pr.color[3], __uint_as_float(rect));
+                }
+            }
+        }
+        // block exclusive scan of the tile counts
+        const uint32_t inc = wave_inclusive_scan(ntiles, lane);
+        if (lane == 63) s_tot[wave] = inc;
+        s_rect[tid] = rect;
+        __syncthreads();
+        const uint32_t w0 = s_tot[0], w1 = s_tot[1], w2 = s_tot[2], w3 = s_tot[3];
+        const uint32_t woff = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+        const uint32_t block_total = w0 + w1 + w2 + w3;
+        s_prefix[tid] = woff + inc - ntiles;
+
+        // chained scan over blocks (64-bit words: totals may exceed 2^32 before clamping)
+        if (tid == 0) {
+            unsigned long long excl = 0ull;
+            if (tile > 0u) {
+                st_agent64(scan_status + tile, S64_AGGREGATE | (unsigned long long)block_total);
+                uint32_t p = tile - 1u, spins = 0u;
+                for (;;) {
+                    const unsigned long long v = ld_agent64(scan_status + p);
+                    const unsigned long long flag = v >> S64_FLAG_SHIFT;
+                    if (flag == 0ull) {
+                        if (++spins > SPIN_LIMIT) { atomicOr(&ctl->error, 2u); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    excl += v & S64_VALUE_MASK;
+                    if (flag == 2ull || p == 0u) break;
+                    --p;
+                }
+            }
+            const unsigned long long incl = excl + (unsigned long long)block_total;
+            st_agent64(scan_status + tile, S64_PREFIX | (incl & S64_VALUE_MASK));
+            s_base = excl;
+            if (tile == num_tiles - 1u) {  // this block owns the grand total
+                const bool overflow = incl > (unsigned long long)capacity;
+                ctl->instance_total_lo = (uint32_t)incl;
+                ctl->instance_total_hi = (uint32_t)(incl >> 32);
+                ctl->overflow = overflow ? 1u : 0u;
+                // on overflow the later stages see an empty list; the host grows and re-runs
+                ctl->instance_count = overflow ? 0u : (uint32_t)incl;
+            }
+        }
+        // per-digit histograms of the tile keys (digit 0 = tile x, digit 1 = tile y): a splat
+        // with a w x h tile rectangle adds h to each of its w columns and w to each of its h rows
+        if (ntiles) {
+            const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u;
+            const uint32_t ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
+            const uint32_t w = tx1 - tx0 + 1u, h = ty1 - ty0 + 1u;
+            for (uint32_t x = tx0; x <= tx1; ++x) atomicAdd(&s_histx[x], h);
+            for (uint32_t y = ty0; y <= ty1; ++y) atomicAdd(&s_histy[y], w);
+        }
+        __syncthreads();
+
+        // cooperative, coalesced expansion: instance i of the block belongs to the splat t with
+        // s_prefix[t] <= i < s_prefix[t+1]
+        const unsigned long long base = s_base;
+        for (uint32_t i = (uint32_t)tid; i < block_total; i += 256u) {
+            uint32_t lo = 0u, hi = 255u;  // largest t with s_prefix[t] <= i
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (s_prefix[mid] <= i) lo = mid; else hi = mid - 1u;
+            }
+            const uint32_t r = s_rect[lo];
+            const uint32_t tx0 = r & 255u, tx1 = (r >> 8) & 255u, ty0 = (r >> 16) & 255u;
+            const uint32_t w = tx1 - tx0 + 1u;
+            const uint32_t k = i - s_prefix[lo];
+            const uint32_t row = k / w, col = k - row * w;
+            const unsigned long long g = base + (unsigned long long)i;
+            if (g < (unsigned long long)capacity)
+                instances[g] = make_uint2(((ty0 + row) << 8) | (tx0 + col), tile * 256u + lo);
+        }
+        __syncthreads();
+    }
+    // flush block-private histograms
+    {
+        const uint32_t hx = s_histx[tid], hy = s_histy[tid];
+        if (hx) atomicAdd(&ctl->hist_tile[0][tid], hx);
+        if (hy) atomicAdd(&ctl->hist_tile[1][tid], hy);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) visible_acc += __shfl_down(visible_acc, off, 64);
+    if (lane == 0 && visible_acc) atomicAdd(&ctl->visible_count, visible_acc);
+}
+
+void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
+                         const uint2* draw_list, Control* ctl, unsigned long long* scan_status,
+                         void* records, uint2* instances, uint32_t capacity, uint32_t ticket_slot,
+                         int max_blocks) {
+    if (fp.n == 0) return;
+    uint32_t blocks = (fp.n + 255u) / 256u;
+    if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
+    const bool surfel = fp.gaussian_mode == 0u && fp.aabb != 0u;
+    float4* rec = (float4*)records;
+#define BGS_LAUNCH_PE(F16, SURFEL)                                                              \
+    hipLaunchKernelGGL((project_emit_kernel<F16, SURFEL>), dim3(blocks), dim3(256), 0, stream, fp, \
+                       cloud, draw_list, ctl, scan_status, rec, instances, capacity, ticket_slot)
+    if (cloud.is_f16) {
+        if (surfel) BGS_LAUNCH_PE(true, true); else BGS_LAUNCH_PE(true, false);
+    } else {
+        if (surfel) BGS_LAUNCH_PE(false, true); else BGS_LAUNCH_PE(false, false);
+    }
+#undef BGS_LAUNCH_PE
+}
+
+// ---------------------------------------------------------------------------------------
+// tile ranges
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint2* __restrict__ inst,
+                                                          const Control* ctl, uint2* ranges) {
+    const uint32_t n = ctl->instance_count;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t key = inst[i].x;
+        if (i == 0u || inst[i - 1u].x != key) ranges[key].x = i;
+        if (i == n - 1u || inst[i + 1u].x != key) ranges[key].y = i + 1u;
+    }
+}
+
+void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Control* ctl, uint2* ranges) {
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(2048), dim3(256), 0, stream, instances, ctl, ranges);
+}
+
+// ---------------------------------------------------------------------------------------
+// tile rasteriser
+// ---------------------------------------------------------------------------------------
+constexpr int RV_OBB = 0, RV_AABB3D = 1, RV_SURFEL = 2;
+constexpr float T_EPS = 1.0f / 65536.0f;  // stop compositing a pixel below this transmittance
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float4* __restrict__ records,
+                                                     const uint2* __restrict__ instances,
+                                                     const uint2* __restrict__ ranges,
+                                                     float4* __restrict__ fb, float4 clear) {
+    // the per-pixel loop is the one place where FMA contraction is wanted (nothing here
+    // feeds a sort key or a cull decision); the rest of this file is built -ffp-contract=off
+#pragma clang fp contract(fast)
+    constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
+    __shared__ float4 s_rec[256 * REC_V4];
+
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch); give each XCD a
+    // contiguous band of tiles so neighbouring tiles (which share records) share an L2.
+    const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
+    uint32_t tile;
+    {
+        const uint32_t b = blockIdx.x, q = ntiles / 8u, r = ntiles % 8u, xcd = b % 8u;
+        tile = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
+    }
+    const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
+    const int tid = threadIdx.x;
+    const int px = (int)tx * TILE_PX + (tid & 15), py = (int)ty * TILE_PX + (tid >> 4);
+    const bool in_image = px < fp.width && py < fp.height;
+    const float qx = (float)px + 0.5f, qy = (float)py + 0.5f;
+
+    const uint2 range = ranges[(ty << 8) | tx];
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    bool done = !in_image;
+
+    for (uint32_t base = range.x; base < range.y; base += 256u) {
+        const uint32_t cnt = min(256u, range.y - base);
+        if ((uint32_t)tid < cnt) {
+            const uint32_t rank = instances[base + (uint32_t)tid].y;
+            const float4* src = records + (size_t)rank * REC_V4;
+#pragma unroll
+            for (int v = 0; v < REC_V4; ++v) s_rec[tid * REC_V4 + v] = src[v];
+        }
+        __syncthreads();
+        if (!__all(done)) {
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4 a0 = s_rec[k * REC_V4 + 0];
+                const float4 a1 = s_rec[k * REC_V4 + 1];
+                const float4 a2 = s_rec[k * REC_V4 + 2];
+                const float dx = qx - a0.x, dy = qy - a0.y;
+                float alpha, r, g, b;
+                bool hit;
+                if constexpr (VARIANT == RV_OBB) {
+                    // a0 = cx cy m00 m01 | a1 = m10 m11 - r | a2 = g b a rect
+                    const float u = a0.z * dx + a0.w * dy;
+                    const float v = a1.x * dx + a1.y * dy;
+                    hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
+                    // fs_main OBB: power = -dot(uv,uv) / (2 * (1/3)^2)  (gaussian.wgsl:474-480)
+                    constexpr float sigma = 1.0f / 3.0f;
+                    constexpr float neg_inv_sigma2 = -1.0f / (2.0f * sigma * sigma);
+                    const float power = (u * u + v * v) * neg_inv_sigma2;
+                    alpha = fminf(__expf(power) * a2.z, 0.999f);
+                    r = a1.w; g = a2.x; b = a2.y;
+                } else if constexpr (VARIANT == RV_AABB3D) {
+                    // a0 = cx cy m00 m11 | a1 = A B C r | a2 = g b a rect
+                    const float u = a0.z * dx, v = a0.w * dy;
+                    hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
+                    const float power = -0.5f * (a1.x * u * u + a1.z * v * v) + a1.y * u * v;
+                    hit = hit && !(power > 0.0f);
+                    alpha = fminf(__expf(power) * a2.z, 0.999f);
+                    r = a1.w; g = a2.x; b = a2.y;
+                } else {
+                    // a0 = cx cy m00 m11 | a1 = radius mean.xy T0 | a2 = T1..T4 | a3 = T5..T8 | a4 = rgba
+                    const float4 a3 = s_rec[k * REC_V4 + 3];
+                    const float4 a4 = s_rec[k * REC_V4 + 4];
+                    const float u = a0.z * dx, v = a0.w * dy;
+                    hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
+                    // fs_main GAUSSIAN_2D + USE_AABB (gaussian.wgsl:440-455), aspect = (1, W/H)
+                    const float pcx = u * a1.x * 1.0f + a1.y;
+                    const float pcy = v * a1.x * (fp.viewport_w / fp.viewport_h) + a1.z;
+                    // surfel_fragment_power (gaussian_2d.wgsl:134-156)
+                    const float T0x = a1.w, T0y = a2.x, T0z = a2.y;
+                    const float T1x = a2.z, T1y = a2.w, T1z = a3.x;
+                    const float T2x = a3.y, T2y = a3.z, T2z = a3.w;
+                    const float hux = pcx * T2x - T0x, huy = pcx * T2y - T0y, huz = pcx * T2z - T0z;
+                    const float hvx = pcy * T2x - T1x, hvy = pcy * T2y - T1y, hvz = pcy * T2z - T1z;
+                    const float cpx = huy * hvz - hvy * huz;
+                    const float cpy = huz * hvx - hvz * hux;
+                    const float cpz = hux * hvy - hvx * huy;
+                    const float us = cpx / cpz, vs = cpy / cpz;
+                    const float ddx = a1.y - pcx, ddy = a1.z - pcy;
+                    const float s3 = us * us + vs * vs;
+                    const float s2 = 2.0f * (ddx * ddx + ddy * ddy);
+                    const float power = -0.5f * fminf(s3, s2);
+                    hit = hit && !(power > 0.0f);
+                    alpha = fminf(__expf(power) * a4.w, 0.999f);
+                    r = a4.x; g = a4.y; b = a4.z;
+                }
+                if (hit && !done) {
+                    const float w = T * alpha;
+                    cr += w * r;
+                    cg += w * g;
+                    cb += w * b;
+                    T *= 1.0f - alpha;
+                    done = T < T_EPS;
+                }
+            }
+        }
+        // also the barrier that protects s_rec before the next batch overwrites it
+        if (__syncthreads_and(done ? 1 : 0)) break;
+    }
+    if (in_image) {
+        // dst = src + dst*(1-src.a) unrolled over the whole list, target cleared to `clear`
+        fb[(size_t)py * (size_t)fp.width + (size_t)px] =
+            make_float4(cr + T * clear.x, cg + T * clear.y, cb + T * clear.z, (1.0f - T) + T * clear.w);
+    }
+}
+
+void launch_raster(hipStream_t stream, const FrameParams& fp, const void* records,
+                   const uint2* instances, const uint2* ranges, float4* framebuffer,
+                   const float clear_color[4]) {
+    const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
+    if (ntiles == 0) return;
+    const float4 clear = make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]);
+    const float4* rec = (const float4*)records;
+    if (fp.aabb == 0u)
+        hipLaunchKernelGGL(raster_kernel<RV_OBB>, dim3(ntiles), dim3(256), 0, stream, fp, rec, instances,
+                           ranges, framebuffer, clear);
+    else if (fp.gaussian_mode != 0u)
+        hipLaunchKernelGGL(raster_kernel<RV_AABB3D>, dim3(ntiles), dim3(256), 0, stream, fp, rec,
+                           instances, ranges, framebuffer, clear);
+    else
+        hipLaunchKernelGGL(raster_kernel<RV_SURFEL>, dim3(ntiles), dim3(256), 0, stream, fp, rec,
+                           instances, ranges, framebuffer, clear);
+}
+
+}  // namespace bgs

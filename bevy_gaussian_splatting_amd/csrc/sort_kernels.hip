@@ -1,0 +1,299 @@
+// sort_kernels.hip — depth keys + device radix sort (gfx950, wave64).
+//
+// Replaces the reference's GPU radix sort (src/sort/radix.wgsl, host src/sort/radix.rs):
+//   radix_reset + radix_sort_a   -> keygen_kernel (keys, pairs, 4 digit histograms, LDS-privatised)
+//   radix_sort_b                 -> folded into every onesweep block (256-bin exclusive scan)
+//   radix_sort_c_{count,scan,scatter} x places
+//                                -> onesweep_kernel x places: ONE kernel per digit place, each
+//                                   pair read once and written once (16 B/pair/pass).
+// Output contract is the reference's: ascending key, ties by ascending input position
+// (stable LSD, 8-bit digits), so the final order is bit-identical to radix.wgsl's.
+//
+// Onesweep pass, per 256-thread block and per tile of 256*KPT pairs (tiles are handed out by
+// an atomic ticket, so a tile's predecessors have always started — no dispatch-order assumption):
+//   1. coalesced load, wave-striped (wave w owns KPT consecutive 64-pair rows)
+//   2. per row: 8 ballots -> same-digit lane mask -> rank = popc(mask & lanes_below); the row
+//      leader bumps the wave's private LDS digit counter (no LDS atomics)
+//   3. per digit (thread = digit): scan over the 4 waves, publish the tile aggregate, decoupled
+//      look-back over predecessor tiles (relaxed agent-scope 4-byte words: the data is the flag)
+//   4. scatter pairs into LDS in digit order, then write runs to HBM coalesced.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "splat_math.h"
+
+namespace bgs {
+
+namespace {
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread over a 256-thread block. s_tot: 4 LDS words.
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* s_tot,
+                                                             uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) s_tot[wave] = inc;
+    __syncthreads();
+    const uint32_t w0 = s_tot[0], w1 = s_tot[1], w2 = s_tot[2], w3 = s_tot[3];
+    const uint32_t woff = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return woff + inc - v;
+}
+
+constexpr int KG_ITEMS = 8;  // splats per thread in keygen
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// keygen: one thread per splat, 16 B read + 8 B write per splat, fully coalesced.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
+                                                     uint2* __restrict__ entries, Control* ctl,
+                                                     uint32_t places) {
+    __shared__ uint32_t s_hist[4][RADIX_BASE];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
+    __syncthreads();
+
+    if (blockIdx.x == 0 && tid == 0) ctl->splat_count = fp.n;
+    const uint32_t sentinel = KEY_CULLED >> fp.key_shift;
+    const uint32_t base = blockIdx.x * (256u * KG_ITEMS);
+    uint32_t drawable = 0;
+#pragma unroll
+    for (int k = 0; k < KG_ITEMS; ++k) {
+        const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
+        if (i < fp.n) {
+            const float4 p = pos[i];
+            const uint32_t key = sort_key(fp, V3{p.x, p.y, p.z});
+            entries[i] = make_uint2(key, i);
+            for (uint32_t pl = 0; pl < places; ++pl)
+                atomicAdd(&s_hist[pl][(key >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
+            // entries that reach the vertex stage: everything unless the radix key is "culled"
+            drawable += (fp.sort_mode != SORT_RADIX || key != sentinel) ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    for (uint32_t pl = 0; pl < places; ++pl) {
+        const uint32_t v = s_hist[pl][tid];
+        if (v) atomicAdd(&ctl->hist_depth[pl][tid], v);
+    }
+    // block-reduce the drawable count: wave shuffle, then one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) drawable += __shfl_down(drawable, off, 64);
+    if ((tid & 63) == 0 && drawable) atomicAdd(&ctl->draw_count, drawable);
+}
+
+void launch_keygen(hipStream_t stream, const FrameParams& fp, const float4* pos, uint2* entries,
+                   Control* ctl, uint32_t places) {
+    if (fp.n == 0) return;
+    const uint32_t per_block = 256u * KG_ITEMS;
+    const uint32_t blocks = (fp.n + per_block - 1) / per_block;
+    hipLaunchKernelGGL(keygen_kernel, dim3(blocks), dim3(256), 0, stream, fp, pos, entries, ctl, places);
+}
+
+// ---------------------------------------------------------------------------------------
+// standalone histogram (test entry point bgs_radix_sort_pairs)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void histogram_kernel(const uint2* __restrict__ pairs, uint32_t n,
+                                                        uint32_t* hist, uint32_t passes) {
+    __shared__ uint32_t s_hist[4][RADIX_BASE];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
+        const uint32_t key = pairs[i].x;
+        for (uint32_t pl = 0; pl < passes; ++pl)
+            atomicAdd(&s_hist[pl][(key >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t pl = 0; pl < passes; ++pl) {
+        const uint32_t v = s_hist[pl][tid];
+        if (v) atomicAdd(&hist[pl * RADIX_BASE + tid], v);
+    }
+}
+
+void launch_histogram(hipStream_t stream, const uint2* pairs, uint32_t n, uint32_t* hist,
+                      uint32_t passes) {
+    if (n == 0) return;
+    uint32_t blocks = (n + 256u * 16u - 1) / (256u * 16u);
+    if (blocks > 1024u) blocks = 1024u;
+    hipLaunchKernelGGL(histogram_kernel, dim3(blocks), dim3(256), 0, stream, pairs, n, hist, passes);
+}
+
+// ---------------------------------------------------------------------------------------
+// Onesweep digit pass
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t SPIN_LIMIT = 1u << 22;  // bounded look-back spin (watchdog, never expected)
+
+template <int KPT>
+__global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__ in,
+                                                       uint2* __restrict__ out,
+                                                       const uint32_t* __restrict__ n_ptr,
+                                                       const uint32_t* __restrict__ hist,
+                                                       uint32_t* status, uint32_t* ticket,
+                                                       uint32_t* error_flag, uint32_t shift,
+                                                       uint32_t key_xor) {
+    constexpr uint32_t TILE = 256u * KPT;
+    __shared__ uint2 s_pairs[TILE];
+    __shared__ uint32_t s_wave_hist[4][RADIX_BASE];
+    __shared__ uint32_t s_block_excl[RADIX_BASE];   // first slot of each digit in the LDS order
+    __shared__ uint32_t s_global_base[RADIX_BASE];  // dst = s_global_base[d] + slot
+    __shared__ uint32_t s_hist_excl[RADIX_BASE];
+    __shared__ uint32_t s_tot[4];
+    __shared__ uint32_t s_tile;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = *n_ptr;
+    const uint32_t num_tiles = (n + TILE - 1u) / TILE;
+    if (num_tiles == 0u) return;
+
+    {   // radix_sort_b: exclusive scan of the global digit histogram, once per block
+        uint32_t total;
+        const uint32_t h = hist[tid];
+        s_hist_excl[tid] = block_exclusive_scan_256(h, s_tot, total);
+    }
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s_wave_hist[w][tid] = 0u;
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= num_tiles) break;
+        const uint32_t tile_base = tile * TILE;
+        const uint32_t row_base = tile_base + (uint32_t)wave * (uint32_t)(KPT * 64) + (uint32_t)lane;
+
+        uint2 kv[KPT];
+        uint32_t rank[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t idx = row_base + (uint32_t)k * 64u;
+            kv[k] = idx < n ? in[idx] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+        // wave-private ranking, one 64-pair row at a time (rows in input order => stable).
+        // DS operations of one wave execute in issue order, so the row leader's counter update
+        // is seen by the next row's read; volatile keeps the compiler from caching the counters.
+        volatile uint32_t* const wh = s_wave_hist[wave];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t idx = row_base + (uint32_t)k * 64u;
+            const bool valid = idx < n;
+            const uint32_t d = (kv[k].x >> shift) & (RADIX_BASE - 1u);
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const uint32_t below = (uint32_t)__popcll(m & lanes_below);
+            const uint32_t prev = wh[d];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && below == 0u) wh[d] = prev + (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            rank[k] = prev + below;
+        }
+        __syncthreads();
+
+        // thread = digit: scan over the 4 waves
+        uint32_t total;
+        {
+            const uint32_t c0 = s_wave_hist[0][tid], c1 = s_wave_hist[1][tid];
+            const uint32_t c2 = s_wave_hist[2][tid], c3 = s_wave_hist[3][tid];
+            s_wave_hist[0][tid] = 0u;
+            s_wave_hist[1][tid] = c0;
+            s_wave_hist[2][tid] = c0 + c1;
+            s_wave_hist[3][tid] = c0 + c1 + c2;
+            total = c0 + c1 + c2 + c3;
+        }
+        // chained scan with decoupled look-back, one chain per digit
+        uint32_t* const my_status = status + (size_t)tile * RADIX_BASE + tid;
+        uint32_t excl = 0u;
+        if (tile > 0u) {
+            st_agent(my_status, STATUS_AGGREGATE | total);
+            uint32_t p = tile - 1u;
+            uint32_t spins = 0u;
+            for (;;) {
+                const uint32_t v = ld_agent(status + (size_t)p * RADIX_BASE + tid);
+                const uint32_t flag = v >> STATUS_FLAG_SHIFT;
+                if (flag == 0u) {
+                    if (++spins > SPIN_LIMIT) { atomicOr(error_flag, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += v & STATUS_VALUE_MASK;
+                if (flag == 2u || p == 0u) break;
+                --p;
+            }
+        }
+        st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
+
+        uint32_t blk_total;
+        const uint32_t bexcl = block_exclusive_scan_256(total, s_tot, blk_total);
+        s_block_excl[tid] = bexcl;
+        s_global_base[tid] = s_hist_excl[tid] + excl - bexcl;
+        __syncthreads();
+
+        // scatter into LDS in digit order
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t idx = row_base + (uint32_t)k * 64u;
+            if (idx < n) {
+                const uint32_t d = (kv[k].x >> shift) & (RADIX_BASE - 1u);
+                const uint32_t slot = s_block_excl[d] + s_wave_hist[wave][d] + rank[k];
+                s_pairs[slot] = kv[k];
+            }
+        }
+        __syncthreads();
+        const uint32_t count = min(TILE, n - tile_base);
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t slot = (uint32_t)k * 256u + (uint32_t)tid;
+            if (slot < count) {
+                uint2 e = s_pairs[slot];
+                const uint32_t d = (e.x >> shift) & (RADIX_BASE - 1u);
+                e.x ^= key_xor;
+                const uint32_t dst = s_global_base[d] + slot;
+                if (dst < n) out[dst] = e;  // always true unless the watchdog tripped
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const uint32_t* n_ptr,
+                          uint32_t max_n, const uint32_t* hist, uint32_t* status, uint32_t* ticket,
+                          uint32_t* error_flag, uint32_t shift, uint32_t key_xor, bool large_tiles,
+                          int max_blocks) {
+    if (max_n == 0) return;
+    const uint32_t tile = sort_tile_size(large_tiles);
+    uint32_t blocks = (max_n + tile - 1u) / tile;
+    if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
+    if (large_tiles)
+        hipLaunchKernelGGL(onesweep_kernel<SORT_KPT_LARGE>, dim3(blocks), dim3(256), 0, stream, in, out,
+                           n_ptr, hist, status, ticket, error_flag, shift, key_xor);
+    else
+        hipLaunchKernelGGL(onesweep_kernel<SORT_KPT_SMALL>, dim3(blocks), dim3(256), 0, stream, in, out,
+                           n_ptr, hist, status, ticket, error_flag, shift, key_xor);
+}
+
+}  // namespace bgs

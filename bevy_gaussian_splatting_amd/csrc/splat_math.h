@@ -1,0 +1,485 @@
+// splat_math.h — per-splat arithmetic of the hot path (device functions).
+//
+// What the reference computes per quad vertex in vs_points (src/render/gaussian.wgsl:184-436)
+// and per key in radix_sort_a (src/sort/radix.wgsl:86-101), done ONCE per splat here.
+//
+// Evaluation order is fixed (see DESIGN.md "arithmetic contract"): the translation units
+// that include this header are compiled with -ffp-contract=off so that
+//   dot(a,b)   = ((a0*b0 + a1*b1) + a2*b2) [+ a3*b3]
+//   (M*v)[r]   = (((M[0][r]*v0 + M[1][r]*v1) + M[2][r]*v2) + M[3][r]*v3)
+//   (A*B)[c][r]= ((A[0][r]*B[c][0] + A[1][r]*B[c][1]) + A[2][r]*B[c][2])
+// which makes the sort keys and every cull decision bit-exact with the parity oracle.
+//
+// BGS_HD expands to __host__ __device__ under hipcc and to nothing under g++; the g++
+// build exists only for tests/test_device_math_host.py (a CPU pre-flight of this header
+// against the oracle, so transcription slips are caught without a GPU). It is not a
+// fallback: libbgs never calls these functions on the host.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "bgs_device.h"
+
+#if defined(__HIPCC__)
+#define BGS_HD __host__ __device__ __forceinline__
+#else
+#define BGS_HD static inline
+#endif
+
+namespace bgs {
+
+struct V2 { float x, y; };
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+struct M3 { float m[9]; };  // column-major m[3*c + r]
+
+BGS_HD uint32_t f2u(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u; memcpy(&u, &f, 4); return u;
+#endif
+}
+
+BGS_HD float dot2(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+BGS_HD float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+BGS_HD V3 mul3(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+BGS_HD V3 sub3(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+BGS_HD V3 scale3(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+BGS_HD V3 normalize3(V3 a) {
+    float len = sqrtf(dot3(a, a));
+    return V3{a.x / len, a.y / len, a.z / len};
+}
+
+BGS_HD V4 m4_mul_point(const float* m, V3 p) {  // M * vec4(p, 1)
+    V4 r;
+    r.x = ((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12] * 1.0f;
+    r.y = ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13] * 1.0f;
+    r.z = ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14] * 1.0f;
+    r.w = ((m[3] * p.x + m[7] * p.y) + m[11] * p.z) + m[15] * 1.0f;
+    return r;
+}
+
+BGS_HD M3 m3_cols(V3 a, V3 b, V3 c) { return M3{{a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z}}; }
+BGS_HD M3 m3_transpose(const M3& a) {
+    return M3{{a.m[0], a.m[3], a.m[6], a.m[1], a.m[4], a.m[7], a.m[2], a.m[5], a.m[8]}};
+}
+BGS_HD M3 m3_mul(const M3& a, const M3& b) {
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+            r.m[3 * c + rr] = (a.m[rr] * b.m[3 * c] + a.m[3 + rr] * b.m[3 * c + 1]) +
+                              a.m[6 + rr] * b.m[3 * c + 2];
+    return r;
+}
+BGS_HD M3 m3_from_m4(const float* m) {
+    return M3{{m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]}};
+}
+
+// src/render/transform.wgsl:5-8
+BGS_HD V4 world_to_clip(const FrameParams& fp, V3 world_pos) {
+    V4 h = m4_mul_point(fp.clip_from_world, world_pos);
+    float d = h.w + 0.000000001f;
+    return V4{h.x / d, h.y / d, h.z / d, h.w / d};
+}
+// src/render/transform.wgsl:10-14
+BGS_HD bool in_frustum(V4 c) {
+    return fabsf(c.x) < 1.1f && fabsf(c.y) < 1.1f && fabsf(c.z - 0.5f) < 0.5f;
+}
+
+// Sort key of one splat for every SortMode.
+//   SORT_RADIX: src/sort/radix.wgsl:86-101 (cull + inverted distance bits, >> key_shift)
+//   SORT_RAYON/STD: src/sort/rayon.rs:91-97 stores bits(dist2) and sorts DESCENDING; the
+//     device sorts ascending on ~bits and un-inverts in the last pass, so this returns ~bits.
+//   SORT_NONE: src/sort/mod.rs:347-354 (key = 1, draw order = index order)
+BGS_HD uint32_t sort_key(const FrameParams& fp, V3 pos) {
+    if (fp.sort_mode == SORT_NONE) return 1u;
+    V4 t4 = m4_mul_point(fp.transform, pos);
+    V3 tp{t4.x, t4.y, t4.z};
+    V3 cam{fp.cam[0], fp.cam[1], fp.cam[2]};
+    if (fp.sort_mode != SORT_RADIX) {
+        V3 d = sub3(cam, tp);
+        float dist2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
+        return 0xFFFFFFFFu - f2u(dist2);
+    }
+    uint32_t key = KEY_CULLED;
+    V4 clip = world_to_clip(fp, tp);
+    V3 diff = sub3(tp, cam);
+    float dist2 = dot3(diff, diff);
+    uint32_t key_distance = 0xFFFFFFFFu - f2u(dist2);
+    if (in_frustum(clip)) key = key_distance;
+    return key >> fp.key_shift;
+}
+
+// src/render/helpers.wgsl:137-157 (column-major constructor), rotation = [w, x, y, z]
+BGS_HD M3 rotation_matrix(const float* rot) {
+    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    return m3_cols(
+        V3{1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - r * z), 2.0f * (x * z + r * y)},
+        V3{2.0f * (x * y + r * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - r * x)},
+        V3{2.0f * (x * z - r * y), 2.0f * (y * z + r * x), 1.0f - 2.0f * (x * x + y * y)});
+}
+// src/render/helpers.wgsl:159-168
+BGS_HD M3 scale_matrix(const float* scale, float gs) {
+    return m3_cols(V3{scale[0] * gs, 0.0f, 0.0f}, V3{0.0f, scale[1] * gs, 0.0f},
+                   V3{0.0f, 0.0f, scale[2] * gs});
+}
+
+// src/render/gaussian_3d.wgsl:49-72 followed by src/render/helpers.wgsl:8-47
+BGS_HD void cov2d_3dgs(const FrameParams& fp, V3 position, const float* scale, const float* rot,
+                       float out[3]) {
+    M3 S = scale_matrix(scale, fp.global_scale);
+    M3 T = m3_from_m4(fp.transform);
+    M3 R = rotation_matrix(rot);
+    M3 M = m3_mul(S, R);
+    M3 Sigma = m3_mul(m3_transpose(M), M);
+    M3 TS = m3_mul(m3_mul(T, Sigma), m3_transpose(T));
+    const float c0 = TS.m[0], c1 = TS.m[1], c2 = TS.m[2], c3 = TS.m[4], c4 = TS.m[5], c5 = TS.m[8];
+    M3 Vrk = m3_cols(V3{c0, c1, c2}, V3{c1, c3, c4}, V3{c2, c4, c5});
+
+    V4 t = m4_mul_point(fp.view_from_world, position);
+    float sI = 1.0f / (t.z * t.z);
+    M3 J = m3_cols(V3{fp.focal_x / t.z, 0.0f, -(fp.focal_x * t.x) * sI},
+                   V3{0.0f, -fp.focal_y / t.z, (fp.focal_y * t.y) * sI}, V3{0.0f, 0.0f, 0.0f});
+    M3 W = m3_transpose(m3_from_m4(fp.view_from_world));
+    M3 Tm = m3_mul(W, J);
+    M3 cov = m3_mul(m3_mul(m3_transpose(Tm), m3_transpose(Vrk)), Tm);
+    out[0] = cov.m[0] + 0.3f;
+    out[1] = cov.m[1];
+    out[2] = cov.m[4] + 0.3f;
+}
+
+// src/render/helpers.wgsl:49-120: bb.xy (NDC offset) and bb.zw for one quad corner.
+BGS_HD void bounding_box_clip(const FrameParams& fp, const float c2d[3], V2 dir, float cutoff,
+                              float out[4]) {
+    float det = c2d[0] * c2d[2] - c2d[1] * c2d[1];
+    float trace = c2d[0] + c2d[2];
+    float mid = 0.5f * trace;
+    float discriminant = fmaxf(0.0f, mid * mid - det);
+    float term = sqrtf(discriminant);
+    float lambda1 = mid + term;
+    float lambda2 = fmaxf(mid - term, 0.0f);
+    float x_axis_length = sqrtf(lambda1);
+    float y_axis_length = sqrtf(lambda2);
+    if (fp.aabb) {
+        float radius_px = cutoff * fmaxf(x_axis_length, y_axis_length);
+        out[0] = (radius_px / fp.viewport_w) * dir.x;
+        out[1] = (radius_px / fp.viewport_h) * dir.y;
+        out[2] = radius_px * dir.x;
+        out[3] = radius_px * dir.y;
+        return;
+    }
+    float a = (c2d[0] - c2d[2]) * (c2d[0] - c2d[2]);
+    float b = sqrtf(a + 4.0f * c2d[1] * c2d[1]);
+    float major_radius = sqrtf((c2d[0] + c2d[2] + b) * 0.5f);
+    float minor_radius = sqrtf((c2d[0] + c2d[2] - b) * 0.5f);
+    V2 bounds{cutoff * major_radius, cutoff * minor_radius};
+    V2 ev{-c2d[1], lambda1 - c2d[0]};
+    float evlen = sqrtf(dot2(ev, ev));
+    V2 e1{ev.x / evlen, ev.y / evlen};
+    V2 e2{e1.y, -e1.x};
+    V2 sv{dir.x * bounds.x, dir.y * bounds.y};
+    V2 rv{dot2(sv, V2{e1.x, e2.x}), dot2(sv, V2{e1.y, e2.y})};
+    out[0] = rv.x * (1.0f / fp.viewport_w);
+    out[1] = rv.y * (1.0f / fp.viewport_h);
+    out[2] = rv.x;
+    out[3] = rv.y;
+}
+
+// src/render/gaussian_2d.wgsl:49-78
+BGS_HD void bounding_box_cov2d(const FrameParams& fp, const float extent[2], V2 dir, float cutoff,
+                               float out[4]) {
+    const float filter_size = 0.707106f;
+    if (extent[0] < 1.e-4f || extent[1] < 1.e-4f) {
+        out[0] = out[1] = out[2] = out[3] = 0.0f;
+        return;
+    }
+    float rx = sqrtf(extent[0]), ry = sqrtf(extent[1]);
+    float mr = fmaxf(fmaxf(rx, ry), cutoff * filter_size);
+    out[0] = (mr / fp.viewport_w) * dir.x;
+    out[1] = (mr / fp.viewport_h) * dir.y;
+    out[2] = mr;
+    out[3] = mr;
+}
+
+struct Surfel {
+    float T[9];
+    float mean_x, mean_y;
+    float extent[2];
+};
+
+// src/render/gaussian_2d.wgsl:80-132 with intrinsic_matrix (src/render/helpers.wgsl:122-135)
+BGS_HD void cov2d_surfel(const FrameParams& fp, V3 gp, const float* rot, const float* scale,
+                         float cutoff, Surfel& o) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.T[i] = 0.0f;
+    o.mean_x = o.mean_y = 0.0f;
+    o.extent[0] = o.extent[1] = 0.0f;
+
+    M3 T_r = m3_from_m4(fp.transform);
+    M3 S = scale_matrix(scale, fp.global_scale);
+    M3 R = rotation_matrix(rot);
+    M3 L = m3_mul(m3_mul(T_r, m3_transpose(R)), S);
+    const float wfl[3][4] = {{L.m[0], L.m[1], L.m[2], 0.0f},
+                             {L.m[3], L.m[4], L.m[5], 0.0f},
+                             {gp.x, gp.y, gp.z, 1.0f}};
+    const float* cfw = fp.clip_from_world;
+    float AB[4][3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            AB[c][r] = ((wfl[r][0] * cfw[0 * 4 + c] + wfl[r][1] * cfw[1 * 4 + c]) +
+                        wfl[r][2] * cfw[2 * 4 + c]) +
+                       wfl[r][3] * cfw[3 * 4 + c];
+    // clip_from_view[0].x * viewport.z / 2.0 == focal_x / 2.0 (same operation order)
+    const float fx = fp.focal_x / 2.0f;
+    const float fy = fp.focal_y / 2.0f;
+    const float K[3][4] = {{fx, 0.0f, 0.0f, (fp.viewport_w - 1.0f) / 2.0f},
+                           {0.0f, fy, 0.0f, (fp.viewport_h - 1.0f) / 2.0f},
+                           {0.0f, 0.0f, 0.0f, 1.0f}};
+    float T[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            T[3 * c + r] = ((AB[0][r] * K[c][0] + AB[1][r] * K[c][1]) + AB[2][r] * K[c][2]) +
+                           AB[3][r] * K[c][3];
+    V3 test{cutoff * cutoff, cutoff * cutoff, -1.0f};
+    V3 T0{T[0], T[1], T[2]}, T1{T[3], T[4], T[5]}, T2{T[6], T[7], T[8]};
+    float d = dot3(mul3(test, T2), T2);
+    if (fabsf(d) < 1.0e-4f) return;
+    V3 f = scale3(1.0f / d, test);
+    float mx = dot3(f, mul3(T0, T2));
+    float my = dot3(f, mul3(T1, T2));
+    float tx = dot3(mul3(f, T0), T0);
+    float ty = dot3(mul3(f, T1), T1);
+    o.extent[0] = mx * mx - tx;
+    o.extent[1] = my * my - ty;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.T[i] = T[i];
+    o.mean_x = mx;
+    o.mean_y = my;
+}
+
+// src/material/spherical_harmonics.wgsl:22-32
+BGS_HD float srgb_to_linear1(float c) {
+    if (c <= 0.04045f) return c / 12.92f;
+    return powf((c + 0.055f) / 1.055f, 2.4f);
+}
+
+// src/render/gaussian.wgsl:166-183
+BGS_HD V3 world_to_local_direction(V3 dir, const float* tr) {
+    V3 bx = normalize3(V3{tr[0], tr[1], tr[2]});
+    V3 by = normalize3(V3{tr[4], tr[5], tr[6]});
+    V3 bz = normalize3(V3{tr[8], tr[9], tr[10]});
+    return normalize3(V3{dot3(bx, dir), dot3(by, dir), dot3(bz, dir)});
+}
+
+// SH basis constants, src/material/spherical_harmonics.wgsl:3-20
+#define BGS_SHC0 0.28209479177387814f
+#define BGS_SHC1 0.4886025119029199f
+#define BGS_SHC4 1.0925484305920792f
+#define BGS_SHC6 0.31539156525252005f
+#define BGS_SHC8 0.5462742152960396f
+#define BGS_SHC9 0.5900435899266435f
+#define BGS_SHC10 2.890611442640554f
+#define BGS_SHC11 0.4570457994644658f
+#define BGS_SHC12 0.3731763325901154f
+#define BGS_SHC14 1.445305721320277f
+
+// Basis weights w[k] = shc[k] * basis_k(dir) (src/material/spherical_harmonics.wgsl:34-68);
+// colour = 0.5 + sum_k w[k] * sh[3k..3k+2]. Weights past the requested degree are 0.
+BGS_HD void sh_weights(V3 d, uint32_t degree, float w[16]) {
+    V3 s = mul3(d, d);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = 0.0f;
+    w[0] = BGS_SHC0;
+    if (degree > 0) {
+        w[1] = -BGS_SHC1 * d.y;
+        w[2] = BGS_SHC1 * d.z;
+        w[3] = -BGS_SHC1 * d.x;
+    }
+    if (degree > 1) {
+        w[4] = BGS_SHC4 * d.x * d.y;
+        w[5] = -BGS_SHC4 * d.y * d.z;
+        w[6] = BGS_SHC6 * (2.0f * s.z - s.x - s.y);
+        w[7] = -BGS_SHC4 * d.x * d.z;
+        w[8] = BGS_SHC8 * (s.x - s.y);
+    }
+    if (degree > 2) {
+        w[9] = -BGS_SHC9 * d.y * (3.0f * s.x - s.y);
+        w[10] = BGS_SHC10 * d.x * d.y * d.z;
+        w[11] = -BGS_SHC11 * d.y * (4.0f * s.z - s.x - s.y);
+        w[12] = BGS_SHC12 * d.z * (2.0f * s.z - 3.0f * s.x - 3.0f * s.y);
+        w[13] = -BGS_SHC11 * d.x * (4.0f * s.z - s.x - s.y);
+        w[14] = BGS_SHC14 * d.z * (s.x - s.y);
+        w[15] = -BGS_SHC9 * d.x * (s.x - 3.0f * s.y);
+    }
+}
+
+// View-dependent direction used for the colour (src/render/gaussian.wgsl:408-412).
+BGS_HD V3 sh_direction(const FrameParams& fp, V3 transformed_position) {
+    V3 cam{fp.cam[0], fp.cam[1], fp.cam[2]};
+    V3 rdw = normalize3(sub3(transformed_position, cam));
+    return world_to_local_direction(rdw, fp.transform);
+}
+
+// src/render/gaussian.wgsl:229-235
+BGS_HD float cutoff_radius(const FrameParams& fp, float opacity) {
+    if (!fp.adaptive_radius) return 3.0f;
+    return sqrtf(fmaxf(9.0f + 2.0f * logf(opacity), 0.000001f));
+}
+
+// The four clip-space quad corners -> pixel-space parallelogram (centre, u axis, v axis).
+// Corner k position = (projected.xy + bb_k.xy) / projected.w, viewport transform y-down
+// (src/render/gaussian.wgsl:219-227,429-433). Returns false for a degenerate / NaN quad.
+struct QuadPx {
+    float cx, cy;      // centre
+    float m00, m01, m10, m11;  // uv = M * (pixel - centre)
+    float minx, maxx, miny, maxy;
+};
+
+BGS_HD bool quad_to_pixels(const FrameParams& fp, V4 projected, const float bb[4][4], QuadPx& q) {
+    float X[4], Y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float nx = (projected.x + bb[k][0]) / projected.w;
+        float ny = (projected.y + bb[k][1]) / projected.w;
+        X[k] = (nx + 1.0f) * 0.5f * fp.viewport_w;
+        Y[k] = (1.0f - ny) * 0.5f * fp.viewport_h;
+    }
+    // vertex 0 = uv(-1,-1), 1 = (-1,+1), 2 = (+1,-1), 3 = (+1,+1)
+    const float esx = X[2] - X[0], esy = Y[2] - Y[0];
+    const float etx = X[1] - X[0], ety = Y[1] - Y[0];
+    const float det = esx * ety - esy * etx;
+    if (!(fabsf(det) > 0.0f) || !(fabsf(det) < INFINITY)) return false;
+    const float inv = 2.0f / det;
+    q.cx = X[0] + 0.5f * (esx + etx);
+    q.cy = Y[0] + 0.5f * (esy + ety);
+    q.m00 = ety * inv;
+    q.m01 = -etx * inv;
+    q.m10 = -esy * inv;
+    q.m11 = esx * inv;
+    q.minx = fminf(fminf(X[0], X[1]), fminf(X[2], X[3]));
+    q.maxx = fmaxf(fmaxf(X[0], X[1]), fmaxf(X[2], X[3]));
+    q.miny = fminf(fminf(Y[0], Y[1]), fminf(Y[2], Y[3]));
+    q.maxy = fmaxf(fmaxf(Y[0], Y[1]), fmaxf(Y[2], Y[3]));
+    if (!(q.minx <= q.maxx) || !(q.miny <= q.maxy)) return false;  // NaN
+    return true;
+}
+
+// Conservative inclusive tile bounds of a pixel-space bounding box (one-pixel guard band;
+// the rasteriser applies the exact coverage test). Returns false if no tile is touched.
+BGS_HD bool tile_rect(const FrameParams& fp, const QuadPx& q, int& tx0, int& ty0, int& tx1, int& ty1) {
+    const float W = (float)fp.width, H = (float)fp.height;
+    float fx0 = floorf(q.minx - 1.5f), fx1 = ceilf(q.maxx + 0.5f);
+    float fy0 = floorf(q.miny - 1.5f), fy1 = ceilf(q.maxy + 0.5f);
+    fx0 = fmaxf(fx0, 0.0f);
+    fy0 = fmaxf(fy0, 0.0f);
+    fx1 = fminf(fx1, W - 1.0f);
+    fy1 = fminf(fy1, H - 1.0f);
+    if (!(fx0 <= fx1) || !(fy0 <= fy1)) return false;
+    tx0 = (int)fx0 / TILE_PX;
+    tx1 = (int)fx1 / TILE_PX;
+    ty0 = (int)fy0 / TILE_PX;
+    ty1 = (int)fy1 / TILE_PX;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------
+// Whole vertex stage for one draw-list entry: cull, cutoff, geometry, colour.
+// `sh(k)` returns SH coefficient triple k (RGB) of the splat as a V3.
+// ------------------------------------------------------------------------------------
+struct Projected {
+    bool visible;   // passed the vertex-stage cull (key != ~0 and in_frustum)
+    bool draw;      // visible AND the quad is non-degenerate and touches the target
+    float color[4];
+    QuadPx quad;
+    float p[5];     // Record.p payload
+    Surfel surfel;  // 2D only
+    float radius;   // 2D: bb.zw
+    int tx0, ty0, tx1, ty1;
+};
+
+template <class ShFn>
+BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const float rot[4],
+                          const float so[4], ShFn sh, Projected& o) {
+    o.visible = false;
+    o.draw = false;
+    bool discard_quad = key == 0xFFFFFFFFu;                        // gaussian.wgsl:196
+    V4 t4 = m4_mul_point(fp.transform, pos);                       // :198-200
+    V3 tp{t4.x, t4.y, t4.z};
+    V4 projected = world_to_clip(fp, tp);                          // :210
+    discard_quad = discard_quad || !in_frustum(projected);         // :211
+    if (discard_quad) return;                                      // :214-218
+    o.visible = true;
+
+    const float opacity = so[3];
+    const float cutoff = cutoff_radius(fp, opacity);               // :229-235
+    float bb[4][4];
+    const V2 corners[4] = {{-1.0f, -1.0f}, {-1.0f, 1.0f}, {1.0f, -1.0f}, {1.0f, 1.0f}};
+    o.p[0] = o.p[1] = o.p[2] = o.p[3] = o.p[4] = 0.0f;
+    o.radius = 0.0f;
+    float conic[3] = {0.0f, 0.0f, 0.0f};
+    if (fp.gaussian_mode == 0u) {                                  // GAUSSIAN_2D :237-255
+        cov2d_surfel(fp, tp, rot, so, cutoff, o.surfel);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bounding_box_cov2d(fp, o.surfel.extent, corners[k], cutoff, bb[k]);
+        o.radius = bb[0][2];
+    } else {                                                       // GAUSSIAN_3D :257-306
+        float c2d[3];
+        cov2d_3dgs(fp, tp, so, rot, c2d);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bounding_box_clip(fp, c2d, corners[k], cutoff, bb[k]);
+        if (fp.aabb) {
+            float det = c2d[0] * c2d[2] - c2d[1] * c2d[1];
+            float det_inv = 1.0f / det;
+            conic[0] = c2d[2] * det_inv;
+            conic[1] = -c2d[1] * det_inv;
+            conic[2] = c2d[0] * det_inv;
+            o.radius = bb[3][2];  // radius_px * (+1)
+        }
+    }
+    if (!quad_to_pixels(fp, projected, bb, o.quad)) return;
+    if (!tile_rect(fp, o.quad, o.tx0, o.ty0, o.tx1, o.ty1)) return;
+    if (!fp.aabb) {
+        o.p[0] = o.quad.m00; o.p[1] = o.quad.m01; o.p[2] = o.quad.m10; o.p[3] = o.quad.m11;
+    } else {
+        // axis-aligned square: m01 = m10 = 0 exactly
+        o.p[0] = o.quad.m00;
+        o.p[1] = o.quad.m11;
+        if (fp.gaussian_mode != 0u) {
+            const float r2 = o.radius * o.radius;
+            o.p[2] = conic[0] * r2;
+            o.p[3] = conic[1] * r2;
+            o.p[4] = conic[2] * r2;
+        }
+    }
+
+    // RASTERIZE_COLOR :406-422, get_color src/render/planar.wgsl:334-339
+    V3 dir = sh_direction(fp, tp);
+    float w[16];
+    sh_weights(dir, fp.sh_degree, w);
+    float r = 0.5f, g = 0.5f, b = 0.5f;
+    const int ncoef = fp.sh_degree == 0 ? 1 : (fp.sh_degree == 1 ? 4 : (fp.sh_degree == 2 ? 9 : 16));
+    for (int k = 0; k < ncoef; ++k) {
+        V3 c = sh(k);
+        r += w[k] * c.x;
+        g += w[k] * c.y;
+        b += w[k] * c.z;
+    }
+    if (fp.color_space != 1u) {                                    // planar.wgsl:91-106
+        r = srgb_to_linear1(r);
+        g = srgb_to_linear1(g);
+        b = srgb_to_linear1(b);
+    }
+    o.color[0] = r; o.color[1] = g; o.color[2] = b;
+    o.color[3] = opacity * fp.global_opacity;
+    o.draw = true;
+}
+
+}  // namespace bgs

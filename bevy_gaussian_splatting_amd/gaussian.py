@@ -1,0 +1,236 @@
+"""Cloud data model: mirror of the reference's `Gaussian3d` / `PlanarGaussian3d`.
+
+Reference: src/gaussian/formats/planar_3d.rs:28-54 (item + planar SoA),
+src/gaussian/f32.rs (PositionVisibility, Rotation [w,x,y,z], ScaleOpacity),
+src/material/spherical_harmonics.rs:114-120 (48 f32, index 3*k + c),
+src/gaussian/f16.rs:29-55,244-263 (packed f16 planes),
+src/gaussian/formats/planar_3d.rs:120-191 (random cloud distributions),
+src/gaussian/formats/planar_3d.rs:193-251 (test_model).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+SH_DEGREE = 3
+SH_CHANNELS = 3
+SH_COEFF_COUNT_PER_CHANNEL = (SH_DEGREE + 1) ** 2
+SH_COEFF_COUNT = SH_COEFF_COUNT_PER_CHANNEL * SH_CHANNELS  # 48, already a multiple of 4
+HALF_SH_COEFF_COUNT = SH_COEFF_COUNT // 2
+
+
+@dataclass
+class Gaussian3d:
+    """One splat (AoS item, src/gaussian/formats/planar_3d.rs:45-54)."""
+
+    position_visibility: np.ndarray  # [x, y, z, visibility]
+    spherical_harmonic: np.ndarray  # [48]
+    rotation: np.ndarray  # [w, x, y, z]
+    scale_opacity: np.ndarray  # [sx, sy, sz, opacity]
+
+
+class SphericalHarmonicCoefficients:
+    """src/material/spherical_harmonics.rs:114-160: `set(channel_index, value)` writes raw
+    coefficient `index` (so index 0/1/2 = DC of R/G/B)."""
+
+    def __init__(self):
+        self.coefficients = np.zeros(SH_COEFF_COUNT, dtype=np.float32)
+
+    def set(self, index: int, value: float) -> None:
+        self.coefficients[index] = value
+
+
+def _f32(a, shape) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+class PlanarGaussian3d:
+    """Planar (SoA) cloud: four planes of `n` rows
+    (bevy_interleave `Planar` derive of `Gaussian3d`, src/gaussian/formats/planar_3d.rs:28-43)."""
+
+    def __init__(self, position_visibility, spherical_harmonic, rotation, scale_opacity):
+        n = len(position_visibility)
+        self.position_visibility = _f32(position_visibility, (n, 4))
+        self.spherical_harmonic = _f32(spherical_harmonic, (n, SH_COEFF_COUNT))
+        self.rotation = _f32(rotation, (n, 4))
+        self.scale_opacity = _f32(scale_opacity, (n, 4))
+
+    def __len__(self) -> int:
+        return self.position_visibility.shape[0]
+
+    def len_sqrt_ceil(self) -> int:
+        """src/gaussian/interface.rs: entry count is rounded up to a square by the caller."""
+        return int(np.ceil(np.sqrt(len(self))))
+
+    @staticmethod
+    def from_interleaved(gaussians) -> "PlanarGaussian3d":
+        gaussians = list(gaussians)
+        n = len(gaussians)
+        pv = np.zeros((n, 4), np.float32)
+        sh = np.zeros((n, SH_COEFF_COUNT), np.float32)
+        rot = np.zeros((n, 4), np.float32)
+        so = np.zeros((n, 4), np.float32)
+        for i, g in enumerate(gaussians):
+            pv[i] = g.position_visibility
+            sh[i] = g.spherical_harmonic
+            rot[i] = g.rotation
+            so[i] = g.scale_opacity
+        return PlanarGaussian3d(pv, sh, rot, so)
+
+    def iter(self):
+        for i in range(len(self)):
+            yield Gaussian3d(
+                self.position_visibility[i].copy(),
+                self.spherical_harmonic[i].copy(),
+                self.rotation[i].copy(),
+                self.scale_opacity[i].copy(),
+            )
+
+    def nbytes(self) -> int:
+        return (
+            self.position_visibility.nbytes
+            + self.spherical_harmonic.nbytes
+            + self.rotation.nbytes
+            + self.scale_opacity.nbytes
+        )
+
+    def to_f16(self) -> "PlanarGaussian3dF16":
+        return PlanarGaussian3dF16.from_f32(self)
+
+    def slice(self, start: int, stop: int) -> "PlanarGaussian3d":
+        return PlanarGaussian3d(
+            self.position_visibility[start:stop],
+            self.spherical_harmonic[start:stop],
+            self.rotation[start:stop],
+            self.scale_opacity[start:stop],
+        )
+
+
+def _pack_f32s_to_u32(upper: np.ndarray, lower: np.ndarray) -> np.ndarray:
+    """src/gaussian/f16.rs:244-252: IEEE round-to-nearest-even f32->f16, first argument in
+    the high half."""
+    u = np.asarray(upper, dtype=np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
+    l = np.asarray(lower, dtype=np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
+    return (u << np.uint32(16)) | l
+
+
+def _unpack_u32(v: np.ndarray):
+    hi = (v >> np.uint32(16)).astype(np.uint16).view(np.float16).astype(np.float32)
+    lo = (v & np.uint32(0xFFFF)).astype(np.uint16).view(np.float16).astype(np.float32)
+    return hi, lo
+
+
+class PlanarGaussian3dF16:
+    """f16 planar cloud (the reference's dormant `f16` storage:
+    src/render/bindings.wgsl:102-140, src/gaussian/f16.rs:29-55).
+
+    position_visibility stays f32 [n,4]; spherical_harmonic is u32 [n,24] with the EVEN
+    coefficient in the low half (src/render/planar.wgsl:117-130); rotation_scale_opacity is
+    u32 [n,4] = [rot0|rot1], [rot2|rot3], [s0|s1], [s2|opacity], first value in the high half.
+    """
+
+    def __init__(self, position_visibility, spherical_harmonic_h2, rotation_scale_opacity):
+        n = len(position_visibility)
+        self.position_visibility = _f32(position_visibility, (n, 4))
+        self.spherical_harmonic = np.ascontiguousarray(spherical_harmonic_h2, dtype=np.uint32)
+        self.rotation_scale_opacity = np.ascontiguousarray(rotation_scale_opacity, dtype=np.uint32)
+        if self.spherical_harmonic.shape != (n, HALF_SH_COEFF_COUNT):
+            raise ValueError("spherical_harmonic must be [n, 24] u32")
+        if self.rotation_scale_opacity.shape != (n, 4):
+            raise ValueError("rotation_scale_opacity must be [n, 4] u32")
+
+    def __len__(self) -> int:
+        return self.position_visibility.shape[0]
+
+    def nbytes(self) -> int:
+        return (
+            self.position_visibility.nbytes
+            + self.spherical_harmonic.nbytes
+            + self.rotation_scale_opacity.nbytes
+        )
+
+    @staticmethod
+    def from_f32(cloud: PlanarGaussian3d) -> "PlanarGaussian3dF16":
+        sh = cloud.spherical_harmonic
+        sh_h2 = _pack_f32s_to_u32(sh[:, 1::2], sh[:, 0::2])
+        rot, so = cloud.rotation, cloud.scale_opacity
+        rso = np.stack(
+            [
+                _pack_f32s_to_u32(rot[:, 0], rot[:, 1]),
+                _pack_f32s_to_u32(rot[:, 2], rot[:, 3]),
+                _pack_f32s_to_u32(so[:, 0], so[:, 1]),
+                _pack_f32s_to_u32(so[:, 2], so[:, 3]),
+            ],
+            axis=1,
+        )
+        return PlanarGaussian3dF16(cloud.position_visibility, sh_h2, rso)
+
+    def to_f32(self) -> PlanarGaussian3d:
+        """Decode exactly as the shader does (src/render/planar.wgsl:117-176)."""
+        n = len(self)
+        hi, lo = _unpack_u32(self.spherical_harmonic)
+        sh = np.empty((n, SH_COEFF_COUNT), np.float32)
+        sh[:, 0::2] = lo
+        sh[:, 1::2] = hi
+        r = self.rotation_scale_opacity
+        r0h, r0l = _unpack_u32(r[:, 0])
+        r1h, r1l = _unpack_u32(r[:, 1])
+        s0h, s0l = _unpack_u32(r[:, 2])
+        s1h, s1l = _unpack_u32(r[:, 3])
+        rot = np.stack([r0h, r0l, r1h, r1l], axis=1)
+        so = np.stack([s0h, s0l, s1h, s1l], axis=1)
+        return PlanarGaussian3d(self.position_visibility, sh, rot, so)
+
+
+def random_gaussians_3d_seeded(n: int, seed: int) -> PlanarGaussian3d:
+    """Seeded synthetic cloud with the reference's distributions
+    (src/gaussian/formats/planar_3d.rs:120-168,182-191): rotation ~ U(-1,1)^4 (NOT
+    normalised), position ~ U(-20,20)^3 with visibility 1, scale ~ U(0,1)^3,
+    opacity ~ U(0,0.8), SH ~ U(-1,1)^48.
+
+    The reference draws from `rand::StdRng` (ChaCha12, third-party, not reproduced); this
+    build uses numpy PCG64 with the same per-field order, so clouds have the same
+    statistics but not the same bits."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rot = rng.uniform(-1.0, 1.0, size=(n, 4)).astype(np.float32)
+    pv = np.empty((n, 4), np.float32)
+    pv[:, :3] = rng.uniform(-20.0, 20.0, size=(n, 3)).astype(np.float32)
+    pv[:, 3] = 1.0
+    so = np.empty((n, 4), np.float32)
+    so[:, :3] = rng.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
+    so[:, 3] = rng.uniform(0.0, 0.8, size=n).astype(np.float32)
+    sh = rng.uniform(-1.0, 1.0, size=(n, SH_COEFF_COUNT)).astype(np.float32)
+    return PlanarGaussian3d(pv, sh, rot, so)
+
+
+def random_gaussians_3d(n: int) -> PlanarGaussian3d:
+    """src/gaussian/formats/planar_3d.rs:171-180 (thread RNG -> OS entropy seed)."""
+    return random_gaussians_3d_seeded(n, int(np.random.SeedSequence().entropy % (1 << 63)))
+
+
+def test_model(seed: int = 0) -> PlanarGaussian3d:
+    """`PlanarGaussian3d::test_model()` geometry (src/gaussian/formats/planar_3d.rs:193-251):
+    8 splats at (+-0.5)^3 + a duplicate of the first; identity rotation, scale 0.125,
+    opacity 0.125, random SH (seeded here)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    base_sh = rng.uniform(-1.0, 1.0, size=SH_COEFF_COUNT).astype(np.float32)
+    gs = []
+    for x in (-0.5, 0.5):
+        for y in (-0.5, 0.5):
+            for z in (-0.5, 0.5):
+                sh = base_sh.copy()
+                rng.shuffle(sh)
+                gs.append(
+                    Gaussian3d(
+                        np.array([x, y, z, 1.0], np.float32),
+                        sh,
+                        np.array([1.0, 0.0, 0.0, 0.0], np.float32),
+                        np.array([0.125, 0.125, 0.125, 0.125], np.float32),
+                    )
+                )
+    gs.append(gs[0])
+    return PlanarGaussian3d.from_interleaved(gs)

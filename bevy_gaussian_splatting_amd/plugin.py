@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's plugin surface for the sort + rasterize path.
+
+Reference call sites this stands behind:
+  - cloud upload: RenderAsset upload of the planar cloud (src/lib.rs:65-68,
+    src/render/mod.rs:279-313)                               -> `upload`
+  - sort: `run_radix_sort` (src/sort/radix.rs:616-756) / `rayon_sort`
+    (src/sort/rayon.rs:27-130), output `SortedEntries` (src/sort/mod.rs:331-393) -> `sort`
+  - draw: `DrawGaussianInstanced::render` (src/render/mod.rs:1513-1569)   -> `render`
+
+All compute happens in libbgs.so (hand-written HIP for gfx950). This module only marshals
+arguments; it has no CPU implementation of any stage.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Union
+
+import numpy as np
+
+from . import _native
+from .camera import View
+from .gaussian import PlanarGaussian3d, PlanarGaussian3dF16
+from .settings import CloudSettings
+
+SORT_ENTRY_DTYPE = np.dtype([("key", np.uint32), ("index", np.uint32)])
+
+
+@dataclass
+class SortedEntries:
+    """src/sort/mod.rs:331-393: `camera_count * entry_count` (key, index) pairs; camera `c`
+    owns `sorted[c * entry_count : (c + 1) * entry_count]` (src/sort/rayon.rs:82-84)."""
+
+    camera_count: int
+    entry_count: int
+    sorted: np.ndarray  # structured SORT_ENTRY_DTYPE
+
+    @staticmethod
+    def new(camera_count: int, entry_count: int) -> "SortedEntries":
+        s = np.empty(camera_count * entry_count, dtype=SORT_ENTRY_DTYPE)
+        s["key"] = 1  # src/sort/mod.rs:349-352
+        s["index"] = np.tile(np.arange(entry_count, dtype=np.uint32), camera_count)
+        return SortedEntries(camera_count, entry_count, s)
+
+    def chunk(self, camera_index: int) -> np.ndarray:
+        return self.sorted[camera_index * self.entry_count : (camera_index + 1) * self.entry_count]
+
+
+class PlanarGaussian3dHandle:
+    """Device-resident cloud (the reference's `PlanarGaussian3dHandle` +
+    `GpuPlanarStorage` rolled into one opaque handle)."""
+
+    def __init__(self, plugin: "GaussianSplattingPlugin", ptr, n: int, fmt: str, nbytes: int):
+        self._plugin = plugin
+        self._ptr = ptr
+        self.n = n
+        self.format = fmt
+        self.nbytes = nbytes
+
+    def __len__(self) -> int:
+        return self.n
+
+    def free(self) -> None:
+        if self._ptr is not None and self._plugin._ctx is not None:
+            self._plugin._lib.bgs_cloud_free(self._plugin._ctx, self._ptr)
+        self._ptr = None
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _uptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+
+
+class GaussianSplattingPlugin:
+    """One instance = one HIP device + one stream (`bgs_ctx`). Not re-entrant, like a Bevy
+    render world. Use one instance per GPU / per process rank."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _native.load()
+        ctx = ctypes.c_void_p()
+        st = self._lib.bgs_create(int(device), ctypes.byref(ctx))
+        if st != _native.BGS_OK:
+            msg = self._lib.bgs_last_error(None)
+            raise _native.BgsError(st, msg.decode("utf-8", "replace") if msg else "")
+        self._ctx = ctx
+        self.device = device
+
+    # -- lifecycle -------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None:
+            self._lib.bgs_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status: int) -> None:
+        _native.check(self._lib, self._ctx, status)
+
+    # -- cloud upload ----------------------------------------------------------------
+    def upload(self, cloud: Union[PlanarGaussian3d, PlanarGaussian3dF16]) -> PlanarGaussian3dHandle:
+        out = ctypes.c_void_p()
+        n = len(cloud)
+        if isinstance(cloud, PlanarGaussian3dF16):
+            self._check(
+                self._lib.bgs_cloud_upload_f16(
+                    self._ctx, n, _fptr(cloud.position_visibility),
+                    _uptr(cloud.spherical_harmonic), _uptr(cloud.rotation_scale_opacity),
+                    ctypes.byref(out)))
+            fmt = "f16"
+        elif isinstance(cloud, PlanarGaussian3d):
+            self._check(
+                self._lib.bgs_cloud_upload_f32(
+                    self._ctx, n, _fptr(cloud.position_visibility),
+                    _fptr(cloud.spherical_harmonic), _fptr(cloud.rotation),
+                    _fptr(cloud.scale_opacity), ctypes.byref(out)))
+            fmt = "f32"
+        else:
+            raise TypeError("cloud must be PlanarGaussian3d or PlanarGaussian3dF16")
+        return PlanarGaussian3dHandle(self, out, n, fmt, cloud.nbytes())
+
+    # -- hot path --------------------------------------------------------------------
+    def sort(self, handle: PlanarGaussian3dHandle, view: View, settings: CloudSettings,
+             download: bool = True) -> Optional[np.ndarray]:
+        """Depth sort for one camera. Returns the (key, index) entries of this camera's
+        chunk in draw order (structured array), or None if `download` is False."""
+        v, s = view.to_native(), settings.to_native()
+        if download:
+            out = np.empty(handle.n, dtype=SORT_ENTRY_DTYPE)
+            ptr = out.ctypes.data_as(ctypes.POINTER(_native.BgsSortEntry))
+        else:
+            out, ptr = None, None
+        self._check(self._lib.bgs_sort(self._ctx, handle._ptr, ctypes.byref(v), ctypes.byref(s), ptr))
+        return out
+
+    def render(self, handle: PlanarGaussian3dHandle, view: View, settings: CloudSettings,
+               download: bool = True) -> Optional[np.ndarray]:
+        """Sort + project + bin + rasterize one view. Returns [H, W, 4] float32
+        (premultiplied linear RGBA, unclamped, row 0 = top) or None if not downloaded."""
+        v, s = view.to_native(), settings.to_native()
+        if download:
+            out = np.empty((view.height, view.width, 4), dtype=np.float32)
+            ptr = _fptr(out)
+        else:
+            out, ptr = None, None
+        self._check(self._lib.bgs_render(self._ctx, handle._ptr, ctypes.byref(v), ctypes.byref(s), ptr))
+        return out
+
+    def radix_sort_pairs(self, keys: np.ndarray, passes: int = 4) -> np.ndarray:
+        """Run the device Onesweep kernel on arbitrary (key, index=i) pairs (test hook)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        e = np.empty(keys.shape[0], dtype=SORT_ENTRY_DTYPE)
+        e["key"] = keys
+        e["index"] = np.arange(keys.shape[0], dtype=np.uint32)
+        self._check(
+            self._lib.bgs_radix_sort_pairs(
+                self._ctx, e.ctypes.data_as(ctypes.POINTER(_native.BgsSortEntry)),
+                keys.shape[0], int(passes)))
+        return e
+
+    # -- interop / introspection -----------------------------------------------------
+    def synchronize(self) -> None:
+        self._check(self._lib.bgs_synchronize(self._ctx))
+
+    def set_profiling(self, enabled: bool) -> None:
+        self._check(self._lib.bgs_set_profiling(self._ctx, 1 if enabled else 0))
+
+    def framebuffer_device_ptr(self):
+        p = ctypes.c_void_p()
+        nbytes = ctypes.c_uint64()
+        self._check(self._lib.bgs_framebuffer_device_ptr(self._ctx, ctypes.byref(p), ctypes.byref(nbytes)))
+        return p.value, nbytes.value
+
+    def stream_handle(self) -> int:
+        p = ctypes.c_void_p()
+        self._check(self._lib.bgs_stream(self._ctx, ctypes.byref(p)))
+        return p.value or 0
+
+    def stats(self) -> dict:
+        st = _native.BgsStats()
+        self._check(self._lib.bgs_get_stats(self._ctx, ctypes.byref(st)))
+        d = {
+            "total_ms": float(st.total_ms),
+            "splat_count": int(st.splat_count),
+            "visible_count": int(st.visible_count),
+            "instance_count": int(st.instance_count),
+            "instance_capacity": int(st.instance_capacity),
+            "tiles": (int(st.tiles_x), int(st.tiles_y)),
+            "depth_passes": int(st.depth_passes),
+            "tile_passes": int(st.tile_passes),
+            "algorithmic_bytes": int(st.algorithmic_bytes),
+            "regrow_count": int(st.regrow_count),
+            "stage_ms": {n: float(st.stage_ms[i]) for i, n in enumerate(_native.STAGE_NAMES)},
+        }
+        return d

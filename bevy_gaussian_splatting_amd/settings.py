@@ -1,0 +1,180 @@
+"""Runtime settings: mirror of the reference's `CloudSettings` surface.
+
+Reference: src/gaussian/settings.rs:6-132 (enums + CloudSettings + Default),
+src/sort/mod.rs:46-74 (SortMode), src/render/mod.rs:698-764 (ShaderDefines).
+Only the fields that select behaviour on the sort + rasterize hot path are honoured by
+the native library; the rest are carried so reference code that sets them keeps working.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+class GaussianMode(enum.IntEnum):
+    """src/gaussian/settings.rs:17-22 (Gaussian4d is out of scope for the hot path)."""
+
+    Gaussian2d = 0
+    Gaussian3d = 1
+
+
+class SortMode(enum.IntEnum):
+    """src/sort/mod.rs:46-58."""
+
+    NONE = 0
+    Radix = 1
+    Rayon = 2
+    Std = 3
+
+
+class RadixSortDepthBits(enum.IntEnum):
+    """src/gaussian/settings.rs:52-77."""
+
+    Bits16 = 16
+    Bits24 = 24
+    Bits32 = 32
+
+    def bits(self) -> int:
+        return int(self)
+
+
+class GaussianColorSpace(enum.IntEnum):
+    """src/gaussian/settings.rs:79-84; uniform value per src/render/mod.rs:1066-1069."""
+
+    SrgbRec709Display = 0
+    LinRec709Display = 1
+
+
+class RasterizeMode(enum.IntEnum):
+    """src/gaussian/settings.rs:36-47. Only Color is on the benchmarked hot path."""
+
+    Color = 1
+
+
+class DrawMode(enum.IntEnum):
+    """src/gaussian/settings.rs:6-12. Only All is on the hot path."""
+
+    All = 0
+
+
+@dataclass(frozen=True)
+class ShaderDefines:
+    """src/render/mod.rs:698-764: radix-sort geometry derived from the depth-bit setting."""
+
+    radix_bits_per_digit: int
+    radix_digit_places: int
+    radix_key_shift: int
+    radix_base: int
+    entries_per_invocation_a: int
+    entries_per_invocation_c: int
+    workgroup_invocations_a: int
+    workgroup_invocations_c: int
+    workgroup_entries_a: int
+    workgroup_entries_c: int
+    sorting_buffer_size: int
+
+    @staticmethod
+    def for_radix_depth_bits(bits: RadixSortDepthBits | int) -> "ShaderDefines":
+        b = int(bits)
+        if b not in (16, 24, 32):
+            raise ValueError(f"unsupported radix depth bits: {b}")
+        per_digit = 8
+        places = b // per_digit
+        base = 1 << per_digit
+        inv_a = base * places
+        return ShaderDefines(
+            radix_bits_per_digit=per_digit,
+            radix_digit_places=places,
+            radix_key_shift=32 - b,
+            radix_base=base,
+            entries_per_invocation_a=4,
+            entries_per_invocation_c=4,
+            workgroup_invocations_a=inv_a,
+            workgroup_invocations_c=base,
+            workgroup_entries_a=inv_a * 4,
+            workgroup_entries_c=base * 4,
+            sorting_buffer_size=base * places * 4 + (5 + base) * 4,
+        )
+
+    def radix_initial_parity(self) -> int:
+        return self.radix_digit_places % 2
+
+    def max_tile_count(self, count: int) -> int:
+        return -(-count // self.workgroup_entries_c)
+
+
+class BgsSettings(ctypes.Structure):
+    """ctypes image of `bgs_settings` (include/bgs.h)."""
+
+    _fields_ = [
+        ("transform", ctypes.c_float * 16),
+        ("global_opacity", ctypes.c_float),
+        ("global_scale", ctypes.c_float),
+        ("gaussian_mode", ctypes.c_uint32),
+        ("aabb", ctypes.c_uint32),
+        ("opacity_adaptive_radius", ctypes.c_uint32),
+        ("color_space", ctypes.c_uint32),
+        ("radix_depth_bits", ctypes.c_uint32),
+        ("sh_degree", ctypes.c_uint32),
+        ("sort_mode", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+    ]
+
+
+def _identity4() -> np.ndarray:
+    return np.eye(4, dtype=np.float32)
+
+
+@dataclass
+class CloudSettings:
+    """src/gaussian/settings.rs:87-132. Defaults equal `CloudSettings::default()`.
+
+    `transform` stands in for the entity's `GlobalTransform` (column-vector 4x4, i.e.
+    `transform @ [x, y, z, 1]`), which the reference passes through `CloudUniform.transform`
+    (src/render/mod.rs:1057). `sh_degree` mirrors the compile-time `sh0..sh3` features.
+    """
+
+    aabb: bool = False
+    global_opacity: float = 1.0
+    global_scale: float = 1.0
+    opacity_adaptive_radius: bool = True
+    visualize_bounding_box: bool = False  # carried, not rendered (debug overlay)
+    sort_mode: SortMode = SortMode.Radix
+    radix_sort_depth_bits: RadixSortDepthBits = RadixSortDepthBits.Bits32
+    draw_mode: DrawMode = DrawMode.All
+    gaussian_mode: GaussianMode = GaussianMode.Gaussian3d
+    rasterize_mode: RasterizeMode = RasterizeMode.Color
+    color_space: GaussianColorSpace = GaussianColorSpace.SrgbRec709Display
+    num_classes: int = 1
+    time: float = 0.0
+    time_scale: float = 1.0
+    time_start: float = 0.0
+    time_stop: float = 1.0
+    sh_degree: int = 3
+    transform: np.ndarray = field(default_factory=_identity4)
+
+    def to_native(self) -> BgsSettings:
+        if self.rasterize_mode != RasterizeMode.Color:
+            raise ValueError("only RasterizeMode.Color is implemented on the hot path")
+        if self.draw_mode != DrawMode.All:
+            raise ValueError("only DrawMode.All is implemented on the hot path")
+        s = BgsSettings()
+        m = np.asarray(self.transform, dtype=np.float32)
+        if m.shape != (4, 4):
+            raise ValueError("transform must be 4x4")
+        # column-major, like glam's Mat4::to_cols_array
+        s.transform[:] = m.T.reshape(16).tolist()
+        s.global_opacity = float(self.global_opacity)
+        s.global_scale = float(self.global_scale)
+        s.gaussian_mode = int(self.gaussian_mode)
+        s.aabb = 1 if self.aabb else 0
+        s.opacity_adaptive_radius = 1 if self.opacity_adaptive_radius else 0
+        s.color_space = int(self.color_space)
+        s.radix_depth_bits = int(self.radix_sort_depth_bits)
+        s.sh_degree = int(self.sh_degree)
+        s.sort_mode = int(self.sort_mode)
+        s.reserved = 0
+        return s

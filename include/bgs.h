@@ -1,0 +1,203 @@
+/*
+ * bgs.h — C ABI of libbgs: the MI355X-native Gaussian-splat sort + rasterize path.
+ *
+ * This is the drop-in boundary for ONE hot path of mosure/bevy_gaussian_splatting
+ * (citations are into the reference tree):
+ *
+ *   cloud upload   <- RenderAsset upload of the planar cloud
+ *                     (src/lib.rs:65-68, src/render/mod.rs:279-313,
+ *                      layout src/gaussian/formats/planar_3d.rs:28-54)
+ *   bgs_sort       <- run_radix_sort   (src/sort/radix.rs:616-756, kernels src/sort/radix.wgsl)
+ *                     rayon_sort       (src/sort/rayon.rs:27-130)   [SortMode::Rayon ordering]
+ *   bgs_render     <- DrawGaussianInstanced::render (src/render/mod.rs:1513-1569),
+ *                     vs_points / fs_main (src/render/gaussian.wgsl:184-505),
+ *                     blend state (src/render/mod.rs:944-948)
+ *
+ * The reference has no FFI of its own (it is a Bevy plugin); these entry points are
+ * what a `hip-sys`-style Rust binding would declare.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary, the library never aborts;
+ *   - every function returns BGS_OK (0) or a negative bgs_status; the message for the
+ *     last failure on a context is available from bgs_last_error();
+ *   - all matrices are column-major float[16] (glam / WGSL convention): m[4*c + r];
+ *   - host pointers are borrowed for the duration of the call only;
+ *   - device memory is owned by the library behind opaque handles;
+ *   - a bgs_ctx binds one HIP device and one HIP stream and is NOT re-entrant
+ *     (matches Bevy: one render thread); distinct contexts are independent.
+ *   - there is NO CPU fallback: without a usable HIP device bgs_create fails with
+ *     BGS_EHIP.
+ */
+#ifndef BGS_H
+#define BGS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGS_VERSION_MAJOR 0
+#define BGS_VERSION_MINOR 1
+
+typedef enum bgs_status {
+    BGS_OK = 0,
+    BGS_EINVAL = -1,    /* bad argument / unsupported setting               */
+    BGS_ENOMEM = -2,    /* host or device allocation failed                 */
+    BGS_EHIP = -3,      /* HIP runtime error (no device, launch failure...) */
+    BGS_ECAPACITY = -4, /* tile-instance buffer could not be grown enough   */
+    BGS_EINTERNAL = -5  /* device-side watchdog tripped (bounded spin)      */
+} bgs_status;
+
+typedef struct bgs_ctx bgs_ctx;
+typedef struct bgs_cloud bgs_cloud;
+
+/* The fields of Bevy's `View` uniform that the reference shaders read
+ * (src/render/helpers.wgsl:18-38, src/render/transform.wgsl:5-8,
+ *  src/render/gaussian_2d.wgsl:104, src/sort/radix.wgsl:90) plus the clear colour
+ * (examples/headless.rs:70). The caller supplies every matrix explicitly, exactly as
+ * Bevy does on the CPU, so the library never re-derives one from another. */
+typedef struct bgs_view {
+    float world_from_view[16]; /* camera transform; world_position = column 3        */
+    float view_from_world[16];
+    float clip_from_view[16];
+    float clip_from_world[16]; /* also used as unjittered_clip_from_world (no TAA)   */
+    float viewport[4];         /* x, y, width, height in pixels (View.viewport)      */
+    float clear_color[4];      /* linear RGBA the target is cleared to before draws  */
+} bgs_view;
+
+/* gaussian_mode: src/gaussian/settings.rs:17-22 */
+#define BGS_GAUSSIAN_2D 0u
+#define BGS_GAUSSIAN_3D 1u
+/* color_space: src/render/mod.rs:1066-1069 */
+#define BGS_COLOR_SRGB 0u
+#define BGS_COLOR_LINEAR 1u
+/* sort_mode: src/sort/mod.rs:46-58 */
+#define BGS_SORT_NONE 0u  /* draw in entry order (key=1,index=i  src/sort/mod.rs:347-354) */
+#define BGS_SORT_RADIX 1u /* GPU radix semantics: cull + inverted key, stable            */
+#define BGS_SORT_RAYON 2u /* CPU-sort semantics: key=bits(dist2), descending, no cull    */
+#define BGS_SORT_STD 3u   /* same ordering contract as RAYON (src/sort/std_sort.rs)      */
+
+/* CloudUniform (src/render/mod.rs:995-1009) + the CloudSettings fields that select the
+ * pipeline specialisation (src/gaussian/settings.rs:87-132, src/render/mod.rs:770-896). */
+typedef struct bgs_settings {
+    float transform[16];              /* model matrix (GlobalTransform)                  */
+    float global_opacity;             /* default 1                                       */
+    float global_scale;               /* default 1                                       */
+    uint32_t gaussian_mode;           /* BGS_GAUSSIAN_3D default                         */
+    uint32_t aabb;                    /* 0 = OBB (default), 1 = AABB   settings.rs:113   */
+    uint32_t opacity_adaptive_radius; /* default 1                     settings.rs:116   */
+    uint32_t color_space;             /* BGS_COLOR_SRGB default                          */
+    uint32_t radix_depth_bits;        /* 16 | 24 | 32 (default 32)     settings.rs:52-77 */
+    uint32_t sh_degree;               /* 0..3; reference is compile-time sh3             */
+    uint32_t sort_mode;               /* BGS_SORT_RADIX default                          */
+    uint32_t reserved;
+} bgs_settings;
+
+/* src/sort/mod.rs:324-329 */
+typedef struct bgs_sort_entry {
+    uint32_t key;
+    uint32_t index;
+} bgs_sort_entry;
+
+/* Per-stage wall time (HIP events on the context's stream) and counters of the most
+ * recent bgs_sort/bgs_render call. Times in milliseconds. */
+#define BGS_STAGE_KEYGEN 0   /* keygen + 4-place global digit histogram             */
+#define BGS_STAGE_DEPTH_SORT 1 /* all onesweep passes over the depth keys            */
+#define BGS_STAGE_PROJECT 2  /* per-splat projection + SH + tile-instance emission   */
+#define BGS_STAGE_TILE_SORT 3 /* stable radix passes over tile ids                   */
+#define BGS_STAGE_RANGES 4   /* per-tile [start,end)                                 */
+#define BGS_STAGE_RASTER 5   /* per-16x16-tile front-to-back blend                   */
+#define BGS_STAGE_COUNT 6
+
+typedef struct bgs_stats {
+    float stage_ms[BGS_STAGE_COUNT];
+    float total_ms;              /* first to last event of the call                    */
+    uint32_t splat_count;        /* N                                                  */
+    uint32_t visible_count;      /* V: splats that pass the frustum test               */
+    uint64_t instance_count;     /* I: (tile, splat) instances emitted                 */
+    uint64_t instance_capacity;
+    uint32_t tiles_x, tiles_y;
+    uint32_t depth_passes;       /* radix digit places used for the depth keys         */
+    uint32_t tile_passes;        /* radix passes used for the tile ids                 */
+    uint64_t algorithmic_bytes;  /* SURVEY 8(d) bytes_frame (or bytes_sort) of the call */
+    uint32_t regrow_count;       /* times the instance buffers were grown + re-run     */
+    uint32_t reserved;
+} bgs_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+int bgs_create(int hip_device, bgs_ctx** out);
+void bgs_destroy(bgs_ctx* ctx);
+const char* bgs_last_error(const bgs_ctx* ctx); /* ctx may be NULL: global message   */
+uint32_t bgs_version(void);                     /* (major << 16) | minor             */
+
+/* Fill defaults equal to CloudSettings::default() (src/gaussian/settings.rs:110-131)
+ * with an identity transform. */
+void bgs_settings_default(bgs_settings* out);
+
+/* Convenience: build a bgs_view the way Bevy builds its View uniform for
+ * `Camera3d::default()` (infinite reverse-Z right-handed perspective) from a camera
+ * world transform. Pure host arithmetic in f32. clear_color is set to opaque black. */
+void bgs_view_perspective(const float world_from_view[16], float fov_y_radians,
+                          float near_plane, uint32_t width, uint32_t height,
+                          bgs_view* out);
+
+/* ---- cloud upload (planar SoA, src/gaussian/formats/planar_3d.rs:45-54) ---------- */
+/* f32 planes: position_visibility[n][4], spherical_harmonic[n][48] (index 3*k+c),
+ * rotation[n][4] as [w,x,y,z], scale_opacity[n][4] (sx,sy,sz,opacity). */
+int bgs_cloud_upload_f32(bgs_ctx* ctx, uint32_t n, const float* position_visibility,
+                         const float* spherical_harmonic, const float* rotation,
+                         const float* scale_opacity, bgs_cloud** out);
+/* f16 planes (src/render/bindings.wgsl:102-140, src/gaussian/f16.rs:29-55):
+ * position_visibility stays f32; spherical_harmonic[n][24] u32 (low half = even
+ * coefficient, src/render/planar.wgsl:117-130); rotation_scale_opacity[n][4] u32 =
+ * [rot0|rot1], [rot2|rot3], [s0|s1], [s2|opacity] with the FIRST value in the high half. */
+int bgs_cloud_upload_f16(bgs_ctx* ctx, uint32_t n, const float* position_visibility,
+                         const uint32_t* spherical_harmonic_h2,
+                         const uint32_t* rotation_scale_opacity, bgs_cloud** out);
+void bgs_cloud_free(bgs_ctx* ctx, bgs_cloud* cloud);
+uint32_t bgs_cloud_len(const bgs_cloud* cloud);
+
+/* ---- the hot path ----------------------------------------------------------------- */
+/* Depth sort for one view. Result is kept on the device (consumed by the next
+ * bgs_render with the same cloud/view/settings) and, if host_out != NULL, copied to
+ * host_out[n]. Order contract for BGS_SORT_RADIX: ascending key, ties by ascending
+ * splat index, culled splats (key all-ones) last  (src/sort/radix.wgsl:109-279). */
+int bgs_sort(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view,
+             const bgs_settings* settings, bgs_sort_entry* host_out);
+
+/* Sort (always re-done: the benchmark sorts every frame) + project + bin +
+ * rasterize one view. Output: viewport.w x viewport.h RGBA f32, premultiplied, linear,
+ * unclamped, row 0 = top. rgba_host_out may be NULL (result stays on the device). */
+int bgs_render(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view,
+               const bgs_settings* settings, float* rgba_host_out);
+
+/* Device pointer + size in bytes of the framebuffer written by the last bgs_render
+ * (for an RCCL gather or zero-copy interop). Valid until the next render/destroy. */
+int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes);
+/* Device pointer of the sorted entries of the last bgs_sort/bgs_render (n entries). */
+int bgs_sorted_entries_device_ptr(bgs_ctx* ctx, void** dptr, uint32_t* n);
+
+/* Block until all work queued on the context's stream has finished. */
+int bgs_synchronize(bgs_ctx* ctx);
+/* The hipStream_t (as void*) the context launches on, so a caller can order its own
+ * HIP work (e.g. torch / RCCL) against it. */
+int bgs_stream(bgs_ctx* ctx, void** hip_stream);
+
+/* Enable/disable per-stage HIP-event timing (default on). */
+int bgs_set_profiling(bgs_ctx* ctx, int enabled);
+/* Stats of the most recent bgs_sort / bgs_render. Synchronises the stream. */
+int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out);
+
+/* ---- building blocks exported for tests and reuse -------------------------------- */
+/* Stable LSD radix sort of n (key,index) pairs on the device, `passes` 8-bit digit
+ * places starting at bit 0 (the Onesweep kernel used for both the depth and the tile
+ * sort). entries_inout is a HOST buffer; used by the parity tests to exercise the sort
+ * kernel on arbitrary keys (ties, all-equal, ragged sizes). */
+int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries_inout, uint32_t n,
+                         uint32_t passes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGS_H */

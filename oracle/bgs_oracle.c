@@ -1,0 +1,896 @@
+/*
+ * bgs_oracle.c — CPU oracle (TEST INFRASTRUCTURE ONLY; see bgs_oracle.h for the rules,
+ * the arithmetic contract and the pinning status: sort keys PINNED by tests/radix.rs,
+ * projection / colour / blending PARITY UNPINNED against a running reference).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC (see Makefile).
+ * All citations are into /root/reference (mosure/bevy_gaussian_splatting v8.0.1).
+ */
+#include "bgs_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------
+ * small f32 linear algebra with the evaluation order fixed by the contract
+ * ---------------------------------------------------------------------------------- */
+typedef struct { float x, y; } v2;
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+typedef struct { float m[9]; } m3; /* column-major: m[3*c + r] */
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static inline float dot2(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
+static inline float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 v3mul(v3 a, v3 b) { v3 r = {a.x * b.x, a.y * b.y, a.z * b.z}; return r; }
+static inline v3 v3sub(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+static inline v3 v3scale(float s, v3 a) { v3 r = {s * a.x, s * a.y, s * a.z}; return r; }
+static inline v3 v3normalize(v3 a) {
+    float len = sqrtf(dot3(a, a));
+    v3 r = {a.x / len, a.y / len, a.z / len};
+    return r;
+}
+static inline v3 cross3(v3 a, v3 b) {
+    v3 r = {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+    return r;
+}
+
+/* M (column-major 4x4) * (v.xyz, w) */
+static inline v4 m4_mul_v4(const float* m, v4 v) {
+    v4 r;
+    r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * v.w;
+    r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * v.w;
+    r.z = ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * v.w;
+    r.w = ((m[3] * v.x + m[7] * v.y) + m[11] * v.z) + m[15] * v.w;
+    return r;
+}
+
+static inline m3 m3_cols(v3 c0, v3 c1, v3 c2) {
+    m3 r = {{c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z}};
+    return r;
+}
+static inline v3 m3_col(const m3* a, int c) {
+    v3 r = {a->m[3 * c], a->m[3 * c + 1], a->m[3 * c + 2]};
+    return r;
+}
+static inline m3 m3_transpose(m3 a) {
+    m3 r;
+    for (int c = 0; c < 3; ++c)
+        for (int rr = 0; rr < 3; ++rr) r.m[3 * c + rr] = a.m[3 * rr + c];
+    return r;
+}
+static inline m3 m3_mul(m3 a, m3 b) {
+    m3 r;
+    for (int c = 0; c < 3; ++c)
+        for (int rr = 0; rr < 3; ++rr)
+            r.m[3 * c + rr] = (a.m[rr] * b.m[3 * c] + a.m[3 + rr] * b.m[3 * c + 1]) +
+                              a.m[6 + rr] * b.m[3 * c + 2];
+    return r;
+}
+/* upper-left 3x3 of a column-major 4x4: mat3x3(m[0].xyz, m[1].xyz, m[2].xyz) */
+static inline m3 m3_from_m4(const float* m) {
+    m3 r = {{m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]}};
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------
+ * src/render/mod.rs:715-758  ShaderDefines::for_radix_depth_bits
+ * ---------------------------------------------------------------------------------- */
+int oracle_radix_defines(uint32_t depth_bits, uint32_t* digit_places, uint32_t* key_shift,
+                         uint32_t* initial_parity) {
+    if (depth_bits != 16 && depth_bits != 24 && depth_bits != 32) return -1;
+    const uint32_t radix_bits_per_digit = 8;
+    const uint32_t places = depth_bits / radix_bits_per_digit; /* mod.rs:718 */
+    if (digit_places) *digit_places = places;
+    if (key_shift) *key_shift = 32 - depth_bits;               /* mod.rs:719 */
+    if (initial_parity) *initial_parity = places % 2;          /* mod.rs:755-757 */
+    return 0;
+}
+
+/* tests/radix.rs:96-101 */
+float oracle_distance_squared(const float p[3], const float c[3]) {
+    float dx = p[0] - c[0];
+    float dy = p[1] - c[1];
+    float dz = p[2] - c[2];
+    return dx * dx + dy * dy + dz * dz;
+}
+
+/* tests/radix.rs:103-106 */
+uint32_t oracle_radix_depth_key(float dist2, uint32_t key_shift) {
+    uint32_t key = 0xFFFFFFFFu - f2u(dist2);
+    return key >> key_shift;
+}
+
+/* src/render/transform.wgsl:5-8 */
+static inline v4 world_to_clip(const bgs_view* view, v3 world_pos) {
+    v4 p = {world_pos.x, world_pos.y, world_pos.z, 1.0f};
+    v4 h = m4_mul_v4(view->clip_from_world, p);
+    float d = h.w + 0.000000001f;
+    v4 r = {h.x / d, h.y / d, h.z / d, h.w / d};
+    return r;
+}
+
+/* src/render/transform.wgsl:10-14 */
+static inline int in_frustum(v4 c) {
+    return fabsf(c.x) < 1.1f && fabsf(c.y) < 1.1f && fabsf(c.z - 0.5f) < 0.5f;
+}
+
+static inline v3 transform_point(const float* transform, const float* pos) {
+    v4 p = {pos[0], pos[1], pos[2], 1.0f};
+    v4 t = m4_mul_v4(transform, p);
+    v3 r = {t.x, t.y, t.z};
+    return r;
+}
+
+static inline v3 view_world_position(const bgs_view* view) {
+    v3 r = {view->world_from_view[12], view->world_from_view[13], view->world_from_view[14]};
+    return r;
+}
+
+int oracle_keygen(const float* pv, uint32_t n, const bgs_view* view, const bgs_settings* s,
+                  bgs_sort_entry* out) {
+    uint32_t places, shift;
+    if (oracle_radix_defines(s->radix_depth_bits, &places, &shift, 0)) return -1;
+    const v3 cam = view_world_position(view);
+#pragma omp parallel for schedule(static)
+    for (int64_t ii = 0; ii < (int64_t)n; ++ii) {
+        uint32_t i = (uint32_t)ii;
+        if (s->sort_mode == BGS_SORT_NONE) {
+            /* src/sort/mod.rs:347-354 */
+            out[i].key = 1u;
+            out[i].index = i;
+            continue;
+        }
+        v3 tp = transform_point(s->transform, pv + 4 * (size_t)i);
+        if (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD) {
+            /* src/sort/rayon.rs:91-97: delta = camera - position; key = bits(|delta|^2) */
+            v3 d = v3sub(cam, tp);
+            float dist2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
+            out[i].key = f2u(dist2);
+            out[i].index = i;
+            continue;
+        }
+        /* src/sort/radix.wgsl:86-101 */
+        uint32_t key = 0xFFFFFFFFu;
+        v4 clip = world_to_clip(view, tp);
+        v3 diff = v3sub(tp, cam);
+        float dist2 = dot3(diff, diff);
+        uint32_t dist_bits = f2u(dist2);
+        uint32_t key_distance = 0xFFFFFFFFu - dist_bits;
+        if (in_frustum(clip)) key = key_distance;
+        key = key >> shift;
+        out[i].key = key;
+        out[i].index = i;
+    }
+    return 0;
+}
+
+/* src/sort/radix.wgsl:109-279. One pass = count_tiles + scan_tiles + scatter over
+ * WORKGROUP_ENTRIES_C = 1024-entry tiles (src/render/mod.rs:724), 8-bit digits. */
+void oracle_radix_sort(bgs_sort_entry* entries, uint32_t n, uint32_t places,
+                       bgs_sort_entry* tmp) {
+    if (n == 0) return;
+    const uint32_t tile_size = 1024;
+    const uint32_t tile_count = (n + tile_size - 1) / tile_size;
+    uint32_t* status = (uint32_t*)malloc((size_t)tile_count * 256 * sizeof(uint32_t));
+    bgs_sort_entry* in = entries;
+    bgs_sort_entry* outb = tmp;
+    for (uint32_t pass = 0; pass < places; ++pass) {
+        const uint32_t sh = pass * 8;
+        /* radix_sort_a global histogram + radix_sort_b exclusive scan (:102-119) */
+        uint32_t hist[256];
+        memset(hist, 0, sizeof hist);
+        for (uint32_t i = 0; i < n; ++i) hist[(in[i].key >> sh) & 255u]++;
+        uint32_t sum = 0;
+        for (int d = 0; d < 256; ++d) { uint32_t t = hist[d]; hist[d] = sum; sum += t; }
+        /* radix_sort_c_count_tiles (:130-161) */
+        memset(status, 0, (size_t)tile_count * 256 * sizeof(uint32_t));
+        for (uint32_t i = 0; i < n; ++i) status[(size_t)(i / tile_size) * 256 + ((in[i].key >> sh) & 255u)]++;
+        /* radix_sort_c_scan_tiles (:166-184) */
+        for (int d = 0; d < 256; ++d) {
+            uint32_t run = hist[d];
+            for (uint32_t t = 0; t < tile_count; ++t) {
+                uint32_t c = status[(size_t)t * 256 + d];
+                status[(size_t)t * 256 + d] = run;
+                run += c;
+            }
+        }
+        /* radix_sort_c_scatter (:186-279): stable, input order within the tile */
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t d = (in[i].key >> sh) & 255u;
+            uint32_t dst = status[(size_t)(i / tile_size) * 256 + d]++;
+            outb[dst] = in[i];
+        }
+        bgs_sort_entry* t = in; in = outb; outb = t;
+    }
+    if (in != entries) memcpy(entries, in, (size_t)n * sizeof(bgs_sort_entry));
+    free(status);
+}
+
+static int cmp_desc_f32(const void* pa, const void* pb) {
+    const bgs_sort_entry* a = (const bgs_sort_entry*)pa;
+    const bgs_sort_entry* b = (const bgs_sort_entry*)pb;
+    float fa = u2f(a->key), fb = u2f(b->key);
+    /* src/sort/rayon.rs:100-104: b.partial_cmp(a), NaN -> Equal */
+    if (fb < fa) return -1;
+    if (fb > fa) return 1;
+    return (a->index > b->index) - (a->index < b->index);
+}
+
+void oracle_sort_descending_f32(bgs_sort_entry* entries, uint32_t n) {
+    qsort(entries, n, sizeof(bgs_sort_entry), cmp_desc_f32);
+}
+
+int oracle_sort(const float* pv, uint32_t n, const bgs_view* view, const bgs_settings* s,
+                bgs_sort_entry* out) {
+    if (oracle_keygen(pv, n, view, s, out)) return -1;
+    if (s->sort_mode == BGS_SORT_NONE) return 0;
+    if (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD) {
+        oracle_sort_descending_f32(out, n);
+        return 0;
+    }
+    uint32_t places;
+    oracle_radix_defines(s->radix_depth_bits, &places, 0, 0);
+    bgs_sort_entry* tmp = (bgs_sort_entry*)malloc((size_t)(n ? n : 1) * sizeof(bgs_sort_entry));
+    if (!tmp) return -2;
+    oracle_radix_sort(out, n, places, tmp);
+    free(tmp);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * per-splat (vertex) stage
+ * ---------------------------------------------------------------------------------- */
+
+/* src/render/helpers.wgsl:137-157 (column-major constructor) */
+static m3 get_rotation_matrix(const float* rot) {
+    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    v3 c0 = {1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - r * z), 2.0f * (x * z + r * y)};
+    v3 c1 = {2.0f * (x * y + r * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - r * x)};
+    v3 c2 = {2.0f * (x * z - r * y), 2.0f * (y * z + r * x), 1.0f - 2.0f * (x * x + y * y)};
+    return m3_cols(c0, c1, c2);
+}
+
+/* src/render/helpers.wgsl:159-168 */
+static m3 get_scale_matrix(const float* scale, float global_scale) {
+    v3 c0 = {scale[0] * global_scale, 0.0f, 0.0f};
+    v3 c1 = {0.0f, scale[1] * global_scale, 0.0f};
+    v3 c2 = {0.0f, 0.0f, scale[2] * global_scale};
+    return m3_cols(c0, c1, c2);
+}
+
+/* src/render/gaussian_3d.wgsl:49-72 */
+static void compute_cov3d(const float* scale, const float* rotation, const bgs_settings* s,
+                          float cov3d[6]) {
+    m3 S = get_scale_matrix(scale, s->global_scale);
+    m3 T = m3_from_m4(s->transform);
+    m3 R = get_rotation_matrix(rotation);
+    m3 M = m3_mul(S, R);
+    m3 Sigma = m3_mul(m3_transpose(M), M);
+    m3 TS = m3_mul(m3_mul(T, Sigma), m3_transpose(T));
+    cov3d[0] = TS.m[0]; /* TS[0][0] */
+    cov3d[1] = TS.m[1]; /* TS[0][1] */
+    cov3d[2] = TS.m[2]; /* TS[0][2] */
+    cov3d[3] = TS.m[4]; /* TS[1][1] */
+    cov3d[4] = TS.m[5]; /* TS[1][2] */
+    cov3d[5] = TS.m[8]; /* TS[2][2] */
+}
+
+/* src/render/helpers.wgsl:8-47 */
+static void cov2d_fn(v3 position, const float cov3d[6], const bgs_view* view, float out[3]) {
+    v3 c0 = {cov3d[0], cov3d[1], cov3d[2]};
+    v3 c1 = {cov3d[1], cov3d[3], cov3d[4]};
+    v3 c2 = {cov3d[2], cov3d[4], cov3d[5]};
+    m3 Vrk = m3_cols(c0, c1, c2);
+
+    v4 p = {position.x, position.y, position.z, 1.0f};
+    v4 t = m4_mul_v4(view->view_from_world, p);
+
+    v2 focal = {view->clip_from_view[0] * view->viewport[2],
+                view->clip_from_view[5] * view->viewport[3]};
+
+    float sI = 1.0f / (t.z * t.z);
+    v3 j0 = {focal.x / t.z, 0.0f, -(focal.x * t.x) * sI};
+    v3 j1 = {0.0f, -focal.y / t.z, (focal.y * t.y) * sI};
+    v3 j2 = {0.0f, 0.0f, 0.0f};
+    m3 J = m3_cols(j0, j1, j2);
+
+    m3 W = m3_transpose(m3_from_m4(view->view_from_world));
+    m3 T = m3_mul(W, J);
+    m3 cov = m3_mul(m3_mul(m3_transpose(T), m3_transpose(Vrk)), T);
+    cov.m[0] += 0.3f; /* cov[0][0] */
+    cov.m[4] += 0.3f; /* cov[1][1] */
+    out[0] = cov.m[0];
+    out[1] = cov.m[1]; /* cov[0][1] */
+    out[2] = cov.m[4];
+}
+
+/* src/render/helpers.wgsl:49-120 */
+static void get_bounding_box_clip(const float cov2d[3], v2 direction, float cutoff,
+                                  const bgs_view* view, int aabb, float out[4]) {
+    float det = cov2d[0] * cov2d[2] - cov2d[1] * cov2d[1];
+    float trace = cov2d[0] + cov2d[2];
+    float mid = 0.5f * trace;
+    float discriminant = fmaxf(0.0f, mid * mid - det);
+    float term = sqrtf(discriminant);
+    float lambda1 = mid + term;
+    float lambda2 = fmaxf(mid - term, 0.0f);
+    float x_axis_length = sqrtf(lambda1);
+    float y_axis_length = sqrtf(lambda2);
+
+    if (aabb) {
+        float radius_px = cutoff * fmaxf(x_axis_length, y_axis_length);
+        v2 radius_ndc = {radius_px / view->viewport[2], radius_px / view->viewport[3]};
+        out[0] = radius_ndc.x * direction.x;
+        out[1] = radius_ndc.y * direction.y;
+        out[2] = radius_px * direction.x;
+        out[3] = radius_px * direction.y;
+        return;
+    }
+    float a = (cov2d[0] - cov2d[2]) * (cov2d[0] - cov2d[2]);
+    float b = sqrtf(a + 4.0f * cov2d[1] * cov2d[1]);
+    float major_radius = sqrtf((cov2d[0] + cov2d[2] + b) * 0.5f);
+    float minor_radius = sqrtf((cov2d[0] + cov2d[2] - b) * 0.5f);
+    v2 bounds = {cutoff * major_radius, cutoff * minor_radius};
+
+    v2 ev = {-cov2d[1], lambda1 - cov2d[0]};
+    float evlen = sqrtf(dot2(ev, ev));
+    v2 eigvec1 = {ev.x / evlen, ev.y / evlen};
+    v2 eigvec2 = {eigvec1.y, -eigvec1.x};
+
+    /* rotation_matrix = transpose(mat2x2(eigvec1, eigvec2)); v * M = (dot(v,M[0]), dot(v,M[1]))
+     * with M[0] = (eigvec1.x, eigvec2.x), M[1] = (eigvec1.y, eigvec2.y) */
+    v2 scaled_vertex = {direction.x * bounds.x, direction.y * bounds.y};
+    v2 col0 = {eigvec1.x, eigvec2.x};
+    v2 col1 = {eigvec1.y, eigvec2.y};
+    v2 rotated_vertex = {dot2(scaled_vertex, col0), dot2(scaled_vertex, col1)};
+
+    v2 scaling_factor = {1.0f / view->viewport[2], 1.0f / view->viewport[3]};
+    out[0] = rotated_vertex.x * scaling_factor.x;
+    out[1] = rotated_vertex.y * scaling_factor.y;
+    out[2] = rotated_vertex.x;
+    out[3] = rotated_vertex.y;
+}
+
+/* src/render/gaussian_2d.wgsl:49-78 */
+static void get_bounding_box_cov2d(const float extent[2], v2 direction, float cutoff,
+                                   const bgs_view* view, float out[4]) {
+    const float filter_size = 0.707106f;
+    if (extent[0] < 1.e-4f || extent[1] < 1.e-4f) {
+        out[0] = out[1] = out[2] = out[3] = 0.0f;
+        return;
+    }
+    v2 radius = {sqrtf(extent[0]), sqrtf(extent[1])};
+    float mr = fmaxf(fmaxf(radius.x, radius.y), cutoff * filter_size);
+    v2 radius_ndc = {mr / view->viewport[2], mr / view->viewport[3]};
+    out[0] = radius_ndc.x * direction.x;
+    out[1] = radius_ndc.y * direction.y;
+    out[2] = mr;
+    out[3] = mr;
+}
+
+/* src/render/gaussian_2d.wgsl:80-132 with intrinsic_matrix (helpers.wgsl:122-135) */
+static void compute_cov2d_surfel(v3 gaussian_position, const float* rotation, const float* scale,
+                                 float cutoff, const bgs_view* view, const bgs_settings* s,
+                                 oracle_vs_out* o) {
+    memset(o->local_to_pixel, 0, sizeof o->local_to_pixel);
+    o->mean_2d[0] = o->mean_2d[1] = 0.0f;
+    o->extent[0] = o->extent[1] = 0.0f;
+
+    m3 T_r = m3_from_m4(s->transform);
+    m3 S = get_scale_matrix(scale, s->global_scale);
+    m3 R = get_rotation_matrix(rotation);
+    m3 L = m3_mul(m3_mul(T_r, m3_transpose(R)), S);
+
+    /* world_from_local: 3 columns of vec4 */
+    float wfl[3][4] = {{L.m[0], L.m[1], L.m[2], 0.0f},
+                       {L.m[3], L.m[4], L.m[5], 0.0f},
+                       {gaussian_position.x, gaussian_position.y, gaussian_position.z, 1.0f}};
+    /* ndc_from_world = transpose(clip_from_world): column c of it = row c of clip_from_world */
+    const float* cfw = view->clip_from_world;
+    /* A = transpose(world_from_local): 4 columns x 3 rows, A[c][r] = wfl[r][c].
+     * AB = A * ndc_from_world: 4 columns x 3 rows,
+     *   AB[c][r] = sum_k A[k][r] * N[c][k],  N[c][k] = cfw[k][c] = cfw[4*k + c]. */
+    float AB[4][3];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 3; ++r)
+            AB[c][r] = ((wfl[r][0] * cfw[0 * 4 + c] + wfl[r][1] * cfw[1 * 4 + c]) +
+                        wfl[r][2] * cfw[2 * 4 + c]) +
+                       wfl[r][3] * cfw[3 * 4 + c];
+    /* intrinsic_matrix: 3 columns of vec4 */
+    v2 focal = {view->clip_from_view[0] * view->viewport[2] / 2.0f,
+                view->clip_from_view[5] * view->viewport[3] / 2.0f};
+    float K[3][4] = {{focal.x, 0.0f, 0.0f, (view->viewport[2] - 1.0f) / 2.0f},
+                     {0.0f, focal.y, 0.0f, (view->viewport[3] - 1.0f) / 2.0f},
+                     {0.0f, 0.0f, 0.0f, 1.0f}};
+    /* T = AB * K: 3 columns x 3 rows, T[c][r] = sum_k AB[k][r] * K[c][k] */
+    m3 T;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r)
+            T.m[3 * c + r] = ((AB[0][r] * K[c][0] + AB[1][r] * K[c][1]) + AB[2][r] * K[c][2]) +
+                             AB[3][r] * K[c][3];
+
+    v3 test = {cutoff * cutoff, cutoff * cutoff, -1.0f};
+    v3 T0 = m3_col(&T, 0), T1 = m3_col(&T, 1), T2 = m3_col(&T, 2);
+    float d = dot3(v3mul(test, T2), T2);
+    if (fabsf(d) < 1.0e-4f) return; /* extent = 0, everything else zero-initialised */
+
+    v3 f = v3scale(1.0f / d, test);
+    v2 mean_2d = {dot3(f, v3mul(T0, T2)), dot3(f, v3mul(T1, T2))};
+    v2 t = {dot3(v3mul(f, T0), T0), dot3(v3mul(f, T1), T1)};
+    o->extent[0] = mean_2d.x * mean_2d.x - t.x;
+    o->extent[1] = mean_2d.y * mean_2d.y - t.y;
+    memcpy(o->local_to_pixel, T.m, sizeof T.m);
+    o->mean_2d[0] = mean_2d.x;
+    o->mean_2d[1] = mean_2d.y;
+}
+
+/* src/material/spherical_harmonics.wgsl:3-20 */
+static const float shc[16] = {
+    0.28209479177387814f, -0.4886025119029199f, 0.4886025119029199f,  -0.4886025119029199f,
+    1.0925484305920792f,  -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+    0.5462742152960396f,  -0.5900435899266435f, 2.890611442640554f,   -0.4570457994644658f,
+    0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,   -0.5900435899266435f,
+};
+
+static inline v3 sh3(const float* sh, int k) {
+    v3 r = {sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]};
+    return r;
+}
+/* color += (c * sh_k) * basis, evaluated left to right as the WGSL expression is */
+static inline void sh_acc1(v3* color, float c, v3 s, float b0) {
+    color->x += c * s.x * b0;
+    color->y += c * s.y * b0;
+    color->z += c * s.z * b0;
+}
+static inline void sh_acc2(v3* color, float c, v3 s, float b0, float b1) {
+    color->x += c * s.x * b0 * b1;
+    color->y += c * s.y * b0 * b1;
+    color->z += c * s.z * b0 * b1;
+}
+static inline void sh_acc3(v3* color, float c, v3 s, float b0, float b1, float b2) {
+    color->x += c * s.x * b0 * b1 * b2;
+    color->y += c * s.y * b0 * b1 * b2;
+    color->z += c * s.z * b0 * b1 * b2;
+}
+
+/* src/material/spherical_harmonics.wgsl:34-68 */
+static v3 spherical_harmonics_lookup(v3 rd, const float* sh, uint32_t degree) {
+    v3 rds = v3mul(rd, rd);
+    v3 color = {0.5f, 0.5f, 0.5f};
+    v3 s0 = sh3(sh, 0);
+    color.x += shc[0] * s0.x;
+    color.y += shc[0] * s0.y;
+    color.z += shc[0] * s0.z;
+    if (degree > 0) {
+        sh_acc1(&color, shc[1], sh3(sh, 1), rd.y);
+        sh_acc1(&color, shc[2], sh3(sh, 2), rd.z);
+        sh_acc1(&color, shc[3], sh3(sh, 3), rd.x);
+    }
+    if (degree > 1) {
+        sh_acc2(&color, shc[4], sh3(sh, 4), rd.x, rd.y);
+        sh_acc2(&color, shc[5], sh3(sh, 5), rd.y, rd.z);
+        sh_acc1(&color, shc[6], sh3(sh, 6), 2.0f * rds.z - rds.x - rds.y);
+        sh_acc2(&color, shc[7], sh3(sh, 7), rd.x, rd.z);
+        sh_acc1(&color, shc[8], sh3(sh, 8), rds.x - rds.y);
+    }
+    if (degree > 2) {
+        sh_acc2(&color, shc[9], sh3(sh, 9), rd.y, 3.0f * rds.x - rds.y);
+        sh_acc3(&color, shc[10], sh3(sh, 10), rd.x, rd.y, rd.z);
+        sh_acc2(&color, shc[11], sh3(sh, 11), rd.y, 4.0f * rds.z - rds.x - rds.y);
+        sh_acc2(&color, shc[12], sh3(sh, 12), rd.z, 2.0f * rds.z - 3.0f * rds.x - 3.0f * rds.y);
+        sh_acc2(&color, shc[13], sh3(sh, 13), rd.x, 4.0f * rds.z - rds.x - rds.y);
+        sh_acc2(&color, shc[14], sh3(sh, 14), rd.z, rds.x - rds.y);
+        sh_acc2(&color, shc[15], sh3(sh, 15), rd.x, rds.x - 3.0f * rds.y);
+    }
+    return color;
+}
+
+/* src/material/spherical_harmonics.wgsl:22-32 */
+static inline float srgb_to_linear1(float c) {
+    if (c <= 0.04045f) return c / 12.92f;
+    return powf((c + 0.055f) / 1.055f, 2.4f);
+}
+
+/* src/render/gaussian.wgsl:166-183 */
+static v3 world_to_local_direction(v3 ray_direction_world, const float* transform) {
+    v3 b0 = {transform[0], transform[1], transform[2]};
+    v3 b1 = {transform[4], transform[5], transform[6]};
+    v3 b2 = {transform[8], transform[9], transform[10]};
+    v3 bx = v3normalize(b0), by = v3normalize(b1), bz = v3normalize(b2);
+    v3 local = {dot3(bx, ray_direction_world), dot3(by, ray_direction_world),
+                dot3(bz, ray_direction_world)};
+    return v3normalize(local);
+}
+
+static const v2 quad_vertices[4] = {{-1.0f, -1.0f}, {-1.0f, 1.0f}, {1.0f, -1.0f}, {1.0f, 1.0f}};
+
+/* src/render/gaussian.wgsl:184-436 (RASTERIZE_COLOR, DrawMode::All, planar f32 storage) */
+int oracle_vs(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_view* view,
+              const bgs_settings* s, oracle_vs_out* o) {
+    memset(o, 0, sizeof *o);
+    const uint32_t splat_index = entry.index;
+    if (splat_index >= cloud->n) { o->discard = 1; return 0; }
+
+    int discard_quad = 0;
+    discard_quad |= entry.key == 0xFFFFFFFFu;                        /* :196 */
+
+    const float* pv = cloud->position_visibility + 4 * (size_t)splat_index;
+    v3 transformed_position = transform_point(s->transform, pv);     /* :198-200 */
+    v4 projected_position = world_to_clip(view, transformed_position); /* :210 */
+    discard_quad |= !in_frustum(projected_position);                 /* :211 */
+    o->projected[0] = projected_position.x;
+    o->projected[1] = projected_position.y;
+    o->projected[2] = projected_position.z;
+    o->projected[3] = projected_position.w;
+    if (discard_quad) { o->discard = 1; return 0; }                  /* :214-218 */
+
+    const float* so = cloud->scale_opacity + 4 * (size_t)splat_index;
+    const float* rot = cloud->rotation + 4 * (size_t)splat_index;
+    float opacity = so[3];
+    float cutoff = 3.0f;
+    if (s->opacity_adaptive_radius)                                  /* :231-235 */
+        cutoff = sqrtf(fmaxf(9.0f + 2.0f * logf(opacity), 0.000001f));
+    o->cutoff = cutoff;
+
+    if (s->gaussian_mode == BGS_GAUSSIAN_2D) {                       /* :237-255 */
+        compute_cov2d_surfel(transformed_position, rot, so, cutoff, view, s, o);
+        for (int k = 0; k < 4; ++k)
+            get_bounding_box_cov2d(o->extent, quad_vertices[k], cutoff, view, o->bb[k]);
+        o->radius[0] = o->bb[0][2];
+        o->radius[1] = o->bb[0][3];
+    } else {                                                         /* :257-306 */
+        float cov3d[6];
+        compute_cov3d(so, rot, s, cov3d);
+        cov2d_fn(transformed_position, cov3d, view, o->cov2d);
+        for (int k = 0; k < 4; ++k)
+            get_bounding_box_clip(o->cov2d, quad_vertices[k], cutoff, view, (int)s->aabb, o->bb[k]);
+        if (s->aabb) {
+            float det = o->cov2d[0] * o->cov2d[2] - o->cov2d[1] * o->cov2d[1];
+            float det_inv = 1.0f / det;
+            o->conic[0] = o->cov2d[2] * det_inv;
+            o->conic[1] = -o->cov2d[1] * det_inv;
+            o->conic[2] = o->cov2d[0] * det_inv;
+        }
+    }
+
+    /* RASTERIZE_COLOR :406-417, get_color src/render/planar.wgsl:334-339 */
+    v3 cam = view_world_position(view);
+    v3 ray_direction_world = v3normalize(v3sub(transformed_position, cam));
+    v3 ray_direction_local = world_to_local_direction(ray_direction_world, s->transform);
+    v3 rgb = spherical_harmonics_lookup(
+        ray_direction_local, cloud->spherical_harmonic + 48 * (size_t)splat_index, s->sh_degree);
+    if (s->color_space != BGS_COLOR_LINEAR) {                        /* planar.wgsl:91-106 */
+        rgb.x = srgb_to_linear1(rgb.x);
+        rgb.y = srgb_to_linear1(rgb.y);
+        rgb.z = srgb_to_linear1(rgb.z);
+    }
+    o->color[0] = rgb.x;
+    o->color[1] = rgb.y;
+    o->color[2] = rgb.z;
+    o->color[3] = opacity * s->global_opacity;                       /* :419-422 */
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * per-pixel (fragment) stage + blend
+ * ---------------------------------------------------------------------------------- */
+
+/* src/render/gaussian_2d.wgsl:134-156 */
+static float surfel_fragment_power(const float* l2p, v2 pixel_coord, v2 mean_2d) {
+    v2 deltas = {mean_2d.x - pixel_coord.x, mean_2d.y - pixel_coord.y};
+    v3 c0 = {l2p[0], l2p[1], l2p[2]}, c1 = {l2p[3], l2p[4], l2p[5]}, c2 = {l2p[6], l2p[7], l2p[8]};
+    v3 hu = v3sub(v3scale(pixel_coord.x, c2), c0);
+    v3 hv = v3sub(v3scale(pixel_coord.y, c2), c1);
+    v3 p = cross3(hu, hv);
+    float us = p.x / p.z;
+    float vs = p.y / p.z;
+    float sigmas_3d = us * us + vs * vs;
+    float sigmas_2d = 2.0f * (deltas.x * deltas.x + deltas.y * deltas.y);
+    float sigmas = 0.5f * fminf(sigmas_3d, sigmas_2d);
+    return -sigmas;
+}
+
+/* src/render/gaussian.wgsl:438-505. Returns 0 if the fragment is discarded. `power_out`
+ * is reported for the ambiguity bound. */
+static int fs_main(const oracle_vs_out* in, v2 uv, v2 major_minor, const bgs_view* view,
+                   const bgs_settings* s, float src[4], float* power_out) {
+    float power;
+    if (s->aabb) {
+        if (s->gaussian_mode == BGS_GAUSSIAN_2D) {
+            v2 aspect = {1.0f, view->viewport[2] / view->viewport[3]};
+            v2 pixel_coord = {uv.x * in->radius[0] * aspect.x + in->mean_2d[0],
+                              uv.y * in->radius[1] * aspect.y + in->mean_2d[1]};
+            v2 mean = {in->mean_2d[0], in->mean_2d[1]};
+            power = surfel_fragment_power(in->local_to_pixel, pixel_coord, mean);
+        } else {
+            v2 d = {-major_minor.x, -major_minor.y};
+            power = -0.5f * (in->conic[0] * d.x * d.x + in->conic[2] * d.y * d.y) +
+                    in->conic[1] * d.x * d.y;
+        }
+        *power_out = power;
+        if (power > 0.0f) return 0;
+    } else {
+        const float sigma = 1.0f / 3.0f;
+        const float sigma_squared = 2.0f * sigma * sigma;
+        float distance_squared = dot2(uv, uv);
+        power = -distance_squared / sigma_squared;
+        *power_out = power;
+        if (distance_squared > 3.0f * 3.0f) return 0;
+    }
+    float alpha = fminf(expf(power) * in->color[3], 0.999f);
+    src[0] = in->color[0] * alpha;
+    src[1] = in->color[1] * alpha;
+    src[2] = in->color[2] * alpha;
+    src[3] = alpha;
+    return 1;
+}
+
+/* One non-discarded quad prepared for the ideal rasteriser (float64). */
+typedef struct prim {
+    oracle_vs_out vs;
+    double p0x, p0y; /* vertex 0 (uv -1,-1) in pixels */
+    double esx, esy; /* vertex 2 - vertex 0 (u axis)  */
+    double etx, ety; /* vertex 1 - vertex 0 (v axis)  */
+    double inv_det;
+    double eps_s, eps_t; /* rounding-distance band, in (s,t) units */
+    int32_t bx0, bx1, by0, by1; /* inclusive pixel bounds, already clipped */
+} prim;
+
+/* Clip-space vertex k -> pixel coordinates (viewport origin at 0,0). */
+static void vertex_pixel(const oracle_vs_out* vs, int k, double W, double H, double* X, double* Y) {
+    /* src/render/gaussian.wgsl:429-433: position = (projected.xy + bb.xy, projected.zw) */
+    float cx = vs->projected[0] + vs->bb[k][0];
+    float cy = vs->projected[1] + vs->bb[k][1];
+    double w = (double)vs->projected[3];
+    double nx = (double)cx / w, ny = (double)cy / w;
+    *X = (nx + 1.0) * 0.5 * W;
+    *Y = (1.0 - ny) * 0.5 * H;
+}
+
+static int build_prim(prim* p, int32_t x0, int32_t y0, int32_t x1, int32_t y1, double W, double H) {
+    double X[4], Y[4];
+    for (int k = 0; k < 4; ++k) vertex_pixel(&p->vs, k, W, H, &X[k], &Y[k]);
+    p->p0x = X[0]; p->p0y = Y[0];
+    p->esx = X[2] - X[0]; p->esy = Y[2] - Y[0];
+    p->etx = X[1] - X[0]; p->ety = Y[1] - Y[0];
+    double det = p->esx * p->ety - p->esy * p->etx;
+    if (!(fabs(det) > 0.0) || !isfinite(det)) return 0; /* degenerate or NaN quad: no coverage */
+    p->inv_det = 1.0 / det;
+    double ls = sqrt(p->esx * p->esx + p->esy * p->esy);
+    double lt = sqrt(p->etx * p->etx + p->ety * p->ety);
+    p->eps_s = 2e-3 / ls;
+    p->eps_t = 2e-3 / lt;
+    double minx = X[0], maxx = X[0], miny = Y[0], maxy = Y[0];
+    for (int k = 1; k < 4; ++k) {
+        if (X[k] < minx) minx = X[k];
+        if (X[k] > maxx) maxx = X[k];
+        if (Y[k] < miny) miny = Y[k];
+        if (Y[k] > maxy) maxy = Y[k];
+    }
+    if (!isfinite(minx) || !isfinite(maxx) || !isfinite(miny) || !isfinite(maxy)) return 0;
+    /* pixel centres x+0.5 in [minx-1, maxx+1] (one-pixel guard band; exact test follows) */
+    double fx0 = floor(minx - 1.5), fx1 = ceil(maxx + 0.5);
+    double fy0 = floor(miny - 1.5), fy1 = ceil(maxy + 0.5);
+    if (fx0 < (double)x0) fx0 = (double)x0;
+    if (fy0 < (double)y0) fy0 = (double)y0;
+    if (fx1 > (double)(x1 - 1)) fx1 = (double)(x1 - 1);
+    if (fy1 > (double)(y1 - 1)) fy1 = (double)(y1 - 1);
+    if (fx0 > fx1 || fy0 > fy1) return 0;
+    p->bx0 = (int32_t)fx0; p->bx1 = (int32_t)fx1;
+    p->by0 = (int32_t)fy0; p->by1 = (int32_t)fy1;
+    return 1;
+}
+
+int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                  const bgs_view* view, const bgs_settings* s, int32_t x0, int32_t y0, int32_t x1,
+                  int32_t y1, float* rgba_out, float* amb_out) {
+    const int32_t Wi = (int32_t)view->viewport[2], Hi = (int32_t)view->viewport[3];
+    if (x0 < 0 || y0 < 0 || x1 > Wi || y1 > Hi || x0 >= x1 || y0 >= y1) return -1;
+    const double W = (double)view->viewport[2], H = (double)view->viewport[3];
+    const int32_t rw = x1 - x0, rh = y1 - y0;
+
+    /* vertex stage for every instance, keeping the non-discarded ones in draw order */
+    uint8_t* keep = (uint8_t*)calloc(count ? count : 1, 1);
+    prim* tmp = (prim*)malloc((size_t)(count ? count : 1) * sizeof(prim));
+    if (!keep || !tmp) { free(keep); free(tmp); return -2; }
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        prim* p = &tmp[i];
+        oracle_vs(cloud, entries[i], view, s, &p->vs);
+        if (p->vs.discard) continue;
+        keep[i] = (uint8_t)build_prim(p, x0, y0, x1, y1, W, H);
+    }
+    size_t np = 0;
+    for (uint32_t i = 0; i < count; ++i)
+        if (keep[i]) { if (np != i) tmp[np] = tmp[i]; ++np; }
+    free(keep);
+
+    /* clear (examples/headless.rs:70 -> view->clear_color) */
+    for (int64_t i = 0; i < (int64_t)rw * rh; ++i) {
+        for (int c = 0; c < 4; ++c) rgba_out[4 * i + c] = view->clear_color[c];
+        if (amb_out) amb_out[i] = 0.0f;
+    }
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int32_t y = y0; y < y1; ++y) {
+        float* row = rgba_out + (size_t)(y - y0) * rw * 4;
+        float* arow = amb_out ? amb_out + (size_t)(y - y0) * rw : 0;
+        const double qy = (double)y + 0.5;
+        for (size_t pi = 0; pi < np; ++pi) {
+            const prim* p = &tmp[pi];
+            if (y < p->by0 || y > p->by1) continue;
+            const oracle_vs_out* vs = &p->vs;
+            for (int32_t x = p->bx0; x <= p->bx1; ++x) {
+                const double qx = (double)x + 0.5;
+                const double dx = qx - p->p0x, dy = qy - p->p0y;
+                /* q - P0 = sp * Es + tp * Et */
+                const double sp = (dx * p->ety - dy * p->etx) * p->inv_det;
+                const double tp = (p->esx * dy - p->esy * dx) * p->inv_det;
+                const int inside = (sp >= 0.0 && sp <= 1.0 && tp >= 0.0 && tp <= 1.0);
+                int near_edge = 0;
+                if (arow) {
+                    const double ds = fmin(fabs(sp), fabs(sp - 1.0));
+                    const double dt = fmin(fabs(tp), fabs(tp - 1.0));
+                    const int in_band_s = sp >= -p->eps_s && sp <= 1.0 + p->eps_s;
+                    const int in_band_t = tp >= -p->eps_t && tp <= 1.0 + p->eps_t;
+                    near_edge = in_band_s && in_band_t && (ds < p->eps_s || dt < p->eps_t);
+                }
+                if (!inside && !near_edge) continue;
+                /* linear (non-perspective) interpolation of uv and major_minor
+                 * (src/render/gaussian.wgsl:148-162): vertex 0 = (-1,-1), 2 = (+1,-1), 1 = (-1,+1) */
+                v2 uv = {(float)(2.0 * sp - 1.0), (float)(2.0 * tp - 1.0)};
+                v2 mm = {(float)((double)vs->bb[0][2] + sp * ((double)vs->bb[2][2] - (double)vs->bb[0][2]) +
+                                 tp * ((double)vs->bb[1][2] - (double)vs->bb[0][2])),
+                         (float)((double)vs->bb[0][3] + sp * ((double)vs->bb[2][3] - (double)vs->bb[0][3]) +
+                                 tp * ((double)vs->bb[1][3] - (double)vs->bb[0][3]))};
+                float src[4] = {0, 0, 0, 0};
+                float power = 0.0f;
+                const int drawn = fs_main(vs, uv, mm, view, s, src, &power);
+                float* dst = row + 4 * (size_t)(x - x0);
+                if (arow) {
+                    int ambiguous = near_edge;
+                    if (s->aabb && fabsf(power) < 1e-5f) ambiguous = 1;
+                    if (ambiguous) {
+                        float a = fminf(expf(fminf(power, 0.0f)) * fabsf(vs->color[3]), 0.999f);
+                        float cm = fmaxf(fmaxf(fabsf(vs->color[0]), fabsf(vs->color[1])),
+                                         fmaxf(fabsf(vs->color[2]), 1.0f));
+                        float dm = fmaxf(fmaxf(fabsf(dst[0]), fabsf(dst[1])),
+                                         fmaxf(fabsf(dst[2]), fabsf(dst[3])));
+                        arow[x - x0] += a * (cm + dm);
+                    }
+                }
+                if (!inside || !drawn) continue;
+                /* BlendState::PREMULTIPLIED_ALPHA_BLENDING (src/render/mod.rs:946) */
+                const float one_minus = 1.0f - src[3];
+                dst[0] = src[0] + dst[0] * one_minus;
+                dst[1] = src[1] + dst[1] * one_minus;
+                dst[2] = src[2] + dst[2] * one_minus;
+                dst[3] = src[3] + dst[3] * one_minus;
+            }
+        }
+    }
+    free(tmp);
+    return 0;
+}
+
+int oracle_instance_stats(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                          const bgs_view* view, const bgs_settings* s, uint32_t* visible_out,
+                          uint64_t* tile_instances_out) {
+    const int32_t Wi = (int32_t)view->viewport[2], Hi = (int32_t)view->viewport[3];
+    const double W = (double)view->viewport[2], H = (double)view->viewport[3];
+    uint64_t inst = 0;
+    uint32_t vis = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : inst, vis)
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        prim p;
+        oracle_vs(cloud, entries[i], view, s, &p.vs);
+        if (p.vs.discard) continue;
+        vis += 1;
+        if (!build_prim(&p, 0, 0, Wi, Hi, W, H)) continue;
+        inst += (uint64_t)(p.bx1 / 16 - p.bx0 / 16 + 1) * (uint64_t)(p.by1 / 16 - p.by0 / 16 + 1);
+    }
+    if (visible_out) *visible_out = vis;
+    if (tile_instances_out) *tile_instances_out = inst;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * f16 planes
+ * ---------------------------------------------------------------------------------- */
+static float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    if (exp == 0) {
+        if (man == 0) return u2f(sign);
+        /* subnormal: value = man * 2^-24 */
+        float f = (float)man * (1.0f / 16777216.0f);
+        return (h & 0x8000u) ? -f : f;
+    }
+    if (exp == 31) return u2f(sign | 0x7F800000u | (man << 13));
+    return u2f(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+/* IEEE binary32 -> binary16, round to nearest even (the `half` crate's f16::from_f32). */
+static uint16_t float_to_half(float f) {
+    uint32_t x = f2u(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t exp = (x >> 23) & 0xFFu;
+    uint32_t man = x & 0x7FFFFFu;
+    if (exp == 255) return (uint16_t)(sign | 0x7C00u | (man ? (0x200u | (man >> 13)) : 0u));
+    int32_t e = (int32_t)exp - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        uint32_t shift = (uint32_t)(14 - e);
+        uint32_t half_man = man >> shift;
+        uint32_t rem = man & ((1u << shift) - 1u);
+        uint32_t halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (half_man & 1u))) half_man++;
+        return (uint16_t)(sign | half_man);
+    }
+    uint32_t half = sign | ((uint32_t)e << 10) | (man >> 13);
+    uint32_t rem = man & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half++;
+    return (uint16_t)half;
+}
+
+/* src/gaussian/f16.rs:244-252: first argument in the high half */
+static inline uint32_t pack_f32s_to_u32(float upper, float lower) {
+    return ((uint32_t)float_to_half(upper) << 16) | (uint32_t)float_to_half(lower);
+}
+
+void oracle_encode_f16(uint32_t n, const float* sh, const float* rotation, const float* so,
+                       uint32_t* sh_out, uint32_t* rso_out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        /* src/render/planar.wgsl:283-292: pack2x16float(sh[2i], sh[2i+1]) -> low half = even */
+        for (int k = 0; k < 24; ++k)
+            sh_out[24 * (size_t)i + k] =
+                pack_f32s_to_u32(sh[48 * (size_t)i + 2 * k + 1], sh[48 * (size_t)i + 2 * k]);
+        /* src/gaussian/f16.rs:38-55 */
+        const float* r = rotation + 4 * (size_t)i;
+        const float* s = so + 4 * (size_t)i;
+        rso_out[4 * (size_t)i + 0] = pack_f32s_to_u32(r[0], r[1]);
+        rso_out[4 * (size_t)i + 1] = pack_f32s_to_u32(r[2], r[3]);
+        rso_out[4 * (size_t)i + 2] = pack_f32s_to_u32(s[0], s[1]);
+        rso_out[4 * (size_t)i + 3] = pack_f32s_to_u32(s[2], s[3]);
+    }
+}
+
+void oracle_decode_f16(uint32_t n, const uint32_t* sh_h2, const uint32_t* rso, float* sh_out,
+                       float* rot_out, float* so_out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        /* src/render/planar.wgsl:117-130: unpack2x16float -> [0] = low half */
+        for (int k = 0; k < 24; ++k) {
+            uint32_t raw = sh_h2[24 * (size_t)i + k];
+            sh_out[48 * (size_t)i + 2 * k] = half_to_float((uint16_t)(raw & 0xFFFFu));
+            sh_out[48 * (size_t)i + 2 * k + 1] = half_to_float((uint16_t)(raw >> 16));
+        }
+        /* src/render/planar.wgsl:154-176: q0.yx, q1.yx / s0.yx, s1.y / opacity = s1.x */
+        const uint32_t* raw = rso + 4 * (size_t)i;
+        rot_out[4 * (size_t)i + 0] = half_to_float((uint16_t)(raw[0] >> 16));
+        rot_out[4 * (size_t)i + 1] = half_to_float((uint16_t)(raw[0] & 0xFFFFu));
+        rot_out[4 * (size_t)i + 2] = half_to_float((uint16_t)(raw[1] >> 16));
+        rot_out[4 * (size_t)i + 3] = half_to_float((uint16_t)(raw[1] & 0xFFFFu));
+        so_out[4 * (size_t)i + 0] = half_to_float((uint16_t)(raw[2] >> 16));
+        so_out[4 * (size_t)i + 1] = half_to_float((uint16_t)(raw[2] & 0xFFFFu));
+        so_out[4 * (size_t)i + 2] = half_to_float((uint16_t)(raw[3] >> 16));
+        so_out[4 * (size_t)i + 3] = half_to_float((uint16_t)(raw[3] & 0xFFFFu));
+    }
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,134 @@
+/*
+ * bgs_oracle.h — CPU oracle for the sort + rasterize hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under bevy_gaussian_splatting_amd/ (the product) may
+ * include, link, import or execute this. Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py use it, and only as the checker / reported baseline.
+ *
+ * What it is: a plain-C, single-precision restatement of the reference's algorithm,
+ * function by function, each citing the reference file:line it follows
+ * (mosure/bevy_gaussian_splatting v8.0.1). The reference is Rust + WGSL and cannot be
+ * compiled or executed in the build container (no cargo/rustc, no wgpu, no GPU), so
+ * there is no oracle/_ref build.
+ *
+ * PINNING STATUS
+ *   - sort keys / order / (places, shift, parity) table: PINNED by the reference's own
+ *     known-answer tests tests/radix.rs:9-106 (fixtures in tests/golden/radix_keys.json).
+ *   - per-splat projection, SH colour, per-pixel falloff and blending: PARITY UNPINNED
+ *     against a running reference (none can run here). Pinned only by (a) float64
+ *     closed-form single-splat cases and (b) the coarse thresholds of
+ *     tests/visibility_render.rs:245-274 applied to the oracle's image.
+ *
+ * Arithmetic contract (so "bit-exact sort order" is well defined; WGSL leaves the
+ * evaluation order of dot()/matrix products implementation-defined):
+ *   - every operation is IEEE-754 binary32, round-to-nearest-even, NO fused multiply-add
+ *     (compile with -ffp-contract=off);
+ *   - dot(a,b)      = ((a0*b0 + a1*b1) + a2*b2) [+ a3*b3]
+ *   - (M * v)[r]    = (((M[0][r]*v0 + M[1][r]*v1) + M[2][r]*v2) + M[3][r]*v3)
+ *   - (A * B)[c][r] = ((A[0][r]*B[c][0] + A[1][r]*B[c][1]) + A[2][r]*B[c][2])
+ *   - the rasteriser between the vertex and fragment stages (pixel coverage and linear
+ *     attribute interpolation, fixed-function in the reference) is evaluated in float64
+ *     ("ideal rasteriser"), its outputs rounded to binary32 before fs_main.
+ *   - the colour target is unclamped f32 (an ideal Rgba16Float/hdr target,
+ *     src/render/mod.rs:917-921), blended in draw order with
+ *     dst = src + dst * (1 - src.a)  (PREMULTIPLIED_ALPHA_BLENDING, src/render/mod.rs:946).
+ */
+#ifndef BGS_ORACLE_H
+#define BGS_ORACLE_H
+
+#include <stdint.h>
+
+#include "../include/bgs.h" /* boundary structs only: bgs_view, bgs_settings, bgs_sort_entry */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Planar f32 cloud (src/gaussian/formats/planar_3d.rs:45-54). */
+typedef struct oracle_cloud {
+    uint32_t n;
+    const float* position_visibility; /* n*4  */
+    const float* spherical_harmonic;  /* n*48 */
+    const float* rotation;            /* n*4 [w,x,y,z] */
+    const float* scale_opacity;       /* n*4  */
+} oracle_cloud;
+
+/* ShaderDefines::for_radix_depth_bits (src/render/mod.rs:715-758): bits -> places, key
+ * shift, initial ping-pong parity. Returns 0, or -1 for an unsupported bit count. */
+int oracle_radix_defines(uint32_t depth_bits, uint32_t* digit_places, uint32_t* key_shift,
+                         uint32_t* initial_parity);
+
+/* tests/radix.rs:96-106 helper pair: dist2 (scalar L->R) and the key derived from it. */
+float oracle_distance_squared(const float position[3], const float camera[3]);
+uint32_t oracle_radix_depth_key(float dist2, uint32_t key_shift);
+
+/* radix_sort_a keygen (src/sort/radix.wgsl:86-101) for SORT_RADIX;
+ * rayon keygen (src/sort/rayon.rs:86-98) for SORT_RAYON/STD;
+ * SortedEntries::new (src/sort/mod.rs:347-354) for SORT_NONE. */
+int oracle_keygen(const float* position_visibility, uint32_t n, const bgs_view* view,
+                  const bgs_settings* settings, bgs_sort_entry* out);
+
+/* radix_sort_b + radix_sort_c_* (src/sort/radix.wgsl:109-279): stable LSD, 8-bit
+ * digits, `places` passes over 1024-entry tiles. entries is sorted in place; tmp has n. */
+void oracle_radix_sort(bgs_sort_entry* entries, uint32_t n, uint32_t places,
+                       bgs_sort_entry* tmp);
+
+/* par_sort_unstable_by descending f32 (src/sort/rayon.rs:100-104). Ties (unspecified in
+ * the reference) are broken by ascending index so the result is deterministic. */
+void oracle_sort_descending_f32(bgs_sort_entry* entries, uint32_t n);
+
+/* keygen + the sort selected by settings->sort_mode. out has n entries. */
+int oracle_sort(const float* position_visibility, uint32_t n, const bgs_view* view,
+                const bgs_settings* settings, bgs_sort_entry* out);
+
+/* Everything vs_points (src/render/gaussian.wgsl:184-436) outputs for one instance,
+ * for all four quad vertices. */
+typedef struct oracle_vs_out {
+    int32_t discard;            /* position = 0,0,0,0 (degenerate quad)                 */
+    float projected[4];         /* world_to_clip(transformed_position)                  */
+    float bb[4][4];             /* per vertex: xy = NDC offset, zw = second pair        */
+    float color[4];             /* rgb, opacity * global_opacity                        */
+    float cov2d[3];             /* 3D: (a,b,c)                                          */
+    float conic[3];             /* AABB 3D                                              */
+    float cutoff;
+    float local_to_pixel[9];    /* 2D: columns u,v,w                                    */
+    float mean_2d[2];           /* 2D                                                   */
+    float extent[2];            /* 2D                                                   */
+    float radius[2];            /* 2D: bb.zw                                            */
+} oracle_vs_out;
+
+int oracle_vs(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_view* view,
+              const bgs_settings* settings, oracle_vs_out* out);
+
+/* Draw entries[0..count) in order into the pixel window [x0,x1) x [y0,y1) of the
+ * viewport-sized target. rgba_out is (y1-y0)*(x1-x0)*4 floats, row 0 = y0 (top).
+ * ambiguity_out (may be NULL, same pixel count, 1 float each) accumulates, per pixel, an
+ * upper bound on how much the result could change if every coverage / discard decision
+ * that lies within rounding distance of its threshold flipped. Uses OpenMP over rows. */
+int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                  const bgs_view* view, const bgs_settings* settings, int32_t x0, int32_t y0,
+                  int32_t x1, int32_t y1, float* rgba_out, float* ambiguity_out);
+
+/* f16 planes -> f32 planes (src/render/planar.wgsl:117-176). */
+void oracle_decode_f16(uint32_t n, const uint32_t* sh_h2 /* n*24 */,
+                       const uint32_t* rot_scale_opacity /* n*4 */, float* sh_out /* n*48 */,
+                       float* rotation_out /* n*4 */, float* scale_opacity_out /* n*4 */);
+/* f32 planes -> f16 planes (src/gaussian/f16.rs:38-55,244-252; SH pairing
+ * src/render/planar.wgsl:283-292). Round-to-nearest-even like the `half` crate. */
+void oracle_encode_f16(uint32_t n, const float* sh /* n*48 */, const float* rotation,
+                       const float* scale_opacity, uint32_t* sh_h2_out,
+                       uint32_t* rot_scale_opacity_out);
+
+/* Per-frame tile-instance statistics of the reference-equivalent quad set: number of
+ * non-discarded splats and the sum over splats of 16x16 tiles overlapped by the quad's
+ * pixel bounding box (used to size benches and to cross-check the binning stage). */
+int oracle_instance_stats(const oracle_cloud* cloud, const bgs_sort_entry* entries,
+                          uint32_t count, const bgs_view* view, const bgs_settings* settings,
+                          uint32_t* visible_out, uint64_t* tile_instances_out);
+
+int oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

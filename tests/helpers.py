@@ -1,0 +1,261 @@
+"""Shared test helpers: scene builders, the host shim of the device math header, and a numpy
+emulation of the device pipeline's DATA FLOW (keys -> stable sort -> records -> front-to-back
+tile blend) that lets the product's per-splat arithmetic be checked against the oracle on a
+machine without a GPU. None of this is a product path."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from bevy_gaussian_splatting_amd import (
+    CloudSettings, GaussianMode, PlanarGaussian3d, SortMode, View, random_gaussians_3d_seeded)
+from bevy_gaussian_splatting_amd.camera import BgsView
+from bevy_gaussian_splatting_amd.gaussian import Gaussian3d, SphericalHarmonicCoefficients
+from bevy_gaussian_splatting_amd.settings import BgsSettings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SHIM_DIR = os.path.join(HERE, "host_shim")
+SHIM_SRC = os.path.join(SHIM_DIR, "device_math_shim.cpp")
+SHIM_LIB = os.path.join(SHIM_DIR, "libdevice_math_shim.so")
+CSRC = os.path.join(HERE, "..", "bevy_gaussian_splatting_amd", "csrc")
+
+
+class FrameParamsC(ctypes.Structure):
+    """ctypes image of bgs::FrameParams (bevy_gaussian_splatting_amd/csrc/bgs_device.h)."""
+
+    _fields_ = [
+        ("transform", ctypes.c_float * 16),
+        ("view_from_world", ctypes.c_float * 16),
+        ("clip_from_world", ctypes.c_float * 16),
+        ("cam", ctypes.c_float * 3),
+        ("focal_x", ctypes.c_float), ("focal_y", ctypes.c_float),
+        ("viewport_w", ctypes.c_float), ("viewport_h", ctypes.c_float),
+        ("global_opacity", ctypes.c_float), ("global_scale", ctypes.c_float),
+        ("n", ctypes.c_uint32), ("key_shift", ctypes.c_uint32),
+        ("gaussian_mode", ctypes.c_uint32), ("aabb", ctypes.c_uint32),
+        ("adaptive_radius", ctypes.c_uint32), ("color_space", ctypes.c_uint32),
+        ("sh_degree", ctypes.c_uint32), ("sort_mode", ctypes.c_uint32),
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("tiles_x", ctypes.c_int32), ("tiles_y", ctypes.c_int32),
+    ]
+
+
+class ShimOut(ctypes.Structure):
+    _fields_ = [
+        ("visible", ctypes.c_int32), ("draw", ctypes.c_int32),
+        ("color", ctypes.c_float * 4),
+        ("cx", ctypes.c_float), ("cy", ctypes.c_float),
+        ("p", ctypes.c_float * 5),
+        ("radius", ctypes.c_float),
+        ("tx0", ctypes.c_int32), ("ty0", ctypes.c_int32), ("tx1", ctypes.c_int32), ("ty1", ctypes.c_int32),
+        ("mean", ctypes.c_float * 2),
+        ("T", ctypes.c_float * 9),
+        ("quad_m", ctypes.c_float * 4),
+        ("bounds", ctypes.c_float * 4),
+    ]
+
+
+_shim = None
+
+
+def shim() -> ctypes.CDLL:
+    """Build (g++, -ffp-contract=off) and load the host shim of splat_math.h."""
+    global _shim
+    if _shim is not None:
+        return _shim
+    deps = [SHIM_SRC] + [os.path.join(CSRC, f) for f in ("splat_math.h", "bgs_device.h", "frame_params.h")]
+    if not os.path.exists(SHIM_LIB) or any(os.path.getmtime(d) > os.path.getmtime(SHIM_LIB) for d in deps):
+        subprocess.run(
+            ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC",
+             "-Wno-unknown-pragmas", SHIM_SRC, "-o", SHIM_LIB], check=True, capture_output=True)
+    l = ctypes.CDLL(SHIM_LIB)
+    fp = ctypes.POINTER(ctypes.c_float)
+    l.shim_fill_params.argtypes = [ctypes.c_uint32, ctypes.POINTER(BgsView), ctypes.POINTER(BgsSettings),
+                                   ctypes.POINTER(FrameParamsC)]
+    l.shim_fill_params.restype = None
+    l.shim_frame_params_size.argtypes = []
+    l.shim_frame_params_size.restype = ctypes.c_uint32
+    l.shim_sort_keys.argtypes = [ctypes.POINTER(FrameParamsC), fp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    l.shim_sort_keys.restype = None
+    l.shim_project.argtypes = [ctypes.POINTER(FrameParamsC), ctypes.c_uint32, fp, fp, fp, fp, ctypes.POINTER(ShimOut)]
+    l.shim_project.restype = None
+    assert l.shim_frame_params_size() == ctypes.sizeof(FrameParamsC)
+    _shim = l
+    return l
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def frame_params(n: int, view: View, settings: CloudSettings) -> FrameParamsC:
+    fpc = FrameParamsC()
+    v, s = view.to_native(), settings.to_native()
+    shim().shim_fill_params(n, ctypes.byref(v), ctypes.byref(s), ctypes.byref(fpc))
+    return fpc
+
+
+def device_keys(cloud: PlanarGaussian3d, view: View, settings: CloudSettings) -> np.ndarray:
+    """Keys exactly as keygen_kernel writes them (SORT_RAYON keys still inverted)."""
+    fpc = frame_params(len(cloud), view, settings)
+    keys = np.empty(len(cloud), np.uint32)
+    shim().shim_sort_keys(ctypes.byref(fpc), _fp(cloud.position_visibility), len(cloud),
+                          keys.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    return keys
+
+
+def device_sorted_entries(cloud, view, settings) -> np.ndarray:
+    """What bgs_sort must return, derived from the product's key arithmetic + a stable sort."""
+    keys = device_keys(cloud, view, settings)
+    n = len(cloud)
+    out = np.empty(n, dtype=[("key", np.uint32), ("index", np.uint32)])
+    if settings.sort_mode == SortMode.NONE:
+        out["key"], out["index"] = keys, np.arange(n, dtype=np.uint32)
+        return out
+    order = np.argsort(keys, kind="stable").astype(np.uint32)
+    out["index"] = order
+    out["key"] = keys[order]
+    if settings.sort_mode in (SortMode.Rayon, SortMode.Std):
+        out["key"] = ~out["key"]
+    return out
+
+
+def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings, entries=None) -> np.ndarray:
+    """numpy emulation of project_emit + raster: records from the HOST BUILD of splat_math.h,
+    composited front-to-back per pixel exactly as raster_kernel does (same record fields, same
+    formulas), without tiling. Small scenes only."""
+    if entries is None:
+        entries = device_sorted_entries(cloud, view, settings)
+    n = len(cloud)
+    W, H = view.width, view.height
+    fpc = frame_params(n, view, settings)
+    sentinel = np.uint32(0xFFFFFFFF >> fpc.key_shift)
+    if settings.sort_mode == SortMode.Radix:
+        count = int((entries["key"] != sentinel).sum())
+    else:
+        count = n
+    qx, qy = np.meshgrid(np.arange(W, dtype=np.float32) + np.float32(0.5),
+                         np.arange(H, dtype=np.float32) + np.float32(0.5))
+    T = np.ones((H, W), np.float32)
+    C = np.zeros((H, W, 3), np.float32)
+    out = ShimOut()
+    surfel = settings.gaussian_mode == GaussianMode.Gaussian2d and settings.aabb
+    eps = np.float32(1.0 / 65536.0)
+    for j in range(count):
+        e = entries[count - 1 - j]
+        si = int(e["index"])
+        shim().shim_project(ctypes.byref(fpc), int(e["key"]), _fp(cloud.position_visibility[si]),
+                            _fp(cloud.rotation[si]), _fp(cloud.scale_opacity[si]),
+                            _fp(cloud.spherical_harmonic[si]), ctypes.byref(out))
+        if not out.draw:
+            continue
+        dx = qx - np.float32(out.cx)
+        dy = qy - np.float32(out.cy)
+        p = [np.float32(v) for v in out.p]
+        col = [np.float32(v) for v in out.color]
+        with np.errstate(all="ignore"):
+            if not settings.aabb:
+                u = p[0] * dx + p[1] * dy
+                v = p[2] * dx + p[3] * dy
+                hit = (np.abs(u) <= 1) & (np.abs(v) <= 1)
+                sigma = np.float32(1.0) / np.float32(3.0)
+                power = (u * u + v * v) * (np.float32(-1.0) / (np.float32(2.0) * sigma * sigma))
+            elif not surfel:
+                u = p[0] * dx
+                v = p[1] * dy
+                hit = (np.abs(u) <= 1) & (np.abs(v) <= 1)
+                power = np.float32(-0.5) * (p[2] * u * u + p[4] * v * v) + p[3] * u * v
+                hit &= ~(power > 0)
+            else:
+                u = p[0] * dx
+                v = p[1] * dy
+                hit = (np.abs(u) <= 1) & (np.abs(v) <= 1)
+                rad = np.float32(out.radius)
+                mx, my = np.float32(out.mean[0]), np.float32(out.mean[1])
+                pcx = u * rad + mx
+                pcy = v * rad * (np.float32(W) / np.float32(H)) + my
+                Tm = [np.float32(t) for t in out.T]
+                hu = [pcx * Tm[6 + i] - Tm[i] for i in range(3)]
+                hv = [pcy * Tm[6 + i] - Tm[3 + i] for i in range(3)]
+                cpx = hu[1] * hv[2] - hv[1] * hu[2]
+                cpy = hu[2] * hv[0] - hv[2] * hu[0]
+                cpz = hu[0] * hv[1] - hv[0] * hu[1]
+                us, vs = cpx / cpz, cpy / cpz
+                s3 = us * us + vs * vs
+                s2 = np.float32(2.0) * ((mx - pcx) ** 2 + (my - pcy) ** 2)
+                power = np.float32(-0.5) * np.minimum(s3, s2)
+                hit &= ~(power > 0)
+            alpha = np.minimum(np.exp(power) * col[3], np.float32(0.999)).astype(np.float32)
+        hit &= ~(T < eps)
+        w = np.where(hit, T * alpha, np.float32(0)).astype(np.float32)
+        C[..., 0] += w * col[0]
+        C[..., 1] += w * col[1]
+        C[..., 2] += w * col[2]
+        T = np.where(hit, T * (np.float32(1) - alpha), T).astype(np.float32)
+    clear = np.asarray(view.clear_color, np.float32)
+    img = np.empty((H, W, 4), np.float32)
+    img[..., :3] = C + T[..., None] * clear[:3]
+    img[..., 3] = (np.float32(1) - T) + T * clear[3]
+    return img
+
+
+# ---- scenes of the reference's own tests / tools ------------------------------------------
+
+def visibility_test_cloud() -> PlanarGaussian3d:
+    """tests/visibility_render.rs:199-222."""
+    red = SphericalHarmonicCoefficients()
+    red.set(0, 6.0)
+    gs = []
+    for x in (-0.35, 0.35):
+        for y in (-0.35, 0.35):
+            for z in (-0.35, 0.35):
+                gs.append(Gaussian3d(np.array([x, y, z, 1.0], np.float32), red.coefficients.copy(),
+                                     np.array([1.0, 0.0, 0.0, 0.0], np.float32),
+                                     np.array([0.22, 0.22, 0.22, 0.85], np.float32)))
+    gs.append(gs[0])
+    return PlanarGaussian3d.from_interleaved(gs)
+
+
+def surfel_plane_cloud(grid: int = 10, spacing: float = 5.0) -> PlanarGaussian3d:
+    """tools/surfel_plane.rs:64-91 (2DGS grid: scale (2,1,0.01), opacity 0.5, rotation about z)."""
+    red = SphericalHarmonicCoefficients()
+    red.set(0, 5.0)
+    gs = []
+    for i in range(grid):
+        for j in range(grid):
+            x = i * spacing - (grid * spacing) / 2.0
+            y = j * spacing - (grid * spacing) / 2.0
+            angle = np.pi / 2.0 * (i + 1) / grid
+            # Quat::from_rotation_z -> (x,y,z,w) = (0,0,sin,cos); reference stores [w,x,y,z]
+            rot = np.array([np.cos(angle / 2), 0.0, 0.0, np.sin(angle / 2)], np.float32)
+            gs.append(Gaussian3d(np.array([x, y, 0.0, 1.0], np.float32), red.coefficients.copy(), rot,
+                                 np.array([2.0, 1.0, 0.01, 0.5], np.float32)))
+    return PlanarGaussian3d.from_interleaved(gs)
+
+
+def aabb_obb_pair_cloud() -> PlanarGaussian3d:
+    """tools/compare_aabb_obb.rs:19-58."""
+    blue = SphericalHarmonicCoefficients()
+    blue.set(2, 5.0)
+    g = Gaussian3d(np.array([0.0, 0.0, 0.0, 1.0], np.float32), blue.coefficients.copy(),
+                   np.array([0.89, 0.0, -0.432, 0.144], np.float32),
+                   np.array([10.0, 1.0, 1.0, 0.5], np.float32))
+    return PlanarGaussian3d.from_interleaved([g, g])
+
+
+def scene_like(n: int, seed: int):
+    """the reference's random distribution, plus the 'scene-like' global_scale."""
+    return random_gaussians_3d_seeded(n, seed)
+
+
+def tolerance_mask(ref: np.ndarray, got: np.ndarray, amb: np.ndarray | None, atol=1e-3, rtol=1e-4):
+    """Per-pixel pass mask for |got - ref| <= atol + rtol*|ref| (+ the oracle's ambiguity
+    bound where a coverage decision sits within rounding distance of its threshold)."""
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    lim = atol + rtol * np.abs(ref.astype(np.float64))
+    if amb is not None:
+        lim = lim + amb.astype(np.float64)[..., None]
+    return err <= lim, err

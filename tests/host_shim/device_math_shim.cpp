@@ -1,0 +1,68 @@
+// device_math_shim.cpp — TEST-ONLY host build of the product's device math header.
+//
+// Compiles bevy_gaussian_splatting_amd/csrc/splat_math.h with g++ (BGS_HD expands to nothing)
+// so tests/test_device_math_host.py can check the per-splat arithmetic the HIP kernels run
+// against the oracle WITHOUT a GPU. This is a pre-flight check, not a product path: libbgs
+// never runs these functions on the host and has no CPU fallback.
+#include "../../bevy_gaussian_splatting_amd/csrc/frame_params.h"
+#include "../../bevy_gaussian_splatting_amd/csrc/splat_math.h"
+
+using namespace bgs;
+
+struct ShimOut {
+    int32_t visible, draw;
+    float color[4];
+    float cx, cy;
+    float p[5];
+    float radius;
+    int32_t tx0, ty0, tx1, ty1;
+    float mean[2];
+    float T[9];
+    float quad_m[4];
+    float bounds[4];  // minx maxx miny maxy
+};
+
+struct ShFloat {
+    const float* base;
+    V3 operator()(int k) const { return V3{base[3 * k], base[3 * k + 1], base[3 * k + 2]}; }
+};
+
+extern "C" {
+
+void shim_fill_params(uint32_t n, const bgs_view* view, const bgs_settings* s, FrameParams* fp) {
+    fill_frame_params(n, view, s, *fp);
+}
+
+uint32_t shim_frame_params_size(void) { return (uint32_t)sizeof(FrameParams); }
+
+// keys exactly as keygen_kernel stores them (before any final-pass un-inversion)
+void shim_sort_keys(const FrameParams* fp, const float* pos_vis, uint32_t n, uint32_t* keys_out) {
+    for (uint32_t i = 0; i < n; ++i)
+        keys_out[i] = sort_key(*fp, V3{pos_vis[4 * i], pos_vis[4 * i + 1], pos_vis[4 * i + 2]});
+}
+
+void shim_project(const FrameParams* fp, uint32_t key, const float* pos, const float* rot,
+                  const float* so, const float* sh48, ShimOut* out) {
+    Projected pr;
+    memset(&pr, 0, sizeof pr);
+    project_splat(*fp, key, V3{pos[0], pos[1], pos[2]}, rot, so, ShFloat{sh48}, pr);
+    memset(out, 0, sizeof *out);
+    out->visible = pr.visible;
+    out->draw = pr.draw;
+    if (!pr.draw) return;
+    memcpy(out->color, pr.color, sizeof out->color);
+    out->cx = pr.quad.cx;
+    out->cy = pr.quad.cy;
+    memcpy(out->p, pr.p, sizeof out->p);
+    out->radius = pr.radius;
+    out->tx0 = pr.tx0; out->ty0 = pr.ty0; out->tx1 = pr.tx1; out->ty1 = pr.ty1;
+    out->mean[0] = pr.surfel.mean_x;
+    out->mean[1] = pr.surfel.mean_y;
+    memcpy(out->T, pr.surfel.T, sizeof out->T);
+    out->quad_m[0] = pr.quad.m00; out->quad_m[1] = pr.quad.m01;
+    out->quad_m[2] = pr.quad.m10; out->quad_m[3] = pr.quad.m11;
+    out->bounds[0] = pr.quad.minx; out->bounds[1] = pr.quad.maxx;
+    out->bounds[2] = pr.quad.miny; out->bounds[3] = pr.quad.maxy;
+}
+
+}  // extern "C"
