@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the sort + rasterize hot path (contract in the task brief).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one view: keygen -> depth radix sort -> project ->
+tile-instance emit -> tile sort -> ranges -> tile raster of a 1920x1080 frame, with the cloud
+already resident in HBM (uploaded once before the timed region, like the reference's asset
+upload). Workload = BASELINE.json configs[1]: 1M random 3DGS splats (the reference's own
+`random_gaussians_3d` distributions), f32 planar cloud, SH degree 3, `CloudSettings::default()`,
+examples/headless.rs camera. With N > 1 ranks every rank renders ITS camera (camera g = the
+headless camera yawed g*45 degrees) of the replicated cloud and rank 0 gathers the N framebuffers
+over RCCL each step (weak scaling: per-GPU work fixed).
+
+Prints ONE JSON line on rank 0. `value` = whole-job frames/s. Extra objects:
+  roofline      dominant kernel, algorithmic bytes per launch / average launch duration measured
+                live with HIP events on the library's own stream (bgs_get_stats)
+  cpu_baseline  the oracle ("port": C restatement, OpenMP) timed on this host on a bounded sample
+  stages        per-stage ms / algorithmic GB/s / %peak, V, I
+  sort_msplats_per_s   "Msplats/s sorted" (keygen + depth sort only, bgs_sort)
+  scene_like    the same workload with global_scale = 0.05
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+N_SPLATS = 1_000_000
+SEED = 2
+WIDTH, HEIGHT = 1920, 1080
+
+
+def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) -> dict:
+    """Algorithmic bytes per stage (SURVEY 8(d) terms) and the launches each stage comprises."""
+    N, V, I = stats["splat_count"], stats["visible_count"], stats["instance_count"]
+    k, kt = stats["depth_passes"], stats["tile_passes"]
+    P = WIDTH * HEIGHT
+    B = cloud_bytes_per_splat
+    return {
+        "keygen": {"bytes": N * 16 + N * 8, "launches": 1},
+        "depth_sort": {"bytes": k * N * 16, "launches": max(k, 1)},
+        "project": {"bytes": V * (B - 16) + V * rec_bytes + I * 8, "launches": 1},
+        "tile_sort": {"bytes": kt * I * 16, "launches": max(kt, 1)},
+        "ranges": {"bytes": I * 8, "launches": 1},  # not in SURVEY's bytes_frame (pure overhead pass)
+        "raster": {"bytes": I * (4 + rec_bytes) + P * 16, "launches": 1},
+    }
+
+
+def measure(plugin, handle, view, settings, steps, warmup, after_step=None, barrier=None):
+    """W untimed + K timed steps; returns (seconds, mean per-stage ms over the timed steps, stats)."""
+    for _ in range(warmup):
+        plugin.render(handle, view, settings, download=False)
+        if after_step:
+            after_step()
+    acc = None
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plugin.render(handle, view, settings, download=False)  # returns after the frame completed
+        st = plugin.stats()
+        if after_step:
+            after_step()
+        ms = st["stage_ms"]
+        acc = ms if acc is None else {k: acc[k] + ms[k] for k in ms}
+    if barrier:
+        barrier()
+    dt = time.perf_counter() - t0
+    mean = {k: v / max(steps, 1) for k, v in (acc or {}).items()}
+    return dt, mean, st
+
+
+def cpu_baseline(cloud, view, settings):
+    """The oracle (C restatement, OpenMP over all host cores) on a bounded sample of the SAME
+    workload: the full 1M-splat sort + the vertex stage for every splat + the raster of the
+    centred 480x270 window (1/16 of the frame), raster time scaled x16."""
+    from oracle import oracle
+
+    oracle.build()
+    t0 = time.perf_counter()
+    entries = oracle.sort(cloud, view, settings)
+    t_sort = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.render(cloud, entries, view, settings, window=(0, 0, 1, 1))
+    t_vs = time.perf_counter() - t0
+    x0, y0 = (WIDTH - 480) // 2, (HEIGHT - 270) // 2
+    t0 = time.perf_counter()
+    oracle.render(cloud, entries, view, settings, window=(x0, y0, x0 + 480, y0 + 270))
+    t_win = max(time.perf_counter() - t0 - t_vs, 1e-6)
+    t_frame = t_sort + t_vs + 16.0 * t_win
+    return {
+        "value": 1.0 / t_frame,
+        "unit": "frames/s",
+        "cores": oracle.max_threads(),
+        "kind": "port",
+        "sample": ("oracle/bgs_oracle.c (gcc -O2 -fopenmp): full 1M-splat keygen+LSD radix sort "
+                   f"({t_sort:.3f}s) + vertex stage of all splats ({t_vs:.3f}s) + raster of the centred "
+                   f"480x270 window ({t_win:.2f}s, scaled x16 to the 1920x1080 frame)"),
+        "sort_msplats_per_s": len(cloud) / t_sort / 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--splats", type=int, default=N_SPLATS)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+
+    from bevy_gaussian_splatting_amd import CloudSettings, GaussianSplattingPlugin, random_gaussians_3d_seeded
+    from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor, gather_framebuffers, headless_view
+
+    cloud = random_gaussians_3d_seeded(args.splats, SEED)  # replicated on every rank
+    plugin = GaussianSplattingPlugin(local_rank)
+    handle = plugin.upload(cloud)
+    view = headless_view(rank, WIDTH, HEIGHT)  # rank g owns camera g
+    settings = CloudSettings()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gather_ms = [0.0]
+    after = None
+    if dist is not None:
+        def after():
+            t = framebuffer_as_tensor(plugin, HEIGHT, WIDTH)
+            t0 = time.perf_counter()
+            gather_framebuffers(t.unsqueeze(0), dst=0)
+            torch.cuda.synchronize()
+            gather_ms[0] += (time.perf_counter() - t0) * 1e3
+
+    # ---- headline: reference distribution, CloudSettings::default() -------------------------
+    dt, stage_ms, st = measure(plugin, handle, view, settings, args.steps, args.warmup, after, barrier)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = world * args.steps / dt
+
+    # ---- side measurements on rank 0 (outside the timed region) -----------------------------
+    out = None
+    if rank == 0:
+        table = stage_table(st, 240)
+        stages = {}
+        for name, info in table.items():
+            ms = stage_ms.get(name, 0.0)
+            gbs = info["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            stages[name] = {"ms": round(ms, 4), "algorithmic_MB": round(info["bytes"] / 1e6, 2),
+                            "GBps": round(gbs, 1), "pct_hbm_peak": round(100 * gbs / HBM_PEAK_GBS, 2)}
+        dom = max(stages, key=lambda k: stages[k]["ms"])
+        launches = table[dom]["launches"]
+        per_launch_bytes = table[dom]["bytes"] / launches
+        per_launch_s = stage_ms[dom] * 1e-3 / launches if stage_ms.get(dom, 0) > 0 else float("inf")
+        achieved = per_launch_bytes / per_launch_s / 1e9
+        kernel_names = {"keygen": "keygen_kernel", "depth_sort": "onesweep_kernel", "project": "project_emit_kernel",
+                        "tile_sort": "onesweep_kernel", "ranges": "tile_ranges_kernel", "raster": "raster_kernel"}
+        roofline = {"bound": "hbm", "kernel": kernel_names[dom], "stage": dom,
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": int(per_launch_bytes), "launch_ms": round(per_launch_s * 1e3, 4)}
+        frame_bytes = st["algorithmic_bytes"]
+        frame_ms = sum(stage_ms.values())
+        frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9 if frame_ms > 0 else 0.0
+
+        # "Msplats/s sorted": keygen + depth sort only
+        for _ in range(3):
+            plugin.sort(handle, view, settings, download=False)
+        t0 = time.perf_counter()
+        reps = max(args.steps, 10)
+        sort_dev_ms = 0.0
+        for _ in range(reps):
+            plugin.sort(handle, view, settings, download=False)
+            sort_dev_ms += plugin.stats()["total_ms"]
+        sort_wall = (time.perf_counter() - t0) / reps
+        sort_dev_ms /= reps
+        sort_bytes = plugin.stats()["algorithmic_bytes"]
+
+        # scene-like variant: global_scale = 0.05
+        s2 = CloudSettings(global_scale=0.05)
+        dt2, stage2, st2 = measure(plugin, handle, view, s2, args.steps, args.warmup)
+        ms2 = sum(stage2.values())
+
+        out = {
+            "metric": "frames/sec @1080p, 1M-splat 3DGS (sort + rasterize every frame)",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.splats}-splat 3DGS f32 planar cloud (seed {SEED}, reference random_gaussians_3d "
+                                   "distributions), 1920x1080, SH degree 3, CloudSettings::default(), "
+                                   "examples/headless.rs camera; one camera per GPU",
+                       "parallelism": f"views{world}", "sort": "radix32", "global_scale": 1.0},
+            "roofline": roofline,
+            "frame": {"device_ms": round(frame_ms, 4), "algorithmic_GB": round(frame_bytes / 1e9, 4),
+                      "GBps": round(frame_gbs, 1), "pct_hbm_peak": round(100 * frame_gbs / HBM_PEAK_GBS, 2),
+                      "visible_splats": st["visible_count"], "tile_instances": st["instance_count"],
+                      "gather_ms_per_step": round(gather_ms[0] / max(args.steps + args.warmup, 1), 4)},
+            "stages": stages,
+            "sort_msplats_per_s": round(args.splats / (sort_dev_ms * 1e-3) / 1e6, 1) if sort_dev_ms > 0 else None,
+            "sort": {"device_ms": round(sort_dev_ms, 4), "wall_ms": round(sort_wall * 1e3, 4),
+                     "GBps": round(sort_bytes / (sort_dev_ms * 1e-3) / 1e9, 1) if sort_dev_ms > 0 else None},
+            "scene_like": {"global_scale": 0.05, "value": round(args.steps / dt2, 2), "unit": "frames/s",
+                           "device_ms": round(ms2, 4), "visible_splats": st2["visible_count"],
+                           "tile_instances": st2["instance_count"],
+                           "GBps": round(st2["algorithmic_bytes"] / (ms2 * 1e-3) / 1e9, 1) if ms2 > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cloud, view, settings)
+            out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)
+            out["cpu_baseline"]["sort_msplats_per_s"] = round(out["cpu_baseline"]["sort_msplats_per_s"], 2)
+        else:
+            out["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+    handle.free()
+    plugin.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""Multi-GPU: independent views (cameras) sharded one per GPU, one gather of framebuffers.
+
+The reference keys its sort state by camera (`SortTrigger.camera_index`, src/sort/mod.rs:143-150;
+per-camera chunk of the entry buffer, src/render/mod.rs:1548-1554) and has no collective of any
+kind. Views are independent units, so the path shards with NO data-path collective: rank g owns
+camera g and a full replica of the cloud; the only exchange is the final gather of the
+framebuffers to rank 0 (RCCL over xGMI on GPUs: every non-root rank sends on its own link; gloo
+in the CPU tests).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import numpy as np
+
+from .camera import View
+
+
+def assign_views(num_views: int, world_size: int) -> List[List[int]]:
+    """View g goes to rank g % world_size (one view per GPU when num_views == world_size)."""
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    for g in range(num_views):
+        out[g % world_size].append(g)
+    return out
+
+
+def headless_view(g: int, width: int = 1920, height: int = 1080) -> View:
+    """SURVEY 8(d) cfg 5: camera g = the examples/headless.rs camera yawed by g * 45 degrees about
+    +Y at the same position; `order` = g is the camera's index into the sorted entries."""
+    return View.headless(width, height, yaw=g * math.pi / 4.0, order=g)
+
+
+def gather_framebuffers(local, dst: int = 0, group=None):
+    """Gather every rank's framebuffer tensor ([k, H, W, 4] float32, same shape on all ranks)
+    to `dst`. Returns the list of per-rank tensors on `dst`, None elsewhere. Works on any
+    torch.distributed backend (nccl == RCCL on ROCm, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [local]
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    if rank == dst:
+        bufs = [torch.empty_like(local) for _ in range(world)]
+        dist.gather(local, gather_list=bufs, dst=dst, group=group)
+        return bufs
+    dist.gather(local, gather_list=None, dst=dst, group=group)
+    return None
+
+
+class _DeviceArray:
+    """Zero-copy view of a raw device pointer for torch (CUDA array interface v2)."""
+
+    def __init__(self, ptr: int, shape, typestr: str = "<f4"):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def framebuffer_as_tensor(plugin, height: int, width: int, device: Optional[str] = None):
+    """Wrap the device framebuffer of the last `render` as a torch tensor [H, W, 4] without a
+    copy (so RCCL can send it straight from where the rasteriser wrote it)."""
+    import torch
+
+    ptr, nbytes = plugin.framebuffer_device_ptr()
+    assert nbytes == height * width * 16
+    return torch.as_tensor(_DeviceArray(ptr, (height, width, 4)), device=device or f"cuda:{plugin.device}")

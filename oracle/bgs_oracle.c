@@ -217,9 +217,17 @@ static int cmp_desc_f32(const void* pa, const void* pb) {
     const bgs_sort_entry* a = (const bgs_sort_entry*)pa;
     const bgs_sort_entry* b = (const bgs_sort_entry*)pb;
     float fa = u2f(a->key), fb = u2f(b->key);
-    /* src/sort/rayon.rs:100-104: b.partial_cmp(a), NaN -> Equal */
-    if (fb < fa) return -1;
-    if (fb > fa) return 1;
+    /* src/sort/rayon.rs:100-104: b.partial_cmp(a), NaN -> Equal. With a NaN key the reference's
+     * unstable sort leaves the order unspecified; to stay a total order the oracle then compares
+     * the raw bits (descending), which for the non-negative finite dist2 values is the same
+     * order as the float comparison. */
+    if (fa != fa || fb != fb) {
+        if (b->key < a->key) return -1;
+        if (b->key > a->key) return 1;
+    } else {
+        if (fb < fa) return -1;
+        if (fb > fa) return 1;
+    }
     return (a->index > b->index) - (a->index < b->index);
 }
 

@@ -1,0 +1,87 @@
+"""The C-ABI library: loads, exports every symbol include/bgs.h declares, fails loudly
+without a device, and its two pure-host helpers agree with the Python mirror. No compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from bevy_gaussian_splatting_amd import CloudSettings, View, _native
+from bevy_gaussian_splatting_amd.camera import BgsView
+from bevy_gaussian_splatting_amd.settings import BgsSettings
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "bgs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bgs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built_and_exports_every_declared_symbol():
+    lib = _native.load()  # raises ImportError if the HIP extension is not built
+    names = _declared()
+    assert len(names) >= 19
+    assert set(names) == set(_native.EXPORTED_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), f"libbgs.so does not export {n}"
+    assert lib.bgs_version() == (0 << 16) | 1
+
+
+def test_struct_layouts_match_the_header():
+    assert ctypes.sizeof(BgsView) == (16 * 4 + 8) * 4
+    assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8) * 4
+    assert ctypes.sizeof(_native.BgsSortEntry) == 8
+    assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 4 * 4 + 8 + 8
+    # the ctypes images include natural padding exactly like the C structs
+    assert _native.BgsStats.instance_count.offset % 8 == 0
+
+
+def test_settings_default_equals_cloud_settings_default():
+    lib = _native.load()
+    s = BgsSettings()
+    lib.bgs_settings_default(ctypes.byref(s))
+    py = CloudSettings().to_native()
+    for name, _ in BgsSettings._fields_:
+        a, b = getattr(s, name), getattr(py, name)
+        if name == "transform":
+            assert list(a) == list(b)
+        else:
+            assert a == b, name
+
+
+def test_view_perspective_matches_python_mirror():
+    lib = _native.load()
+    v = View.headless(1920, 1080, yaw=0.4)
+    out = BgsView()
+    wfv = v.to_native().world_from_view
+    lib.bgs_view_perspective(wfv, ctypes.c_float(np.pi / 4), ctypes.c_float(0.1), 1920, 1080, ctypes.byref(out))
+    ref = v.to_native()
+    for name in ("world_from_view", "view_from_world", "clip_from_view", "clip_from_world", "viewport", "clear_color"):
+        assert np.allclose(list(getattr(out, name)), list(getattr(ref, name)), rtol=1e-5, atol=1e-6), name
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the loud-failure path is covered on the CPU box")
+    lib = _native.load()
+    ctx = ctypes.c_void_p()
+    rc = lib.bgs_create(0, ctypes.byref(ctx))
+    assert rc == _native.BGS_EHIP and not ctx.value
+    assert b"no usable HIP device" in lib.bgs_last_error(None)
+    from bevy_gaussian_splatting_amd import GaussianSplattingPlugin
+    with pytest.raises(_native.BgsError):
+        GaussianSplattingPlugin(0)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The product path must not import/link/execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "bevy_gaussian_splatting_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "bgs_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f

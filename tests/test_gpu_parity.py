@@ -1,0 +1,355 @@
+"""GPU parity tests proper: the HIP path (through the C ABI in libbgs.so) against the oracle on
+the same seeded inputs, against the committed goldens, and — at BASELINE.json's full sizes —
+through size-independent properties plus oracle-checked crops.
+
+Bars (north_star): sort entries BIT-EXACT; RGBA within 1e-3 per channel (abs, plus 1e-4 relative
+for the unclamped HDR values, plus the oracle's ambiguity bound on the rare pixels whose coverage
+decision sits within rounding distance of a quad edge)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from bevy_gaussian_splatting_amd import (
+    CloudSettings, GaussianColorSpace, GaussianMode, PlanarGaussian3d, RadixSortDepthBits, SortMode,
+    View, random_gaussians_3d_seeded, transform_from, rotation_y)
+from bevy_gaussian_splatting_amd.multiview import headless_view
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _assert_image(ref, got, amb, frac_slack=0.002, what=""):
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    ok, err = H.tolerance_mask(ref, got, amb)
+    assert ok.all(), f"{what}: {(~ok).sum()} values out of tolerance, max err {err.max():.3e}"
+    strict, _ = H.tolerance_mask(ref, got, None)
+    assert (~strict).sum() <= frac_slack * strict.size, f"{what}: ambiguity slack used by too many pixels"
+
+
+# ---------------------------------------------------------------------------------------------
+# sort: bit-exact
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 2047, 2048, 2049, 4097, 100_000])
+def test_sort_bit_exact_ragged_sizes(plugin, oracle, n):
+    c = random_gaussians_3d_seeded(n, 100 + n)
+    v = View.headless(640, 360)
+    s = CloudSettings()
+    h = plugin.upload(c)
+    got = plugin.sort(h, v, s)
+    ref = oracle.sort(c, v, s)
+    assert np.array_equal(got["key"], ref["key"])
+    assert np.array_equal(got["index"], ref["index"])
+    h.free()
+
+
+@pytest.mark.parametrize("bits", [16, 24, 32])
+@pytest.mark.parametrize("mode", [SortMode.Radix, SortMode.Rayon, SortMode.Std, SortMode.NONE])
+def test_sort_bit_exact_modes_and_depth_bits(plugin, oracle, mode, bits):
+    c = random_gaussians_3d_seeded(50_000, 7)
+    c.position_visibility[:4, :3] = [[0, 1.5, 5], [np.nan, 0, 0], [np.inf, 0, 0], [0, 1.5, 4.9]]
+    v = View.headless(640, 360, yaw=0.3)
+    s = CloudSettings(sort_mode=mode, radix_sort_depth_bits=RadixSortDepthBits(bits),
+                      transform=transform_from((0.5, -0.25, 1.0), rotation_y(0.2)))
+    h = plugin.upload(c)
+    got = plugin.sort(h, v, s)
+    ref = oracle.sort(c, v, s)
+    assert np.array_equal(got["key"], ref["key"])
+    assert np.array_equal(got["index"], ref["index"])
+    h.free()
+
+
+def test_sort_collisions_ties_by_index(plugin, oracle):
+    """Duplicated positions (exact key collisions) and the 16-bit collapse of tests/radix.rs:82-94:
+    equal keys must stay in ascending splat index (stable LSD)."""
+    base = random_gaussians_3d_seeded(3000, 5)
+    pv = np.tile(base.position_visibility, (8, 1))
+    c = PlanarGaussian3d(pv, np.tile(base.spherical_harmonic, (8, 1)), np.tile(base.rotation, (8, 1)),
+                         np.tile(base.scale_opacity, (8, 1)))
+    v = View.headless(320, 180)
+    for bits in (16, 32):
+        s = CloudSettings(radix_sort_depth_bits=RadixSortDepthBits(bits))
+        h = plugin.upload(c)
+        got = plugin.sort(h, v, s)
+        ref = oracle.sort(c, v, s)
+        assert np.array_equal(got["key"], ref["key"]) and np.array_equal(got["index"], ref["index"])
+        same = np.diff(got["key"].astype(np.int64)) == 0
+        assert same.sum() > 1000 and np.all(np.diff(got["index"].astype(np.int64))[same] > 0)
+        h.free()
+
+
+@pytest.mark.parametrize("n,passes", [(0, 4), (1, 1), (255, 2), (2048, 4), (2049, 3), (300_001, 4),
+                                      (5_000_001, 2), (5_000_001, 4)])
+def test_onesweep_kernel_on_arbitrary_keys(plugin, n, passes):
+    """The radix kernel itself (both tile sizes: > 4M pairs uses 4096-pair tiles) on adversarial
+    keys: random with many ties, all-equal, already sorted, reversed."""
+    rng = np.random.default_rng(n + passes)
+    mask = np.uint32((1 << (8 * passes)) - 1) if passes < 4 else np.uint32(0xFFFFFFFF)
+    variants = [rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32) & mask]
+    if n <= 300_001:
+        variants += [
+            (rng.integers(0, 7, size=n, dtype=np.uint64).astype(np.uint32) * np.uint32(0x01010101)) & mask,
+            np.full(n, 0x00ABCDEF, np.uint32) & mask,
+            (np.arange(n, dtype=np.uint32) * np.uint32(3)) & mask,
+            (np.arange(n, dtype=np.uint32)[::-1].copy()) & mask,
+        ]
+    for keys in variants:
+        out = plugin.radix_sort_pairs(keys, passes)
+        order = np.argsort(keys, kind="stable").astype(np.uint32)
+        assert np.array_equal(out["index"], order)
+        assert np.array_equal(out["key"], keys[order])
+
+
+# ---------------------------------------------------------------------------------------------
+# render: <= 1e-3 per channel
+# ---------------------------------------------------------------------------------------------
+VARIANTS = {
+    "obb3d": {},
+    "aabb3d": {"aabb": True},
+    "obb3d_fixed_radius_linear": {"opacity_adaptive_radius": False,
+                                  "color_space": GaussianColorSpace.LinRec709Display, "global_scale": 0.3},
+    "obb3d_sh0": {"sh_degree": 0},
+    "obb3d_sh2_opacity2": {"sh_degree": 2, "global_opacity": 2.0},
+    "obb3d_24bit": {"radix_sort_depth_bits": RadixSortDepthBits.Bits24},
+    "obb3d_rayon": {"sort_mode": SortMode.Rayon},
+    "obb3d_unsorted": {"sort_mode": SortMode.NONE},
+    "obb2d": {"gaussian_mode": GaussianMode.Gaussian2d},
+    "aabb2d": {"gaussian_mode": GaussianMode.Gaussian2d, "aabb": True},
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+@pytest.mark.parametrize("size", [(160, 96), (250, 130)])
+def test_render_parity_small(plugin, oracle, name, size):
+    c = random_gaussians_3d_seeded(6000, 11)
+    v = View.headless(*size)
+    s = CloudSettings(**VARIANTS[name])
+    h = plugin.upload(c)
+    got = plugin.render(h, v, s)
+    e = oracle.sort(c, v, s)
+    ref, amb = oracle.render(c, e, v, s, with_ambiguity=True)
+    _assert_image(ref, got, amb, what=name)
+    st = plugin.stats()
+    vis, inst = oracle.instance_stats(c, e, v, s)
+    assert st["visible_count"] == vis
+    assert st["instance_count"] >= inst * 0.5 and st["instance_count"] <= inst * 2 + 64
+    h.free()
+
+
+def test_render_10k_config0(plugin, oracle):
+    """BASELINE.json configs[0]: 10k random splats, 256x256, single camera."""
+    c = random_gaussians_3d_seeded(10_000, 1)
+    v = View.headless(256, 256)
+    s = CloudSettings()
+    h = plugin.upload(c)
+    got = plugin.render(h, v, s)
+    e = oracle.sort(c, v, s)
+    ref, amb = oracle.render(c, e, v, s, with_ambiguity=True)
+    _assert_image(ref, got, amb, what="cfg0")
+    got_sort = plugin.sort(h, v, s)
+    assert np.array_equal(got_sort["key"], e["key"]) and np.array_equal(got_sort["index"], e["index"])
+    h.free()
+
+
+def test_render_f16_cloud(plugin, oracle):
+    c = random_gaussians_3d_seeded(8000, 3)
+    c16 = c.to_f16()
+    v = View.headless(192, 108)
+    for kw in ({}, {"aabb": True}):
+        s = CloudSettings(**kw)
+        h = plugin.upload(c16)
+        got = plugin.render(h, v, s)
+        c_dec = oracle.decode_f16(c16)
+        e = oracle.sort(c_dec, v, s)
+        ref, amb = oracle.render(c_dec, e, v, s, with_ambiguity=True)
+        _assert_image(ref, got, amb, what="f16")
+        gs = plugin.sort(h, v, s)
+        assert np.array_equal(gs["index"], e["index"])
+        h.free()
+
+
+def test_reference_tool_scenes(plugin, oracle):
+    cases = [
+        ("visibility", H.visibility_test_cloud(), View.perspective(transform_from((0, 0, 5)), 128, 128),
+         CloudSettings(sort_mode=SortMode.NONE, global_opacity=2.0, opacity_adaptive_radius=False)),
+        ("surfel_plane", H.surfel_plane_cloud(), View.perspective(transform_from((0, 1.5, 20)), 128, 72),
+         CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, aabb=True, transform=transform_from((5.0, 5.0, 0.0)))),
+        ("pair_aabb", H.aabb_obb_pair_cloud(), View.headless(192, 108), CloudSettings(aabb=True)),
+        ("pair_obb", H.aabb_obb_pair_cloud(), View.headless(192, 108), CloudSettings()),
+    ]
+    for name, c, v, s in cases:
+        h = plugin.upload(c)
+        got = plugin.render(h, v, s)
+        ref, amb = oracle.render(c, oracle.sort(c, v, s), v, s, with_ambiguity=True)
+        _assert_image(ref, got, amb, what=name)
+        h.free()
+    # the reference's own visibility thresholds (tests/visibility_render.rs:245-252) on the GPU image
+    name, c, v, s = cases[0]
+    h = plugin.upload(c)
+    lin = np.clip(plugin.render(h, v, s)[..., :3], 0, 1)
+    u8 = np.round(np.where(lin <= 0.0031308, lin * 12.92, 1.055 * lin ** (1 / 2.4) - 0.055) * 255)
+    assert (u8.max(-1) > 8).sum() >= 64 and u8.max() > 32
+    h.free()
+
+
+@pytest.mark.parametrize("name,kw,cloud,view", [
+    ("render_random2k_obb.npz", {}, "r2k", (96, 64)),
+    ("render_random2k_aabb.npz", {"aabb": True}, "r2k", (96, 64)),
+    ("render_random2k_2d_aabb.npz", {"gaussian_mode": GaussianMode.Gaussian2d, "aabb": True}, "r2k", (96, 64)),
+])
+def test_render_against_committed_goldens(plugin, name, kw, cloud, view):
+    g = np.load(os.path.join(GOLDEN, name))
+    c = random_gaussians_3d_seeded(2000, 1)
+    v = View.headless(*view)
+    s = CloudSettings(**kw)
+    h = plugin.upload(c)
+    got = plugin.render(h, v, s)
+    es = plugin.sort(h, v, s)
+    assert np.array_equal(es["key"], g["keys"]) and np.array_equal(es["index"], g["index"])
+    ok, err = H.tolerance_mask(g["rgba"], got, None, atol=1e-3, rtol=1e-4)
+    # goldens carry no ambiguity map: allow the edge-flip pixels (<= 0.5 %) a 2e-2 bound
+    assert (~ok).sum() <= 0.005 * ok.size and err.max() < 2e-2, f"max err {err.max():.3e}"
+    h.free()
+
+
+def test_edge_cases(plugin, oracle):
+    v = View.headless(100, 60)
+    s = CloudSettings()
+    clear = np.array(v.clear_color, np.float32)
+    # empty cloud
+    c0 = random_gaussians_3d_seeded(0, 1)
+    h = plugin.upload(c0)
+    img = plugin.render(h, v, s)
+    assert img.shape == (60, 100, 4) and np.all(img == clear)
+    assert plugin.sort(h, v, s).shape == (0,)
+    h.free()
+    # everything culled (cloud behind the camera)
+    c = random_gaussians_3d_seeded(5000, 2)
+    c.position_visibility[:, 2] = np.abs(c.position_visibility[:, 2]) + 10.0
+    h = plugin.upload(c)
+    img = plugin.render(h, v, s)
+    assert np.all(img == clear)
+    assert plugin.stats()["visible_count"] == 0 and plugin.stats()["instance_count"] == 0
+    h.free()
+    # one splat, non-black transparent clear colour, non-multiple-of-16 target
+    v2 = View.perspective(transform_from((0, 0, 0)), 37, 21, clear_color=(0.25, 0.5, 0.75, 0.0))
+    c1 = PlanarGaussian3d(np.array([[0.2, 0.1, -3.0, 1.0]], np.float32), np.full((1, 48), 0.3, np.float32),
+                          np.array([[0.9, 0.1, 0.2, 0.3]], np.float32), np.array([[0.3, 0.1, 0.2, 0.7]], np.float32))
+    h = plugin.upload(c1)
+    got = plugin.render(h, v2, s)
+    ref, amb = oracle.render(c1, oracle.sort(c1, v2, s), v2, s, with_ambiguity=True)
+    _assert_image(ref, got, amb, frac_slack=0.02, what="single")
+    h.free()
+
+
+def test_invalid_arguments_are_reported_not_fatal(plugin):
+    from bevy_gaussian_splatting_amd import _native
+    c = random_gaussians_3d_seeded(10, 1)
+    h = plugin.upload(c)
+    bad = CloudSettings(sh_degree=7)
+    with pytest.raises(_native.BgsError) as ei:
+        plugin.render(h, View.headless(64, 64), bad)
+    assert ei.value.status == _native.BGS_EINVAL and "sh_degree" in str(ei.value)
+    with pytest.raises(_native.BgsError):
+        plugin.render(h, View.headless(8192, 64), CloudSettings())
+    # the context is still usable afterwards
+    assert plugin.render(h, View.headless(64, 64), CloudSettings()).shape == (64, 64, 4)
+    h.free()
+
+
+def test_render_is_deterministic_and_views_are_independent(plugin, oracle):
+    c = random_gaussians_3d_seeded(20_000, 9)
+    s = CloudSettings(global_scale=0.5)
+    h = plugin.upload(c)
+    v0, v1 = headless_view(0, 192, 108), headless_view(3, 192, 108)
+    a0 = plugin.render(h, v0, s)
+    a1 = plugin.render(h, v1, s)
+    b0 = plugin.render(h, v0, s)
+    assert np.array_equal(a0, b0)  # bitwise: no atomics-order dependence anywhere in the frame
+    assert not np.array_equal(a0, a1)
+    ref, amb = oracle.render(c, oracle.sort(c, v1, s), v1, s, with_ambiguity=True)
+    _assert_image(ref, a1, amb, what="yawed view")
+    h.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full sizes
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cloud_1m():
+    return random_gaussians_3d_seeded(1_000_000, 2)
+
+
+def test_full_size_sort_1m(plugin, oracle, cloud_1m):
+    """configs[1] sort leg: bit-exact against the oracle AND the size-independent properties."""
+    v = View.headless(1920, 1080)
+    s = CloudSettings()
+    h = plugin.upload(cloud_1m)
+    got = plugin.sort(h, v, s)
+    k = got["key"].astype(np.int64)
+    assert np.all(np.diff(k) >= 0)                                   # sortedness
+    same = np.diff(k) == 0
+    assert np.all(np.diff(got["index"].astype(np.int64))[same] > 0)  # stability
+    assert np.array_equal(np.sort(got["index"]), np.arange(len(cloud_1m), dtype=np.uint32))  # permutation
+    ref = oracle.sort(cloud_1m, v, s)
+    assert np.array_equal(got["key"], ref["key"]) and np.array_equal(got["index"], ref["index"])
+    assert plugin.stats()["visible_count"] == int((ref["key"] != 0xFFFFFFFF).sum())
+    h.free()
+
+
+@pytest.mark.parametrize("global_scale", [1.0, 0.05])
+def test_full_size_render_1m_1080p(plugin, oracle, cloud_1m, global_scale):
+    """configs[1]: 1M splats, 1920x1080, sh3. The oracle renders three 48x48 crops of the SAME
+    frame (all 1M splats, every overlapping quad) for the parity check; the whole frame is checked
+    through properties (finite, alpha == 1 over an opaque clear colour, bitwise repeatable)."""
+    v = View.headless(1920, 1080)
+    s = CloudSettings(global_scale=global_scale)
+    h = plugin.upload(cloud_1m)
+    got = plugin.render(h, v, s)
+    st = plugin.stats()
+    assert got.shape == (1080, 1920, 4) and np.isfinite(got).all()
+    assert np.allclose(got[..., 3], 1.0, atol=1e-5)
+    again = plugin.render(h, v, s)
+    assert np.array_equal(got, again)
+    e = oracle.sort(cloud_1m, v, s)
+    vis, inst = oracle.instance_stats(cloud_1m, e, v, s)
+    assert st["visible_count"] == vis
+    assert 0.5 * inst <= st["instance_count"] <= 2 * inst + 1024
+    for (x0, y0) in ((936, 516), (40, 30), (1800, 1000)):
+        win = (x0, y0, x0 + 48, y0 + 48)
+        ref, amb = oracle.render(cloud_1m, e, v, s, window=win, with_ambiguity=True)
+        _assert_image(ref, got[y0:y0 + 48, x0:x0 + 48], amb, frac_slack=0.01, what=f"crop {win} gs={global_scale}")
+    h.free()
+
+
+def test_full_size_f16_5m_sort_and_crop(plugin, oracle):
+    """configs[2]: 5M-splat f16 cloud at 1080p (scene-like scale to keep the oracle crop cheap)."""
+    c = random_gaussians_3d_seeded(5_000_000, 3).to_f16()
+    v = View.headless(1920, 1080)
+    s = CloudSettings(global_scale=0.05)
+    h = plugin.upload(c)
+    got = plugin.render(h, v, s)
+    assert np.isfinite(got).all()
+    es = plugin.sort(h, v, s)
+    dec = oracle.decode_f16(c)
+    e = oracle.sort(dec, v, s)
+    assert np.array_equal(es["key"], e["key"]) and np.array_equal(es["index"], e["index"])
+    win = (936, 516, 984, 564)
+    ref, amb = oracle.render(dec, e, v, s, window=win, with_ambiguity=True)
+    _assert_image(ref, got[516:564, 936:984], amb, frac_slack=0.01, what="5M f16 crop")
+    h.free()
+
+
+def test_full_size_2dgs_1m_crop(plugin, oracle, cloud_1m):
+    """configs[3]: 1M-splat 2DGS surfel cloud, both the true surfel path (aabb) and default OBB."""
+    v = View.headless(1920, 1080)
+    for kw in ({"aabb": True}, {}):
+        s = CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, global_scale=0.25, **kw)
+        h = plugin.upload(cloud_1m)
+        got = plugin.render(h, v, s)
+        e = oracle.sort(cloud_1m, v, s)
+        win = (936, 516, 984, 564)
+        ref, amb = oracle.render(cloud_1m, e, v, s, window=win, with_ambiguity=True)
+        _assert_image(ref, got[516:564, 936:984], amb, frac_slack=0.01, what=f"2dgs {kw}")
+        h.free()

@@ -1,0 +1,95 @@
+"""Host-side mirror of the reference's data model / settings (no GPU, no oracle)."""
+import numpy as np
+import pytest
+
+from bevy_gaussian_splatting_amd import (
+    CloudSettings, GaussianMode, PlanarGaussian3d, PlanarGaussian3dF16, RadixSortDepthBits,
+    ShaderDefines, SortedEntries, SortMode, View, random_gaussians_3d_seeded)
+from bevy_gaussian_splatting_amd import gaussian as G
+from bevy_gaussian_splatting_amd.multiview import assign_views, headless_view
+
+
+def test_shader_defines_geometry():
+    # src/render/mod.rs:715-758
+    d = ShaderDefines.for_radix_depth_bits(RadixSortDepthBits.Bits32)
+    assert (d.radix_base, d.radix_bits_per_digit, d.workgroup_entries_c) == (256, 8, 1024)
+    assert d.workgroup_entries_a == 256 * 4 * 4
+    assert d.sorting_buffer_size == 256 * 4 * 4 + (5 + 256) * 4
+    assert d.max_tile_count(1_000_000) == 977
+    with pytest.raises(ValueError):
+        ShaderDefines.for_radix_depth_bits(12)
+
+
+def test_cloud_settings_defaults_match_reference():
+    s = CloudSettings()  # src/gaussian/settings.rs:110-131
+    assert (s.aabb, s.global_opacity, s.global_scale, s.opacity_adaptive_radius) == (False, 1.0, 1.0, True)
+    assert s.sort_mode == SortMode.Radix and s.radix_sort_depth_bits == RadixSortDepthBits.Bits32
+    assert s.gaussian_mode == GaussianMode.Gaussian3d
+    n = s.to_native()
+    assert list(n.transform) == [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    t = np.eye(4, dtype=np.float32); t[:3, 3] = [1, 2, 3]
+    n2 = CloudSettings(transform=t).to_native()
+    assert list(n2.transform)[12:15] == [1, 2, 3]  # column-major: translation in column 3
+
+
+def test_sorted_entries_initialisation():
+    se = SortedEntries.new(3, 5)  # src/sort/mod.rs:347-354
+    assert se.sorted.shape == (15,) and np.all(se.sorted["key"] == 1)
+    assert se.chunk(2)["index"].tolist() == [0, 1, 2, 3, 4]
+
+
+def test_random_cloud_distributions_and_determinism():
+    a = random_gaussians_3d_seeded(20000, 5)
+    b = random_gaussians_3d_seeded(20000, 5)
+    assert np.array_equal(a.position_visibility, b.position_visibility)
+    assert len(a) == 20000 and a.nbytes() == 20000 * 240
+    p = a.position_visibility
+    assert p[:, :3].min() >= -20 and p[:, :3].max() < 20 and np.all(p[:, 3] == 1)
+    assert a.scale_opacity[:, :3].min() >= 0 and a.scale_opacity[:, :3].max() < 1
+    assert a.scale_opacity[:, 3].max() < 0.8
+    assert a.rotation.min() >= -1 and a.rotation.max() < 1
+    assert abs(np.linalg.norm(a.rotation, axis=1).mean() - 1.0) > 0.05  # NOT normalised
+    assert abs(a.spherical_harmonic.mean()) < 0.01
+
+
+def test_f16_layout():
+    c = random_gaussians_3d_seeded(16, 2)
+    h = c.to_f16()
+    assert isinstance(h, PlanarGaussian3dF16) and h.nbytes() == 16 * 128
+    # low half = even coefficient (src/render/planar.wgsl:117-130)
+    lo = (h.spherical_harmonic[:, 0] & 0xFFFF).astype(np.uint16).view(np.float16)
+    assert np.array_equal(lo, c.spherical_harmonic[:, 0].astype(np.float16))
+    # first value in the high half (src/gaussian/f16.rs:244-252)
+    hi = (h.rotation_scale_opacity[:, 0] >> 16).astype(np.uint16).view(np.float16)
+    assert np.array_equal(hi, c.rotation[:, 0].astype(np.float16))
+    op = (h.rotation_scale_opacity[:, 3] & 0xFFFF).astype(np.uint16).view(np.float16)
+    assert np.array_equal(op, c.scale_opacity[:, 3].astype(np.float16))
+    back = h.to_f32()
+    assert np.allclose(back.scale_opacity, c.scale_opacity, atol=1e-3)
+
+
+def test_test_model_geometry():
+    m = G.test_model(0)  # src/gaussian/formats/planar_3d.rs:193-251
+    assert len(m) == 9 and np.array_equal(m.position_visibility[8], m.position_visibility[0])
+    assert set(np.abs(m.position_visibility[:, :3]).ravel().tolist()) == {0.5}
+
+
+def test_headless_camera_matches_reference_example():
+    v = View.headless()  # examples/headless.rs:177-184
+    assert np.allclose(v.world_position, [0, 1.5, 5])
+    f = 1 / np.tan(np.pi / 8)
+    assert np.isclose(v.clip_from_view[1, 1], f) and np.isclose(v.clip_from_view[0, 0], f / (1920 / 1080))
+    assert v.clip_from_view[3, 2] == -1 and np.isclose(v.clip_from_view[2, 3], 0.1)
+    p = v.clip_from_world @ np.array([0, 1.5, 5 - 0.1, 1], np.float32)  # point on the near plane
+    assert np.isclose(p[2] / p[3], 1.0, atol=1e-5)  # reverse-Z: near -> 1
+    assert np.allclose(v.view_from_world @ v.world_from_view, np.eye(4), atol=1e-6)
+
+
+def test_view_assignment():
+    assert assign_views(8, 8) == [[g] for g in range(8)]
+    assert assign_views(8, 2) == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert assign_views(3, 4) == [[0], [1], [2], []]
+    v = headless_view(2, 64, 32)
+    assert v.camera.order == 2 and np.allclose(v.world_position, [0, 1.5, 5])
+    fwd = v.world_from_view[:3, :3] @ np.array([0, 0, -1], np.float32)
+    assert np.allclose(fwd, [-1, 0, 0], atol=1e-6)  # yawed 90 degrees about +Y
