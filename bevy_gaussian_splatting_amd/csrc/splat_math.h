@@ -103,7 +103,10 @@ BGS_HD uint32_t sort_key(const FrameParams& fp, V3 pos) {
     if (fp.sort_mode != SORT_RADIX) {
         V3 d = sub3(cam, tp);
         float dist2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
-        return 0xFFFFFFFFu - f2u(dist2);
+        // a NaN key's sign/payload is platform-dependent (x86 vs gfx950) and its order is
+        // unspecified in the reference (partial_cmp -> Equal): store the canonical quiet NaN
+        const uint32_t bits = dist2 != dist2 ? 0x7FC00000u : f2u(dist2);
+        return 0xFFFFFFFFu - bits;
     }
     uint32_t key = KEY_CULLED;
     V4 clip = world_to_clip(fp, tp);

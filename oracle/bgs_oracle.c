@@ -152,7 +152,9 @@ int oracle_keygen(const float* pv, uint32_t n, const bgs_view* view, const bgs_s
             /* src/sort/rayon.rs:91-97: delta = camera - position; key = bits(|delta|^2) */
             v3 d = v3sub(cam, tp);
             float dist2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
-            out[i].key = f2u(dist2);
+            /* NaN sign/payload is platform-dependent and its order unspecified in the reference:
+             * canonical quiet NaN (documented deviation) */
+            out[i].key = dist2 != dist2 ? 0x7FC00000u : f2u(dist2);
             out[i].index = i;
             continue;
         }
