@@ -47,6 +47,15 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
     k, kt = stats["depth_passes"], stats["tile_passes"]
     P = WIDTH * HEIGHT
     B = cloud_bytes_per_splat
+    if stats.get("binning") == "scan":
+        # I = coarse (supertile) list entries: written once by project_bin (4 B), read once by the
+        # rasteriser (4 B) which also reads each visible record at least once
+        return {
+            "keygen": {"bytes": N * 16 + N * 8, "launches": 1},
+            "depth_sort": {"bytes": k * N * 16, "launches": max(k, 1)},
+            "project": {"bytes": V * 8 + V * (B - 16) + V * rec_bytes + V * 4 + I * 4, "launches": 1},
+            "raster": {"bytes": I * 4 + V * 4 + V * rec_bytes + P * 16, "launches": 1},
+        }
     return {
         "keygen": {"bytes": N * 16 + N * 8, "launches": 1},
         "depth_sort": {"bytes": k * N * 16, "launches": max(k, 1)},
@@ -184,8 +193,11 @@ def main():
         per_launch_bytes = table[dom]["bytes"] / launches
         per_launch_s = stage_ms[dom] * 1e-3 / launches if stage_ms.get(dom, 0) > 0 else float("inf")
         achieved = per_launch_bytes / per_launch_s / 1e9
-        kernel_names = {"keygen": "keygen_kernel", "depth_sort": "onesweep_kernel", "project": "project_emit_kernel",
-                        "tile_sort": "onesweep_kernel", "ranges": "tile_ranges_kernel", "raster": "raster_kernel"}
+        scan_mode = st.get("binning") == "scan"
+        kernel_names = {"keygen": "keygen_kernel", "depth_sort": "onesweep_kernel",
+                        "project": "project_bin_kernel" if scan_mode else "project_emit_kernel",
+                        "tile_sort": "onesweep_kernel", "ranges": "tile_ranges_kernel",
+                        "raster": "raster_scan_kernel" if scan_mode else "raster_kernel"}
         roofline = {"bound": "hbm", "kernel": kernel_names[dom], "stage": dom,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -212,6 +224,12 @@ def main():
         dt2, stage2, st2 = measure(plugin, handle, view, s2, args.steps, args.warmup)
         ms2 = sum(stage2.values())
 
+        # the named instance-sort pipeline (tile-major|depth radix sort) on the same workload
+        plugin.set_binning("sort")
+        dt3, stage3, st3 = measure(plugin, handle, view, settings, max(args.steps // 3, 3), 2)
+        dt4, stage4, st4 = measure(plugin, handle, view, s2, max(args.steps // 3, 3), 2)
+        plugin.set_binning("scan")
+
         out = {
             "metric": "frames/sec @1080p, 1M-splat 3DGS (sort + rasterize every frame)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -235,6 +253,15 @@ def main():
                            "device_ms": round(ms2, 4), "visible_splats": st2["visible_count"],
                            "tile_instances": st2["instance_count"],
                            "GBps": round(st2["algorithmic_bytes"] / (ms2 * 1e-3) / 1e9, 1) if ms2 > 0 else None},
+            "binning": st["binning"],
+            "instance_sort_pipeline": {
+                "note": "bgs_set_binning(SORT): (tile,splat) instances + stable radix sort on tile ids + ranges",
+                "value": round(max(args.steps // 3, 3) / dt3, 2), "unit": "frames/s",
+                "tile_instances": st3["instance_count"],
+                "stage_ms": {k: round(v, 4) for k, v in stage3.items()},
+                "GBps": round(st3["algorithmic_bytes"] / (sum(stage3.values()) * 1e-3) / 1e9, 1),
+                "scene_like_value": round(max(args.steps // 3, 3) / dt4, 2),
+                "scene_like_stage_ms": {k: round(v, 4) for k, v in stage4.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cloud, view, settings)

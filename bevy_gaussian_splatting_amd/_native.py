@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = (
     "bgs_synchronize",
     "bgs_stream",
     "bgs_set_profiling",
+    "bgs_set_binning",
     "bgs_get_stats",
     "bgs_radix_sort_pairs",
 )
@@ -67,7 +68,7 @@ class BgsStats(ctypes.Structure):
         ("tile_passes", ctypes.c_uint32),
         ("algorithmic_bytes", ctypes.c_uint64),
         ("regrow_count", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32),
+        ("binning_mode", ctypes.c_uint32),
     ]
 
 
@@ -133,6 +134,8 @@ def load() -> ctypes.CDLL:
     lib.bgs_stream.restype = ctypes.c_int
     lib.bgs_set_profiling.argtypes = [vp, ctypes.c_int]
     lib.bgs_set_profiling.restype = ctypes.c_int
+    lib.bgs_set_binning.argtypes = [vp, u32]
+    lib.bgs_set_binning.restype = ctypes.c_int
     lib.bgs_get_stats.argtypes = [vp, ctypes.POINTER(BgsStats)]
     lib.bgs_get_stats.restype = ctypes.c_int
     lib.bgs_radix_sort_pairs.argtypes = [vp, ctypes.POINTER(BgsSortEntry), u32, u32]

@@ -60,7 +60,7 @@ struct bgs_ctx {
     // zeroed-every-frame scratch: [Control | depth status | scan status | tile status | ranges]
     uint8_t* scratch = nullptr;
     size_t scratch_bytes = 0;
-    size_t off_depth_status = 0, off_scan_status = 0, off_tile_status = 0, off_ranges = 0;
+    size_t off_depth_status = 0, off_scan_status = 0, off_tile_status = 0, off_ranges = 0, off_bin_status = 0;
     uint32_t scratch_n = 0;          // splat capacity the scratch was laid out for
     uint64_t scratch_inst_cap = 0;   // instance capacity the scratch was laid out for
 
@@ -70,6 +70,11 @@ struct bgs_ctx {
     size_t records_bytes = 0;
     uint2* inst[2] = {nullptr, nullptr};
     uint64_t inst_cap = 0;
+    uint32_t* rects = nullptr;       // BINNING_SCAN: packed tile rectangle per rank
+    uint32_t rects_cap = 0;
+    uint32_t* coarse = nullptr;      // BINNING_SCAN: [num_supertiles][coarse_cap] ordered rank lists
+    size_t coarse_words = 0;
+    uint32_t binning = BINNING_SCAN;
     float4* fb = nullptr;
     size_t fb_pixels = 0;
     uint32_t fb_w = 0, fb_h = 0;
@@ -119,6 +124,8 @@ int ensure_scratch(bgs_ctx* ctx, uint32_t n, uint64_t inst_cap) {
     off += align_up(2 * inst_tiles * RADIX_BASE * sizeof(uint32_t), 256);
     const size_t off_ranges = off;
     off += align_up((size_t)RADIX_BASE * RADIX_BASE * sizeof(uint2), 256);
+    const size_t off_bin = off;
+    off += align_up(scan_tiles * MAX_SUPERTILES * sizeof(uint32_t), 256);
     if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; }
     void* p = nullptr;
     if (hipMalloc(&p, off) != hipSuccess) return fail(ctx, BGS_ENOMEM, "hipMalloc(scratch) failed");
@@ -128,6 +135,7 @@ int ensure_scratch(bgs_ctx* ctx, uint32_t n, uint64_t inst_cap) {
     ctx->off_scan_status = off_scan;
     ctx->off_tile_status = off_tile;
     ctx->off_ranges = off_ranges;
+    ctx->off_bin_status = off_bin;
     ctx->scratch_n = n;
     ctx->scratch_inst_cap = inst_cap;
     return BGS_OK;
@@ -166,6 +174,26 @@ int ensure_records(bgs_ctx* ctx, size_t bytes) {
         return fail(ctx, BGS_ENOMEM, "hipMalloc(records) failed");
     ctx->records = p;
     ctx->records_bytes = bytes;
+    return BGS_OK;
+}
+
+int ensure_coarse(bgs_ctx* ctx, uint32_t n, uint32_t num_st) {
+    if (n > ctx->rects_cap || !ctx->rects) {
+        if (ctx->rects) (void)hipFree(ctx->rects);
+        ctx->rects = dev_alloc<uint32_t>(n);
+        if (!ctx->rects) return fail(ctx, BGS_ENOMEM, "hipMalloc(rects) failed");
+        ctx->rects_cap = n;
+    }
+    // worst case: every rank lands in every supertile list -> num_st * n words (no overflow path)
+    const size_t words = (size_t)num_st * std::max<uint32_t>(n, 1);
+    if (words > ctx->coarse_words || !ctx->coarse) {
+        if (words * sizeof(uint32_t) > (64ull << 30))
+            return fail(ctx, BGS_ECAPACITY, "coarse bin lists would exceed 64 GiB; use bgs_set_binning(ctx, 1)");
+        if (ctx->coarse) (void)hipFree(ctx->coarse);
+        ctx->coarse = dev_alloc<uint32_t>(words);
+        if (!ctx->coarse) return fail(ctx, BGS_ENOMEM, "hipMalloc(coarse lists) failed");
+        ctx->coarse_words = words;
+    }
     return BGS_OK;
 }
 
@@ -214,8 +242,20 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
 
     int rc;
     if ((rc = ensure_entries(ctx, n)) != BGS_OK) return rc;
+    const bool scan = ctx->binning == BINNING_SCAN;
+    // supertile edge (in tiles): smallest power of two that keeps the coarse bins <= 256
+    uint32_t sup_shift = 3;
+    while ((((uint32_t)fp.tiles_x + (1u << sup_shift) - 1) >> sup_shift) *
+               (((uint32_t)fp.tiles_y + (1u << sup_shift) - 1) >> sup_shift) > MAX_SUPERTILES)
+        ++sup_shift;
+    const uint32_t num_st = (((uint32_t)fp.tiles_x + (1u << sup_shift) - 1) >> sup_shift) *
+                            (((uint32_t)fp.tiles_y + (1u << sup_shift) - 1) >> sup_shift);
     if (render) {
-        if ((rc = ensure_instances(ctx, std::max<uint64_t>(ctx->inst_cap, MIN_INSTANCE_CAPACITY))) != BGS_OK) return rc;
+        if (scan) {
+            if ((rc = ensure_coarse(ctx, n, num_st)) != BGS_OK) return rc;
+        } else {
+            if ((rc = ensure_instances(ctx, std::max<uint64_t>(ctx->inst_cap, MIN_INSTANCE_CAPACITY))) != BGS_OK) return rc;
+        }
         if ((rc = ensure_records(ctx, (size_t)n * rec_bytes)) != BGS_OK) return rc;
         if ((rc = ensure_framebuffer(ctx, (uint32_t)fp.width, (uint32_t)fp.height)) != BGS_OK) return rc;
     }
@@ -227,6 +267,7 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
     unsigned long long* scan_status = (unsigned long long*)(ctx->scratch + ctx->off_scan_status);
     uint32_t* tile_status = (uint32_t*)(ctx->scratch + ctx->off_tile_status);
     uint2* ranges = (uint2*)(ctx->scratch + ctx->off_ranges);
+    uint32_t* bin_status = (uint32_t*)(ctx->scratch + ctx->off_bin_status);
     const bool prof = ctx->profiling;
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(ctx->ev[i], st); };
 
@@ -253,7 +294,17 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
     ctx->last_sorted = draw_list;
     ctx->last_sorted_n = n;
 
-    if (render) {
+    if (render && scan) {
+        const uint32_t coarse_cap = std::max<uint32_t>(n, 1);
+        launch_project_bin(st, fp, cloud->ptrs, draw_list, ctl, bin_status, ctx->records, ctx->rects,
+                           ctx->coarse, coarse_cap, sup_shift, /*ticket_slot=*/4, ctx->num_cus * 3);
+        mark(3);
+        mark(4);
+        mark(5);
+        launch_raster_scan(st, fp, ctx->records, ctx->rects, ctx->coarse, coarse_cap, sup_shift, ctl,
+                           ctx->fb, view->clear_color);
+        mark(6);
+    } else if (render) {
         const uint32_t capacity = (uint32_t)std::min<uint64_t>(ctx->inst_cap, MAX_INSTANCE_CAPACITY);
         CloudPtrs cp = cloud->ptrs;
         launch_project_emit(st, fp, cp, draw_list, ctl, scan_status, ctx->records, ctx->inst[0], capacity,
@@ -276,7 +327,11 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
 
     const Control& h = *ctx->h_ctl;
     if (h.error) return fail(ctx, BGS_EINTERNAL, "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
-    const uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
+    uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
+    if (render && scan) {
+        total = 0;
+        for (uint32_t i = 0; i < num_st; ++i) total += h.coarse_total[i];
+    }
     if (render && h.overflow) {
         *need_cap = total;
         return BGS_OK;
@@ -294,7 +349,8 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
     stt.tiles_x = render ? (uint32_t)fp.tiles_x : 0;
     stt.tiles_y = render ? (uint32_t)fp.tiles_y : 0;
     stt.depth_passes = places;
-    stt.tile_passes = render ? 2 : 0;
+    stt.tile_passes = (render && !scan) ? 2 : 0;
+    stt.binning_mode = ctx->binning;
     {
         // SURVEY 8(d) algorithmic bytes
         const uint64_t N = n, k = places;
@@ -302,7 +358,10 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
         if (render) {
             const uint64_t B = cloud->ptrs.is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
             const uint64_t P = (uint64_t)fp.width * fp.height;
-            bytes += V * (B - 16) + V * R + I * 8 + 2 * I * 16 + I * (4 + R) + P * 16;
+            if (scan)  // coarse entries: written once (4 B), read by up to 2^(2*sup_shift) tiles
+                bytes += V * (B - 16) + V * R + V * 8 + I * 4 + I * 4 + P * 16;
+            else
+                bytes += V * (B - 16) + V * R + I * 8 + 2 * I * 16 + I * (4 + R) + P * 16;
         }
         stt.algorithmic_bytes = bytes;
     }
@@ -433,6 +492,8 @@ void bgs_destroy(bgs_ctx* ctx) {
     for (auto e : ctx->entries) if (e) (void)hipFree(e);
     for (auto e : ctx->inst) if (e) (void)hipFree(e);
     if (ctx->records) (void)hipFree(ctx->records);
+    if (ctx->rects) (void)hipFree(ctx->rects);
+    if (ctx->coarse) (void)hipFree(ctx->coarse);
     if (ctx->fb) (void)hipFree(ctx->fb);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     for (auto ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
@@ -606,6 +667,13 @@ int bgs_stream(bgs_ctx* ctx, void** hip_stream) {
 int bgs_set_profiling(bgs_ctx* ctx, int enabled) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     ctx->profiling = enabled != 0;
+    return BGS_OK;
+}
+
+int bgs_set_binning(bgs_ctx* ctx, uint32_t mode) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (mode > BINNING_SORT) return fail(ctx, BGS_EINVAL, "binning mode must be 0 (scan) or 1 (sort)");
+    ctx->binning = mode;
     return BGS_OK;
 }
 

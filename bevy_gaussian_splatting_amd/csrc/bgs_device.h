@@ -76,7 +76,16 @@ struct Control {
     uint32_t ticket[16];      // dynamic tile ids: one word per kernel launch of the frame
     uint32_t hist_depth[4][RADIX_BASE];  // global digit histograms of the depth keys
     uint32_t hist_tile[2][RADIX_BASE];   // digit 0 = tile x, digit 1 = tile y
+    uint32_t coarse_total[RADIX_BASE];   // scan binning: entries in each supertile's ordered list
 };
+
+// packed tile rectangle x0 | x1 << 8 | y0 << 16 | y1 << 24 (inclusive); x0 > x1 = touches no tile
+constexpr uint32_t RECT_EMPTY = 0x000000FFu;
+constexpr uint32_t MAX_SUPERTILES = 256;  // coarse bins ride the 256-wide chained scan
+
+// binning modes (bgs_set_binning)
+constexpr uint32_t BINNING_SCAN = 0;  // ordered coarse lists + lazy per-tile scan (default)
+constexpr uint32_t BINNING_SORT = 1;  // (tile, rank) instances + stable radix sort on the tile id
 
 // look-back status word: flag in the top 2 bits, 30-bit value
 constexpr uint32_t STATUS_FLAG_SHIFT = 30;

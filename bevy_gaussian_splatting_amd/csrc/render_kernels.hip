@@ -85,7 +85,57 @@ struct ShF16 {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
-// project + ordered instance emission
+// vertex stage for one front-to-back rank: load the splat, project, write its record.
+// Returns the packed tile rectangle (RECT_EMPTY if nothing is to be drawn).
+// ---------------------------------------------------------------------------------------
+template <bool F16, bool SURFEL>
+__device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const CloudPtrs& cloud,
+                                                 const uint2 entry, const uint32_t j,
+                                                 float4* __restrict__ records, bool& visible) {
+    const uint32_t si = entry.y;
+    const float4 pv = cloud.position_visibility[si];
+    float rot[4], so[4];
+    if constexpr (F16) {
+        // src/render/planar.wgsl:154-176: first value of each pair in the HIGH half
+        const uint4 raw = cloud.rot_scale_opacity_f16[si];
+        rot[0] = half_hi(raw.x); rot[1] = half_lo(raw.x);
+        rot[2] = half_hi(raw.y); rot[3] = half_lo(raw.y);
+        so[0] = half_hi(raw.z); so[1] = half_lo(raw.z);
+        so[2] = half_hi(raw.w); so[3] = half_lo(raw.w);
+    } else {
+        const float4 r4 = cloud.rotation[si];
+        const float4 s4 = cloud.scale_opacity[si];
+        rot[0] = r4.x; rot[1] = r4.y; rot[2] = r4.z; rot[3] = r4.w;
+        so[0] = s4.x; so[1] = s4.y; so[2] = s4.z; so[3] = s4.w;
+    }
+    Projected pr;
+    if constexpr (F16)
+        project_splat(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF16{cloud.sh_f16 + (size_t)si * 24u}, pr);
+    else
+        project_splat(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{cloud.sh_f32 + (size_t)si * 48u}, pr);
+    visible = pr.visible;
+    if (!pr.draw) return RECT_EMPTY;
+    const uint32_t rect = (uint32_t)pr.tx0 | ((uint32_t)pr.tx1 << 8) | ((uint32_t)pr.ty0 << 16) |
+                          ((uint32_t)pr.ty1 << 24);
+    if constexpr (SURFEL) {
+        float4* dst = records + (size_t)j * 6u;
+        dst[0] = make_float4(pr.quad.cx, pr.quad.cy, pr.p[0], pr.p[1]);
+        dst[1] = make_float4(pr.radius, pr.surfel.mean_x, pr.surfel.mean_y, pr.surfel.T[0]);
+        dst[2] = make_float4(pr.surfel.T[1], pr.surfel.T[2], pr.surfel.T[3], pr.surfel.T[4]);
+        dst[3] = make_float4(pr.surfel.T[5], pr.surfel.T[6], pr.surfel.T[7], pr.surfel.T[8]);
+        dst[4] = make_float4(pr.color[0], pr.color[1], pr.color[2], pr.color[3]);
+        dst[5] = make_float4(__uint_as_float(rect), 0.0f, 0.0f, 0.0f);
+    } else {
+        float4* dst = records + (size_t)j * 3u;
+        dst[0] = make_float4(pr.quad.cx, pr.quad.cy, pr.p[0], pr.p[1]);
+        dst[1] = make_float4(pr.p[2], pr.p[3], pr.p[4], pr.color[0]);
+        dst[2] = make_float4(pr.color[1], pr.color[2], pr.color[3], __uint_as_float(rect));
+    }
+    return rect;
+}
+
+// ---------------------------------------------------------------------------------------
+// BINNING_SORT: project + ordered instance emission
 // ---------------------------------------------------------------------------------------
 template <bool F16, bool SURFEL>
 __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, CloudPtrs cloud,
@@ -120,49 +170,12 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
         uint32_t ntiles = 0u, rect = 0u;
         if (j < count) {
             // the LAST entry of the draw list is drawn on top => it is the front-most
-            const uint2 entry = draw_list[count - 1u - j];
-            const uint32_t si = entry.y;
-            const float4 pv = cloud.position_visibility[si];
-            float rot[4], so[4];
-            if constexpr (F16) {
-                // src/render/planar.wgsl:154-176: first value of each pair in the HIGH half
-                const uint4 raw = cloud.rot_scale_opacity_f16[si];
-                rot[0] = half_hi(raw.x); rot[1] = half_lo(raw.x);
-                rot[2] = half_hi(raw.y); rot[3] = half_lo(raw.y);
-                so[0] = half_hi(raw.z); so[1] = half_lo(raw.z);
-                so[2] = half_hi(raw.w); so[3] = half_lo(raw.w);
-            } else {
-                const float4 r4 = cloud.rotation[si];
-                const float4 s4 = cloud.scale_opacity[si];
-                rot[0] = r4.x; rot[1] = r4.y; rot[2] = r4.z; rot[3] = r4.w;
-                so[0] = s4.x; so[1] = s4.y; so[2] = s4.z; so[3] = s4.w;
-            }
-            Projected pr;
-            if constexpr (F16)
-                project_splat(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so,
-                              ShF16{cloud.sh_f16 + (size_t)si * 24u}, pr);
-            else
-                project_splat(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so,
-                              ShF32{cloud.sh_f32 + (size_t)si * 48u}, pr);
-            visible_acc += pr.visible ? 1u : 0u;
-            if (pr.draw) {
-                ntiles = (uint32_t)(pr.tx1 - pr.tx0 + 1) * (uint32_t)(pr.ty1 - pr.ty0 + 1);
-                rect = (uint32_t)pr.tx0 | ((uint32_t)pr.tx1 << 8) | ((uint32_t)pr.ty0 << 16) |
-                       ((uint32_t)pr.ty1 << 24);
-                if constexpr (SURFEL) {
-                    float4* dst = records + (size_t)j * 6u;
-                    dst[0] = make_float4(pr.quad.cx, pr.quad.cy, pr.p[0], pr.p[1]);
-                    dst[1] = make_float4(pr.radius, pr.surfel.mean_x, pr.surfel.mean_y, pr.surfel.T[0]);
-                    dst[2] = make_float4(pr.surfel.T[1], pr.surfel.T[2], pr.surfel.T[3], pr.surfel.T[4]);
-                    dst[3] = make_float4(pr.surfel.T[5], pr.surfel.T[6], pr.surfel.T[7], pr.surfel.T[8]);
-                    dst[4] = make_float4(pr.color[0], pr.color[1], pr.color[2], pr.color[3]);
-                    dst[5] = make_float4(__uint_as_float(rect), 0.0f, 0.0f, 0.0f);
-                } else {
-                    float4* dst = records + (size_t)j * 3u;
-                    dst[0] = make_float4(pr.quad.cx, pr.quad.cy, pr.p[0], pr.p[1]);
-                    dst[1] = make_float4(pr.p[2], pr.p[3], pr.p[4], pr.color[0]);
-                    dst[2] = make_float4(pr.color[1], pr.color[2], pr.color[3], __uint_as_float(rect));
-                }
+            bool vis;
+            const uint32_t r = project_rank<F16, SURFEL>(fp, cloud, draw_list[count - 1u - j], j, records, vis);
+            visible_acc += vis ? 1u : 0u;
+            if (r != RECT_EMPTY) {
+                rect = r;
+                ntiles = (((r >> 8) & 255u) - (r & 255u) + 1u) * ((r >> 24) - ((r >> 16) & 255u) + 1u);
             }
         }
         // block exclusive scan of the tile counts
@@ -270,6 +283,135 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
 }
 
 // ---------------------------------------------------------------------------------------
+// BINNING_SCAN: project + ordered coarse binning (supertile lists), one pass
+// ---------------------------------------------------------------------------------------
+template <bool F16, bool SURFEL>
+__global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudPtrs cloud,
+                                                          const uint2* __restrict__ draw_list,
+                                                          Control* ctl, uint32_t* bin_status,
+                                                          float4* __restrict__ records,
+                                                          uint32_t* __restrict__ rects,
+                                                          uint32_t* __restrict__ coarse,
+                                                          uint32_t coarse_cap, uint32_t sup_shift,
+                                                          uint32_t sup_x, uint32_t num_st,
+                                                          uint32_t ticket_slot) {
+    __shared__ unsigned long long s_mask[4][MAX_SUPERTILES];  // per wave: lanes hitting supertile s
+    __shared__ uint32_t s_wave_excl[4][MAX_SUPERTILES];
+    __shared__ uint32_t s_base[MAX_SUPERTILES];               // list position of the block's first hit
+    __shared__ uint32_t s_tile;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t count = ctl->draw_count;
+    const uint32_t num_tiles = (count + 255u) / 256u;
+    if (num_tiles == 0u) return;
+    uint32_t visible_acc = 0u;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= num_tiles) break;
+        const uint32_t j = tile * 256u + (uint32_t)tid;  // front-to-back rank
+        uint32_t rect = RECT_EMPTY;
+        if (j < count) {
+            bool vis;
+            rect = project_rank<F16, SURFEL>(fp, cloud, draw_list[count - 1u - j], j, records, vis);
+            visible_acc += vis ? 1u : 0u;
+            rects[j] = rect;
+        }
+        // supertile bounds of the rectangle (empty rect: sx0 > sx1)
+        const uint32_t sx0 = (rect & 255u) >> sup_shift, sx1 = ((rect >> 8) & 255u) >> sup_shift;
+        const uint32_t sy0 = ((rect >> 16) & 255u) >> sup_shift, sy1 = (rect >> 24) >> sup_shift;
+        const bool nonempty = (rect & 255u) <= ((rect >> 8) & 255u);
+        // one ballot per supertile: which of this wave's 64 ranks overlap it
+        {
+            uint32_t stx = 0u, sty = 0u;
+            for (uint32_t st = 0u; st < num_st; ++st) {
+                const bool hit = nonempty && stx >= sx0 && stx <= sx1 && sty >= sy0 && sty <= sy1;
+                const unsigned long long b = __ballot(hit);
+                if ((uint32_t)lane == (st & 63u)) s_mask[wave][st] = b;
+                if (++stx == sup_x) { stx = 0u; ++sty; }
+            }
+        }
+        __syncthreads();
+        // thread = supertile: scan over the 4 waves, chained scan over the blocks
+        if ((uint32_t)tid < num_st) {
+            const uint32_t c0 = (uint32_t)__popcll(s_mask[0][tid]), c1 = (uint32_t)__popcll(s_mask[1][tid]);
+            const uint32_t c2 = (uint32_t)__popcll(s_mask[2][tid]), c3 = (uint32_t)__popcll(s_mask[3][tid]);
+            s_wave_excl[0][tid] = 0u;
+            s_wave_excl[1][tid] = c0;
+            s_wave_excl[2][tid] = c0 + c1;
+            s_wave_excl[3][tid] = c0 + c1 + c2;
+            const uint32_t total = c0 + c1 + c2 + c3;
+            uint32_t* const my_status = bin_status + (size_t)tile * MAX_SUPERTILES + tid;
+            uint32_t excl = 0u;
+            if (tile > 0u) {
+                __hip_atomic_store(my_status, STATUS_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t p = tile - 1u, spins = 0u;
+                for (;;) {
+                    const uint32_t v = __hip_atomic_load(bin_status + (size_t)p * MAX_SUPERTILES + tid,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t flag = v >> STATUS_FLAG_SHIFT;
+                    if (flag == 0u) {
+                        if (++spins > SPIN_LIMIT) { atomicOr(&ctl->error, 4u); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    excl += v & STATUS_VALUE_MASK;
+                    if (flag == 2u || p == 0u) break;
+                    --p;
+                }
+            }
+            __hip_atomic_store(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base[tid] = excl;
+            if (tile == num_tiles - 1u) ctl->coarse_total[tid] = excl + total;
+        }
+        __syncthreads();
+        // append this rank to every supertile list it overlaps (rank order is preserved: position =
+        // list base of the block + ranks of earlier waves + earlier lanes of this wave)
+        if (nonempty) {
+            for (uint32_t sy = sy0; sy <= sy1; ++sy)
+                for (uint32_t sx = sx0; sx <= sx1; ++sx) {
+                    const uint32_t st = sy * sup_x + sx;
+                    const uint32_t pos = s_base[st] + s_wave_excl[wave][st] +
+                                         (uint32_t)__popcll(s_mask[wave][st] & lanes_below);
+                    if (pos < coarse_cap) coarse[(size_t)st * coarse_cap + pos] = j;
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) visible_acc += __shfl_down(visible_acc, off, 64);
+    if (lane == 0 && visible_acc) atomicAdd(&ctl->visible_count, visible_acc);
+}
+
+void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
+                        const uint2* draw_list, Control* ctl, uint32_t* bin_status, void* records,
+                        uint32_t* rects, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
+                        uint32_t ticket_slot, int max_blocks) {
+    if (fp.n == 0) return;
+    uint32_t blocks = (fp.n + 255u) / 256u;
+    if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
+    const uint32_t sup = 1u << sup_shift;
+    const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup, sup_y = ((uint32_t)fp.tiles_y + sup - 1u) / sup;
+    const uint32_t num_st = sup_x * sup_y;
+    const bool surfel = fp.gaussian_mode == 0u && fp.aabb != 0u;
+    float4* rec = (float4*)records;
+#define BGS_LAUNCH_PB(F16, SURFEL)                                                                \
+    hipLaunchKernelGGL((project_bin_kernel<F16, SURFEL>), dim3(blocks), dim3(256), 0, stream, fp,  \
+                       cloud, draw_list, ctl, bin_status, rec, rects, coarse, coarse_cap, sup_shift, \
+                       sup_x, num_st, ticket_slot)
+    if (cloud.is_f16) {
+        if (surfel) BGS_LAUNCH_PB(true, true); else BGS_LAUNCH_PB(true, false);
+    } else {
+        if (surfel) BGS_LAUNCH_PB(false, true); else BGS_LAUNCH_PB(false, false);
+    }
+#undef BGS_LAUNCH_PB
+}
+
+// ---------------------------------------------------------------------------------------
 // tile ranges
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint2* __restrict__ inst,
@@ -292,30 +434,99 @@ void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Contro
 constexpr int RV_OBB = 0, RV_AABB3D = 1, RV_SURFEL = 2;
 constexpr float T_EPS = 1.0f / 65536.0f;  // stop compositing a pixel below this transmittance
 
+// fs_main + blend for ONE staged record and ONE pixel (src/render/gaussian.wgsl:438-505,
+// src/render/mod.rs:944-948), front-to-back form: C += T*alpha*c; T *= 1 - alpha.
+template <int VARIANT>
+__device__ __forceinline__ void blend_one(const float4* __restrict__ rec, const float qx, const float qy,
+                                          const float aspect, float& T, float& cr, float& cg,
+                                          float& cb, bool& done) {
+#pragma clang fp contract(fast)
+    const float4 a0 = rec[0];
+    const float4 a1 = rec[1];
+    const float4 a2 = rec[2];
+    const float dx = qx - a0.x, dy = qy - a0.y;
+    float alpha, r, g, b;
+    bool hit;
+    if constexpr (VARIANT == RV_OBB) {
+        // a0 = cx cy m00 m01 | a1 = m10 m11 - r | a2 = g b a rect
+        const float u = a0.z * dx + a0.w * dy;
+        const float v = a1.x * dx + a1.y * dy;
+        hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
+        // fs_main OBB: power = -dot(uv,uv) / (2 * (1/3)^2)  (gaussian.wgsl:474-480)
+        constexpr float sigma = 1.0f / 3.0f;
+        constexpr float neg_inv_sigma2 = -1.0f / (2.0f * sigma * sigma);
+        const float power = (u * u + v * v) * neg_inv_sigma2;
+        alpha = fminf(__expf(power) * a2.z, 0.999f);
+        r = a1.w; g = a2.x; b = a2.y;
+    } else if constexpr (VARIANT == RV_AABB3D) {
+        // a0 = cx cy m00 m11 | a1 = A B C r | a2 = g b a rect
+        const float u = a0.z * dx, v = a0.w * dy;
+        hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
+        const float power = -0.5f * (a1.x * u * u + a1.z * v * v) + a1.y * u * v;
+        hit = hit && !(power > 0.0f);
+        alpha = fminf(__expf(power) * a2.z, 0.999f);
+        r = a1.w; g = a2.x; b = a2.y;
+    } else {
+        // a0 = cx cy m00 m11 | a1 = radius mean.xy T0 | a2 = T1..T4 | a3 = T5..T8 | a4 = rgba
+        const float4 a3 = rec[3];
+        const float4 a4 = rec[4];
+        const float u = a0.z * dx, v = a0.w * dy;
+        hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
+        // fs_main GAUSSIAN_2D + USE_AABB (gaussian.wgsl:440-455), aspect = (1, W/H)
+        const float pcx = u * a1.x * 1.0f + a1.y;
+        const float pcy = v * a1.x * aspect + a1.z;
+        // surfel_fragment_power (gaussian_2d.wgsl:134-156)
+        const float T0x = a1.w, T0y = a2.x, T0z = a2.y;
+        const float T1x = a2.z, T1y = a2.w, T1z = a3.x;
+        const float T2x = a3.y, T2y = a3.z, T2z = a3.w;
+        const float hux = pcx * T2x - T0x, huy = pcx * T2y - T0y, huz = pcx * T2z - T0z;
+        const float hvx = pcy * T2x - T1x, hvy = pcy * T2y - T1y, hvz = pcy * T2z - T1z;
+        const float cpx = huy * hvz - hvy * huz;
+        const float cpy = huz * hvx - hvz * hux;
+        const float cpz = hux * hvy - hvx * huy;
+        const float us = cpx / cpz, vs = cpy / cpz;
+        const float ddx = a1.y - pcx, ddy = a1.z - pcy;
+        const float s3 = us * us + vs * vs;
+        const float s2 = 2.0f * (ddx * ddx + ddy * ddy);
+        const float power = -0.5f * fminf(s3, s2);
+        hit = hit && !(power > 0.0f);
+        alpha = fminf(__expf(power) * a4.w, 0.999f);
+        r = a4.x; g = a4.y; b = a4.z;
+    }
+    if (hit && !done) {
+        const float w = T * alpha;
+        cr += w * r;
+        cg += w * g;
+        cb += w * b;
+        T *= 1.0f - alpha;
+        done = T < T_EPS;
+    }
+}
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch, a speed assumption
+// only); give each XCD a contiguous band of tiles so neighbouring tiles, which share records
+// and coarse lists, share an L2.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t ntiles) {
+    const uint32_t q = ntiles / 8u, r = ntiles % 8u, xcd = b % 8u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
+}
+
+// BINNING_SORT rasteriser: the tile's instances are a contiguous range of the sorted list.
 template <int VARIANT>
 __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float4* __restrict__ records,
                                                      const uint2* __restrict__ instances,
                                                      const uint2* __restrict__ ranges,
                                                      float4* __restrict__ fb, float4 clear) {
-    // the per-pixel loop is the one place where FMA contraction is wanted (nothing here
-    // feeds a sort key or a cull decision); the rest of this file is built -ffp-contract=off
-#pragma clang fp contract(fast)
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     __shared__ float4 s_rec[256 * REC_V4];
 
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch); give each XCD a
-    // contiguous band of tiles so neighbouring tiles (which share records) share an L2.
-    const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
-    uint32_t tile;
-    {
-        const uint32_t b = blockIdx.x, q = ntiles / 8u, r = ntiles % 8u, xcd = b % 8u;
-        tile = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
-    }
+    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)(fp.tiles_x * fp.tiles_y));
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
     const int tid = threadIdx.x;
     const int px = (int)tx * TILE_PX + (tid & 15), py = (int)ty * TILE_PX + (tid >> 4);
     const bool in_image = px < fp.width && py < fp.height;
     const float qx = (float)px + 0.5f, qy = (float)py + 0.5f;
+    const float aspect = fp.viewport_w / fp.viewport_h;
 
     const uint2 range = ranges[(ty << 8) | tx];
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
@@ -330,70 +541,9 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
             for (int v = 0; v < REC_V4; ++v) s_rec[tid * REC_V4 + v] = src[v];
         }
         __syncthreads();
-        if (!__all(done)) {
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float4 a0 = s_rec[k * REC_V4 + 0];
-                const float4 a1 = s_rec[k * REC_V4 + 1];
-                const float4 a2 = s_rec[k * REC_V4 + 2];
-                const float dx = qx - a0.x, dy = qy - a0.y;
-                float alpha, r, g, b;
-                bool hit;
-                if constexpr (VARIANT == RV_OBB) {
-                    // a0 = cx cy m00 m01 | a1 = m10 m11 - r | a2 = g b a rect
-                    const float u = a0.z * dx + a0.w * dy;
-                    const float v = a1.x * dx + a1.y * dy;
-                    hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
-                    // fs_main OBB: power = -dot(uv,uv) / (2 * (1/3)^2)  (gaussian.wgsl:474-480)
-                    constexpr float sigma = 1.0f / 3.0f;
-                    constexpr float neg_inv_sigma2 = -1.0f / (2.0f * sigma * sigma);
-                    const float power = (u * u + v * v) * neg_inv_sigma2;
-                    alpha = fminf(__expf(power) * a2.z, 0.999f);
-                    r = a1.w; g = a2.x; b = a2.y;
-                } else if constexpr (VARIANT == RV_AABB3D) {
-                    // a0 = cx cy m00 m11 | a1 = A B C r | a2 = g b a rect
-                    const float u = a0.z * dx, v = a0.w * dy;
-                    hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
-                    const float power = -0.5f * (a1.x * u * u + a1.z * v * v) + a1.y * u * v;
-                    hit = hit && !(power > 0.0f);
-                    alpha = fminf(__expf(power) * a2.z, 0.999f);
-                    r = a1.w; g = a2.x; b = a2.y;
-                } else {
-                    // a0 = cx cy m00 m11 | a1 = radius mean.xy T0 | a2 = T1..T4 | a3 = T5..T8 | a4 = rgba
-                    const float4 a3 = s_rec[k * REC_V4 + 3];
-                    const float4 a4 = s_rec[k * REC_V4 + 4];
-                    const float u = a0.z * dx, v = a0.w * dy;
-                    hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
-                    // fs_main GAUSSIAN_2D + USE_AABB (gaussian.wgsl:440-455), aspect = (1, W/H)
-                    const float pcx = u * a1.x * 1.0f + a1.y;
-                    const float pcy = v * a1.x * (fp.viewport_w / fp.viewport_h) + a1.z;
-                    // surfel_fragment_power (gaussian_2d.wgsl:134-156)
-                    const float T0x = a1.w, T0y = a2.x, T0z = a2.y;
-                    const float T1x = a2.z, T1y = a2.w, T1z = a3.x;
-                    const float T2x = a3.y, T2y = a3.z, T2z = a3.w;
-                    const float hux = pcx * T2x - T0x, huy = pcx * T2y - T0y, huz = pcx * T2z - T0z;
-                    const float hvx = pcy * T2x - T1x, hvy = pcy * T2y - T1y, hvz = pcy * T2z - T1z;
-                    const float cpx = huy * hvz - hvy * huz;
-                    const float cpy = huz * hvx - hvz * hux;
-                    const float cpz = hux * hvy - hvx * huy;
-                    const float us = cpx / cpz, vs = cpy / cpz;
-                    const float ddx = a1.y - pcx, ddy = a1.z - pcy;
-                    const float s3 = us * us + vs * vs;
-                    const float s2 = 2.0f * (ddx * ddx + ddy * ddy);
-                    const float power = -0.5f * fminf(s3, s2);
-                    hit = hit && !(power > 0.0f);
-                    alpha = fminf(__expf(power) * a4.w, 0.999f);
-                    r = a4.x; g = a4.y; b = a4.z;
-                }
-                if (hit && !done) {
-                    const float w = T * alpha;
-                    cr += w * r;
-                    cg += w * g;
-                    cb += w * b;
-                    T *= 1.0f - alpha;
-                    done = T < T_EPS;
-                }
-            }
-        }
+        if (!__all(done))
+            for (uint32_t k = 0; k < cnt; ++k)
+                blend_one<VARIANT>(s_rec + k * REC_V4, qx, qy, aspect, T, cr, cg, cb, done);
         // also the barrier that protects s_rec before the next batch overwrites it
         if (__syncthreads_and(done ? 1 : 0)) break;
     }
@@ -402,6 +552,90 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
         fb[(size_t)py * (size_t)fp.width + (size_t)px] =
             make_float4(cr + T * clear.x, cg + T * clear.y, cb + T * clear.z, (1.0f - T) + T * clear.w);
     }
+}
+
+// BINNING_SCAN rasteriser: lazily bins while it composites. Per group of 256 candidates from the
+// supertile's depth-ordered list: keep those whose tile rectangle contains this tile (ordered
+// ballot compaction into LDS), stage their records, blend, stop at saturation.
+template <int VARIANT>
+__global__ __launch_bounds__(256) void raster_scan_kernel(FrameParams fp, const float4* __restrict__ records,
+                                                          const uint32_t* __restrict__ rects,
+                                                          const uint32_t* __restrict__ coarse,
+                                                          uint32_t coarse_cap, uint32_t sup_shift,
+                                                          uint32_t sup_x, const Control* __restrict__ ctl,
+                                                          float4* __restrict__ fb, float4 clear) {
+    constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
+    __shared__ float4 s_rec[256 * REC_V4];
+    __shared__ uint32_t s_queue[256];
+    __shared__ uint32_t s_wcnt[4];
+
+    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)(fp.tiles_x * fp.tiles_y));
+    const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = (int)tx * TILE_PX + (tid & 15), py = (int)ty * TILE_PX + (tid >> 4);
+    const bool in_image = px < fp.width && py < fp.height;
+    const float qx = (float)px + 0.5f, qy = (float)py + 0.5f;
+    const float aspect = fp.viewport_w / fp.viewport_h;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    const uint32_t st = (ty >> sup_shift) * sup_x + (tx >> sup_shift);
+    const uint32_t total = min(ctl->coarse_total[st], coarse_cap);
+    const uint32_t* __restrict__ list = coarse + (size_t)st * coarse_cap;
+
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    bool done = !in_image;
+
+    for (uint32_t base = 0u; base < total; base += 256u) {
+        const uint32_t i = base + (uint32_t)tid;
+        uint32_t rank = 0u;
+        bool hit = false;
+        if (i < total) {
+            rank = list[i];
+            const uint32_t r = rects[rank];
+            hit = tx >= (r & 255u) && tx <= ((r >> 8) & 255u) && ty >= ((r >> 16) & 255u) && ty <= (r >> 24);
+        }
+        const unsigned long long b = __ballot(hit);
+        if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        const uint32_t w0 = s_wcnt[0], w1 = s_wcnt[1], w2 = s_wcnt[2], w3 = s_wcnt[3];
+        const uint32_t woff = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+        const uint32_t cnt = w0 + w1 + w2 + w3;
+        if (hit) s_queue[woff + (uint32_t)__popcll(b & lanes_below)] = rank;
+        __syncthreads();
+        if ((uint32_t)tid < cnt) {
+            const float4* src = records + (size_t)s_queue[tid] * REC_V4;
+#pragma unroll
+            for (int v = 0; v < REC_V4; ++v) s_rec[tid * REC_V4 + v] = src[v];
+        }
+        __syncthreads();
+        if (!__all(done))
+            for (uint32_t k = 0; k < cnt; ++k)
+                blend_one<VARIANT>(s_rec + k * REC_V4, qx, qy, aspect, T, cr, cg, cb, done);
+        if (__syncthreads_and(done ? 1 : 0)) break;
+    }
+    if (in_image) {
+        fb[(size_t)py * (size_t)fp.width + (size_t)px] =
+            make_float4(cr + T * clear.x, cg + T * clear.y, cb + T * clear.z, (1.0f - T) + T * clear.w);
+    }
+}
+
+void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* records,
+                        const uint32_t* rects, const uint32_t* coarse, uint32_t coarse_cap,
+                        uint32_t sup_shift, const Control* ctl, float4* framebuffer,
+                        const float clear_color[4]) {
+    const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
+    if (ntiles == 0) return;
+    const float4 clear = make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]);
+    const float4* rec = (const float4*)records;
+    const uint32_t sup = 1u << sup_shift;
+    const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
+#define BGS_LAUNCH_RS(V)                                                                          \
+    hipLaunchKernelGGL(raster_scan_kernel<V>, dim3(ntiles), dim3(256), 0, stream, fp, rec, rects, \
+                       coarse, coarse_cap, sup_shift, sup_x, ctl, framebuffer, clear)
+    if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
+    else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
+    else BGS_LAUNCH_RS(RV_SURFEL);
+#undef BGS_LAUNCH_RS
 }
 
 void launch_raster(hipStream_t stream, const FrameParams& fp, const void* records,

@@ -177,6 +177,11 @@ class GaussianSplattingPlugin:
     def set_profiling(self, enabled: bool) -> None:
         self._check(self._lib.bgs_set_profiling(self._ctx, 1 if enabled else 0))
 
+    def set_binning(self, mode: str) -> None:
+        """'scan' (default): ordered coarse lists + lazy per-tile scan; 'sort': (tile, splat)
+        instances + stable radix sort on the tile id. Images are bit-identical."""
+        self._check(self._lib.bgs_set_binning(self._ctx, {"scan": 0, "sort": 1}[mode]))
+
     def framebuffer_device_ptr(self):
         p = ctypes.c_void_p()
         nbytes = ctypes.c_uint64()
@@ -202,6 +207,7 @@ class GaussianSplattingPlugin:
             "tile_passes": int(st.tile_passes),
             "algorithmic_bytes": int(st.algorithmic_bytes),
             "regrow_count": int(st.regrow_count),
+            "binning": "sort" if st.binning_mode else "scan",
             "stage_ms": {n: float(st.stage_ms[i]) for i, n in enumerate(_native.STAGE_NAMES)},
         }
         return d

@@ -122,7 +122,7 @@ typedef struct bgs_stats {
     uint32_t tile_passes;        /* radix passes used for the tile ids                 */
     uint64_t algorithmic_bytes;  /* SURVEY 8(d) bytes_frame (or bytes_sort) of the call */
     uint32_t regrow_count;       /* times the instance buffers were grown + re-run     */
-    uint32_t reserved;
+    uint32_t binning_mode;       /* BGS_BINNING_* used by the call                     */
 } bgs_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -183,6 +183,16 @@ int bgs_synchronize(bgs_ctx* ctx);
 /* The hipStream_t (as void*) the context launches on, so a caller can order its own
  * HIP work (e.g. torch / RCCL) against it. */
 int bgs_stream(bgs_ctx* ctx, void** hip_stream);
+
+/* How splats are binned to 16x16 tiles (results are bit-identical between the two):
+ *   BGS_BINNING_SCAN (default): ordered coarse (supertile) lists built during projection, each
+ *     tile's rasteriser scans its list lazily and stops at saturation; instance_count in the
+ *     stats is then the number of coarse list entries.
+ *   BGS_BINNING_SORT: materialise every (tile, splat) instance and stable-radix-sort them by
+ *     tile id ("tile-major|depth keys"), then per-tile ranges; instance_count = instances. */
+#define BGS_BINNING_SCAN 0u
+#define BGS_BINNING_SORT 1u
+int bgs_set_binning(bgs_ctx* ctx, uint32_t mode);
 
 /* Enable/disable per-stage HIP-event timing (default on). */
 int bgs_set_profiling(bgs_ctx* ctx, int enabled);
