@@ -434,84 +434,95 @@ void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Contro
 constexpr int RV_OBB = 0, RV_AABB3D = 1, RV_SURFEL = 2;
 constexpr float T_EPS = 1.0f / 65536.0f;  // stop compositing a pixel below this transmittance
 
-// fs_main + blend for ONE staged record and ONE pixel (src/render/gaussian.wgsl:438-505,
-// src/render/mod.rs:944-948), front-to-back form: C += T*alpha*c; T *= 1 - alpha.
+// One staged record, decoded once per splat and shared by every pixel a lane owns.
 template <int VARIANT>
-__device__ __forceinline__ void blend_one(const float4* __restrict__ rec, const float qx, const float qy,
-                                          const float aspect, float& T, float& cr, float& cg,
-                                          float& cb, bool& done) {
-#pragma clang fp contract(fast)
-    const float4 a0 = rec[0];
-    const float4 a1 = rec[1];
-    const float4 a2 = rec[2];
-    const float dx = qx - a0.x, dy = qy - a0.y;
+struct StagedRecord {
+    float4 a0, a1, a2, a3, a4;
+    __device__ __forceinline__ void load(const float4* __restrict__ rec) {
+        a0 = rec[0];
+        a1 = rec[1];
+        a2 = rec[2];
+        if constexpr (VARIANT == 2) {
+            a3 = rec[3];
+            a4 = rec[4];
+        }
+    }
+};
+
+// fs_main + blend for ONE record and ONE pixel (src/render/gaussian.wgsl:438-505,
+// src/render/mod.rs:944-948), front-to-back form, branch-free:
+//     w = covered && T >= T_EPS ? T * alpha : 0;   C += w * c;   T -= w
+// (T - T*alpha == T*(1 - alpha); a pixel stops accumulating once T < T_EPS, a per-pixel rule that
+// does not depend on how splats are batched, so every rasteriser variant gives the same bits).
+// Explicit fmaf so both rasterisers contract identically.
+template <int VARIANT>
+__device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const float qx, const float qy,
+                                         const float aspect, float& T, float& cr, float& cg, float& cb) {
+    const float dx = qx - s.a0.x, dy = qy - s.a0.y;
     float alpha, r, g, b;
     bool hit;
     if constexpr (VARIANT == RV_OBB) {
         // a0 = cx cy m00 m01 | a1 = m10 m11 - r | a2 = g b a rect
-        const float u = a0.z * dx + a0.w * dy;
-        const float v = a1.x * dx + a1.y * dy;
-        hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
-        // fs_main OBB: power = -dot(uv,uv) / (2 * (1/3)^2)  (gaussian.wgsl:474-480)
+        const float u = fmaf(s.a0.w, dy, s.a0.z * dx);
+        const float v = fmaf(s.a1.y, dy, s.a1.x * dx);
+        hit = fmaxf(fabsf(u), fabsf(v)) <= 1.0f;
+        // fs_main OBB: power = -dot(uv,uv) / (2 * (1/3)^2)  (gaussian.wgsl:474-480);
+        // exp(power) = exp2(power * log2(e)), constants folded
         constexpr float sigma = 1.0f / 3.0f;
-        constexpr float neg_inv_sigma2 = -1.0f / (2.0f * sigma * sigma);
-        const float power = (u * u + v * v) * neg_inv_sigma2;
-        alpha = fminf(__expf(power) * a2.z, 0.999f);
-        r = a1.w; g = a2.x; b = a2.y;
+        constexpr float k = -1.0f / (2.0f * sigma * sigma) * 1.4426950408889634f;
+        const float e = __builtin_amdgcn_exp2f(fmaf(u, u, v * v) * k);
+        alpha = fminf(e * s.a2.z, 0.999f);
+        r = s.a1.w; g = s.a2.x; b = s.a2.y;
     } else if constexpr (VARIANT == RV_AABB3D) {
         // a0 = cx cy m00 m11 | a1 = A B C r | a2 = g b a rect
-        const float u = a0.z * dx, v = a0.w * dy;
-        hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
-        const float power = -0.5f * (a1.x * u * u + a1.z * v * v) + a1.y * u * v;
+        const float u = s.a0.z * dx, v = s.a0.w * dy;
+        hit = fmaxf(fabsf(u), fabsf(v)) <= 1.0f;
+        const float power = fmaf(s.a1.y * u, v, -0.5f * fmaf(s.a1.x * u, u, s.a1.z * v * v));
         hit = hit && !(power > 0.0f);
-        alpha = fminf(__expf(power) * a2.z, 0.999f);
-        r = a1.w; g = a2.x; b = a2.y;
+        alpha = fminf(__expf(power) * s.a2.z, 0.999f);
+        r = s.a1.w; g = s.a2.x; b = s.a2.y;
     } else {
         // a0 = cx cy m00 m11 | a1 = radius mean.xy T0 | a2 = T1..T4 | a3 = T5..T8 | a4 = rgba
-        const float4 a3 = rec[3];
-        const float4 a4 = rec[4];
-        const float u = a0.z * dx, v = a0.w * dy;
-        hit = fabsf(u) <= 1.0f && fabsf(v) <= 1.0f;
+        const float u = s.a0.z * dx, v = s.a0.w * dy;
+        hit = fmaxf(fabsf(u), fabsf(v)) <= 1.0f;
         // fs_main GAUSSIAN_2D + USE_AABB (gaussian.wgsl:440-455), aspect = (1, W/H)
-        const float pcx = u * a1.x * 1.0f + a1.y;
-        const float pcy = v * a1.x * aspect + a1.z;
+        const float pcx = fmaf(u, s.a1.x, s.a1.y);
+        const float pcy = fmaf(v * s.a1.x, aspect, s.a1.z);
         // surfel_fragment_power (gaussian_2d.wgsl:134-156)
-        const float T0x = a1.w, T0y = a2.x, T0z = a2.y;
-        const float T1x = a2.z, T1y = a2.w, T1z = a3.x;
-        const float T2x = a3.y, T2y = a3.z, T2z = a3.w;
-        const float hux = pcx * T2x - T0x, huy = pcx * T2y - T0y, huz = pcx * T2z - T0z;
-        const float hvx = pcy * T2x - T1x, hvy = pcy * T2y - T1y, hvz = pcy * T2z - T1z;
-        const float cpx = huy * hvz - hvy * huz;
-        const float cpy = huz * hvx - hvz * hux;
-        const float cpz = hux * hvy - hvx * huy;
+        const float T0x = s.a1.w, T0y = s.a2.x, T0z = s.a2.y;
+        const float T1x = s.a2.z, T1y = s.a2.w, T1z = s.a3.x;
+        const float T2x = s.a3.y, T2y = s.a3.z, T2z = s.a3.w;
+        const float hux = fmaf(pcx, T2x, -T0x), huy = fmaf(pcx, T2y, -T0y), huz = fmaf(pcx, T2z, -T0z);
+        const float hvx = fmaf(pcy, T2x, -T1x), hvy = fmaf(pcy, T2y, -T1y), hvz = fmaf(pcy, T2z, -T1z);
+        const float cpx = fmaf(huy, hvz, -(hvy * huz));
+        const float cpy = fmaf(huz, hvx, -(hvz * hux));
+        const float cpz = fmaf(hux, hvy, -(hvx * huy));
         const float us = cpx / cpz, vs = cpy / cpz;
-        const float ddx = a1.y - pcx, ddy = a1.z - pcy;
-        const float s3 = us * us + vs * vs;
-        const float s2 = 2.0f * (ddx * ddx + ddy * ddy);
+        const float ddx = s.a1.y - pcx, ddy = s.a1.z - pcy;
+        const float s3 = fmaf(us, us, vs * vs);
+        const float s2 = 2.0f * fmaf(ddx, ddx, ddy * ddy);
         const float power = -0.5f * fminf(s3, s2);
         hit = hit && !(power > 0.0f);
-        alpha = fminf(__expf(power) * a4.w, 0.999f);
-        r = a4.x; g = a4.y; b = a4.z;
+        alpha = fminf(__expf(power) * s.a4.w, 0.999f);
+        r = s.a4.x; g = s.a4.y; b = s.a4.z;
     }
-    if (hit && !done) {
-        const float w = T * alpha;
-        cr += w * r;
-        cg += w * g;
-        cb += w * b;
-        T *= 1.0f - alpha;
-        done = T < T_EPS;
-    }
+    const float w = (hit && T >= T_EPS) ? T * alpha : 0.0f;
+    cr = fmaf(w, r, cr);
+    cg = fmaf(w, g, cg);
+    cb = fmaf(w, b, cb);
+    T -= w;
 }
 
-// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch, a speed assumption
-// only); give each XCD a contiguous band of tiles so neighbouring tiles, which share records
+// XCD-aware work order: workgroup b runs on XCD b % 8 (observed dispatch, a speed assumption
+// only); give each XCD a contiguous band of work items so neighbouring tiles, which share records
 // and coarse lists, share an L2.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t ntiles) {
-    const uint32_t q = ntiles / 8u, r = ntiles % 8u, xcd = b % 8u;
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    const uint32_t q = n / 8u, r = n % 8u, xcd = b % 8u;
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
 }
 
-// BINNING_SORT rasteriser: the tile's instances are a contiguous range of the sorted list.
+// BINNING_SORT rasteriser: one workgroup per tile, one pixel per thread; the tile's instances are
+// a contiguous range of the tile-sorted list, staged 256 records at a time in LDS.
 template <int VARIANT>
 __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float4* __restrict__ records,
                                                      const uint2* __restrict__ instances,
@@ -520,7 +531,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     __shared__ float4 s_rec[256 * REC_V4];
 
-    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)(fp.tiles_x * fp.tiles_y));
+    const uint32_t tile = xcd_remap(blockIdx.x, (uint32_t)(fp.tiles_x * fp.tiles_y));
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
     const int tid = threadIdx.x;
     const int px = (int)tx * TILE_PX + (tid & 15), py = (int)ty * TILE_PX + (tid >> 4);
@@ -529,8 +540,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     const float aspect = fp.viewport_w / fp.viewport_h;
 
     const uint2 range = ranges[(ty << 8) | tx];
-    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    bool done = !in_image;
+    float T = in_image ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
 
     for (uint32_t base = range.x; base < range.y; base += 256u) {
         const uint32_t cnt = min(256u, range.y - base);
@@ -541,22 +551,30 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
             for (int v = 0; v < REC_V4; ++v) s_rec[tid * REC_V4 + v] = src[v];
         }
         __syncthreads();
-        if (!__all(done))
-            for (uint32_t k = 0; k < cnt; ++k)
-                blend_one<VARIANT>(s_rec + k * REC_V4, qx, qy, aspect, T, cr, cg, cb, done);
+        if (!__all(T < T_EPS))
+            for (uint32_t k = 0; k < cnt; ++k) {
+                StagedRecord<VARIANT> sr;
+                sr.load(s_rec + k * REC_V4);
+                blend_px<VARIANT>(sr, qx, qy, aspect, T, cr, cg, cb);
+            }
         // also the barrier that protects s_rec before the next batch overwrites it
-        if (__syncthreads_and(done ? 1 : 0)) break;
+        if (__syncthreads_and(T < T_EPS ? 1 : 0)) break;
     }
     if (in_image) {
         // dst = src + dst*(1-src.a) unrolled over the whole list, target cleared to `clear`
         fb[(size_t)py * (size_t)fp.width + (size_t)px] =
-            make_float4(cr + T * clear.x, cg + T * clear.y, cb + T * clear.z, (1.0f - T) + T * clear.w);
+            make_float4(fmaf(T, clear.x, cr), fmaf(T, clear.y, cg), fmaf(T, clear.z, cb),
+                        fmaf(T, clear.w, 1.0f - T));
     }
 }
 
-// BINNING_SCAN rasteriser: lazily bins while it composites. Per group of 256 candidates from the
-// supertile's depth-ordered list: keep those whose tile rectangle contains this tile (ordered
-// ballot compaction into LDS), stage their records, blend, stop at saturation.
+// BINNING_SCAN rasteriser: ONE WAVE per 16x16 tile (4 tiles per workgroup, no workgroup barriers),
+// each lane owns 4 pixels (column lane&15, rows (lane>>4) + {0,4,8,12}), so one LDS broadcast read
+// of a record feeds 256 pixel evaluations of a single wave. The wave bins lazily while it
+// composites: per group of 64 candidates from its supertile's depth-ordered list it keeps those
+// whose tile rectangle contains this tile (order-preserving ballot compaction), stages their
+// records in its private LDS slice, blends, and stops at saturation. The candidate stream is
+// prefetched two groups (ranks) / one group (rectangles) ahead of the blend.
 template <int VARIANT>
 __global__ __launch_bounds__(256) void raster_scan_kernel(FrameParams fp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ rects,
@@ -565,57 +583,83 @@ __global__ __launch_bounds__(256) void raster_scan_kernel(FrameParams fp, const 
                                                           uint32_t sup_x, const Control* __restrict__ ctl,
                                                           float4* __restrict__ fb, float4 clear) {
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
-    __shared__ float4 s_rec[256 * REC_V4];
-    __shared__ uint32_t s_queue[256];
-    __shared__ uint32_t s_wcnt[4];
+    __shared__ float4 s_rec_all[4][64 * REC_V4];
+    __shared__ uint32_t s_queue_all[4][64];
 
-    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)(fp.tiles_x * fp.tiles_y));
-    const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int px = (int)tx * TILE_PX + (tid & 15), py = (int)ty * TILE_PX + (tid >> 4);
-    const bool in_image = px < fp.width && py < fp.height;
-    const float qx = (float)px + 0.5f, qy = (float)py + 0.5f;
+    const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
+    const uint32_t nblocks = (ntiles + 3u) / 4u;
+    const uint32_t tile = xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
+    if (tile >= ntiles) return;  // whole wave; nothing below synchronises across waves
+    float4* const s_rec = s_rec_all[wave];
+    volatile uint32_t* const s_queue = s_queue_all[wave];
+
+    const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
+    const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + (lane >> 4);
+    const float qx = (float)px + 0.5f;
     const float aspect = fp.viewport_w / fp.viewport_h;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    float T[4], cr[4], cg[4], cb[4], qy[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int py = py0 + 4 * r;
+        qy[r] = (float)py + 0.5f;
+        T[r] = (px < fp.width && py < fp.height) ? 1.0f : 0.0f;
+        cr[r] = cg[r] = cb[r] = 0.0f;
+    }
 
     const uint32_t st = (ty >> sup_shift) * sup_x + (tx >> sup_shift);
     const uint32_t total = min(ctl->coarse_total[st], coarse_cap);
     const uint32_t* __restrict__ list = coarse + (size_t)st * coarse_cap;
 
-    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    bool done = !in_image;
+    // candidate stream: ranks two groups ahead, rectangles one group ahead
+    uint32_t rank_cur = (uint32_t)lane < total ? list[lane] : 0u;
+    uint32_t rank_nxt = (uint32_t)lane + 64u < total ? list[lane + 64] : 0u;
+    uint32_t rect_cur = (uint32_t)lane < total ? rects[rank_cur] : RECT_EMPTY;
 
-    for (uint32_t base = 0u; base < total; base += 256u) {
-        const uint32_t i = base + (uint32_t)tid;
-        uint32_t rank = 0u;
-        bool hit = false;
-        if (i < total) {
-            rank = list[i];
-            const uint32_t r = rects[rank];
-            hit = tx >= (r & 255u) && tx <= ((r >> 8) & 255u) && ty >= ((r >> 16) & 255u) && ty <= (r >> 24);
-        }
+    for (uint32_t base = 0u; base < total; base += 64u) {
+        const uint32_t i2 = base + 128u + (uint32_t)lane;
+        const uint32_t rank_nn = i2 < total ? list[i2] : 0u;
+        const uint32_t rect_nxt = base + 64u + (uint32_t)lane < total ? rects[rank_nxt] : RECT_EMPTY;
+
+        const bool hit = tx >= (rect_cur & 255u) && tx <= ((rect_cur >> 8) & 255u) &&
+                         ty >= ((rect_cur >> 16) & 255u) && ty <= (rect_cur >> 24);
         const unsigned long long b = __ballot(hit);
-        if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(b);
-        __syncthreads();
-        const uint32_t w0 = s_wcnt[0], w1 = s_wcnt[1], w2 = s_wcnt[2], w3 = s_wcnt[3];
-        const uint32_t woff = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
-        const uint32_t cnt = w0 + w1 + w2 + w3;
-        if (hit) s_queue[woff + (uint32_t)__popcll(b & lanes_below)] = rank;
-        __syncthreads();
-        if ((uint32_t)tid < cnt) {
-            const float4* src = records + (size_t)s_queue[tid] * REC_V4;
+        const uint32_t cnt = (uint32_t)__popcll(b);
+        if (cnt) {
+            if (hit) s_queue[__popcll(b & lanes_below)] = rank_cur;
+            __builtin_amdgcn_wave_barrier();
+            if ((uint32_t)lane < cnt) {
+                const float4* src = records + (size_t)s_queue[lane] * REC_V4;
 #pragma unroll
-            for (int v = 0; v < REC_V4; ++v) s_rec[tid * REC_V4 + v] = src[v];
+                for (int v = 0; v < REC_V4; ++v) s_rec[lane * REC_V4 + v] = src[v];
+            }
+            // make the staged records visible to every lane of this wave before the broadcast reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t k = 0; k < cnt; ++k) {
+                StagedRecord<VARIANT> sr;
+                sr.load(s_rec + k * REC_V4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, T[r], cr[r], cg[r], cb[r]);
+            }
+            const bool sat = T[0] < T_EPS && T[1] < T_EPS && T[2] < T_EPS && T[3] < T_EPS;
+            if (__all(sat)) break;
+            __builtin_amdgcn_wave_barrier();  // blend reads of s_rec done before the next staging
         }
-        __syncthreads();
-        if (!__all(done))
-            for (uint32_t k = 0; k < cnt; ++k)
-                blend_one<VARIANT>(s_rec + k * REC_V4, qx, qy, aspect, T, cr, cg, cb, done);
-        if (__syncthreads_and(done ? 1 : 0)) break;
+        rank_cur = rank_nxt;
+        rank_nxt = rank_nn;
+        rect_cur = rect_nxt;
     }
-    if (in_image) {
-        fb[(size_t)py * (size_t)fp.width + (size_t)px] =
-            make_float4(cr + T * clear.x, cg + T * clear.y, cb + T * clear.z, (1.0f - T) + T * clear.w);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int py = py0 + 4 * r;
+        if (px < fp.width && py < fp.height)
+            fb[(size_t)py * (size_t)fp.width + (size_t)px] =
+                make_float4(fmaf(T[r], clear.x, cr[r]), fmaf(T[r], clear.y, cg[r]), fmaf(T[r], clear.z, cb[r]),
+                            fmaf(T[r], clear.w, 1.0f - T[r]));
     }
 }
 
@@ -630,7 +674,7 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* r
     const uint32_t sup = 1u << sup_shift;
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
 #define BGS_LAUNCH_RS(V)                                                                          \
-    hipLaunchKernelGGL(raster_scan_kernel<V>, dim3(ntiles), dim3(256), 0, stream, fp, rec, rects, \
+    hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, fp, rec, rects, \
                        coarse, coarse_cap, sup_shift, sup_x, ctl, framebuffer, clear)
     if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
