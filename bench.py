@@ -67,27 +67,28 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
 
 
 def measure(plugin, handle, view, settings, steps, warmup, after_step=None, barrier=None):
-    """W untimed + K timed steps; returns (seconds, mean per-stage ms over the timed steps, stats)."""
+    """W untimed + K timed steps. A step ENQUEUES one frame (async frames: the scan pipeline needs
+    no host round trip); the closing barrier waits for all of them, so dt covers exactly K complete
+    frames. Returns (seconds, per-stage ms averaged by the library over the timed frames' HIP
+    events, stats of the last frame)."""
     for _ in range(warmup):
         plugin.render(handle, view, settings, download=False)
         if after_step:
             after_step()
-    acc = None
+    plugin.synchronize()
     if barrier:
         barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        plugin.render(handle, view, settings, download=False)  # returns after the frame completed
-        st = plugin.stats()
+        plugin.render(handle, view, settings, download=False)
         if after_step:
             after_step()
-        ms = st["stage_ms"]
-        acc = ms if acc is None else {k: acc[k] + ms[k] for k in ms}
+    plugin.synchronize()  # also checks the device watchdog word of the last frame
     if barrier:
         barrier()
     dt = time.perf_counter() - t0
-    mean = {k: v / max(steps, 1) for k, v in (acc or {}).items()}
-    return dt, mean, st
+    st = plugin.stats()
+    return dt, dict(st["stage_ms"]), st
 
 
 def cpu_baseline(cloud, view, settings):
@@ -154,6 +155,7 @@ def main():
     handle = plugin.upload(cloud)
     view = headless_view(rank, WIDTH, HEIGHT)  # rank g owns camera g
     settings = CloudSettings()
+    plugin.set_async(True)
 
     def barrier():
         if dist is not None:
@@ -164,7 +166,7 @@ def main():
     after = None
     if dist is not None:
         def after():
-            t = framebuffer_as_tensor(plugin, HEIGHT, WIDTH)
+            t = framebuffer_as_tensor(plugin, HEIGHT, WIDTH)  # completes the pending frame
             t0 = time.perf_counter()
             gather_framebuffers(t.unsqueeze(0), dst=0)
             torch.cuda.synchronize()

@@ -42,9 +42,11 @@ EXPORTED_SYMBOLS = (
     "bgs_framebuffer_device_ptr",
     "bgs_sorted_entries_device_ptr",
     "bgs_synchronize",
+    "bgs_set_async",
     "bgs_stream",
     "bgs_set_profiling",
     "bgs_set_binning",
+    "bgs_set_debug_flags",
     "bgs_get_stats",
     "bgs_radix_sort_pairs",
 )
@@ -69,6 +71,8 @@ class BgsStats(ctypes.Structure):
         ("algorithmic_bytes", ctypes.c_uint64),
         ("regrow_count", ctypes.c_uint32),
         ("binning_mode", ctypes.c_uint32),
+        ("frames_averaged", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 
@@ -130,12 +134,16 @@ def load() -> ctypes.CDLL:
     lib.bgs_sorted_entries_device_ptr.restype = ctypes.c_int
     lib.bgs_synchronize.argtypes = [vp]
     lib.bgs_synchronize.restype = ctypes.c_int
+    lib.bgs_set_async.argtypes = [vp, ctypes.c_int]
+    lib.bgs_set_async.restype = ctypes.c_int
     lib.bgs_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.bgs_stream.restype = ctypes.c_int
     lib.bgs_set_profiling.argtypes = [vp, ctypes.c_int]
     lib.bgs_set_profiling.restype = ctypes.c_int
     lib.bgs_set_binning.argtypes = [vp, u32]
     lib.bgs_set_binning.restype = ctypes.c_int
+    lib.bgs_set_debug_flags.argtypes = [vp, u32]
+    lib.bgs_set_debug_flags.restype = ctypes.c_int
     lib.bgs_get_stats.argtypes = [vp, ctypes.POINTER(BgsStats)]
     lib.bgs_get_stats.restype = ctypes.c_int
     lib.bgs_radix_sort_pairs.argtypes = [vp, ctypes.POINTER(BgsSortEntry), u32, u32]

@@ -41,6 +41,7 @@ constexpr uint64_t MIN_INSTANCE_CAPACITY = 1ull << 22;  // 4M instances (32 MB p
 constexpr uint64_t MAX_INSTANCE_CAPACITY = 1ull << 30;  // look-back words carry 30-bit values
 constexpr uint32_t MAX_SPLATS = (1u << 30) - 1u;
 constexpr int EV_COUNT = BGS_STAGE_COUNT + 1;
+constexpr int EV_RING = 64;  // per-stage timings are averaged over up to this many async frames
 
 template <class T>
 T* dev_alloc(size_t count) {
@@ -60,11 +61,13 @@ struct bgs_ctx {
     // zeroed-every-frame scratch: [Control | depth status | scan status | tile status | ranges]
     uint8_t* scratch = nullptr;
     size_t scratch_bytes = 0;
-    size_t off_depth_status = 0, off_scan_status = 0, off_tile_status = 0, off_ranges = 0, off_bin_status = 0;
+    size_t off_depth_status = 0, off_scan_status = 0, off_tile_status = 0, off_ranges = 0, off_bin_status = 0,
+           off_part_status = 0;
     uint32_t scratch_n = 0;          // splat capacity the scratch was laid out for
     uint64_t scratch_inst_cap = 0;   // instance capacity the scratch was laid out for
 
     uint2* entries[2] = {nullptr, nullptr};
+    uint2* culled = nullptr;         // entries with the culled sentinel key, in index order
     uint32_t entries_cap = 0;
     void* records = nullptr;
     size_t records_bytes = 0;
@@ -75,13 +78,22 @@ struct bgs_ctx {
     uint32_t* coarse = nullptr;      // BINNING_SCAN: [num_supertiles][coarse_cap] ordered rank lists
     size_t coarse_words = 0;
     uint32_t binning = BINNING_SCAN;
+    uint32_t debug_flags = 0;
     float4* fb = nullptr;
     size_t fb_pixels = 0;
     uint32_t fb_w = 0, fb_h = 0;
 
     Control* h_ctl = nullptr;  // pinned
-    hipEvent_t ev[EV_COUNT] = {};
-    bool profiling = true;
+    hipEvent_t ev_ring[EV_RING][EV_COUNT] = {};
+    uint8_t ev_kind[EV_RING] = {};   // 0 unused, 1 sort-only frame, 2 render/scan, 3 render/sort-binning
+    uint32_t ev_head = 0;            // slot of the most recently enqueued frame
+    uint32_t frames_pending = 0;     // frames enqueued since the last finish_frame
+    int profiling = 2;         // 0 = no events, 1 = frame start/end only, 2 = every stage
+    bool async_frames = false; // bgs_render(host_out = NULL) returns without waiting (scan binning)
+    bool pending = false;      // a frame has been enqueued whose Control block was not read back yet
+    bool pending_render = false;
+    uint32_t pending_n = 0, pending_places = 0, pending_num_st = 0, pending_rec_bytes = 0, pending_is_f16 = 0;
+    uint32_t pending_w = 0, pending_h = 0, pending_tx = 0, pending_ty = 0;
     bool have_stats = false;
     bgs_stats stats{};
 
@@ -126,6 +138,8 @@ int ensure_scratch(bgs_ctx* ctx, uint32_t n, uint64_t inst_cap) {
     off += align_up((size_t)RADIX_BASE * RADIX_BASE * sizeof(uint2), 256);
     const size_t off_bin = off;
     off += align_up(scan_tiles * MAX_SUPERTILES * sizeof(uint32_t), 256);
+    const size_t off_part = off;
+    off += align_up((((size_t)n + KEYGEN_TILE - 1) / KEYGEN_TILE + 1) * sizeof(uint32_t), 256);
     if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; }
     void* p = nullptr;
     if (hipMalloc(&p, off) != hipSuccess) return fail(ctx, BGS_ENOMEM, "hipMalloc(scratch) failed");
@@ -136,6 +150,7 @@ int ensure_scratch(bgs_ctx* ctx, uint32_t n, uint64_t inst_cap) {
     ctx->off_tile_status = off_tile;
     ctx->off_ranges = off_ranges;
     ctx->off_bin_status = off_bin;
+    ctx->off_part_status = off_part;
     ctx->scratch_n = n;
     ctx->scratch_inst_cap = inst_cap;
     return BGS_OK;
@@ -144,10 +159,13 @@ int ensure_scratch(bgs_ctx* ctx, uint32_t n, uint64_t inst_cap) {
 int ensure_entries(bgs_ctx* ctx, uint32_t n) {
     if (n <= ctx->entries_cap && ctx->entries[0]) return BGS_OK;
     for (auto& e : ctx->entries) { if (e) (void)hipFree(e); e = nullptr; }
+    if (ctx->culled) { (void)hipFree(ctx->culled); ctx->culled = nullptr; }
     for (auto& e : ctx->entries) {
         e = dev_alloc<uint2>(n);
         if (!e) return fail(ctx, BGS_ENOMEM, "hipMalloc(sort entries) failed");
     }
+    ctx->culled = dev_alloc<uint2>(n);
+    if (!ctx->culled) return fail(ctx, BGS_ENOMEM, "hipMalloc(culled entries) failed");
     ctx->entries_cap = n;
     return BGS_OK;
 }
@@ -229,12 +247,118 @@ int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
     return BGS_OK;
 }
 
-// Enqueue + complete one frame. Returns BGS_OK, or BGS_ECAPACITY-internal signal via *need_cap.
+// Read back the Control block of the last enqueued frame, check the watchdog / overflow words and
+// fill the stats. Called right after enqueueing (synchronous mode) or from bgs_synchronize /
+// bgs_get_stats / the next blocking call (async mode).
+int finish_frame(bgs_ctx* ctx, uint64_t* need_cap) {
+    if (need_cap) *need_cap = 0;
+    if (!ctx->pending) return BGS_OK;
+    hipStream_t st = ctx->stream;
+    Control* ctl = (Control*)ctx->scratch;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    ctx->pending = false;
+    const bool render = ctx->pending_render;
+    const bool scan = ctx->binning == BINNING_SCAN;
+    const uint32_t n = ctx->pending_n, places = ctx->pending_places, num_st = ctx->pending_num_st;
+    const size_t rec_bytes = ctx->pending_rec_bytes;
+
+    const Control& h = *ctx->h_ctl;
+    // after a render only the drawable prefix of the list is materialised (the culled tail stays
+    // in its side buffer); bgs_sort appends it so that callers get the reference's full list
+    ctx->last_sorted_n = render ? h.draw_count : n;
+    if (!render && h.draw_count < n) {
+        // bgs_sort contract: one contiguous list, culled entries last (ascending index)
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint2*>(ctx->last_sorted) + h.draw_count, ctx->culled,
+                                    (size_t)(n - h.draw_count) * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    if (h.error) return fail(ctx, BGS_EINTERNAL, "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
+    uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
+    if (render && scan) {
+        total = 0;
+        for (uint32_t i = 0; i < num_st; ++i) total += h.coarse_total[i];
+    }
+    if (render && h.overflow) {
+        if (need_cap) *need_cap = total;
+        return BGS_OK;
+    }
+
+    // stats
+    bgs_stats& stt = ctx->stats;
+    const uint32_t regrow = stt.regrow_count;
+    std::memset(&stt, 0, sizeof stt);
+    stt.regrow_count = regrow;
+    stt.splat_count = n;
+    stt.visible_count = render ? h.visible_count : h.draw_count;
+    stt.instance_count = render ? total : 0;
+    stt.instance_capacity = ctx->inst_cap;
+    stt.tiles_x = render ? ctx->pending_tx : 0;
+    stt.tiles_y = render ? ctx->pending_ty : 0;
+    stt.depth_passes = places;
+    stt.tile_passes = (render && !scan) ? 2 : 0;
+    stt.binning_mode = ctx->binning;
+    {
+        // SURVEY 8(d) algorithmic bytes
+        const uint64_t N = n, k = places;
+        uint64_t bytes = N * 16 + N * 8 + k * N * 16;  // bytes_sort
+        if (render) {
+            const uint64_t B = ctx->pending_is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
+            const uint64_t P = (uint64_t)ctx->pending_w * ctx->pending_h;
+            if (scan)  // coarse entries: written once (4 B), read by the tiles of their supertile
+                bytes += V * (B - 16) + V * R + V * 8 + I * 4 + I * 4 + P * 16;
+            else
+                bytes += V * (B - 16) + V * R + I * 8 + 2 * I * 16 + I * (4 + R) + P * 16;
+        }
+        stt.algorithmic_bytes = bytes;
+    }
+    const int prof = ctx->profiling;
+    if (prof >= 1) {
+        // mean over the frames enqueued since the last read-back that ran the same pipeline
+        const int last = render ? 6 : 2;
+        const uint8_t kind = ctx->ev_kind[ctx->ev_head];
+        const uint32_t frames = std::min<uint32_t>(ctx->frames_pending, EV_RING);
+        uint32_t used = 0;
+        float acc[BGS_STAGE_COUNT] = {0, 0, 0, 0, 0, 0}, acc_total = 0.0f;
+        for (uint32_t f = 0; f < frames; ++f) {
+            const uint32_t slot = (ctx->ev_head + EV_RING - f) % EV_RING;
+            if (ctx->ev_kind[slot] != kind) continue;
+            hipEvent_t* const ev = ctx->ev_ring[slot];
+            auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ev[a], ev[b]); return t; };
+            if (prof >= 2) {
+                acc[BGS_STAGE_KEYGEN] += ms(0, 1);
+                acc[BGS_STAGE_DEPTH_SORT] += ms(1, 2);
+                if (render && scan) {
+                    acc[BGS_STAGE_PROJECT] += ms(2, 3);
+                    acc[BGS_STAGE_RASTER] += ms(3, 6);
+                } else if (render) {
+                    acc[BGS_STAGE_PROJECT] += ms(2, 3);
+                    acc[BGS_STAGE_TILE_SORT] += ms(3, 4);
+                    acc[BGS_STAGE_RANGES] += ms(4, 5);
+                    acc[BGS_STAGE_RASTER] += ms(5, 6);
+                }
+            }
+            acc_total += ms(0, last);
+            ++used;
+        }
+        if (used) {
+            for (int i = 0; i < BGS_STAGE_COUNT; ++i) stt.stage_ms[i] = acc[i] / (float)used;
+            stt.total_ms = acc_total / (float)used;
+        }
+        stt.frames_averaged = used;
+    }
+    ctx->frames_pending = 0;
+    ctx->have_stats = true;
+    return BGS_OK;
+}
+
+// Enqueue (and, unless async, complete) one frame. Returns BGS_OK, or BGS_ECAPACITY-internal signal via *need_cap.
 int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s,
               bool render, uint64_t* need_cap) {
     *need_cap = 0;
     FrameParams fp{};
     fill_frame_params(cloud->ptrs.n, view, s, fp);
+    fp.debug = ctx->debug_flags;
     const uint32_t n = fp.n;
     const uint32_t places = depth_places(s);
     const bool surfel = render && fp.gaussian_mode == 0u && fp.aabb != 0u;
@@ -268,12 +392,21 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
     uint32_t* tile_status = (uint32_t*)(ctx->scratch + ctx->off_tile_status);
     uint2* ranges = (uint2*)(ctx->scratch + ctx->off_ranges);
     uint32_t* bin_status = (uint32_t*)(ctx->scratch + ctx->off_bin_status);
-    const bool prof = ctx->profiling;
-    auto mark = [&](int i) { if (prof) (void)hipEventRecord(ctx->ev[i], st); };
+    uint32_t* part_status = (uint32_t*)(ctx->scratch + ctx->off_part_status);
+    const int prof = ctx->profiling;
+    const int last_mark = render ? 6 : 2;
+    ctx->ev_head = (ctx->ev_head + 1) % EV_RING;
+    ctx->ev_kind[ctx->ev_head] = (uint8_t)(!render ? 1 : (scan ? 2 : 3));
+    ctx->frames_pending += 1;
+    hipEvent_t* const ev = ctx->ev_ring[ctx->ev_head];
+    auto mark = [&](int i) {
+        if (prof >= 2 || (prof == 1 && (i == 0 || i == last_mark))) (void)hipEventRecord(ev[i], st);
+    };
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, st));
     mark(0);
-    launch_keygen(st, fp, cloud->ptrs.position_visibility, ctx->entries[0], ctl, places);
+    launch_keygen(st, fp, cloud->ptrs.position_visibility, ctx->entries[0], ctx->culled, ctl, part_status,
+                  places, /*ticket_slot=*/7, ctx->num_cus * 4);
     mark(1);
     const bool large = n > (4u << 20);
     const uint32_t dtile = sort_tile_size(large);
@@ -284,23 +417,22 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
     for (uint32_t p = 0; p < places; ++p) {
         const uint32_t key_xor =
             (p + 1 == places && (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD)) ? 0xFFFFFFFFu : 0u;
-        launch_onesweep_pass(st, ctx->entries[cur], ctx->entries[cur ^ 1], &ctl->splat_count, n,
+        // only the V' drawable entries are sorted; the culled tail is already in its final order
+        launch_onesweep_pass(st, ctx->entries[cur], ctx->entries[cur ^ 1], &ctl->draw_count, n,
                              ctl->hist_depth[p], depth_status + (size_t)p * depth_tiles * RADIX_BASE,
                              &ctl->ticket[p], &ctl->error, p * RADIX_BITS, key_xor, large, sort_blocks);
         cur ^= 1;
     }
     mark(2);
-    const uint2* draw_list = ctx->entries[cur];
+    uint2* const draw_list = ctx->entries[cur];
     ctx->last_sorted = draw_list;
     ctx->last_sorted_n = n;
 
     if (render && scan) {
         const uint32_t coarse_cap = std::max<uint32_t>(n, 1);
         launch_project_bin(st, fp, cloud->ptrs, draw_list, ctl, bin_status, ctx->records, ctx->rects,
-                           ctx->coarse, coarse_cap, sup_shift, /*ticket_slot=*/4, ctx->num_cus * 3);
+                           ctx->coarse, coarse_cap, sup_shift, /*ticket_slot=*/4, ctx->num_cus * 2);
         mark(3);
-        mark(4);
-        mark(5);
         launch_raster_scan(st, fp, ctx->records, ctx->rects, ctx->coarse, coarse_cap, sup_shift, ctl,
                            ctx->fb, view->clear_color);
         mark(6);
@@ -322,70 +454,30 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
         mark(6);
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-
-    const Control& h = *ctx->h_ctl;
-    if (h.error) return fail(ctx, BGS_EINTERNAL, "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
-    uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
-    if (render && scan) {
-        total = 0;
-        for (uint32_t i = 0; i < num_st; ++i) total += h.coarse_total[i];
-    }
-    if (render && h.overflow) {
-        *need_cap = total;
-        return BGS_OK;
-    }
-
-    // stats
-    bgs_stats& stt = ctx->stats;
-    const uint32_t regrow = stt.regrow_count;
-    std::memset(&stt, 0, sizeof stt);
-    stt.regrow_count = regrow;
-    stt.splat_count = n;
-    stt.visible_count = render ? h.visible_count : h.draw_count;
-    stt.instance_count = render ? total : 0;
-    stt.instance_capacity = ctx->inst_cap;
-    stt.tiles_x = render ? (uint32_t)fp.tiles_x : 0;
-    stt.tiles_y = render ? (uint32_t)fp.tiles_y : 0;
-    stt.depth_passes = places;
-    stt.tile_passes = (render && !scan) ? 2 : 0;
-    stt.binning_mode = ctx->binning;
-    {
-        // SURVEY 8(d) algorithmic bytes
-        const uint64_t N = n, k = places;
-        uint64_t bytes = N * 16 + N * 8 + k * N * 16;  // bytes_sort
-        if (render) {
-            const uint64_t B = cloud->ptrs.is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
-            const uint64_t P = (uint64_t)fp.width * fp.height;
-            if (scan)  // coarse entries: written once (4 B), read by up to 2^(2*sup_shift) tiles
-                bytes += V * (B - 16) + V * R + V * 8 + I * 4 + I * 4 + P * 16;
-            else
-                bytes += V * (B - 16) + V * R + I * 8 + 2 * I * 16 + I * (4 + R) + P * 16;
-        }
-        stt.algorithmic_bytes = bytes;
-    }
-    if (prof) {
-        const int last = render ? 6 : 2;
-        auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ctx->ev[a], ctx->ev[b]); return t; };
-        stt.stage_ms[BGS_STAGE_KEYGEN] = ms(0, 1);
-        stt.stage_ms[BGS_STAGE_DEPTH_SORT] = ms(1, 2);
-        if (render) {
-            stt.stage_ms[BGS_STAGE_PROJECT] = ms(2, 3);
-            stt.stage_ms[BGS_STAGE_TILE_SORT] = ms(3, 4);
-            stt.stage_ms[BGS_STAGE_RANGES] = ms(4, 5);
-            stt.stage_ms[BGS_STAGE_RASTER] = ms(5, 6);
-        }
-        stt.total_ms = ms(0, last);
-    }
-    ctx->have_stats = true;
-    return BGS_OK;
+    ctx->pending = true;
+    ctx->pending_render = render;
+    ctx->pending_n = n;
+    ctx->pending_places = places;
+    ctx->pending_num_st = num_st;
+    ctx->pending_rec_bytes = (uint32_t)rec_bytes;
+    ctx->pending_is_f16 = cloud->ptrs.is_f16;
+    ctx->pending_w = (uint32_t)fp.width;
+    ctx->pending_h = (uint32_t)fp.height;
+    ctx->pending_tx = (uint32_t)fp.tiles_x;
+    ctx->pending_ty = (uint32_t)fp.tiles_y;
+    if (ctx->async_frames && render && scan) return BGS_OK;  // nothing the host must see before the next frame
+    return finish_frame(ctx, need_cap);
 }
 
 int run(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s, bool render) {
     int rc = validate(ctx, cloud, view, s, render);
     if (rc != BGS_OK) return rc;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    const bool will_be_async = ctx->async_frames && render && ctx->binning == BINNING_SCAN;
+    if (ctx->pending && !will_be_async) {  // a blocking call: surface the queued frames' watchdog state first
+        rc = finish_frame(ctx, nullptr);
+        if (rc != BGS_OK) return rc;
+    }
     ctx->stats.regrow_count = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
         uint64_t need = 0;
@@ -475,8 +567,9 @@ int bgs_create(int hip_device, bgs_ctx** out) {
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
-    for (auto& ev : ctx->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    for (auto& slot : ctx->ev_ring)
+        for (auto& ev : slot)
+            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     void* h = nullptr;
     if ((e = hipHostMalloc(&h, sizeof(Control), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     ctx->h_ctl = (Control*)h;
@@ -490,13 +583,15 @@ void bgs_destroy(bgs_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto e : ctx->entries) if (e) (void)hipFree(e);
+    if (ctx->culled) (void)hipFree(ctx->culled);
     for (auto e : ctx->inst) if (e) (void)hipFree(e);
     if (ctx->records) (void)hipFree(ctx->records);
     if (ctx->rects) (void)hipFree(ctx->rects);
     if (ctx->coarse) (void)hipFree(ctx->coarse);
     if (ctx->fb) (void)hipFree(ctx->fb);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
-    for (auto ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& slot : ctx->ev_ring)
+        for (auto ev : slot) if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -630,6 +725,7 @@ int bgs_render(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const
                float* rgba_host_out) {
     int rc = run(ctx, cloud, view, settings, /*render=*/true);
     if (rc != BGS_OK) return rc;
+    if (rgba_host_out && ctx->pending && (rc = finish_frame(ctx, nullptr)) != BGS_OK) return rc;
     if (rgba_host_out)
         HIP_TRY(ctx, hipMemcpy(rgba_host_out, ctx->fb, (size_t)ctx->fb_w * ctx->fb_h * sizeof(float4),
                                hipMemcpyDeviceToHost));
@@ -638,6 +734,10 @@ int bgs_render(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const
 
 int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes) {
     if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
+    if (ctx->pending) {
+        int rc = finish_frame(ctx, nullptr);
+        if (rc != BGS_OK) return rc;
+    }
     if (!ctx->fb) return fail(ctx, BGS_EINVAL, "no frame has been rendered yet");
     *dptr = ctx->fb;
     if (bytes) *bytes = (uint64_t)ctx->fb_w * ctx->fb_h * sizeof(float4);
@@ -654,7 +754,19 @@ int bgs_sorted_entries_device_ptr(bgs_ctx* ctx, void** dptr, uint32_t* n) {
 
 int bgs_synchronize(bgs_ctx* ctx) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    if (ctx->pending) return finish_frame(ctx, nullptr);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BGS_OK;
+}
+
+int bgs_set_async(bgs_ctx* ctx, int enabled) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (!enabled && ctx->pending) {
+        int rc = finish_frame(ctx, nullptr);
+        if (rc != BGS_OK) return rc;
+    }
+    ctx->async_frames = enabled != 0;
     return BGS_OK;
 }
 
@@ -666,7 +778,8 @@ int bgs_stream(bgs_ctx* ctx, void** hip_stream) {
 
 int bgs_set_profiling(bgs_ctx* ctx, int enabled) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
-    ctx->profiling = enabled != 0;
+    if (enabled < 0 || enabled > 2) return fail(ctx, BGS_EINVAL, "profiling level must be 0, 1 or 2");
+    ctx->profiling = enabled;
     return BGS_OK;
 }
 
@@ -677,8 +790,18 @@ int bgs_set_binning(bgs_ctx* ctx, uint32_t mode) {
     return BGS_OK;
 }
 
+int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    ctx->debug_flags = flags;
+    return BGS_OK;
+}
+
 int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out) {
     if (!ctx || !out) return fail(ctx, BGS_EINVAL, "NULL argument");
+    if (ctx->pending) {
+        int rc = finish_frame(ctx, nullptr);
+        if (rc != BGS_OK) return rc;
+    }
     if (!ctx->have_stats) return fail(ctx, BGS_EINVAL, "no frame has been run yet");
     *out = ctx->stats;
     return BGS_OK;
@@ -687,6 +810,10 @@ int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out) {
 int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries, uint32_t n, uint32_t passes) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     if (passes < 1 || passes > 4) return fail(ctx, BGS_EINVAL, "passes must be 1..4");
+    if (ctx->pending) {
+        int rc0 = finish_frame(ctx, nullptr);
+        if (rc0 != BGS_OK) return rc0;
+    }
     if (n > MAX_SPLATS) return fail(ctx, BGS_EINVAL, "too many pairs");
     if (n == 0) return BGS_OK;
     if (!entries) return fail(ctx, BGS_EINVAL, "entries is NULL");

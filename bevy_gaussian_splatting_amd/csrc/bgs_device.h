@@ -34,6 +34,7 @@ struct FrameParams {
     uint32_t sort_mode;
     int32_t width, height;      // render target size in pixels
     int32_t tiles_x, tiles_y;
+    uint32_t debug;             // experiment switches (bgs_set_debug_flags); 0 in production
 };
 
 // Projected record, one per draw-list rank, stored in front-to-back order.

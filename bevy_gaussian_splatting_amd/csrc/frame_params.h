@@ -40,6 +40,7 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     fp.height = (int32_t)view->viewport[3];
     fp.tiles_x = (fp.width + TILE_PX - 1) / TILE_PX;
     fp.tiles_y = (fp.height + TILE_PX - 1) / TILE_PX;
+    fp.debug = 0;
 }
 
 }  // namespace bgs

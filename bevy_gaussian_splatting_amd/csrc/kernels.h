@@ -26,9 +26,14 @@ constexpr int SORT_KPT_SMALL = 8;   // 2048-pair tiles: more tiles for <= ~4M ke
 constexpr int SORT_KPT_LARGE = 16;  // 4096-pair tiles
 inline uint32_t sort_tile_size(bool large) { return SORT_THREADS * (large ? SORT_KPT_LARGE : SORT_KPT_SMALL); }
 
-// keygen + fused global digit histograms (radix_sort_a, src/sort/radix.wgsl:71-107).
+// keygen + fused global digit histograms (radix_sort_a, src/sort/radix.wgsl:71-107) + stable
+// partition: drawable entries -> `entries` (index order), culled-sentinel entries -> `culled`
+// (index order); ctl->draw_count = number of drawable entries. part_status: zeroed chain words,
+// one per 2048-splat tile.
 void launch_keygen(hipStream_t stream, const FrameParams& fp, const float4* position_visibility,
-                   uint2* entries, Control* ctl, uint32_t places);
+                   uint2* entries, uint2* culled, Control* ctl, uint32_t* part_status,
+                   uint32_t places, uint32_t ticket_slot, int max_blocks);
+constexpr uint32_t KEYGEN_TILE = 2048;
 
 // Standalone digit histograms of existing pairs (used by bgs_radix_sort_pairs).
 void launch_histogram(hipStream_t stream, const uint2* pairs, uint32_t n, uint32_t* hist /*[4][256]*/,

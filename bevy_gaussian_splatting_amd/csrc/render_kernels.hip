@@ -44,6 +44,39 @@ constexpr unsigned long long S64_AGGREGATE = 1ull << S64_FLAG_SHIFT;
 constexpr unsigned long long S64_PREFIX = 2ull << S64_FLAG_SHIFT;
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
 
+// batched decoupled look-back (see sort_kernels.hip): 4 predecessors per L2 round trip
+__device__ __forceinline__ uint32_t lookback_u32(const uint32_t* chain, uint32_t tile, uint32_t stride,
+                                                 uint32_t* error_flag, uint32_t error_code) {
+    uint32_t excl = 0u, spins = 0u;
+    int p = (int)tile - 1;
+    while (p >= 0) {
+        uint32_t v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            v[b] = p - b >= 0 ? __hip_atomic_load(chain + (size_t)(p - b) * stride, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : STATUS_PREFIX;
+        int used = 0;
+        bool finished = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (finished || used != b) continue;
+            const uint32_t flag = v[b] >> STATUS_FLAG_SHIFT;
+            if (flag == 0u) continue;
+            excl += v[b] & STATUS_VALUE_MASK;
+            used = b + 1;
+            if (flag == 2u) finished = true;
+        }
+        if (finished) break;
+        if (used == 0) {
+            if (++spins > SPIN_LIMIT) { atomicOr(error_flag, error_code); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        p -= used;
+    }
+    return excl;
+}
+
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -62,23 +95,32 @@ __device__ __forceinline__ float half_bits_to_float(unsigned short h) {
 __device__ __forceinline__ float half_lo(uint32_t v) { return half_bits_to_float((unsigned short)(v & 0xFFFFu)); }
 __device__ __forceinline__ float half_hi(uint32_t v) { return half_bits_to_float((unsigned short)(v >> 16)); }
 
-// SH coefficient fetchers: coefficient triple k = floats 3k..3k+2 of the splat's 48.
+// SH coefficient fetchers: all 48 coefficients of one splat, as 16-byte loads.
 struct ShF32 {
-    const float* base;
-    __device__ __forceinline__ V3 operator()(int k) const {
-        return V3{base[3 * k], base[3 * k + 1], base[3 * k + 2]};
+    const float* base;  // 192-byte records, 16-byte aligned
+    __device__ __forceinline__ void load_all(float* c) const {
+        const float4* p = reinterpret_cast<const float4*>(base);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const float4 v = p[i];
+            c[4 * i] = v.x; c[4 * i + 1] = v.y; c[4 * i + 2] = v.z; c[4 * i + 3] = v.w;
+        }
     }
 };
 // f16 plane: u32 word i holds coefficient 2i in the low half, 2i+1 in the high half
-// (src/render/planar.wgsl:117-130).
+// (src/render/planar.wgsl:117-130); 96-byte records, 16-byte aligned.
 struct ShF16 {
     const uint32_t* base;
-    __device__ __forceinline__ float coef(int i) const {
-        const uint32_t w = base[i >> 1];
-        return (i & 1) ? half_hi(w) : half_lo(w);
-    }
-    __device__ __forceinline__ V3 operator()(int k) const {
-        return V3{coef(3 * k), coef(3 * k + 1), coef(3 * k + 2)};
+    __device__ __forceinline__ void load_all(float* c) const {
+        const uint4* p = reinterpret_cast<const uint4*>(base);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const uint4 v = p[i];
+            c[8 * i] = half_lo(v.x); c[8 * i + 1] = half_hi(v.x);
+            c[8 * i + 2] = half_lo(v.y); c[8 * i + 3] = half_hi(v.y);
+            c[8 * i + 4] = half_lo(v.z); c[8 * i + 5] = half_hi(v.z);
+            c[8 * i + 6] = half_lo(v.w); c[8 * i + 7] = half_hi(v.w);
+        }
     }
 };
 
@@ -293,19 +335,22 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
                                                           uint32_t* __restrict__ rects,
                                                           uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_shift,
-                                                          uint32_t sup_x, uint32_t num_st,
+                                                          uint32_t sup_x, uint32_t sup_y,
                                                           uint32_t ticket_slot) {
-    __shared__ unsigned long long s_mask[4][MAX_SUPERTILES];  // per wave: lanes hitting supertile s
-    __shared__ uint32_t s_wave_excl[4][MAX_SUPERTILES];
-    __shared__ uint32_t s_base[MAX_SUPERTILES];               // list position of the block's first hit
+    // A rank overlaps supertile (sx, sy) iff sx is in its x-range AND sy is in its y-range, so the
+    // per-supertile lane masks factor into sup_x column masks and sup_y row masks per wave:
+    // sup_x + sup_y ballots instead of sup_x * sup_y.
+    __shared__ unsigned long long s_xmask[4][32];
+    __shared__ unsigned long long s_ymask[4][32];
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t count = ctl->draw_count;
     const uint32_t num_tiles = (count + 255u) / 256u;
     if (num_tiles == 0u) return;
+    const uint32_t num_st = sup_x * sup_y;
+    const uint32_t my_sy = (uint32_t)tid / sup_x, my_sx = (uint32_t)tid - my_sy * sup_x;  // thread = supertile
     uint32_t visible_acc = 0u;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
@@ -315,70 +360,65 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
         const uint32_t j = tile * 256u + (uint32_t)tid;  // front-to-back rank
         uint32_t rect = RECT_EMPTY;
         if (j < count) {
-            bool vis;
-            rect = project_rank<F16, SURFEL>(fp, cloud, draw_list[count - 1u - j], j, records, vis);
+            bool vis = false;
+            if (fp.debug & 1u) {  // ablation: no projection, a fixed 2x1-tile rectangle
+                rect = 0x01000000u | (j & 63u) | (((j & 63u) + 1u) << 8);
+            } else {
+                rect = project_rank<F16, SURFEL>(fp, cloud, draw_list[count - 1u - j], j, records, vis);
+            }
             visible_acc += vis ? 1u : 0u;
             rects[j] = rect;
         }
-        // supertile bounds of the rectangle (empty rect: sx0 > sx1)
-        const uint32_t sx0 = (rect & 255u) >> sup_shift, sx1 = ((rect >> 8) & 255u) >> sup_shift;
-        const uint32_t sy0 = ((rect >> 16) & 255u) >> sup_shift, sy1 = (rect >> 24) >> sup_shift;
-        const bool nonempty = (rect & 255u) <= ((rect >> 8) & 255u);
-        // one ballot per supertile: which of this wave's 64 ranks overlap it
+        if (fp.debug & 2u) { __syncthreads(); continue; }  // ablation: no coarse binning at all
         {
-            uint32_t stx = 0u, sty = 0u;
-            for (uint32_t st = 0u; st < num_st; ++st) {
-                const bool hit = nonempty && stx >= sx0 && stx <= sx1 && sty >= sy0 && sty <= sy1;
-                const unsigned long long b = __ballot(hit);
-                if ((uint32_t)lane == (st & 63u)) s_mask[wave][st] = b;
-                if (++stx == sup_x) { stx = 0u; ++sty; }
+            // supertile bounds of the rectangle; an empty rect has sx0 = 31 > sx1 = 0: no column matches
+            const uint32_t sx0 = (rect & 255u) >> sup_shift, sx1 = ((rect >> 8) & 255u) >> sup_shift;
+            const uint32_t sy0 = ((rect >> 16) & 255u) >> sup_shift, sy1 = (rect >> 24) >> sup_shift;
+            for (uint32_t c = 0u; c < sup_x; ++c) {
+                const unsigned long long b = __ballot(c >= sx0 && c <= sx1);
+                if (lane == 0) s_xmask[wave][c] = b;
+            }
+            for (uint32_t r = 0u; r < sup_y; ++r) {
+                const unsigned long long b = __ballot(r >= sy0 && r <= sy1);
+                if (lane == 0) s_ymask[wave][r] = b;
             }
         }
         __syncthreads();
-        // thread = supertile: scan over the 4 waves, chained scan over the blocks
+        if (fp.debug & 4u) { __syncthreads(); continue; }  // ablation: ballots only
+        // thread = supertile: lane masks of the 4 waves, chained scan over the blocks, then this
+        // thread appends the block's hits to ITS list in rank order (wave 0 lanes first, ...)
         if ((uint32_t)tid < num_st) {
-            const uint32_t c0 = (uint32_t)__popcll(s_mask[0][tid]), c1 = (uint32_t)__popcll(s_mask[1][tid]);
-            const uint32_t c2 = (uint32_t)__popcll(s_mask[2][tid]), c3 = (uint32_t)__popcll(s_mask[3][tid]);
-            s_wave_excl[0][tid] = 0u;
-            s_wave_excl[1][tid] = c0;
-            s_wave_excl[2][tid] = c0 + c1;
-            s_wave_excl[3][tid] = c0 + c1 + c2;
-            const uint32_t total = c0 + c1 + c2 + c3;
+            unsigned long long m[4];
+            uint32_t total = 0u;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                m[w] = s_xmask[w][my_sx] & s_ymask[w][my_sy];
+                total += (uint32_t)__popcll(m[w]);
+            }
             uint32_t* const my_status = bin_status + (size_t)tile * MAX_SUPERTILES + tid;
             uint32_t excl = 0u;
             if (tile > 0u) {
                 __hip_atomic_store(my_status, STATUS_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t p = tile - 1u, spins = 0u;
-                for (;;) {
-                    const uint32_t v = __hip_atomic_load(bin_status + (size_t)p * MAX_SUPERTILES + tid,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t flag = v >> STATUS_FLAG_SHIFT;
-                    if (flag == 0u) {
-                        if (++spins > SPIN_LIMIT) { atomicOr(&ctl->error, 4u); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        continue;
-                    }
-                    excl += v & STATUS_VALUE_MASK;
-                    if (flag == 2u || p == 0u) break;
-                    --p;
-                }
+                excl = lookback_u32(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u);
             }
             __hip_atomic_store(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_base[tid] = excl;
             if (tile == num_tiles - 1u) ctl->coarse_total[tid] = excl + total;
-        }
-        __syncthreads();
-        // append this rank to every supertile list it overlaps (rank order is preserved: position =
-        // list base of the block + ranks of earlier waves + earlier lanes of this wave)
-        if (nonempty) {
-            for (uint32_t sy = sy0; sy <= sy1; ++sy)
-                for (uint32_t sx = sx0; sx <= sx1; ++sx) {
-                    const uint32_t st = sy * sup_x + sx;
-                    const uint32_t pos = s_base[st] + s_wave_excl[wave][st] +
-                                         (uint32_t)__popcll(s_mask[wave][st] & lanes_below);
-                    if (pos < coarse_cap) coarse[(size_t)st * coarse_cap + pos] = j;
+            if (!(fp.debug & 8u)) {  // ablation bit 8: chain but no list writes
+                uint32_t* __restrict__ dst = coarse + (size_t)tid * coarse_cap;
+                uint32_t pos = excl;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    unsigned long long bits = m[w];
+                    const uint32_t rank0 = tile * 256u + (uint32_t)w * 64u;
+                    while (bits) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(bits);
+                        bits &= bits - 1ull;
+                        if (pos < coarse_cap) dst[pos] = rank0 + l;
+                        ++pos;
+                    }
                 }
+            }
         }
         __syncthreads();
     }
@@ -396,13 +436,12 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPt
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
     const uint32_t sup = 1u << sup_shift;
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup, sup_y = ((uint32_t)fp.tiles_y + sup - 1u) / sup;
-    const uint32_t num_st = sup_x * sup_y;
     const bool surfel = fp.gaussian_mode == 0u && fp.aabb != 0u;
     float4* rec = (float4*)records;
 #define BGS_LAUNCH_PB(F16, SURFEL)                                                                \
     hipLaunchKernelGGL((project_bin_kernel<F16, SURFEL>), dim3(blocks), dim3(256), 0, stream, fp,  \
                        cloud, draw_list, ctl, bin_status, rec, rects, coarse, coarse_cap, sup_shift, \
-                       sup_x, num_st, ticket_slot)
+                       sup_x, sup_y, ticket_slot)
     if (cloud.is_f16) {
         if (surfel) BGS_LAUNCH_PB(true, true); else BGS_LAUNCH_PB(true, false);
     } else {

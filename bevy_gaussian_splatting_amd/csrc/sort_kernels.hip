@@ -57,55 +57,150 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 }
 
 constexpr int KG_ITEMS = 8;  // splats per thread in keygen
+constexpr uint32_t SPIN_LIMIT = 1u << 22;  // bounded look-back spin (watchdog, never expected)
+
+// Decoupled look-back over predecessor tiles of one chain (status words `stride` apart).
+// With every tile in flight at once a one-hop-at-a-time walk serialises ~tile/2 dependent L2
+// round trips, so 4 predecessors are fetched per round trip and consumed in order.
+__device__ __forceinline__ uint32_t lookback_u32(const uint32_t* chain, uint32_t tile, uint32_t stride,
+                                                 uint32_t* error_flag, uint32_t error_code) {
+    uint32_t excl = 0u, spins = 0u;
+    int p = (int)tile - 1;
+    while (p >= 0) {
+        uint32_t v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[b] = p - b >= 0 ? ld_agent(chain + (size_t)(p - b) * stride) : STATUS_PREFIX;
+        int used = 0;
+        bool finished = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (finished || used != b) continue;
+            const uint32_t flag = v[b] >> STATUS_FLAG_SHIFT;
+            if (flag == 0u) continue;           // not published yet: retry from p - b
+            excl += v[b] & STATUS_VALUE_MASK;
+            used = b + 1;
+            if (flag == 2u) finished = true;    // inclusive prefix: done
+        }
+        if (finished) break;
+        if (used == 0) {
+            if (++spins > SPIN_LIMIT) { atomicOr(error_flag, error_code); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        p -= used;
+    }
+    return excl;
+}
 
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
-// keygen: one thread per splat, 16 B read + 8 B write per splat, fully coalesced.
+// keygen + stable partition: one thread per splat, 16 B read + 8 B write per splat, coalesced.
+//
+// Entries whose key is the "culled" sentinel (all ones >> shift) all compare equal and sort to
+// the END of the reference's output in ascending index order. So instead of dragging them through
+// every radix pass, they are split off here, in index order, into `culled`, and only the V'
+// drawable entries (also kept in index order, which the stable LSD passes need for ties) go to
+// `entries` and into the digit histograms. sorted(drawable) ++ culled is bit-identical to the
+// reference's full stable sort. The ordered split is a chained scan over 2048-splat tiles.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
-                                                     uint2* __restrict__ entries, Control* ctl,
-                                                     uint32_t places) {
+                                                     uint2* __restrict__ entries,
+                                                     uint2* __restrict__ culled, Control* ctl,
+                                                     uint32_t* part_status, uint32_t places,
+                                                     uint32_t ticket_slot) {
     __shared__ uint32_t s_hist[4][RADIX_BASE];
-    const int tid = threadIdx.x;
+    __shared__ uint32_t s_cnt[KG_ITEMS][4];  // drawable per (row, wave)
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
-    __syncthreads();
-
-    if (blockIdx.x == 0 && tid == 0) ctl->splat_count = fp.n;
     const uint32_t sentinel = KEY_CULLED >> fp.key_shift;
-    const uint32_t base = blockIdx.x * (256u * KG_ITEMS);
-    uint32_t drawable = 0;
+    const uint32_t per_tile = 256u * KG_ITEMS;
+    const uint32_t num_tiles = (fp.n + per_tile - 1u) / per_tile;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= num_tiles) break;
+        const uint32_t base = tile * per_tile;
+        uint32_t key[KG_ITEMS], below[KG_ITEMS];
+        bool draw[KG_ITEMS];
 #pragma unroll
-    for (int k = 0; k < KG_ITEMS; ++k) {
-        const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
-        if (i < fp.n) {
-            const float4 p = pos[i];
-            const uint32_t key = sort_key(fp, V3{p.x, p.y, p.z});
-            entries[i] = make_uint2(key, i);
-            for (uint32_t pl = 0; pl < places; ++pl)
-                atomicAdd(&s_hist[pl][(key >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
-            // entries that reach the vertex stage: everything unless the radix key is "culled"
-            drawable += (fp.sort_mode != SORT_RADIX || key != sentinel) ? 1u : 0u;
+        for (int k = 0; k < KG_ITEMS; ++k) {
+            const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
+            key[k] = sentinel;
+            draw[k] = false;
+            if (i < fp.n) {
+                const float4 p = pos[i];
+                key[k] = sort_key(fp, V3{p.x, p.y, p.z});
+                // entries that reach the vertex stage: everything unless the radix key is "culled"
+                draw[k] = fp.sort_mode != SORT_RADIX || key[k] != sentinel;
+                if (draw[k])
+                    for (uint32_t pl = 0; pl < places; ++pl)
+                        atomicAdd(&s_hist[pl][(key[k] >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
+            }
+            const unsigned long long b = __ballot(draw[k]);
+            below[k] = (uint32_t)__popcll(b & lanes_below);
+            if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(b);
         }
+        __syncthreads();
+        // exclusive offsets in (row, wave, lane) = index order
+        uint32_t off[KG_ITEMS];
+        uint32_t run = 0u;
+#pragma unroll
+        for (int k = 0; k < KG_ITEMS; ++k) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w == wave) off[k] = run;
+                run += s_cnt[k][w];
+            }
+        }
+        const uint32_t total = run;
+        if (tid == 0) {
+            uint32_t* const my_status = part_status + tile;
+            uint32_t excl = 0u;
+            if (tile > 0u) {
+                st_agent(my_status, STATUS_AGGREGATE | total);
+                excl = lookback_u32(part_status, tile, 1u, &ctl->error, 8u);
+            }
+            st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
+            s_base = excl;
+            if (tile == num_tiles - 1u) {
+                ctl->draw_count = excl + total;
+                ctl->splat_count = fp.n;
+            }
+        }
+        __syncthreads();
+        const uint32_t vis_base = s_base;
+#pragma unroll
+        for (int k = 0; k < KG_ITEMS; ++k) {
+            const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
+            if (i < fp.n) {
+                const uint32_t before = vis_base + off[k] + below[k];  // drawable entries before i
+                if (draw[k]) entries[before] = make_uint2(key[k], i);
+                else culled[i - before] = make_uint2(key[k], i);
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (uint32_t pl = 0; pl < places; ++pl) {
         const uint32_t v = s_hist[pl][tid];
         if (v) atomicAdd(&ctl->hist_depth[pl][tid], v);
     }
-    // block-reduce the drawable count: wave shuffle, then one atomic per wave
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) drawable += __shfl_down(drawable, off, 64);
-    if ((tid & 63) == 0 && drawable) atomicAdd(&ctl->draw_count, drawable);
 }
 
 void launch_keygen(hipStream_t stream, const FrameParams& fp, const float4* pos, uint2* entries,
-                   Control* ctl, uint32_t places) {
+                   uint2* culled, Control* ctl, uint32_t* part_status, uint32_t places,
+                   uint32_t ticket_slot, int max_blocks) {
     if (fp.n == 0) return;
     const uint32_t per_block = 256u * KG_ITEMS;
-    const uint32_t blocks = (fp.n + per_block - 1) / per_block;
-    hipLaunchKernelGGL(keygen_kernel, dim3(blocks), dim3(256), 0, stream, fp, pos, entries, ctl, places);
+    uint32_t blocks = (fp.n + per_block - 1) / per_block;
+    if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
+    hipLaunchKernelGGL(keygen_kernel, dim3(blocks), dim3(256), 0, stream, fp, pos, entries, culled, ctl,
+                       part_status, places, ticket_slot);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -141,8 +236,6 @@ void launch_histogram(hipStream_t stream, const uint2* pairs, uint32_t n, uint32
 // ---------------------------------------------------------------------------------------
 // Onesweep digit pass
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t SPIN_LIMIT = 1u << 22;  // bounded look-back spin (watchdog, never expected)
-
 template <int KPT>
 __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__ in,
                                                        uint2* __restrict__ out,
@@ -230,20 +323,7 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
         uint32_t excl = 0u;
         if (tile > 0u) {
             st_agent(my_status, STATUS_AGGREGATE | total);
-            uint32_t p = tile - 1u;
-            uint32_t spins = 0u;
-            for (;;) {
-                const uint32_t v = ld_agent(status + (size_t)p * RADIX_BASE + tid);
-                const uint32_t flag = v >> STATUS_FLAG_SHIFT;
-                if (flag == 0u) {
-                    if (++spins > SPIN_LIMIT) { atomicOr(error_flag, 1u); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                excl += v & STATUS_VALUE_MASK;
-                if (flag == 2u || p == 0u) break;
-                --p;
-            }
+            excl = lookback_u32(status + tid, tile, RADIX_BASE, error_flag, 1u);
         }
         st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
 

@@ -27,6 +27,16 @@
 #define BGS_HD static inline
 #endif
 
+// Transcendentals that feed only colour or the quad SIZE (never a cull decision or a sort key)
+// use the hardware exp2/log2 on the device (~1 ulp); the host build keeps libm.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BGS_FAST_LOG(x) (__builtin_amdgcn_logf(x) * 0.6931471805599453f)
+#define BGS_FAST_POW(x, y) __builtin_amdgcn_exp2f((y) * __builtin_amdgcn_logf(x))
+#else
+#define BGS_FAST_LOG(x) logf(x)
+#define BGS_FAST_POW(x, y) powf(x, y)
+#endif
+
 namespace bgs {
 
 struct V2 { float x, y; };
@@ -271,7 +281,7 @@ BGS_HD void cov2d_surfel(const FrameParams& fp, V3 gp, const float* rot, const f
 // src/material/spherical_harmonics.wgsl:22-32
 BGS_HD float srgb_to_linear1(float c) {
     if (c <= 0.04045f) return c / 12.92f;
-    return powf((c + 0.055f) / 1.055f, 2.4f);
+    return BGS_FAST_POW((c + 0.055f) / 1.055f, 2.4f);
 }
 
 // src/render/gaussian.wgsl:166-183
@@ -334,7 +344,7 @@ BGS_HD V3 sh_direction(const FrameParams& fp, V3 transformed_position) {
 // src/render/gaussian.wgsl:229-235
 BGS_HD float cutoff_radius(const FrameParams& fp, float opacity) {
     if (!fp.adaptive_radius) return 3.0f;
-    return sqrtf(fmaxf(9.0f + 2.0f * logf(opacity), 0.000001f));
+    return sqrtf(fmaxf(9.0f + 2.0f * BGS_FAST_LOG(opacity), 0.000001f));
 }
 
 // The four clip-space quad corners -> pixel-space parallelogram (centre, u axis, v axis).
@@ -395,7 +405,9 @@ BGS_HD bool tile_rect(const FrameParams& fp, const QuadPx& q, int& tx0, int& ty0
 
 // ------------------------------------------------------------------------------------
 // Whole vertex stage for one draw-list entry: cull, cutoff, geometry, colour.
-// `sh(k)` returns SH coefficient triple k (RGB) of the splat as a V3.
+// `sh.load_all(c)` fetches the splat's 48 SH coefficients (index 3*k + channel) into c[]. It is
+// called BEFORE the geometry so the 12 x 16-byte loads are in flight while the covariance math
+// runs (a per-coefficient fetch inside the accumulation loop serialises 16 memory round trips).
 // ------------------------------------------------------------------------------------
 struct Projected {
     bool visible;   // passed the vertex-stage cull (key != ~0 and in_frustum)
@@ -420,6 +432,8 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
     discard_quad = discard_quad || !in_frustum(projected);         // :211
     if (discard_quad) return;                                      // :214-218
     o.visible = true;
+    float shc[48];
+    sh.load_all(shc);
 
     const float opacity = so[3];
     const float cutoff = cutoff_radius(fp, opacity);               // :229-235
@@ -469,11 +483,13 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
     sh_weights(dir, fp.sh_degree, w);
     float r = 0.5f, g = 0.5f, b = 0.5f;
     const int ncoef = fp.sh_degree == 0 ? 1 : (fp.sh_degree == 1 ? 4 : (fp.sh_degree == 2 ? 9 : 16));
-    for (int k = 0; k < ncoef; ++k) {
-        V3 c = sh(k);
-        r += w[k] * c.x;
-        g += w[k] * c.y;
-        b += w[k] * c.z;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < ncoef) {  // coefficients past the requested degree are never touched (may be garbage)
+            r += w[k] * shc[3 * k];
+            g += w[k] * shc[3 * k + 1];
+            b += w[k] * shc[3 * k + 2];
+        }
     }
     if (fp.color_space != 1u) {                                    // planar.wgsl:91-106
         r = srgb_to_linear1(r);

@@ -174,13 +174,22 @@ class GaussianSplattingPlugin:
     def synchronize(self) -> None:
         self._check(self._lib.bgs_synchronize(self._ctx))
 
-    def set_profiling(self, enabled: bool) -> None:
-        self._check(self._lib.bgs_set_profiling(self._ctx, 1 if enabled else 0))
+    def set_profiling(self, level: int) -> None:
+        """0 = no HIP events, 1 = frame start/end only, 2 = every stage (default)."""
+        self._check(self._lib.bgs_set_profiling(self._ctx, int(level)))
+
+    def set_async(self, enabled: bool) -> None:
+        """Async frames: render(download=False) only enqueues (scan binning); see bgs_set_async."""
+        self._check(self._lib.bgs_set_async(self._ctx, 1 if enabled else 0))
 
     def set_binning(self, mode: str) -> None:
         """'scan' (default): ordered coarse lists + lazy per-tile scan; 'sort': (tile, splat)
         instances + stable radix sort on the tile id. Images are bit-identical."""
         self._check(self._lib.bgs_set_binning(self._ctx, {"scan": 0, "sort": 1}[mode]))
+
+    def set_debug_flags(self, flags: int) -> None:
+        """Kernel-ablation switches for experiments only (non-zero => wrong images)."""
+        self._check(self._lib.bgs_set_debug_flags(self._ctx, int(flags)))
 
     def framebuffer_device_ptr(self):
         p = ctypes.c_void_p()
@@ -208,6 +217,7 @@ class GaussianSplattingPlugin:
             "algorithmic_bytes": int(st.algorithmic_bytes),
             "regrow_count": int(st.regrow_count),
             "binning": "sort" if st.binning_mode else "scan",
+            "frames_averaged": int(st.frames_averaged),
             "stage_ms": {n: float(st.stage_ms[i]) for i, n in enumerate(_native.STAGE_NAMES)},
         }
         return d

@@ -123,6 +123,9 @@ typedef struct bgs_stats {
     uint64_t algorithmic_bytes;  /* SURVEY 8(d) bytes_frame (or bytes_sort) of the call */
     uint32_t regrow_count;       /* times the instance buffers were grown + re-run     */
     uint32_t binning_mode;       /* BGS_BINNING_* used by the call                     */
+    uint32_t frames_averaged;    /* stage_ms/total_ms = mean over this many frames (async: all
+                                    frames since the last read-back, at most 64)        */
+    uint32_t reserved;
 } bgs_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -175,11 +178,20 @@ int bgs_render(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view,
 /* Device pointer + size in bytes of the framebuffer written by the last bgs_render
  * (for an RCCL gather or zero-copy interop). Valid until the next render/destroy. */
 int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes);
-/* Device pointer of the sorted entries of the last bgs_sort/bgs_render (n entries). */
+/* Device pointer of the sorted entries of the last call: after bgs_sort all n entries (culled
+ * ones last); after bgs_render only the drawable prefix (*n = entries that reach the vertex
+ * stage), because the culled tail is never needed for drawing. */
 int bgs_sorted_entries_device_ptr(bgs_ctx* ctx, void** dptr, uint32_t* n);
 
-/* Block until all work queued on the context's stream has finished. */
+/* Block until all work queued on the context's stream has finished; in async mode this is also
+ * where the last frame's device watchdog word is checked (BGS_EINTERNAL) and its stats collected. */
 int bgs_synchronize(bgs_ctx* ctx);
+/* Async frames (default off). When on, bgs_render(..., rgba_host_out = NULL) under
+ * BGS_BINNING_SCAN only ENQUEUES the frame and returns: that pipeline needs no host round trip
+ * (every data-dependent size stays on the device and its lists cannot overflow), so successive
+ * frames run back-to-back on the GPU. Any call that needs results (a host copy, bgs_get_stats,
+ * bgs_framebuffer_device_ptr, bgs_synchronize, bgs_sort) completes the pending frame first. */
+int bgs_set_async(bgs_ctx* ctx, int enabled);
 /* The hipStream_t (as void*) the context launches on, so a caller can order its own
  * HIP work (e.g. torch / RCCL) against it. */
 int bgs_stream(bgs_ctx* ctx, void** hip_stream);
@@ -194,7 +206,12 @@ int bgs_stream(bgs_ctx* ctx, void** hip_stream);
 #define BGS_BINNING_SORT 1u
 int bgs_set_binning(bgs_ctx* ctx, uint32_t mode);
 
-/* Enable/disable per-stage HIP-event timing (default on). */
+/* Kernel-ablation switches for performance experiments (scripts/ablate.py). Non-zero flags
+ * produce WRONG images; production code must leave this at 0. */
+int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags);
+
+/* HIP-event timing level: 0 = none, 1 = frame start/end only (total_ms), 2 = every stage
+ * (default). Each recorded event costs a few microseconds of GPU timeline. */
 int bgs_set_profiling(bgs_ctx* ctx, int enabled);
 /* Stats of the most recent bgs_sort / bgs_render. Synchronises the stream. */
 int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out);

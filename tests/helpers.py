@@ -40,6 +40,7 @@ class FrameParamsC(ctypes.Structure):
         ("sh_degree", ctypes.c_uint32), ("sort_mode", ctypes.c_uint32),
         ("width", ctypes.c_int32), ("height", ctypes.c_int32),
         ("tiles_x", ctypes.c_int32), ("tiles_y", ctypes.c_int32),
+        ("debug", ctypes.c_uint32),
     ]
 
 

@@ -24,7 +24,7 @@ struct ShimOut {
 
 struct ShFloat {
     const float* base;
-    V3 operator()(int k) const { return V3{base[3 * k], base[3 * k + 1], base[3 * k + 2]}; }
+    void load_all(float* c) const { memcpy(c, base, 48 * sizeof(float)); }
 };
 
 extern "C" {

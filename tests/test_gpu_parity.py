@@ -379,3 +379,32 @@ def test_full_size_2dgs_1m_crop(plugin, oracle, cloud_1m):
         ref, amb = oracle.render(cloud_1m, e, v, s, window=win, with_ambiguity=True)
         _assert_image(ref, got[516:564, 936:984], amb, frac_slack=0.01, what=f"2dgs {kw}")
         h.free()
+
+
+def test_async_frames_match_synchronous_frames(plugin, oracle):
+    """bgs_set_async: frames are only enqueued; results and the watchdog check arrive at the next
+    blocking call. Images must be bit-identical to the synchronous path."""
+    c = random_gaussians_3d_seeded(30_000, 23)
+    h = plugin.upload(c)
+    s = CloudSettings(global_scale=0.5)
+    views = [headless_view(g, 320, 180) for g in range(4)]
+    sync_imgs = [plugin.render(h, v, s) for v in views]
+    plugin.set_async(True)
+    try:
+        for v in views[:-1]:
+            assert plugin.render(h, v, s, download=False) is None
+        last = plugin.render(h, views[-1], s)  # download => completes the queue
+        assert np.array_equal(last, sync_imgs[-1])
+        for _ in range(5):
+            plugin.render(h, views[1], s, download=False)
+        plugin.synchronize()
+        st = plugin.stats()
+        assert st["frames_averaged"] == 5 and st["total_ms"] > 0
+        again = plugin.render(h, views[1], s)
+        assert np.array_equal(again, sync_imgs[1])
+        es = plugin.sort(h, views[0], s)  # a blocking call right after async frames
+        ref = oracle.sort(c, views[0], s)
+        assert np.array_equal(es["index"], ref["index"])
+    finally:
+        plugin.set_async(False)
+    h.free()
