@@ -44,6 +44,7 @@ WIDTH, HEIGHT = 1920, 1080
 def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) -> dict:
     """Algorithmic bytes per stage (SURVEY 8(d) terms) and the launches each stage comprises."""
     N, V, I = stats["splat_count"], stats["visible_count"], stats["instance_count"]
+    D = stats["draw_count"]  # pairs that actually go through the radix passes (culled ones are partitioned off)
     k, kt = stats["depth_passes"], stats["tile_passes"]
     P = WIDTH * HEIGHT
     B = cloud_bytes_per_splat
@@ -52,13 +53,13 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
         # rasteriser (4 B) which also reads each visible record at least once
         return {
             "keygen": {"bytes": N * 16 + N * 8, "launches": 1},
-            "depth_sort": {"bytes": k * N * 16, "launches": max(k, 1)},
+            "depth_sort": {"bytes": k * D * 16, "launches": max(k, 1)},
             "project": {"bytes": V * 8 + V * (B - 16) + V * rec_bytes + V * 4 + I * 4, "launches": 1},
             "raster": {"bytes": I * 4 + V * 4 + V * rec_bytes + P * 16, "launches": 1},
         }
     return {
         "keygen": {"bytes": N * 16 + N * 8, "launches": 1},
-        "depth_sort": {"bytes": k * N * 16, "launches": max(k, 1)},
+        "depth_sort": {"bytes": k * D * 16, "launches": max(k, 1)},
         "project": {"bytes": V * (B - 16) + V * rec_bytes + I * 8, "launches": 1},
         "tile_sort": {"bytes": kt * I * 16, "launches": max(kt, 1)},
         "ranges": {"bytes": I * 8, "launches": 1},  # not in SURVEY's bytes_frame (pure overhead pass)

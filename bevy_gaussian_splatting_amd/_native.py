@@ -62,6 +62,8 @@ class BgsStats(ctypes.Structure):
         ("total_ms", ctypes.c_float),
         ("splat_count", ctypes.c_uint32),
         ("visible_count", ctypes.c_uint32),
+        ("draw_count", ctypes.c_uint32),
+        ("pad", ctypes.c_uint32),
         ("instance_count", ctypes.c_uint64),
         ("instance_capacity", ctypes.c_uint64),
         ("tiles_x", ctypes.c_uint32),

@@ -291,6 +291,7 @@ int finish_frame(bgs_ctx* ctx, uint64_t* need_cap) {
     stt.regrow_count = regrow;
     stt.splat_count = n;
     stt.visible_count = render ? h.visible_count : h.draw_count;
+    stt.draw_count = h.draw_count;
     stt.instance_count = render ? total : 0;
     stt.instance_capacity = ctx->inst_cap;
     stt.tiles_x = render ? ctx->pending_tx : 0;
@@ -300,8 +301,10 @@ int finish_frame(bgs_ctx* ctx, uint64_t* need_cap) {
     stt.binning_mode = ctx->binning;
     {
         // SURVEY 8(d) algorithmic bytes
-        const uint64_t N = n, k = places;
-        uint64_t bytes = N * 16 + N * 8 + k * N * 16;  // bytes_sort
+        // SURVEY's bytes_sort is N*16 + N*8 + k*N*16; the partition in keygen means only the D
+        // drawable pairs go through the k passes, so that is what is counted
+        const uint64_t N = n, k = places, D = h.draw_count;
+        uint64_t bytes = N * 16 + N * 8 + k * D * 16;
         if (render) {
             const uint64_t B = ctx->pending_is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
             const uint64_t P = (uint64_t)ctx->pending_w * ctx->pending_h;

@@ -209,6 +209,7 @@ class GaussianSplattingPlugin:
             "total_ms": float(st.total_ms),
             "splat_count": int(st.splat_count),
             "visible_count": int(st.visible_count),
+            "draw_count": int(st.draw_count),
             "instance_count": int(st.instance_count),
             "instance_capacity": int(st.instance_capacity),
             "tiles": (int(st.tiles_x), int(st.tiles_y)),

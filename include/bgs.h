@@ -115,6 +115,9 @@ typedef struct bgs_stats {
     float total_ms;              /* first to last event of the call                    */
     uint32_t splat_count;        /* N                                                  */
     uint32_t visible_count;      /* V: splats that pass the frustum test               */
+    uint32_t draw_count;         /* D: entries that go through the radix passes / reach the
+                                    vertex stage (key != culled sentinel)               */
+    uint32_t pad;
     uint64_t instance_count;     /* I: (tile, splat) instances emitted                 */
     uint64_t instance_capacity;
     uint32_t tiles_x, tiles_y;

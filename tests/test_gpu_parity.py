@@ -408,3 +408,37 @@ def test_async_frames_match_synchronous_frames(plugin, oracle):
     finally:
         plugin.set_async(False)
     h.free()
+
+
+def test_framebuffer_zero_copy_tensor_and_rccl_gather_single_rank(plugin):
+    """The multi-GPU leg of bench.py: the device framebuffer wrapped zero-copy as a torch tensor
+    (what RCCL sends) and gathered with the nccl backend (world_size 1 here; world_size 2 is
+    covered on CPU with gloo in tests/test_multi_gpu_cpu.py)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor, gather_framebuffers
+
+    c = random_gaussians_3d_seeded(20_000, 31)
+    h = plugin.upload(c)
+    v = headless_view(1, 320, 180)
+    img = plugin.render(h, v, CloudSettings(global_scale=0.5))
+    t = framebuffer_as_tensor(plugin, 180, 320)
+    assert t.is_cuda and tuple(t.shape) == (180, 320, 4)
+    assert np.array_equal(t.cpu().numpy(), img)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        bufs = [torch.empty_like(t.unsqueeze(0))]
+        dist.gather(t.unsqueeze(0).contiguous(), gather_list=bufs, dst=0)
+        torch.cuda.synchronize()
+        assert np.array_equal(bufs[0][0].cpu().numpy(), img)
+        assert gather_framebuffers(t.unsqueeze(0))[0].shape == (1, 180, 320, 4)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    h.free()
