@@ -545,11 +545,15 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
         alpha = fminf(__expf(power) * s.a4.w, 0.999f);
         r = s.a4.x; g = s.a4.y; b = s.a4.z;
     }
-    const float w = (hit && T >= T_EPS) ? T * alpha : 0.0f;
-    cr = fmaf(w, r, cr);
-    cg = fmaf(w, g, cg);
-    cb = fmaf(w, b, cb);
-    T -= w;
+    // a real branch on purpose: it becomes an exec-mask region that a wave skips entirely when none
+    // of its 64 pixels (a 16x4 strip in the wave-per-tile rasteriser) is covered
+    if (hit && T >= T_EPS) {
+        const float w = T * alpha;
+        cr = fmaf(w, r, cr);
+        cg = fmaf(w, g, cg);
+        cb = fmaf(w, b, cb);
+        T -= w;
+    }
 }
 
 // XCD-aware work order: workgroup b runs on XCD b % 8 (observed dispatch, a speed assumption
@@ -614,8 +618,10 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 // whose tile rectangle contains this tile (order-preserving ballot compaction), stages their
 // records in its private LDS slice, blends, and stops at saturation. The candidate stream is
 // prefetched two groups (ranks) / one group (rectangles) ahead of the blend.
+// __launch_bounds__(256, 8): 8 waves/SIMD (<= 64 VGPRs). A 1080p frame is 8160 one-wave tiles for
+// 1024 SIMDs x 8 slots, so at 7 waves/SIMD a second, nearly empty round of waves appears.
 template <int VARIANT>
-__global__ __launch_bounds__(256) void raster_scan_kernel(FrameParams fp, const float4* __restrict__ records,
+__global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(FrameParams fp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ rects,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_shift,
@@ -638,6 +644,7 @@ __global__ __launch_bounds__(256) void raster_scan_kernel(FrameParams fp, const 
     const float qx = (float)px + 0.5f;
     const float aspect = fp.viewport_w / fp.viewport_h;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const float tile_cx = (float)((int)tx * TILE_PX + 8), tile_cy = (float)((int)ty * TILE_PX + 8);
 
     float T[4], cr[4], cg[4], cb[4], qy[4];
 #pragma unroll
@@ -666,21 +673,61 @@ __global__ __launch_bounds__(256) void raster_scan_kernel(FrameParams fp, const 
                          ty >= ((rect_cur >> 16) & 255u) && ty <= (rect_cur >> 24);
         const unsigned long long b = __ballot(hit);
         const uint32_t cnt = (uint32_t)__popcll(b);
-        if (cnt) {
+        if (cnt && !(fp.debug & 32u)) {  // ablation bit 32: candidate scan only
             if (hit) s_queue[__popcll(b & lanes_below)] = rank_cur;
             __builtin_amdgcn_wave_barrier();
             if ((uint32_t)lane < cnt) {
                 const float4* src = records + (size_t)s_queue[lane] * REC_V4;
+                float4 r0 = src[0], r1 = src[1];
+                // exact test the tile rect cannot do: the quad is the parallelogram |u|,|v| <= 1, so
+                // it misses the tile iff the tile's pixel-centre box lies wholly beyond one of its
+                // two axes (the box's own axes are the rect test). The verdict rides in a spare
+                // dword of the staged record and the blend loop skips rejected records.
+                const float dcx = tile_cx - r0.x, dcy = tile_cy - r0.y;
+                float uc, vc, eu, ev;
+                if constexpr (VARIANT == RV_OBB) {
+                    uc = fmaf(r0.w, dcy, r0.z * dcx);
+                    vc = fmaf(r1.y, dcy, r1.x * dcx);
+                    eu = 7.5f * (fabsf(r0.z) + fabsf(r0.w));
+                    ev = 7.5f * (fabsf(r1.x) + fabsf(r1.y));
+                } else {  // axis-aligned square: uv = (m00 * dx, m11 * dy)
+                    uc = r0.z * dcx;
+                    vc = r0.w * dcy;
+                    eu = 7.5f * fabsf(r0.z);
+                    ev = 7.5f * fabsf(r0.w);
+                }
+                const bool keep = (!(fabsf(uc) - eu > 1.0001f) && !(fabsf(vc) - ev > 1.0001f)) || (fp.debug & 64u);
+                s_rec[lane * REC_V4 + 0] = r0;
+                if constexpr (VARIANT == RV_OBB) {
+                    r1.z = __uint_as_float(keep ? 1u : 0u);  // p[4] is unused by the OBB record
+                    s_rec[lane * REC_V4 + 1] = r1;
+                    s_rec[lane * REC_V4 + 2] = src[2];
+                } else {
+                    s_rec[lane * REC_V4 + 1] = r1;
+                    float4 r2 = src[2];
+                    if constexpr (VARIANT == RV_AABB3D) r2.w = __uint_as_float(keep ? 1u : 0u);  // rect dword
+                    s_rec[lane * REC_V4 + 2] = r2;
 #pragma unroll
-                for (int v = 0; v < REC_V4; ++v) s_rec[lane * REC_V4 + v] = src[v];
+                    for (int v = 3; v < REC_V4; ++v) {
+                        float4 rr = src[v];
+                        if (v == 5) rr.y = __uint_as_float(keep ? 1u : 0u);  // surfel: pad dword
+                        s_rec[lane * REC_V4 + v] = rr;
+                    }
+                }
             }
             // make the staged records visible to every lane of this wave before the broadcast reads
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (uint32_t k = 0; k < cnt; ++k) {
+            const uint32_t kend = (fp.debug & 16u) ? min(cnt, 1u) : cnt;  // ablation bit 16: stage, blend 1
+            for (uint32_t k = 0; k < kend; ++k) {
                 StagedRecord<VARIANT> sr;
                 sr.load(s_rec + k * REC_V4);
+                uint32_t keep_flag;
+                if constexpr (VARIANT == RV_OBB) keep_flag = __float_as_uint(sr.a1.z);
+                else if constexpr (VARIANT == RV_AABB3D) keep_flag = __float_as_uint(sr.a2.w);
+                else keep_flag = __float_as_uint(s_rec[k * REC_V4 + 5].y);
+                if (__builtin_amdgcn_readfirstlane(keep_flag) == 0u) continue;  // scalar branch
 #pragma unroll
                 for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, T[r], cr[r], cg[r], cb[r]);
             }

@@ -1,0 +1,29 @@
+#!/bin/bash
+# PMC counters per kernel for one workload: bash scripts/gpu_pmc.sh <global_scale> <tag>
+GS=$1; TAG=$2
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/pmc_$TAG
+cd /tmp
+for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" \
+           "GRBM_GUI_ACTIVE SQ_LEVEL_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $pmc | tr ' ' '_' | cut -c1-30)
+  rm -rf /tmp/p_$tag
+  rocprofv3 --pmc $pmc --output-format csv -d /tmp/p_$tag -o pmc -- python $R/scripts/loop_render.py $GS 12 > /dev/null 2> /tmp/pmc_$tag.err
+  for f in $(find /tmp/p_$tag -name "*counter_collection.csv"); do python - "$f" <<'PY' >> $R/gpurun_out/pmc_$TAG/counters.txt
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    agg[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in agg.items():
+    if "rocclr" in k: continue
+    for c, v in cs.items():
+        print(f"{k:62s} {c:24s} calls {len(v):4d} mean {sum(v)/len(v):16.1f}")
+PY
+  done
+  tail -2 /tmp/pmc_$tag.err | cut -c1-200
+done
+cat $R/gpurun_out/pmc_$TAG/counters.txt
