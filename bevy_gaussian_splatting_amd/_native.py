@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "bgs_set_async",
     "bgs_stream",
     "bgs_set_profiling",
+    "bgs_set_profiling_stride",
     "bgs_set_binning",
     "bgs_set_debug_flags",
     "bgs_get_stats",
@@ -142,6 +143,8 @@ def load() -> ctypes.CDLL:
     lib.bgs_stream.restype = ctypes.c_int
     lib.bgs_set_profiling.argtypes = [vp, ctypes.c_int]
     lib.bgs_set_profiling.restype = ctypes.c_int
+    lib.bgs_set_profiling_stride.argtypes = [vp, u32]
+    lib.bgs_set_profiling_stride.restype = ctypes.c_int
     lib.bgs_set_binning.argtypes = [vp, u32]
     lib.bgs_set_binning.restype = ctypes.c_int
     lib.bgs_set_debug_flags.argtypes = [vp, u32]

@@ -89,6 +89,8 @@ struct bgs_ctx {
     uint32_t ev_head = 0;            // slot of the most recently enqueued frame
     uint32_t frames_pending = 0;     // frames enqueued since the last finish_frame
     int profiling = 2;         // 0 = no events, 1 = frame start/end only, 2 = every stage
+    uint32_t profiling_stride = 1;  // record events only on every Nth frame
+    uint32_t frame_counter = 0;
     bool async_frames = false; // bgs_render(host_out = NULL) returns without waiting (scan binning)
     bool pending = false;      // a frame has been enqueued whose Control block was not read back yet
     bool pending_render = false;
@@ -320,7 +322,7 @@ int finish_frame(bgs_ctx* ctx, uint64_t* need_cap) {
         // mean over the frames enqueued since the last read-back that ran the same pipeline
         const int last = render ? 6 : 2;
         const uint8_t kind = ctx->ev_kind[ctx->ev_head];
-        const uint32_t frames = std::min<uint32_t>(ctx->frames_pending, EV_RING);
+        const uint32_t frames = std::min<uint32_t>(ctx->frames_pending, EV_RING);  // timed frames only
         uint32_t used = 0;
         float acc[BGS_STAGE_COUNT] = {0, 0, 0, 0, 0, 0}, acc_total = 0.0f;
         for (uint32_t f = 0; f < frames; ++f) {
@@ -396,11 +398,14 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
     uint2* ranges = (uint2*)(ctx->scratch + ctx->off_ranges);
     uint32_t* bin_status = (uint32_t*)(ctx->scratch + ctx->off_bin_status);
     uint32_t* part_status = (uint32_t*)(ctx->scratch + ctx->off_part_status);
-    const int prof = ctx->profiling;
+    const bool timed_frame = (ctx->frame_counter++ % ctx->profiling_stride) == 0;
+    const int prof = timed_frame ? ctx->profiling : 0;
     const int last_mark = render ? 6 : 2;
-    ctx->ev_head = (ctx->ev_head + 1) % EV_RING;
-    ctx->ev_kind[ctx->ev_head] = (uint8_t)(!render ? 1 : (scan ? 2 : 3));
-    ctx->frames_pending += 1;
+    if (prof) {  // untimed frames do not consume a ring slot
+        ctx->ev_head = (ctx->ev_head + 1) % EV_RING;
+        ctx->ev_kind[ctx->ev_head] = (uint8_t)(!render ? 1 : (scan ? 2 : 3));
+        ctx->frames_pending += 1;
+    }
     hipEvent_t* const ev = ctx->ev_ring[ctx->ev_head];
     auto mark = [&](int i) {
         if (prof >= 2 || (prof == 1 && (i == 0 || i == last_mark))) (void)hipEventRecord(ev[i], st);
@@ -783,6 +788,14 @@ int bgs_set_profiling(bgs_ctx* ctx, int enabled) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     if (enabled < 0 || enabled > 2) return fail(ctx, BGS_EINVAL, "profiling level must be 0, 1 or 2");
     ctx->profiling = enabled;
+    return BGS_OK;
+}
+
+int bgs_set_profiling_stride(bgs_ctx* ctx, uint32_t every_nth_frame) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (every_nth_frame == 0) return fail(ctx, BGS_EINVAL, "stride must be >= 1");
+    ctx->profiling_stride = every_nth_frame;
+    ctx->frame_counter = 0;
     return BGS_OK;
 }
 

@@ -178,6 +178,10 @@ class GaussianSplattingPlugin:
         """0 = no HIP events, 1 = frame start/end only, 2 = every stage (default)."""
         self._check(self._lib.bgs_set_profiling(self._ctx, int(level)))
 
+    def set_profiling_stride(self, every_nth_frame: int) -> None:
+        """Record HIP events only on every Nth frame (each record costs ~4 us of GPU timeline)."""
+        self._check(self._lib.bgs_set_profiling_stride(self._ctx, int(every_nth_frame)))
+
     def set_async(self, enabled: bool) -> None:
         """Async frames: render(download=False) only enqueues (scan binning); see bgs_set_async."""
         self._check(self._lib.bgs_set_async(self._ctx, 1 if enabled else 0))

@@ -216,6 +216,9 @@ int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags);
 /* HIP-event timing level: 0 = none, 1 = frame start/end only (total_ms), 2 = every stage
  * (default). Each recorded event costs a few microseconds of GPU timeline. */
 int bgs_set_profiling(bgs_ctx* ctx, int enabled);
+/* Record the events only on every Nth frame (default 1 = every frame); stage_ms is then the mean
+ * over the timed frames since the last read-back. */
+int bgs_set_profiling_stride(bgs_ctx* ctx, uint32_t every_nth_frame);
 /* Stats of the most recent bgs_sort / bgs_render. Synchronises the stream. */
 int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out);
 
