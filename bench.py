@@ -203,9 +203,17 @@ def main():
                         "project": "project_bin_kernel" if scan_mode else "project_emit_kernel",
                         "tile_sort": "onesweep_kernel", "ranges": "tile_ranges_kernel",
                         "raster": "raster_scan_kernel" if scan_mode else "raster_kernel"}
+        # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
+        # doubled per the gfx950 correction + WRITE_SIZE), for the same dense workload; null if absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"][kernel_names[dom]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": kernel_names[dom], "stage": dom,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": int(per_launch_bytes), "launch_ms": round(per_launch_s * 1e3, 4)}
         frame_bytes = st["algorithmic_bytes"]
         frame_ms = sum(stage_ms.values())
