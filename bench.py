@@ -67,24 +67,28 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
     }
 
 
-def measure(plugin, handle, view, settings, steps, warmup, after_step=None, barrier=None):
-    """W untimed + K timed steps. A step ENQUEUES one frame (async frames: the scan pipeline needs
-    no host round trip); the closing barrier waits for all of them, so dt covers exactly K complete
-    frames. Returns (seconds, per-stage ms averaged by the library over the timed frames' HIP
-    events, stats of the last frame)."""
-    for _ in range(warmup):
-        plugin.render(handle, view, settings, download=False)
-        if after_step:
-            after_step()
-    plugin.synchronize()
+def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=None, depth=1):
+    """W untimed + K timed steps. A step ENQUEUES one frame: the scan pipeline needs no host round
+    trip, and the context keeps `depth` frames in flight on separate HIP streams (lanes). With a
+    `gather` callback (N > 1 ranks) the oldest frame is popped and handed to it as soon as `depth`
+    frames are in flight, so gathers overlap the following frames. The closing synchronize waits for
+    everything, so dt covers exactly K complete frames (and their gathers). Returns (seconds,
+    per-stage ms averaged by the library over the timed frames' HIP events, stats)."""
+    def run(k):
+        for _ in range(k):
+            plugin.render(handle, view, settings, download=False)
+            if gather is not None and plugin.frames_in_flight() >= depth:
+                gather(*plugin.pipeline_pop())
+        if gather is not None:
+            while plugin.frames_in_flight():
+                gather(*plugin.pipeline_pop())
+        plugin.synchronize()  # also checks the device watchdog word of every frame
+
+    run(warmup)
     if barrier:
         barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        plugin.render(handle, view, settings, download=False)
-        if after_step:
-            after_step()
-    plugin.synchronize()  # also checks the device watchdog word of the last frame
+    run(steps)
     if barrier:
         barrier()
     dt = time.perf_counter() - t0
@@ -129,6 +133,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splats", type=int, default=N_SPLATS)
+    ap.add_argument("--depth", type=int, default=3, help="frames in flight (pipeline lanes, 1..4)")
     args = ap.parse_args()
 
     import torch
@@ -156,7 +161,9 @@ def main():
     handle = plugin.upload(cloud)
     view = headless_view(rank, WIDTH, HEIGHT)  # rank g owns camera g
     settings = CloudSettings()
+    DEPTH = max(1, min(4, args.depth))  # frames in flight (lanes); 1 = a single stream
     plugin.set_async(True)
+    plugin.set_pipeline_depth(DEPTH)
     # every kernel of every 4th frame is bracketed by HIP events (a record costs ~4 us of GPU time)
     plugin.set_profiling_stride(4)
 
@@ -166,17 +173,23 @@ def main():
         torch.cuda.synchronize()
 
     gather_ms = [0.0]
-    after = None
+    gather = None
     if dist is not None:
-        def after():
-            t = framebuffer_as_tensor(plugin, HEIGHT, WIDTH)  # completes the pending frame
+        # the gathered frame is the reference's colour-attachment format (Rgba8UnormSrgb, 8.3 MB at
+        # 1080p); the f32 target stays on its GPU
+        from bevy_gaussian_splatting_amd.multiview import device_ptr_as_tensor
+        plugin.set_output_srgb8(True)
+        recv = [torch.empty((HEIGHT, WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(world)] if rank == 0 else None
+
+        def gather(f32_ptr, srgb8_ptr):
+            t = device_ptr_as_tensor(srgb8_ptr, (HEIGHT, WIDTH, 4), "|u1", f"cuda:{local_rank}")
             t0 = time.perf_counter()
-            gather_framebuffers(t.unsqueeze(0), dst=0)
-            torch.cuda.synchronize()
+            dist.gather(t, gather_list=recv, dst=0)
+            torch.cuda.current_stream().synchronize()  # the lane may be reused once its frame was sent
             gather_ms[0] += (time.perf_counter() - t0) * 1e3
 
     # ---- headline: reference distribution, CloudSettings::default() -------------------------
-    dt, stage_ms, st = measure(plugin, handle, view, settings, args.steps, args.warmup, after, barrier)
+    dt, stage_ms, st = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, DEPTH)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,6 +232,18 @@ def main():
         frame_ms = sum(stage_ms.values())
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9 if frame_ms > 0 else 0.0
 
+        # the same frames on ONE stream (pipeline depth 1): per-kernel times without overlap
+        plugin.set_pipeline_depth(1)
+        dt1, stage1, st1 = measure(plugin, handle, view, settings, args.steps, args.warmup)
+        single = {"value": round(args.steps / dt1, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt1 / args.steps, 4),
+                  "stage_ms": {k: round(v, 4) for k, v in stage1.items() if v}}
+        dom1 = max(stage1, key=lambda k: stage1[k] / table[k]["launches"] if k in table else 0.0)
+        b1 = table[dom1]["bytes"] / table[dom1]["launches"]
+        t1 = stage1[dom1] * 1e-3 / table[dom1]["launches"]
+        single["roofline"] = {"bound": "hbm", "kernel": kernel_names[dom1], "achieved": round(b1 / t1 / 1e9, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b1 / t1 / 1e9 / HBM_PEAK_GBS, 4),
+                              "launch_ms": round(t1 * 1e3, 4), "bytes_per_launch": int(b1)}
+
         # "Msplats/s sorted": keygen + depth sort only (blocking calls, every one timed)
         plugin.set_profiling_stride(1)
         for _ in range(3):
@@ -235,9 +260,12 @@ def main():
 
         # scene-like variant: global_scale = 0.05
         plugin.set_profiling_stride(4)
+        plugin.set_pipeline_depth(DEPTH)
         s2 = CloudSettings(global_scale=0.05)
-        dt2, stage2, st2 = measure(plugin, handle, view, s2, args.steps, args.warmup)
+        dt2, stage2, st2 = measure(plugin, handle, view, s2, args.steps, args.warmup, depth=DEPTH)
         ms2 = sum(stage2.values())
+        plugin.set_pipeline_depth(1)
+        dt2s, _, _ = measure(plugin, handle, view, s2, args.steps, args.warmup)
 
         # the named instance-sort pipeline (tile-major|depth radix sort) on the same workload
         plugin.set_binning("sort")
@@ -255,17 +283,21 @@ def main():
             "config": {"workload": f"{args.splats}-splat 3DGS f32 planar cloud (seed {SEED}, reference random_gaussians_3d "
                                    "distributions), 1920x1080, SH degree 3, CloudSettings::default(), "
                                    "examples/headless.rs camera; one camera per GPU",
-                       "parallelism": f"views{world}", "sort": "radix32", "global_scale": 1.0},
+                       "parallelism": f"views{world}", "sort": "radix32", "global_scale": 1.0,
+                       "frames_in_flight": DEPTH},
+            "single_stream": single,
             "roofline": roofline,
             "frame": {"device_ms": round(frame_ms, 4), "algorithmic_GB": round(frame_bytes / 1e9, 4),
                       "GBps": round(frame_gbs, 1), "pct_hbm_peak": round(100 * frame_gbs / HBM_PEAK_GBS, 2),
                       "visible_splats": st["visible_count"], "tile_instances": st["instance_count"],
-                      "gather_ms_per_step": round(gather_ms[0] / max(args.steps + args.warmup, 1), 4)},
+                      "gather_ms_per_step": round(gather_ms[0] / max(args.steps + args.warmup, 1), 4),
+                      "gathered_format": "Rgba8UnormSrgb" if world > 1 else None},
             "stages": stages,
             "sort_msplats_per_s": round(args.splats / (sort_dev_ms * 1e-3) / 1e6, 1) if sort_dev_ms > 0 else None,
             "sort": {"device_ms": round(sort_dev_ms, 4), "wall_ms": round(sort_wall * 1e3, 4),
                      "GBps": round(sort_bytes / (sort_dev_ms * 1e-3) / 1e9, 1) if sort_dev_ms > 0 else None},
             "scene_like": {"global_scale": 0.05, "value": round(args.steps / dt2, 2), "unit": "frames/s",
+                           "single_stream_value": round(args.steps / dt2s, 2),
                            "device_ms": round(ms2, 4), "visible_splats": st2["visible_count"],
                            "tile_instances": st2["instance_count"],
                            "GBps": round(st2["algorithmic_bytes"] / (ms2 * 1e-3) / 1e9, 1) if ms2 > 0 else None},

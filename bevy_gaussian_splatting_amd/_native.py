@@ -41,6 +41,11 @@ EXPORTED_SYMBOLS = (
     "bgs_render",
     "bgs_framebuffer_device_ptr",
     "bgs_sorted_entries_device_ptr",
+    "bgs_set_output_srgb8",
+    "bgs_framebuffer_srgb8_device_ptr",
+    "bgs_set_pipeline_depth",
+    "bgs_pipeline_pop",
+    "bgs_frames_in_flight",
     "bgs_synchronize",
     "bgs_set_async",
     "bgs_stream",
@@ -137,6 +142,16 @@ def load() -> ctypes.CDLL:
     lib.bgs_sorted_entries_device_ptr.restype = ctypes.c_int
     lib.bgs_synchronize.argtypes = [vp]
     lib.bgs_synchronize.restype = ctypes.c_int
+    lib.bgs_set_output_srgb8.argtypes = [vp, ctypes.c_int]
+    lib.bgs_set_output_srgb8.restype = ctypes.c_int
+    lib.bgs_framebuffer_srgb8_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
+    lib.bgs_framebuffer_srgb8_device_ptr.restype = ctypes.c_int
+    lib.bgs_set_pipeline_depth.argtypes = [vp, u32]
+    lib.bgs_set_pipeline_depth.restype = ctypes.c_int
+    lib.bgs_pipeline_pop.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    lib.bgs_pipeline_pop.restype = ctypes.c_int
+    lib.bgs_frames_in_flight.argtypes = [vp, up]
+    lib.bgs_frames_in_flight.restype = ctypes.c_int
     lib.bgs_set_async.argtypes = [vp, ctypes.c_int]
     lib.bgs_set_async.restype = ctypes.c_int
     lib.bgs_stream.argtypes = [vp, ctypes.POINTER(vp)]

@@ -1,16 +1,24 @@
-// bgs_api.hip — libbgs host side: context, device buffers, per-frame orchestration, C ABI.
+// bgs_api.hip — libbgs host side: context, frame lanes, device buffers, orchestration, C ABI.
 //
-// One frame (bgs_render) is 11 enqueues on the context's stream, no host round trip in
-// between; every size that depends on the data (draw-list length V', instance count I) stays
-// on the device in the Control block and is consumed by persistent, ticket-driven kernels:
+// One frame (bgs_render, default BGS_BINNING_SCAN) is 9 enqueues on ONE lane's stream with no host
+// round trip in between; every size that depends on the data (drawable count V', list lengths)
+// stays on the device in the lane's Control block and is consumed by persistent, ticket-driven
+// kernels:
 //
-//   memset(zeroed scratch: Control | look-back words | tile ranges)
-//   keygen                        N x (16 B read, 8 B write) + 4 digit histograms
-//   onesweep x places             depth keys, 16 B/pair/pass
-//   project_emit                  V' splats -> records (front-to-back) + I instances
-//   onesweep x 2                  instances by tile x, then tile y (stable)
-//   tile_ranges, raster
-//   copy Control -> pinned host, sync, check overflow/watchdog (regrow + re-run on overflow)
+//   memset(zeroed scratch: Control | look-back words)
+//   keygen                        N x (16 B read, 8 B write) + digit histograms + stable partition
+//   onesweep x places             the V' drawable depth keys, 16 B/pair/pass
+//   project_bin                   V' splats -> records, rects (front-to-back) + ordered coarse lists
+//   raster_scan                   one wave per 16x16 tile, lazy binning, saturation exit
+//   [encode_srgb8]                optional Rgba8UnormSrgb image (the reference's target format)
+//   copy Control -> pinned host   read when the frame is completed
+//
+// FRAME LANES (bgs_set_pipeline_depth): a single stream of these latency-bound kernels leaves most
+// of the chip idle (1.9k waves of projection work, 59-tile sort passes), so the context owns K
+// lanes, each with its own stream and per-frame buffers; async frames go round-robin over the
+// lanes and the GPU overlaps one frame's sort with another frame's rasteriser (measured 1.8x at
+// K = 3). A lane is completed (stream wait + watchdog check) when it is reused, popped, or on any
+// blocking call.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -41,7 +49,8 @@ constexpr uint64_t MIN_INSTANCE_CAPACITY = 1ull << 22;  // 4M instances (32 MB p
 constexpr uint64_t MAX_INSTANCE_CAPACITY = 1ull << 30;  // look-back words carry 30-bit values
 constexpr uint32_t MAX_SPLATS = (1u << 30) - 1u;
 constexpr int EV_COUNT = BGS_STAGE_COUNT + 1;
-constexpr int EV_RING = 64;  // per-stage timings are averaged over up to this many async frames
+constexpr int EV_RING = 64;   // per-stage timings are averaged over up to this many frames per lane
+constexpr int MAX_LANES = 4;
 
 template <class T>
 T* dev_alloc(size_t count) {
@@ -50,57 +59,81 @@ T* dev_alloc(size_t count) {
     return (T*)p;
 }
 
-}  // namespace
-
-struct bgs_ctx {
-    int device = 0;
+// Everything one in-flight frame owns.
+struct Lane {
     hipStream_t stream = nullptr;
-    int num_cus = 256;
-    std::string error;
 
-    // zeroed-every-frame scratch: [Control | depth status | scan status | tile status | ranges]
+    // zeroed-every-frame scratch: [Control | depth status | scan status | tile status | ranges |
+    //                              bin status | partition status]
     uint8_t* scratch = nullptr;
     size_t scratch_bytes = 0;
     size_t off_depth_status = 0, off_scan_status = 0, off_tile_status = 0, off_ranges = 0, off_bin_status = 0,
            off_part_status = 0;
-    uint32_t scratch_n = 0;          // splat capacity the scratch was laid out for
-    uint64_t scratch_inst_cap = 0;   // instance capacity the scratch was laid out for
+    uint32_t scratch_n = 0;         // splat capacity the scratch was laid out for
+    uint64_t scratch_inst_cap = 0;  // instance capacity the scratch was laid out for
 
     uint2* entries[2] = {nullptr, nullptr};
-    uint2* culled = nullptr;         // entries with the culled sentinel key, in index order
+    uint2* culled = nullptr;  // entries with the culled sentinel key, in index order
     uint32_t entries_cap = 0;
     void* records = nullptr;
     size_t records_bytes = 0;
-    uint2* inst[2] = {nullptr, nullptr};
+    uint2* inst[2] = {nullptr, nullptr};  // BINNING_SORT only
     uint64_t inst_cap = 0;
-    uint32_t* rects = nullptr;       // BINNING_SCAN: packed tile rectangle per rank
+    uint32_t* rects = nullptr;   // BINNING_SCAN: packed tile rectangle per rank
     uint32_t rects_cap = 0;
-    uint32_t* coarse = nullptr;      // BINNING_SCAN: [num_supertiles][coarse_cap] ordered rank lists
+    uint32_t* coarse = nullptr;  // BINNING_SCAN: [num_supertiles][coarse_cap] ordered rank lists
     size_t coarse_words = 0;
-    uint32_t binning = BINNING_SCAN;
-    uint32_t debug_flags = 0;
     float4* fb = nullptr;
     size_t fb_pixels = 0;
+    uint32_t* fb8 = nullptr;     // Rgba8UnormSrgb image (optional)
+    size_t fb8_pixels = 0;
     uint32_t fb_w = 0, fb_h = 0;
+    bool fb8_valid = false;
 
-    Control* h_ctl = nullptr;  // pinned
+    Control* h_ctl = nullptr;  // pinned; filled by a copy enqueued with the frame
     hipEvent_t ev_ring[EV_RING][EV_COUNT] = {};
-    uint8_t ev_kind[EV_RING] = {};   // 0 unused, 1 sort-only frame, 2 render/scan, 3 render/sort-binning
-    uint32_t ev_head = 0;            // slot of the most recently enqueued frame
-    uint32_t frames_pending = 0;     // frames enqueued since the last finish_frame
-    int profiling = 2;         // 0 = no events, 1 = frame start/end only, 2 = every stage
-    uint32_t profiling_stride = 1;  // record events only on every Nth frame
-    uint32_t frame_counter = 0;
-    bool async_frames = false; // bgs_render(host_out = NULL) returns without waiting (scan binning)
-    bool pending = false;      // a frame has been enqueued whose Control block was not read back yet
-    bool pending_render = false;
+    uint8_t ev_kind[EV_RING] = {};  // 0 unused, 1 sort-only frame, 2 render/scan, 3 render/sort-binning
+    uint32_t ev_head = 0;
+    uint32_t frames_timed = 0;  // timed frames since the last stats read-back
+
+    bool pending = false;  // a frame is enqueued whose Control block has not been checked yet
+    bool pending_render = false, pending_scan = false;
     uint32_t pending_n = 0, pending_places = 0, pending_num_st = 0, pending_rec_bytes = 0, pending_is_f16 = 0;
     uint32_t pending_w = 0, pending_h = 0, pending_tx = 0, pending_ty = 0;
-    bool have_stats = false;
-    bgs_stats stats{};
+    uint64_t seq = 0;  // enqueue sequence number (to find the oldest pending lane)
 
     const uint2* last_sorted = nullptr;
     uint32_t last_sorted_n = 0;
+
+    bgs_stats result{};      // counters of the last completed frame of this lane (no timings)
+    bool has_result = false;
+    uint8_t result_kind = 0; // ev_kind of that frame
+};
+
+}  // namespace
+
+struct bgs_ctx {
+    int device = 0;
+    int num_cus = 256;
+    std::string error;
+
+    Lane lanes[MAX_LANES];
+    int depth = 1;    // lanes in use
+    int next = 0;     // lane the next frame goes to
+    int recent = 0;   // lane of the most recently enqueued frame
+    uint64_t seq = 0;
+
+    uint32_t binning = BINNING_SCAN;
+    uint32_t debug_flags = 0;
+    int profiling = 2;              // 0 = no events, 1 = frame start/end only, 2 = every stage
+    uint32_t profiling_stride = 1;  // record events only on every Nth frame
+    uint32_t frame_counter = 0;
+    bool async_frames = false;
+    bool output_srgb8 = false;
+
+    bool have_stats = false;
+    bgs_stats stats{};
+    uint32_t regrow_count = 0;
 };
 
 namespace {
@@ -120,11 +153,41 @@ int fail(bgs_ctx* ctx, int status, const std::string& msg) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+int lane_create(bgs_ctx* ctx, Lane& L) {
+    if (L.stream) return BGS_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    for (auto& slot : L.ev_ring)
+        for (auto& ev : slot) HIP_TRY(ctx, hipEventCreate(&ev));
+    void* h = nullptr;
+    HIP_TRY(ctx, hipHostMalloc(&h, sizeof(Control), hipHostMallocDefault));
+    L.h_ctl = (Control*)h;
+    std::memset(L.h_ctl, 0, sizeof(Control));
+    return BGS_OK;
+}
+
+void lane_destroy(Lane& L) {
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    if (L.scratch) (void)hipFree(L.scratch);
+    for (auto e : L.entries) if (e) (void)hipFree(e);
+    if (L.culled) (void)hipFree(L.culled);
+    for (auto e : L.inst) if (e) (void)hipFree(e);
+    if (L.records) (void)hipFree(L.records);
+    if (L.rects) (void)hipFree(L.rects);
+    if (L.coarse) (void)hipFree(L.coarse);
+    if (L.fb) (void)hipFree(L.fb);
+    if (L.fb8) (void)hipFree(L.fb8);
+    if (L.h_ctl) (void)hipHostFree(L.h_ctl);
+    for (auto& slot : L.ev_ring)
+        for (auto ev : slot) if (ev) (void)hipEventDestroy(ev);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+    L = Lane();
+}
+
 // (Re)build the zeroed scratch region for n splats and inst_cap instances.
-int ensure_scratch(bgs_ctx* ctx, uint32_t n, uint64_t inst_cap) {
-    if (ctx->scratch && n <= ctx->scratch_n && inst_cap <= ctx->scratch_inst_cap) return BGS_OK;
-    n = std::max(n, ctx->scratch_n);
-    inst_cap = std::max(inst_cap, ctx->scratch_inst_cap);
+int ensure_scratch(bgs_ctx* ctx, Lane& L, uint32_t n, uint64_t inst_cap) {
+    if (L.scratch && n <= L.scratch_n && inst_cap <= L.scratch_inst_cap) return BGS_OK;
+    n = std::max(n, L.scratch_n);
+    inst_cap = std::max(inst_cap, L.scratch_inst_cap);
     // depth sort may use either tile size; size for the smaller one
     const size_t depth_tiles = ((size_t)n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
     const size_t scan_tiles = ((size_t)n + 255) / 256 + 1;
@@ -142,96 +205,101 @@ int ensure_scratch(bgs_ctx* ctx, uint32_t n, uint64_t inst_cap) {
     off += align_up(scan_tiles * MAX_SUPERTILES * sizeof(uint32_t), 256);
     const size_t off_part = off;
     off += align_up((((size_t)n + KEYGEN_TILE - 1) / KEYGEN_TILE + 1) * sizeof(uint32_t), 256);
-    if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; }
+    if (L.scratch) { (void)hipFree(L.scratch); L.scratch = nullptr; }
     void* p = nullptr;
     if (hipMalloc(&p, off) != hipSuccess) return fail(ctx, BGS_ENOMEM, "hipMalloc(scratch) failed");
-    ctx->scratch = (uint8_t*)p;
-    ctx->scratch_bytes = off;
-    ctx->off_depth_status = off_depth;
-    ctx->off_scan_status = off_scan;
-    ctx->off_tile_status = off_tile;
-    ctx->off_ranges = off_ranges;
-    ctx->off_bin_status = off_bin;
-    ctx->off_part_status = off_part;
-    ctx->scratch_n = n;
-    ctx->scratch_inst_cap = inst_cap;
+    L.scratch = (uint8_t*)p;
+    L.scratch_bytes = off;
+    L.off_depth_status = off_depth;
+    L.off_scan_status = off_scan;
+    L.off_tile_status = off_tile;
+    L.off_ranges = off_ranges;
+    L.off_bin_status = off_bin;
+    L.off_part_status = off_part;
+    L.scratch_n = n;
+    L.scratch_inst_cap = inst_cap;
     return BGS_OK;
 }
 
-int ensure_entries(bgs_ctx* ctx, uint32_t n) {
-    if (n <= ctx->entries_cap && ctx->entries[0]) return BGS_OK;
-    for (auto& e : ctx->entries) { if (e) (void)hipFree(e); e = nullptr; }
-    if (ctx->culled) { (void)hipFree(ctx->culled); ctx->culled = nullptr; }
-    for (auto& e : ctx->entries) {
+int ensure_entries(bgs_ctx* ctx, Lane& L, uint32_t n) {
+    if (n <= L.entries_cap && L.entries[0]) return BGS_OK;
+    for (auto& e : L.entries) { if (e) (void)hipFree(e); e = nullptr; }
+    if (L.culled) { (void)hipFree(L.culled); L.culled = nullptr; }
+    for (auto& e : L.entries) {
         e = dev_alloc<uint2>(n);
         if (!e) return fail(ctx, BGS_ENOMEM, "hipMalloc(sort entries) failed");
     }
-    ctx->culled = dev_alloc<uint2>(n);
-    if (!ctx->culled) return fail(ctx, BGS_ENOMEM, "hipMalloc(culled entries) failed");
-    ctx->entries_cap = n;
+    L.culled = dev_alloc<uint2>(n);
+    if (!L.culled) return fail(ctx, BGS_ENOMEM, "hipMalloc(culled entries) failed");
+    L.entries_cap = n;
     return BGS_OK;
 }
 
-int ensure_instances(bgs_ctx* ctx, uint64_t cap) {
-    if (cap <= ctx->inst_cap && ctx->inst[0]) return BGS_OK;
-    for (auto& e : ctx->inst) { if (e) (void)hipFree(e); e = nullptr; }
-    ctx->inst_cap = 0;
-    for (auto& e : ctx->inst) {
+int ensure_instances(bgs_ctx* ctx, Lane& L, uint64_t cap) {
+    if (cap <= L.inst_cap && L.inst[0]) return BGS_OK;
+    for (auto& e : L.inst) { if (e) (void)hipFree(e); e = nullptr; }
+    L.inst_cap = 0;
+    for (auto& e : L.inst) {
         e = dev_alloc<uint2>(cap);
         if (!e) return fail(ctx, BGS_ENOMEM, "hipMalloc(tile instances) failed");
     }
-    ctx->inst_cap = cap;
+    L.inst_cap = cap;
     return BGS_OK;
 }
 
-int ensure_records(bgs_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->records_bytes && ctx->records) return BGS_OK;
-    if (ctx->records) (void)hipFree(ctx->records);
-    ctx->records = nullptr;
-    ctx->records_bytes = 0;
+int ensure_records(bgs_ctx* ctx, Lane& L, size_t bytes) {
+    if (bytes <= L.records_bytes && L.records) return BGS_OK;
+    if (L.records) (void)hipFree(L.records);
+    L.records = nullptr;
+    L.records_bytes = 0;
     void* p = nullptr;
     if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess)
         return fail(ctx, BGS_ENOMEM, "hipMalloc(records) failed");
-    ctx->records = p;
-    ctx->records_bytes = bytes;
+    L.records = p;
+    L.records_bytes = bytes;
     return BGS_OK;
 }
 
-int ensure_coarse(bgs_ctx* ctx, uint32_t n, uint32_t num_st) {
-    if (n > ctx->rects_cap || !ctx->rects) {
-        if (ctx->rects) (void)hipFree(ctx->rects);
-        ctx->rects = dev_alloc<uint32_t>(n);
-        if (!ctx->rects) return fail(ctx, BGS_ENOMEM, "hipMalloc(rects) failed");
-        ctx->rects_cap = n;
+int ensure_coarse(bgs_ctx* ctx, Lane& L, uint32_t n, uint32_t num_st) {
+    if (n > L.rects_cap || !L.rects) {
+        if (L.rects) (void)hipFree(L.rects);
+        L.rects = dev_alloc<uint32_t>(n);
+        if (!L.rects) return fail(ctx, BGS_ENOMEM, "hipMalloc(rects) failed");
+        L.rects_cap = n;
     }
     // worst case: every rank lands in every supertile list -> num_st * n words (no overflow path)
     const size_t words = (size_t)num_st * std::max<uint32_t>(n, 1);
-    if (words > ctx->coarse_words || !ctx->coarse) {
+    if (words > L.coarse_words || !L.coarse) {
         if (words * sizeof(uint32_t) > (64ull << 30))
             return fail(ctx, BGS_ECAPACITY, "coarse bin lists would exceed 64 GiB; use bgs_set_binning(ctx, 1)");
-        if (ctx->coarse) (void)hipFree(ctx->coarse);
-        ctx->coarse = dev_alloc<uint32_t>(words);
-        if (!ctx->coarse) return fail(ctx, BGS_ENOMEM, "hipMalloc(coarse lists) failed");
-        ctx->coarse_words = words;
+        if (L.coarse) (void)hipFree(L.coarse);
+        L.coarse = dev_alloc<uint32_t>(words);
+        if (!L.coarse) return fail(ctx, BGS_ENOMEM, "hipMalloc(coarse lists) failed");
+        L.coarse_words = words;
     }
     return BGS_OK;
 }
 
-int ensure_framebuffer(bgs_ctx* ctx, uint32_t w, uint32_t h) {
+int ensure_framebuffer(bgs_ctx* ctx, Lane& L, uint32_t w, uint32_t h, bool want8) {
     const size_t px = (size_t)w * h;
-    if (px > ctx->fb_pixels || !ctx->fb) {
-        if (ctx->fb) (void)hipFree(ctx->fb);
-        ctx->fb = dev_alloc<float4>(px);
-        if (!ctx->fb) return fail(ctx, BGS_ENOMEM, "hipMalloc(framebuffer) failed");
-        ctx->fb_pixels = px;
+    if (px > L.fb_pixels || !L.fb) {
+        if (L.fb) (void)hipFree(L.fb);
+        L.fb = dev_alloc<float4>(px);
+        if (!L.fb) return fail(ctx, BGS_ENOMEM, "hipMalloc(framebuffer) failed");
+        L.fb_pixels = px;
     }
-    ctx->fb_w = w;
-    ctx->fb_h = h;
+    if (want8 && (px > L.fb8_pixels || !L.fb8)) {
+        if (L.fb8) (void)hipFree(L.fb8);
+        L.fb8 = dev_alloc<uint32_t>(px);
+        if (!L.fb8) return fail(ctx, BGS_ENOMEM, "hipMalloc(srgb8 framebuffer) failed");
+        L.fb8_pixels = px;
+    }
+    L.fb_w = w;
+    L.fb_h = h;
     return BGS_OK;
 }
 
-int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s,
-             bool render) {
+int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s, bool render) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     if (!cloud || !view || !s) return fail(ctx, BGS_EINVAL, "cloud, view and settings must be non-NULL");
     if (s->radix_depth_bits != 16 && s->radix_depth_bits != 24 && s->radix_depth_bits != 32)
@@ -242,40 +310,37 @@ int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
     if (s->color_space > BGS_COLOR_LINEAR) return fail(ctx, BGS_EINVAL, "unknown color_space");
     if (render) {
         const float w = view->viewport[2], h = view->viewport[3];
-        if (!(w >= 1.0f) || !(h >= 1.0f) || w > 4096.0f || h > 4096.0f || w != std::floor(w) ||
-            h != std::floor(h))
+        if (!(w >= 1.0f) || !(h >= 1.0f) || w > 4096.0f || h > 4096.0f || w != std::floor(w) || h != std::floor(h))
             return fail(ctx, BGS_EINVAL, "viewport width/height must be integers in [1, 4096]");
     }
     return BGS_OK;
 }
 
-// Read back the Control block of the last enqueued frame, check the watchdog / overflow words and
-// fill the stats. Called right after enqueueing (synchronous mode) or from bgs_synchronize /
-// bgs_get_stats / the next blocking call (async mode).
-int finish_frame(bgs_ctx* ctx, uint64_t* need_cap) {
+// Complete the frame pending on a lane: wait for its stream, check the watchdog / overflow words of
+// the Control copy that travelled with the frame, fill the context's stats.
+int finish_lane(bgs_ctx* ctx, Lane& L, uint64_t* need_cap) {
     if (need_cap) *need_cap = 0;
-    if (!ctx->pending) return BGS_OK;
-    hipStream_t st = ctx->stream;
-    Control* ctl = (Control*)ctx->scratch;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+    if (!L.pending) return BGS_OK;
+    hipStream_t st = L.stream;
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    ctx->pending = false;
-    const bool render = ctx->pending_render;
-    const bool scan = ctx->binning == BINNING_SCAN;
-    const uint32_t n = ctx->pending_n, places = ctx->pending_places, num_st = ctx->pending_num_st;
-    const size_t rec_bytes = ctx->pending_rec_bytes;
+    L.pending = false;
+    const bool render = L.pending_render, scan = L.pending_scan;
+    const uint32_t n = L.pending_n, places = L.pending_places, num_st = L.pending_num_st;
+    const size_t rec_bytes = L.pending_rec_bytes;
 
-    const Control& h = *ctx->h_ctl;
+    const Control& h = *L.h_ctl;
     // after a render only the drawable prefix of the list is materialised (the culled tail stays
     // in its side buffer); bgs_sort appends it so that callers get the reference's full list
-    ctx->last_sorted_n = render ? h.draw_count : n;
+    L.last_sorted_n = render ? h.draw_count : n;
     if (!render && h.draw_count < n) {
         // bgs_sort contract: one contiguous list, culled entries last (ascending index)
-        HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint2*>(ctx->last_sorted) + h.draw_count, ctx->culled,
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint2*>(L.last_sorted) + h.draw_count, L.culled,
                                     (size_t)(n - h.draw_count) * sizeof(uint2), hipMemcpyDeviceToDevice, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
     }
-    if (h.error) return fail(ctx, BGS_EINTERNAL, "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
+    if (h.error)
+        return fail(ctx, BGS_EINTERNAL,
+                    "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
     uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
     if (render && scan) {
         total = 0;
@@ -286,30 +351,27 @@ int finish_frame(bgs_ctx* ctx, uint64_t* need_cap) {
         return BGS_OK;
     }
 
-    // stats
-    bgs_stats& stt = ctx->stats;
-    const uint32_t regrow = stt.regrow_count;
+    bgs_stats& stt = L.result;
     std::memset(&stt, 0, sizeof stt);
-    stt.regrow_count = regrow;
+    stt.regrow_count = ctx->regrow_count;
     stt.splat_count = n;
     stt.visible_count = render ? h.visible_count : h.draw_count;
     stt.draw_count = h.draw_count;
     stt.instance_count = render ? total : 0;
-    stt.instance_capacity = ctx->inst_cap;
-    stt.tiles_x = render ? ctx->pending_tx : 0;
-    stt.tiles_y = render ? ctx->pending_ty : 0;
+    stt.instance_capacity = L.inst_cap;
+    stt.tiles_x = render ? L.pending_tx : 0;
+    stt.tiles_y = render ? L.pending_ty : 0;
     stt.depth_passes = places;
     stt.tile_passes = (render && !scan) ? 2 : 0;
-    stt.binning_mode = ctx->binning;
+    stt.binning_mode = scan ? BINNING_SCAN : BINNING_SORT;
     {
-        // SURVEY 8(d) algorithmic bytes
-        // SURVEY's bytes_sort is N*16 + N*8 + k*N*16; the partition in keygen means only the D
-        // drawable pairs go through the k passes, so that is what is counted
+        // SURVEY 8(d) algorithmic bytes. SURVEY's bytes_sort is N*16 + N*8 + k*N*16; the partition
+        // in keygen means only the D drawable pairs go through the k passes, so that is counted.
         const uint64_t N = n, k = places, D = h.draw_count;
         uint64_t bytes = N * 16 + N * 8 + k * D * 16;
         if (render) {
-            const uint64_t B = ctx->pending_is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
-            const uint64_t P = (uint64_t)ctx->pending_w * ctx->pending_h;
+            const uint64_t B = L.pending_is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
+            const uint64_t P = (uint64_t)L.pending_w * L.pending_h;
             if (scan)  // coarse entries: written once (4 B), read by the tiles of their supertile
                 bytes += V * (B - 16) + V * R + V * 8 + I * 4 + I * 4 + P * 16;
             else
@@ -317,34 +379,60 @@ int finish_frame(bgs_ctx* ctx, uint64_t* need_cap) {
         }
         stt.algorithmic_bytes = bytes;
     }
-    const int prof = ctx->profiling;
-    if (prof >= 1) {
-        // mean over the frames enqueued since the last read-back that ran the same pipeline
+    L.has_result = true;
+    L.result_kind = (uint8_t)(!render ? 1 : (scan ? 2 : 3));
+    return BGS_OK;
+}
+
+int finish_all(bgs_ctx* ctx) {
+    // oldest first, so that the stats left behind are those of the most recent frame
+    for (;;) {
+        int best = -1;
+        for (int i = 0; i < MAX_LANES; ++i)
+            if (ctx->lanes[i].pending && (best < 0 || ctx->lanes[i].seq < ctx->lanes[best].seq)) best = i;
+        if (best < 0) return BGS_OK;
+        int rc = finish_lane(ctx, ctx->lanes[best], nullptr);
+        if (rc != BGS_OK) return rc;
+    }
+}
+
+// Build ctx->stats: counters of the most recent frame + per-stage times averaged over every timed
+// frame (all lanes) of the same pipeline since the previous call. All lanes must be complete.
+int collect_stats(bgs_ctx* ctx) {
+    Lane& R = ctx->lanes[ctx->recent];
+    if (!R.has_result) return fail(ctx, BGS_EINVAL, "no frame has been run yet");
+    ctx->stats = R.result;
+    bgs_stats& stt = ctx->stats;
+    if (ctx->profiling >= 1) {
+        const uint8_t kind = R.result_kind;
+        const bool render = kind != 1, scan = kind == 2;
         const int last = render ? 6 : 2;
-        const uint8_t kind = ctx->ev_kind[ctx->ev_head];
-        const uint32_t frames = std::min<uint32_t>(ctx->frames_pending, EV_RING);  // timed frames only
         uint32_t used = 0;
         float acc[BGS_STAGE_COUNT] = {0, 0, 0, 0, 0, 0}, acc_total = 0.0f;
-        for (uint32_t f = 0; f < frames; ++f) {
-            const uint32_t slot = (ctx->ev_head + EV_RING - f) % EV_RING;
-            if (ctx->ev_kind[slot] != kind) continue;
-            hipEvent_t* const ev = ctx->ev_ring[slot];
-            auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ev[a], ev[b]); return t; };
-            if (prof >= 2) {
-                acc[BGS_STAGE_KEYGEN] += ms(0, 1);
-                acc[BGS_STAGE_DEPTH_SORT] += ms(1, 2);
-                if (render && scan) {
-                    acc[BGS_STAGE_PROJECT] += ms(2, 3);
-                    acc[BGS_STAGE_RASTER] += ms(3, 6);
-                } else if (render) {
-                    acc[BGS_STAGE_PROJECT] += ms(2, 3);
-                    acc[BGS_STAGE_TILE_SORT] += ms(3, 4);
-                    acc[BGS_STAGE_RANGES] += ms(4, 5);
-                    acc[BGS_STAGE_RASTER] += ms(5, 6);
+        for (auto& L : ctx->lanes) {
+            const uint32_t frames = std::min<uint32_t>(L.frames_timed, EV_RING);
+            for (uint32_t f = 0; f < frames; ++f) {
+                const uint32_t slot = (L.ev_head + EV_RING - f) % EV_RING;
+                if (L.ev_kind[slot] != kind) continue;
+                hipEvent_t* const ev = L.ev_ring[slot];
+                auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ev[a], ev[b]); return t; };
+                if (ctx->profiling >= 2) {
+                    acc[BGS_STAGE_KEYGEN] += ms(0, 1);
+                    acc[BGS_STAGE_DEPTH_SORT] += ms(1, 2);
+                    if (render && scan) {
+                        acc[BGS_STAGE_PROJECT] += ms(2, 3);
+                        acc[BGS_STAGE_RASTER] += ms(3, 6);
+                    } else if (render) {
+                        acc[BGS_STAGE_PROJECT] += ms(2, 3);
+                        acc[BGS_STAGE_TILE_SORT] += ms(3, 4);
+                        acc[BGS_STAGE_RANGES] += ms(4, 5);
+                        acc[BGS_STAGE_RASTER] += ms(5, 6);
+                    }
                 }
+                acc_total += ms(0, last);
+                ++used;
             }
-            acc_total += ms(0, last);
-            ++used;
+            L.frames_timed = 0;
         }
         if (used) {
             for (int i = 0; i < BGS_STAGE_COUNT; ++i) stt.stage_ms[i] = acc[i] / (float)used;
@@ -352,15 +440,13 @@ int finish_frame(bgs_ctx* ctx, uint64_t* need_cap) {
         }
         stt.frames_averaged = used;
     }
-    ctx->frames_pending = 0;
     ctx->have_stats = true;
     return BGS_OK;
 }
 
-// Enqueue (and, unless async, complete) one frame. Returns BGS_OK, or BGS_ECAPACITY-internal signal via *need_cap.
-int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s,
-              bool render, uint64_t* need_cap) {
-    *need_cap = 0;
+// Enqueue one frame on lane L. Returns without waiting; the caller decides when to finish the lane.
+int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s,
+                  bool render) {
     FrameParams fp{};
     fill_frame_params(cloud->ptrs.n, view, s, fp);
     fp.debug = ctx->debug_flags;
@@ -370,7 +456,8 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
     const size_t rec_bytes = surfel ? sizeof(RecordSurfel) : sizeof(Record);
 
     int rc;
-    if ((rc = ensure_entries(ctx, n)) != BGS_OK) return rc;
+    if ((rc = lane_create(ctx, L)) != BGS_OK) return rc;
+    if ((rc = ensure_entries(ctx, L, n)) != BGS_OK) return rc;
     const bool scan = ctx->binning == BINNING_SCAN;
     // supertile edge (in tiles): smallest power of two that keeps the coarse bins <= 256
     uint32_t sup_shift = 3;
@@ -381,100 +468,107 @@ int run_frame(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const 
                             (((uint32_t)fp.tiles_y + (1u << sup_shift) - 1) >> sup_shift);
     if (render) {
         if (scan) {
-            if ((rc = ensure_coarse(ctx, n, num_st)) != BGS_OK) return rc;
+            if ((rc = ensure_coarse(ctx, L, n, num_st)) != BGS_OK) return rc;
         } else {
-            if ((rc = ensure_instances(ctx, std::max<uint64_t>(ctx->inst_cap, MIN_INSTANCE_CAPACITY))) != BGS_OK) return rc;
+            if ((rc = ensure_instances(ctx, L, std::max<uint64_t>(L.inst_cap, MIN_INSTANCE_CAPACITY))) != BGS_OK) return rc;
         }
-        if ((rc = ensure_records(ctx, (size_t)n * rec_bytes)) != BGS_OK) return rc;
-        if ((rc = ensure_framebuffer(ctx, (uint32_t)fp.width, (uint32_t)fp.height)) != BGS_OK) return rc;
+        if ((rc = ensure_records(ctx, L, (size_t)n * rec_bytes)) != BGS_OK) return rc;
+        if ((rc = ensure_framebuffer(ctx, L, (uint32_t)fp.width, (uint32_t)fp.height, ctx->output_srgb8)) != BGS_OK) return rc;
     }
-    if ((rc = ensure_scratch(ctx, n, ctx->inst_cap)) != BGS_OK) return rc;
+    if ((rc = ensure_scratch(ctx, L, n, L.inst_cap)) != BGS_OK) return rc;
 
-    hipStream_t st = ctx->stream;
-    Control* ctl = (Control*)ctx->scratch;
-    uint32_t* depth_status = (uint32_t*)(ctx->scratch + ctx->off_depth_status);
-    unsigned long long* scan_status = (unsigned long long*)(ctx->scratch + ctx->off_scan_status);
-    uint32_t* tile_status = (uint32_t*)(ctx->scratch + ctx->off_tile_status);
-    uint2* ranges = (uint2*)(ctx->scratch + ctx->off_ranges);
-    uint32_t* bin_status = (uint32_t*)(ctx->scratch + ctx->off_bin_status);
-    uint32_t* part_status = (uint32_t*)(ctx->scratch + ctx->off_part_status);
+    hipStream_t st = L.stream;
+    Control* ctl = (Control*)L.scratch;
+    uint32_t* depth_status = (uint32_t*)(L.scratch + L.off_depth_status);
+    unsigned long long* scan_status = (unsigned long long*)(L.scratch + L.off_scan_status);
+    uint32_t* tile_status = (uint32_t*)(L.scratch + L.off_tile_status);
+    uint2* ranges = (uint2*)(L.scratch + L.off_ranges);
+    uint32_t* bin_status = (uint32_t*)(L.scratch + L.off_bin_status);
+    uint32_t* part_status = (uint32_t*)(L.scratch + L.off_part_status);
+
     const bool timed_frame = (ctx->frame_counter++ % ctx->profiling_stride) == 0;
     const int prof = timed_frame ? ctx->profiling : 0;
     const int last_mark = render ? 6 : 2;
     if (prof) {  // untimed frames do not consume a ring slot
-        ctx->ev_head = (ctx->ev_head + 1) % EV_RING;
-        ctx->ev_kind[ctx->ev_head] = (uint8_t)(!render ? 1 : (scan ? 2 : 3));
-        ctx->frames_pending += 1;
+        L.ev_head = (L.ev_head + 1) % EV_RING;
+        L.ev_kind[L.ev_head] = (uint8_t)(!render ? 1 : (scan ? 2 : 3));
+        L.frames_timed += 1;
     }
-    hipEvent_t* const ev = ctx->ev_ring[ctx->ev_head];
+    hipEvent_t* const ev = L.ev_ring[L.ev_head];
     auto mark = [&](int i) {
         if (prof >= 2 || (prof == 1 && (i == 0 || i == last_mark))) (void)hipEventRecord(ev[i], st);
     };
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, st));
+    HIP_TRY(ctx, hipMemsetAsync(L.scratch, 0, L.scratch_bytes, st));
     mark(0);
-    launch_keygen(st, fp, cloud->ptrs.position_visibility, ctx->entries[0], ctx->culled, ctl, part_status,
-                  places, /*ticket_slot=*/7, ctx->num_cus * 4);
+    launch_keygen(st, fp, cloud->ptrs.position_visibility, L.entries[0], L.culled, ctl, part_status, places,
+                  /*ticket_slot=*/7, ctx->num_cus * 4);
     mark(1);
     const bool large = n > (4u << 20);
-    const uint32_t dtile = sort_tile_size(large);
-    const size_t depth_tiles = ((size_t)ctx->scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
-    (void)dtile;
+    const size_t depth_tiles = ((size_t)L.scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
     const int sort_blocks = ctx->num_cus * 4;
     int cur = 0;
     for (uint32_t p = 0; p < places; ++p) {
         const uint32_t key_xor =
             (p + 1 == places && (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD)) ? 0xFFFFFFFFu : 0u;
         // only the V' drawable entries are sorted; the culled tail is already in its final order
-        launch_onesweep_pass(st, ctx->entries[cur], ctx->entries[cur ^ 1], &ctl->draw_count, n,
-                             ctl->hist_depth[p], depth_status + (size_t)p * depth_tiles * RADIX_BASE,
-                             &ctl->ticket[p], &ctl->error, p * RADIX_BITS, key_xor, large, sort_blocks);
+        launch_onesweep_pass(st, L.entries[cur], L.entries[cur ^ 1], &ctl->draw_count, n, ctl->hist_depth[p],
+                             depth_status + (size_t)p * depth_tiles * RADIX_BASE, &ctl->ticket[p], &ctl->error,
+                             p * RADIX_BITS, key_xor, large, sort_blocks);
         cur ^= 1;
     }
     mark(2);
-    uint2* const draw_list = ctx->entries[cur];
-    ctx->last_sorted = draw_list;
-    ctx->last_sorted_n = n;
+    uint2* const draw_list = L.entries[cur];
+    L.last_sorted = draw_list;
+    L.last_sorted_n = n;
 
     if (render && scan) {
         const uint32_t coarse_cap = std::max<uint32_t>(n, 1);
-        launch_project_bin(st, fp, cloud->ptrs, draw_list, ctl, bin_status, ctx->records, ctx->rects,
-                           ctx->coarse, coarse_cap, sup_shift, /*ticket_slot=*/4, ctx->num_cus * 2);
+        launch_project_bin(st, fp, cloud->ptrs, draw_list, ctl, bin_status, L.records, L.rects, L.coarse, coarse_cap,
+                           sup_shift, /*ticket_slot=*/4, ctx->num_cus * 2);
         mark(3);
-        launch_raster_scan(st, fp, ctx->records, ctx->rects, ctx->coarse, coarse_cap, sup_shift, ctl,
-                           ctx->fb, view->clear_color);
+        launch_raster_scan(st, fp, L.records, L.rects, L.coarse, coarse_cap, sup_shift, ctl, L.fb,
+                           view->clear_color);
         mark(6);
     } else if (render) {
-        const uint32_t capacity = (uint32_t)std::min<uint64_t>(ctx->inst_cap, MAX_INSTANCE_CAPACITY);
-        CloudPtrs cp = cloud->ptrs;
-        launch_project_emit(st, fp, cp, draw_list, ctl, scan_status, ctx->records, ctx->inst[0], capacity,
+        const uint32_t capacity = (uint32_t)std::min<uint64_t>(L.inst_cap, MAX_INSTANCE_CAPACITY);
+        launch_project_emit(st, fp, cloud->ptrs, draw_list, ctl, scan_status, L.records, L.inst[0], capacity,
                             /*ticket_slot=*/4, ctx->num_cus * 3);
         mark(3);
-        const size_t inst_tiles = (ctx->scratch_inst_cap + sort_tile_size(true) - 1) / sort_tile_size(true) + 1;
+        const size_t inst_tiles = (L.scratch_inst_cap + sort_tile_size(true) - 1) / sort_tile_size(true) + 1;
         for (uint32_t p = 0; p < 2; ++p)
-            launch_onesweep_pass(st, ctx->inst[p], ctx->inst[p ^ 1], &ctl->instance_count, capacity,
-                                 ctl->hist_tile[p], tile_status + (size_t)p * inst_tiles * RADIX_BASE,
-                                 &ctl->ticket[5 + p], &ctl->error, p * RADIX_BITS, 0u, true, sort_blocks);
+            launch_onesweep_pass(st, L.inst[p], L.inst[p ^ 1], &ctl->instance_count, capacity, ctl->hist_tile[p],
+                                 tile_status + (size_t)p * inst_tiles * RADIX_BASE, &ctl->ticket[5 + p],
+                                 &ctl->error, p * RADIX_BITS, 0u, true, sort_blocks);
         mark(4);
-        launch_tile_ranges(st, ctx->inst[0], ctl, ranges);
+        launch_tile_ranges(st, L.inst[0], ctl, ranges);
         mark(5);
-        launch_raster(st, fp, ctx->records, ctx->inst[0], ranges, ctx->fb, view->clear_color);
+        launch_raster(st, fp, L.records, L.inst[0], ranges, L.fb, view->clear_color);
         mark(6);
     }
+    L.fb8_valid = false;
+    if (render && ctx->output_srgb8) {
+        launch_encode_srgb8(st, L.fb, L.fb8, (uint32_t)fp.width * (uint32_t)fp.height);
+        L.fb8_valid = true;
+    }
     HIP_TRY(ctx, hipGetLastError());
-    ctx->pending = true;
-    ctx->pending_render = render;
-    ctx->pending_n = n;
-    ctx->pending_places = places;
-    ctx->pending_num_st = num_st;
-    ctx->pending_rec_bytes = (uint32_t)rec_bytes;
-    ctx->pending_is_f16 = cloud->ptrs.is_f16;
-    ctx->pending_w = (uint32_t)fp.width;
-    ctx->pending_h = (uint32_t)fp.height;
-    ctx->pending_tx = (uint32_t)fp.tiles_x;
-    ctx->pending_ty = (uint32_t)fp.tiles_y;
-    if (ctx->async_frames && render && scan) return BGS_OK;  // nothing the host must see before the next frame
-    return finish_frame(ctx, need_cap);
+    // the Control block travels back with the frame; it is looked at when the lane is completed
+    HIP_TRY(ctx, hipMemcpyAsync(L.h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+
+    L.pending = true;
+    L.pending_render = render;
+    L.pending_scan = scan;
+    L.pending_n = n;
+    L.pending_places = places;
+    L.pending_num_st = num_st;
+    L.pending_rec_bytes = (uint32_t)rec_bytes;
+    L.pending_is_f16 = cloud->ptrs.is_f16;
+    L.pending_w = (uint32_t)fp.width;
+    L.pending_h = (uint32_t)fp.height;
+    L.pending_tx = (uint32_t)fp.tiles_x;
+    L.pending_ty = (uint32_t)fp.tiles_y;
+    L.seq = ++ctx->seq;
+    return BGS_OK;
 }
 
 int run(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s, bool render) {
@@ -482,27 +576,36 @@ int run(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_se
     if (rc != BGS_OK) return rc;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
     const bool will_be_async = ctx->async_frames && render && ctx->binning == BINNING_SCAN;
-    if (ctx->pending && !will_be_async) {  // a blocking call: surface the queued frames' watchdog state first
-        rc = finish_frame(ctx, nullptr);
-        if (rc != BGS_OK) return rc;
+    if (!will_be_async) {
+        // a blocking call: complete whatever is queued first (surfaces its watchdog state), use lane 0
+        if ((rc = finish_all(ctx)) != BGS_OK) return rc;
+        Lane& L = ctx->lanes[0];
+        ctx->recent = 0;
+        ctx->regrow_count = 0;
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            if ((rc = enqueue_frame(ctx, L, cloud, view, s, render)) != BGS_OK) return rc;
+            uint64_t need = 0;
+            if ((rc = finish_lane(ctx, L, &need)) != BGS_OK) return rc;
+            if (!need) return BGS_OK;
+            // BINNING_SORT overflow: grow to the next power of two with 25 % headroom and re-run
+            uint64_t cap = MIN_INSTANCE_CAPACITY;
+            while (cap < need + need / 4) cap <<= 1;
+            if (need > MAX_INSTANCE_CAPACITY)
+                return fail(ctx, BGS_ECAPACITY,
+                            "frame needs " + std::to_string(need) + " tile instances, above the 2^30 limit");
+            cap = std::min(cap, MAX_INSTANCE_CAPACITY);
+            if ((rc = ensure_instances(ctx, L, cap)) != BGS_OK) return rc;
+            ctx->regrow_count += 1;
+        }
+        return fail(ctx, BGS_ECAPACITY, "instance buffer kept overflowing");
     }
-    ctx->stats.regrow_count = 0;
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        uint64_t need = 0;
-        rc = run_frame(ctx, cloud, view, s, render, &need);
-        if (rc != BGS_OK) return rc;
-        if (!need) return BGS_OK;
-        // grow to the next power of two with 25 % headroom and re-run the frame
-        uint64_t cap = MIN_INSTANCE_CAPACITY;
-        while (cap < need + need / 4) cap <<= 1;
-        if (need > MAX_INSTANCE_CAPACITY)
-            return fail(ctx, BGS_ECAPACITY, "frame needs " + std::to_string(need) +
-                                                " tile instances, above the 2^30 limit");
-        cap = std::min(cap, MAX_INSTANCE_CAPACITY);
-        if ((rc = ensure_instances(ctx, cap)) != BGS_OK) return rc;
-        ctx->stats.regrow_count += 1;
-    }
-    return fail(ctx, BGS_ECAPACITY, "instance buffer kept overflowing");
+    // async frame: next lane of the ring; completing its previous occupant first
+    Lane& L = ctx->lanes[ctx->next];
+    if (L.pending && (rc = finish_lane(ctx, L, nullptr)) != BGS_OK) return rc;
+    if ((rc = enqueue_frame(ctx, L, cloud, view, s, render)) != BGS_OK) return rc;
+    ctx->recent = ctx->next;
+    ctx->next = (ctx->next + 1) % ctx->depth;
+    return BGS_OK;
 }
 
 void mat4_mul(const float* a, const float* b, float* out) {  // column-major out = a * b
@@ -564,23 +667,16 @@ int bgs_create(int hip_device, bgs_ctx** out) {
     bgs_ctx* ctx = new (std::nothrow) bgs_ctx();
     if (!ctx) return fail(nullptr, BGS_ENOMEM, "out of host memory");
     ctx->device = hip_device;
-    auto bail = [&](const char* what, hipError_t err) {
-        std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+    auto bail = [&](const std::string& msg) {
         bgs_destroy(ctx);
         return fail(nullptr, BGS_EHIP, msg);
     };
-    if ((e = hipSetDevice(hip_device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipSetDevice(hip_device)) != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(e));
     hipDeviceProp_t prop;
-    if ((e = hipGetDeviceProperties(&prop, hip_device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    if ((e = hipGetDeviceProperties(&prop, hip_device)) != hipSuccess)
+        return bail(std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
-        return bail("hipStreamCreate", e);
-    for (auto& slot : ctx->ev_ring)
-        for (auto& ev : slot)
-            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    void* h = nullptr;
-    if ((e = hipHostMalloc(&h, sizeof(Control), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-    ctx->h_ctl = (Control*)h;
+    if (lane_create(ctx, ctx->lanes[0]) != BGS_OK) return bail(ctx->error);
     *out = ctx;
     return BGS_OK;
 }
@@ -588,19 +684,7 @@ int bgs_create(int hip_device, bgs_ctx** out) {
 void bgs_destroy(bgs_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
-    for (auto e : ctx->entries) if (e) (void)hipFree(e);
-    if (ctx->culled) (void)hipFree(ctx->culled);
-    for (auto e : ctx->inst) if (e) (void)hipFree(e);
-    if (ctx->records) (void)hipFree(ctx->records);
-    if (ctx->rects) (void)hipFree(ctx->rects);
-    if (ctx->coarse) (void)hipFree(ctx->coarse);
-    if (ctx->fb) (void)hipFree(ctx->fb);
-    if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
-    for (auto& slot : ctx->ev_ring)
-        for (auto ev : slot) if (ev) (void)hipEventDestroy(ev);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (auto& L : ctx->lanes) lane_destroy(L);
     delete ctx;
 }
 
@@ -711,7 +795,8 @@ void bgs_cloud_free(bgs_ctx* ctx, bgs_cloud* cloud) {
     if (!cloud) return;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
-        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        for (auto& L : ctx->lanes)
+            if (L.stream) (void)hipStreamSynchronize(L.stream);
     }
     for (auto p : cloud->allocs) if (p) (void)hipFree(p);
     delete cloud;
@@ -723,9 +808,9 @@ int bgs_sort(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
              bgs_sort_entry* host_out) {
     int rc = run(ctx, cloud, view, settings, /*render=*/false);
     if (rc != BGS_OK) return rc;
-    if (host_out && ctx->last_sorted_n)
-        HIP_TRY(ctx, hipMemcpy(host_out, ctx->last_sorted, (size_t)ctx->last_sorted_n * sizeof(uint2),
-                               hipMemcpyDeviceToHost));
+    Lane& L = ctx->lanes[0];
+    if (host_out && L.last_sorted_n)
+        HIP_TRY(ctx, hipMemcpy(host_out, L.last_sorted, (size_t)L.last_sorted_n * sizeof(uint2), hipMemcpyDeviceToHost));
     return BGS_OK;
 }
 
@@ -733,54 +818,120 @@ int bgs_render(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const
                float* rgba_host_out) {
     int rc = run(ctx, cloud, view, settings, /*render=*/true);
     if (rc != BGS_OK) return rc;
-    if (rgba_host_out && ctx->pending && (rc = finish_frame(ctx, nullptr)) != BGS_OK) return rc;
-    if (rgba_host_out)
-        HIP_TRY(ctx, hipMemcpy(rgba_host_out, ctx->fb, (size_t)ctx->fb_w * ctx->fb_h * sizeof(float4),
-                               hipMemcpyDeviceToHost));
+    if (rgba_host_out) {
+        Lane& L = ctx->lanes[ctx->recent];
+        if (L.pending && (rc = finish_lane(ctx, L, nullptr)) != BGS_OK) return rc;
+        HIP_TRY(ctx, hipMemcpy(rgba_host_out, L.fb, (size_t)L.fb_w * L.fb_h * sizeof(float4), hipMemcpyDeviceToHost));
+    }
     return BGS_OK;
 }
 
 int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes) {
     if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
-    if (ctx->pending) {
-        int rc = finish_frame(ctx, nullptr);
+    Lane& L = ctx->lanes[ctx->recent];
+    if (L.pending) {
+        int rc = finish_lane(ctx, L, nullptr);
         if (rc != BGS_OK) return rc;
     }
-    if (!ctx->fb) return fail(ctx, BGS_EINVAL, "no frame has been rendered yet");
-    *dptr = ctx->fb;
-    if (bytes) *bytes = (uint64_t)ctx->fb_w * ctx->fb_h * sizeof(float4);
+    if (!L.fb) return fail(ctx, BGS_EINVAL, "no frame has been rendered yet");
+    *dptr = L.fb;
+    if (bytes) *bytes = (uint64_t)L.fb_w * L.fb_h * sizeof(float4);
+    return BGS_OK;
+}
+
+int bgs_framebuffer_srgb8_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes) {
+    if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
+    Lane& L = ctx->lanes[ctx->recent];
+    if (L.pending) {
+        int rc = finish_lane(ctx, L, nullptr);
+        if (rc != BGS_OK) return rc;
+    }
+    if (!L.fb8 || !L.fb8_valid)
+        return fail(ctx, BGS_EINVAL, "no Rgba8UnormSrgb frame: call bgs_set_output_srgb8(ctx, 1) before rendering");
+    *dptr = L.fb8;
+    if (bytes) *bytes = (uint64_t)L.fb_w * L.fb_h * 4u;
+    return BGS_OK;
+}
+
+int bgs_pipeline_pop(bgs_ctx* ctx, void** rgba_f32, void** rgba8) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    int best = -1;
+    for (int i = 0; i < MAX_LANES; ++i)
+        if (ctx->lanes[i].pending && (best < 0 || ctx->lanes[i].seq < ctx->lanes[best].seq)) best = i;
+    if (best < 0) return fail(ctx, BGS_EINVAL, "no frame in flight");
+    Lane& L = ctx->lanes[best];
+    int rc = finish_lane(ctx, L, nullptr);
+    if (rc != BGS_OK) return rc;
+    if (rgba_f32) *rgba_f32 = L.fb;
+    if (rgba8) *rgba8 = L.fb8_valid ? L.fb8 : nullptr;
+    return BGS_OK;
+}
+
+int bgs_frames_in_flight(bgs_ctx* ctx, uint32_t* count) {
+    if (!ctx || !count) return fail(ctx, BGS_EINVAL, "NULL argument");
+    uint32_t c = 0;
+    for (auto& L : ctx->lanes) c += L.pending ? 1u : 0u;
+    *count = c;
     return BGS_OK;
 }
 
 int bgs_sorted_entries_device_ptr(bgs_ctx* ctx, void** dptr, uint32_t* n) {
     if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
-    if (!ctx->last_sorted) return fail(ctx, BGS_EINVAL, "no sort has been run yet");
-    *dptr = (void*)ctx->last_sorted;
-    if (n) *n = ctx->last_sorted_n;
+    Lane& L = ctx->lanes[ctx->recent];
+    if (L.pending) {
+        int rc = finish_lane(ctx, L, nullptr);
+        if (rc != BGS_OK) return rc;
+    }
+    if (!L.last_sorted) return fail(ctx, BGS_EINVAL, "no sort has been run yet");
+    *dptr = (void*)L.last_sorted;
+    if (n) *n = L.last_sorted_n;
     return BGS_OK;
 }
 
 int bgs_synchronize(bgs_ctx* ctx) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
-    if (ctx->pending) return finish_frame(ctx, nullptr);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = finish_all(ctx);
+    if (rc != BGS_OK) return rc;
+    for (auto& L : ctx->lanes)
+        if (L.stream) HIP_TRY(ctx, hipStreamSynchronize(L.stream));
     return BGS_OK;
 }
 
 int bgs_set_async(bgs_ctx* ctx, int enabled) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
-    if (!enabled && ctx->pending) {
-        int rc = finish_frame(ctx, nullptr);
+    if (!enabled) {
+        int rc = finish_all(ctx);
         if (rc != BGS_OK) return rc;
     }
     ctx->async_frames = enabled != 0;
     return BGS_OK;
 }
 
+int bgs_set_pipeline_depth(bgs_ctx* ctx, uint32_t lanes) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (lanes < 1 || lanes > (uint32_t)MAX_LANES) return fail(ctx, BGS_EINVAL, "pipeline depth must be 1..4");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    int rc = finish_all(ctx);
+    if (rc != BGS_OK) return rc;
+    for (uint32_t i = 0; i < lanes; ++i)
+        if ((rc = lane_create(ctx, ctx->lanes[i])) != BGS_OK) return rc;
+    ctx->depth = (int)lanes;
+    ctx->next = 0;
+    ctx->recent = 0;
+    return BGS_OK;
+}
+
+int bgs_set_output_srgb8(bgs_ctx* ctx, int enabled) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    ctx->output_srgb8 = enabled != 0;
+    return BGS_OK;
+}
+
 int bgs_stream(bgs_ctx* ctx, void** hip_stream) {
     if (!ctx || !hip_stream) return fail(ctx, BGS_EINVAL, "NULL argument");
-    *hip_stream = (void*)ctx->stream;
+    *hip_stream = (void*)ctx->lanes[ctx->recent].stream;
     return BGS_OK;
 }
 
@@ -802,6 +953,8 @@ int bgs_set_profiling_stride(bgs_ctx* ctx, uint32_t every_nth_frame) {
 int bgs_set_binning(bgs_ctx* ctx, uint32_t mode) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     if (mode > BINNING_SORT) return fail(ctx, BGS_EINVAL, "binning mode must be 0 (scan) or 1 (sort)");
+    int rc = finish_all(ctx);
+    if (rc != BGS_OK) return rc;
     ctx->binning = mode;
     return BGS_OK;
 }
@@ -814,11 +967,9 @@ int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags) {
 
 int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out) {
     if (!ctx || !out) return fail(ctx, BGS_EINVAL, "NULL argument");
-    if (ctx->pending) {
-        int rc = finish_frame(ctx, nullptr);
-        if (rc != BGS_OK) return rc;
-    }
-    if (!ctx->have_stats) return fail(ctx, BGS_EINVAL, "no frame has been run yet");
+    int rc = finish_all(ctx);
+    if (rc != BGS_OK) return rc;
+    if ((rc = collect_stats(ctx)) != BGS_OK) return rc;
     *out = ctx->stats;
     return BGS_OK;
 }
@@ -826,38 +977,36 @@ int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out) {
 int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries, uint32_t n, uint32_t passes) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     if (passes < 1 || passes > 4) return fail(ctx, BGS_EINVAL, "passes must be 1..4");
-    if (ctx->pending) {
-        int rc0 = finish_frame(ctx, nullptr);
-        if (rc0 != BGS_OK) return rc0;
-    }
     if (n > MAX_SPLATS) return fail(ctx, BGS_EINVAL, "too many pairs");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    int rc = finish_all(ctx);
+    if (rc != BGS_OK) return rc;
     if (n == 0) return BGS_OK;
     if (!entries) return fail(ctx, BGS_EINVAL, "entries is NULL");
-    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
-    int rc;
-    if ((rc = ensure_entries(ctx, n)) != BGS_OK) return rc;
-    if ((rc = ensure_scratch(ctx, n, ctx->inst_cap)) != BGS_OK) return rc;
-    hipStream_t st = ctx->stream;
-    Control* ctl = (Control*)ctx->scratch;
-    uint32_t* depth_status = (uint32_t*)(ctx->scratch + ctx->off_depth_status);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->scratch, 0, ctx->scratch_bytes, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->entries[0], entries, (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, st));
+    Lane& L = ctx->lanes[0];
+    if ((rc = ensure_entries(ctx, L, n)) != BGS_OK) return rc;
+    if ((rc = ensure_scratch(ctx, L, n, L.inst_cap)) != BGS_OK) return rc;
+    hipStream_t st = L.stream;
+    Control* ctl = (Control*)L.scratch;
+    uint32_t* depth_status = (uint32_t*)(L.scratch + L.off_depth_status);
+    HIP_TRY(ctx, hipMemsetAsync(L.scratch, 0, L.scratch_bytes, st));
+    HIP_TRY(ctx, hipMemcpyAsync(L.entries[0], entries, (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)&ctl->splat_count, (int)n, 1, st));
-    launch_histogram(st, ctx->entries[0], n, &ctl->hist_depth[0][0], passes);
+    launch_histogram(st, L.entries[0], n, &ctl->hist_depth[0][0], passes);
     const bool large = n > (4u << 20);
-    const size_t depth_tiles = ((size_t)ctx->scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
+    const size_t depth_tiles = ((size_t)L.scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
     int cur = 0;
     for (uint32_t p = 0; p < passes; ++p) {
-        launch_onesweep_pass(st, ctx->entries[cur], ctx->entries[cur ^ 1], &ctl->splat_count, n, ctl->hist_depth[p],
+        launch_onesweep_pass(st, L.entries[cur], L.entries[cur ^ 1], &ctl->splat_count, n, ctl->hist_depth[p],
                              depth_status + (size_t)p * depth_tiles * RADIX_BASE, &ctl->ticket[p], &ctl->error,
                              p * RADIX_BITS, 0u, large, ctx->num_cus * 4);
         cur ^= 1;
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(entries, ctx->entries[cur], (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(entries, L.entries[cur], (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(L.h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (ctx->h_ctl->error) return fail(ctx, BGS_EINTERNAL, "device watchdog tripped in radix sort");
+    if (L.h_ctl->error) return fail(ctx, BGS_EINTERNAL, "device watchdog tripped in radix sort");
     return BGS_OK;
 }
 

@@ -83,4 +83,7 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
                    const uint2* instances, const uint2* ranges, float4* framebuffer,
                    const float clear_color[4]);
 
+// Rgba8UnormSrgb image of the f32 framebuffer (the reference's render-target format).
+void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* out, uint32_t pixels);
+
 }  // namespace bgs

@@ -786,4 +786,34 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
                            instances, ranges, framebuffer, clear);
 }
 
+// ---------------------------------------------------------------------------------------
+// Rgba8UnormSrgb encode of the f32 target: what the reference's colour attachment stores
+// (TextureFormat::Rgba8UnormSrgb, src/render/mod.rs:917-921, examples/headless.rs:120-123).
+// Linear RGB -> sRGB OETF -> unorm8 (round to nearest); alpha is linear. 33 MB read, 8 MB write.
+// Used for the multi-GPU framebuffer gather (8.3 MB per 1080p frame instead of 33 MB).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t unorm8(float x) {
+    x = fminf(fmaxf(x, 0.0f), 1.0f);  // NaN -> 0
+    return (uint32_t)(x * 255.0f + 0.5f);
+}
+__device__ __forceinline__ float srgb_oetf(float x) {
+    x = fminf(fmaxf(x, 0.0f), 1.0f);
+    return x <= 0.0031308f ? 12.92f * x : fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)), -0.055f);
+}
+__global__ __launch_bounds__(256) void encode_srgb8_kernel(const float4* __restrict__ fb,
+                                                           uint32_t* __restrict__ out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 c = fb[i];
+        out[i] = unorm8(srgb_oetf(c.x)) | (unorm8(srgb_oetf(c.y)) << 8) | (unorm8(srgb_oetf(c.z)) << 16) |
+                 (unorm8(c.w) << 24);
+    }
+}
+
+void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* out, uint32_t pixels) {
+    if (pixels == 0) return;
+    uint32_t blocks = (pixels + 255u) / 256u;
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(encode_srgb8_kernel, dim3(blocks), dim3(256), 0, stream, framebuffer, out, pixels);
+}
+
 }  // namespace bgs

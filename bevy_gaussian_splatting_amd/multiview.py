@@ -61,6 +61,13 @@ class _DeviceArray:
             "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+def device_ptr_as_tensor(ptr: int, shape, typestr: str, device: str):
+    """Zero-copy torch view of raw device memory (e.g. a popped pipeline frame)."""
+    import torch
+
+    return torch.as_tensor(_DeviceArray(ptr, shape, typestr), device=device)
+
+
 def framebuffer_as_tensor(plugin, height: int, width: int, device: Optional[str] = None):
     """Wrap the device framebuffer of the last `render` as a torch tensor [H, W, 4] without a
     copy (so RCCL can send it straight from where the rasteriser wrote it)."""

@@ -182,6 +182,31 @@ class GaussianSplattingPlugin:
         """Record HIP events only on every Nth frame (each record costs ~4 us of GPU timeline)."""
         self._check(self._lib.bgs_set_profiling_stride(self._ctx, int(every_nth_frame)))
 
+    def set_pipeline_depth(self, lanes: int) -> None:
+        """Frames in flight (1..4), each on its own HIP stream; see bgs_set_pipeline_depth."""
+        self._check(self._lib.bgs_set_pipeline_depth(self._ctx, int(lanes)))
+
+    def set_output_srgb8(self, enabled: bool) -> None:
+        """Also produce every frame as Rgba8UnormSrgb (the reference's target format)."""
+        self._check(self._lib.bgs_set_output_srgb8(self._ctx, 1 if enabled else 0))
+
+    def framebuffer_srgb8_device_ptr(self):
+        p = ctypes.c_void_p()
+        nbytes = ctypes.c_uint64()
+        self._check(self._lib.bgs_framebuffer_srgb8_device_ptr(self._ctx, ctypes.byref(p), ctypes.byref(nbytes)))
+        return p.value, nbytes.value
+
+    def pipeline_pop(self):
+        """Complete the oldest frame in flight; returns (f32 framebuffer ptr, srgb8 ptr or None)."""
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.bgs_pipeline_pop(self._ctx, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def frames_in_flight(self) -> int:
+        c = ctypes.c_uint32()
+        self._check(self._lib.bgs_frames_in_flight(self._ctx, ctypes.byref(c)))
+        return int(c.value)
+
     def set_async(self, enabled: bool) -> None:
         """Async frames: render(download=False) only enqueues (scan binning); see bgs_set_async."""
         self._check(self._lib.bgs_set_async(self._ctx, 1 if enabled else 0))

@@ -181,6 +181,23 @@ int bgs_render(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view,
 /* Device pointer + size in bytes of the framebuffer written by the last bgs_render
  * (for an RCCL gather or zero-copy interop). Valid until the next render/destroy. */
 int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes);
+/* Also produce, with every bgs_render, the frame in the reference's colour-attachment format
+ * TextureFormat::Rgba8UnormSrgb (src/render/mod.rs:917-921, examples/headless.rs:120-123): linear
+ * RGB -> sRGB transfer -> unorm8, alpha linear, 4 bytes per pixel R,G,B,A. Default off. */
+int bgs_set_output_srgb8(bgs_ctx* ctx, int enabled);
+int bgs_framebuffer_srgb8_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes);
+
+/* Frame pipelining. A single stream of this path's kernels is latency bound at 1M splats, so the
+ * context can keep up to 4 frames in flight on separate HIP streams ("lanes", each with its own
+ * per-frame buffers): with bgs_set_async(1), successive bgs_render(..., NULL) calls go round-robin
+ * over the lanes and overlap on the GPU. A lane's previous frame is completed (stream wait +
+ * watchdog check) when the lane is reused. bgs_pipeline_pop completes the OLDEST frame in flight
+ * and returns its f32 / sRGB8 framebuffers (valid until that lane is reused, i.e. for depth-1 more
+ * enqueues). bgs_framebuffer_device_ptr & co refer to the most recently enqueued frame. */
+int bgs_set_pipeline_depth(bgs_ctx* ctx, uint32_t lanes /* 1..4, default 1 */);
+int bgs_pipeline_pop(bgs_ctx* ctx, void** rgba_f32_dptr_or_null, void** rgba8_dptr_or_null);
+int bgs_frames_in_flight(bgs_ctx* ctx, uint32_t* count);
+
 /* Device pointer of the sorted entries of the last call: after bgs_sort all n entries (culled
  * ones last); after bgs_render only the drawable prefix (*n = entries that reach the vertex
  * stage), because the culled tail is never needed for drawing. */

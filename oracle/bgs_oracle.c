@@ -897,6 +897,25 @@ void oracle_decode_f16(uint32_t n, const uint32_t* sh_h2, const uint32_t* rso, f
     }
 }
 
+static inline uint8_t unorm8(double x) {
+    if (!(x > 0.0)) return 0; /* also NaN */
+    if (x > 1.0) x = 1.0;
+    return (uint8_t)floor(x * 255.0 + 0.5);
+}
+static inline double srgb_oetf(double x) {
+    if (!(x > 0.0)) return 0.0;
+    if (x > 1.0) x = 1.0;
+    return x <= 0.0031308 ? 12.92 * x : 1.055 * pow(x, 1.0 / 2.4) - 0.055;
+}
+void oracle_encode_srgb8(const float* rgba, uint32_t n, uint8_t* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        out[4 * (size_t)i + 0] = unorm8(srgb_oetf(rgba[4 * (size_t)i + 0]));
+        out[4 * (size_t)i + 1] = unorm8(srgb_oetf(rgba[4 * (size_t)i + 1]));
+        out[4 * (size_t)i + 2] = unorm8(srgb_oetf(rgba[4 * (size_t)i + 2]));
+        out[4 * (size_t)i + 3] = unorm8(rgba[4 * (size_t)i + 3]);
+    }
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

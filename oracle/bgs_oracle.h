@@ -126,6 +126,12 @@ int oracle_instance_stats(const oracle_cloud* cloud, const bgs_sort_entry* entri
                           uint32_t count, const bgs_view* view, const bgs_settings* settings,
                           uint32_t* visible_out, uint64_t* tile_instances_out);
 
+/* Store of the f32 target into the reference's colour attachment format Rgba8UnormSrgb
+ * (src/render/mod.rs:917-921, examples/headless.rs:120-123): per channel clamp to [0,1], RGB
+ * through the sRGB transfer function (third-party wgpu / Vulkan format conversion: parity
+ * unpinned), round to nearest unorm8; alpha linear. out = n*4 bytes R,G,B,A. */
+void oracle_encode_srgb8(const float* rgba, uint32_t n, uint8_t* out);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -100,6 +100,8 @@ def lib() -> ctypes.CDLL:
         l.oracle_instance_stats.argtypes = [
             ctypes.POINTER(_Cloud), ep, u32, vp, sp, up, ctypes.POINTER(ctypes.c_uint64)]
         l.oracle_instance_stats.restype = ctypes.c_int
+        l.oracle_encode_srgb8.argtypes = [fp, u32, ctypes.POINTER(ctypes.c_uint8)]
+        l.oracle_encode_srgb8.restype = None
         l.oracle_max_threads.argtypes = []
         l.oracle_max_threads.restype = ctypes.c_int
         _lib = l
@@ -235,6 +237,14 @@ def encode_f16(cloud: PlanarGaussian3d) -> PlanarGaussian3dF16:
     lib().oracle_encode_f16(n, _fp(cloud.spherical_harmonic), _fp(cloud.rotation),
                             _fp(cloud.scale_opacity), _up(sh), _up(rso))
     return PlanarGaussian3dF16(cloud.position_visibility, sh, rso)
+
+
+def encode_srgb8(rgba: np.ndarray) -> np.ndarray:
+    """[h, w, 4] float32 -> [h, w, 4] uint8 in the reference's Rgba8UnormSrgb target format."""
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    out = np.empty(a.shape, np.uint8)
+    lib().oracle_encode_srgb8(_fp(a), a.size // 4, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    return out
 
 
 def max_threads() -> int:

@@ -395,6 +395,7 @@ def test_async_frames_match_synchronous_frames(plugin, oracle):
             assert plugin.render(h, v, s, download=False) is None
         last = plugin.render(h, views[-1], s)  # download => completes the queue
         assert np.array_equal(last, sync_imgs[-1])
+        plugin.stats()  # reading the stats resets the timing average
         for _ in range(5):
             plugin.render(h, views[1], s, download=False)
         plugin.synchronize()
@@ -441,4 +442,52 @@ def test_framebuffer_zero_copy_tensor_and_rccl_gather_single_rank(plugin):
     finally:
         if created:
             dist.destroy_process_group()
+    h.free()
+
+
+def test_pipelined_frames_and_srgb8_output(plugin, oracle):
+    """bgs_set_pipeline_depth: frames in flight on separate streams (lanes) must give exactly the
+    images of the blocking path, in FIFO order from bgs_pipeline_pop; the Rgba8UnormSrgb copy must
+    match the oracle's format conversion of the same f32 frame (+-1 LSB: pow vs exp2/log2)."""
+    import torch
+    from bevy_gaussian_splatting_amd.multiview import device_ptr_as_tensor
+
+    c = random_gaussians_3d_seeded(30_000, 41)
+    h = plugin.upload(c)
+    s = CloudSettings(global_scale=0.5)
+    views = [headless_view(g, 320, 180) for g in range(7)]
+    ref = [plugin.render(h, v, s) for v in views]
+    plugin.set_output_srgb8(True)
+    plugin.set_async(True)
+    try:
+        for depth in (1, 2, 3, 4):
+            plugin.set_pipeline_depth(depth)
+            got = []
+            for v in views:
+                plugin.render(h, v, s, download=False)
+                if plugin.frames_in_flight() >= depth:
+                    f32, u8 = plugin.pipeline_pop()
+                    got.append((device_ptr_as_tensor(f32, (180, 320, 4), "<f4", "cuda:0").cpu().numpy(),
+                                device_ptr_as_tensor(u8, (180, 320, 4), "|u1", "cuda:0").cpu().numpy()))
+            while plugin.frames_in_flight():
+                f32, u8 = plugin.pipeline_pop()
+                got.append((device_ptr_as_tensor(f32, (180, 320, 4), "<f4", "cuda:0").cpu().numpy(),
+                            device_ptr_as_tensor(u8, (180, 320, 4), "|u1", "cuda:0").cpu().numpy()))
+            assert len(got) == len(views)
+            for (f, u), r in zip(got, ref):
+                assert np.array_equal(f, r)
+                exp = oracle.encode_srgb8(r)
+                assert np.abs(u.astype(np.int16) - exp.astype(np.int16)).max() <= 1
+        # more frames than lanes without popping: older frames are completed when their lane is reused
+        plugin.set_pipeline_depth(3)
+        for v in views:
+            plugin.render(h, v, s, download=False)
+        plugin.synchronize()
+        assert plugin.frames_in_flight() == 0
+        last = plugin.render(h, views[-1], s)  # blocking call after async ones
+        assert np.array_equal(last, ref[-1])
+    finally:
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.set_output_srgb8(False)
     h.free()
