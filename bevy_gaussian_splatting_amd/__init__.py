@@ -25,6 +25,8 @@ from .settings import (
     ShaderDefines,
     SortMode,
 )
+from .io_ply import parse_ply_3d, write_ply_3d
+from .sort_policy import SortConfig, SortTrigger, update_sort_trigger
 from .plugin import (
     GaussianSplattingPlugin,
     PlanarGaussian3dHandle,
@@ -38,5 +40,6 @@ __all__ = [
     "SH_COEFF_COUNT", "random_gaussians_3d", "random_gaussians_3d_seeded",
     "CloudSettings", "DrawMode", "GaussianColorSpace", "GaussianMode", "RadixSortDepthBits",
     "RasterizeMode", "ShaderDefines", "SortMode",
+    "parse_ply_3d", "write_ply_3d", "SortConfig", "SortTrigger", "update_sort_trigger",
     "GaussianSplattingPlugin", "PlanarGaussian3dHandle", "SortedEntries", "SORT_ENTRY_DTYPE",
 ]

@@ -491,3 +491,28 @@ def test_pipelined_frames_and_srgb8_output(plugin, oracle):
         plugin.set_pipeline_depth(1)
         plugin.set_output_srgb8(False)
     h.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# a cloud that arrives through the INRIA .ply loader, padding splats included
+# ---------------------------------------------------------------------------------------------
+def test_ply_loaded_cloud_renders_like_the_oracle(plugin, oracle, binning, tmp_path):
+    from bevy_gaussian_splatting_amd import parse_ply_3d, write_ply_3d
+    c = random_gaussians_3d_seeded(5000, 11)
+    c.scale_opacity[:, :3] = c.scale_opacity[:, :3] * 0.2 + 0.02
+    c.scale_opacity[:, 3] = c.scale_opacity[:, 3] * 0.9 + 0.05
+    path = os.path.join(tmp_path, "cloud.ply")
+    write_ply_3d(c, path)
+    loaded = parse_ply_3d(path)
+    assert len(loaded) == 5024  # padded with Gaussian3d::default(): zero rotation / scale / opacity at the origin
+    v = View.headless(160, 90)
+    for kw in ({}, {"aabb": True}, {"gaussian_mode": GaussianMode.Gaussian2d}):
+        s = CloudSettings(**kw)
+        h = plugin.upload(loaded)
+        got = plugin.render(h, v, s)
+        e = oracle.sort(loaded, v, s)
+        gs = plugin.sort(h, v, s)
+        assert np.array_equal(gs["key"], e["key"]) and np.array_equal(gs["index"], e["index"])
+        ref, amb = oracle.render(loaded, e, v, s, with_ambiguity=True)
+        _assert_image(ref, got, amb, what=f"ply {kw}")
+        h.free()
