@@ -24,6 +24,7 @@ from .settings import (
     RasterizeMode,
     ShaderDefines,
     SortMode,
+    compute_aabb,
 )
 from .io_ply import parse_ply_3d, write_ply_3d
 from .sort_policy import SortConfig, SortTrigger, update_sort_trigger
@@ -39,7 +40,7 @@ __all__ = [
     "Gaussian3d", "PlanarGaussian3d", "PlanarGaussian3dF16", "SphericalHarmonicCoefficients",
     "SH_COEFF_COUNT", "random_gaussians_3d", "random_gaussians_3d_seeded",
     "CloudSettings", "DrawMode", "GaussianColorSpace", "GaussianMode", "RadixSortDepthBits",
-    "RasterizeMode", "ShaderDefines", "SortMode",
+    "RasterizeMode", "ShaderDefines", "SortMode", "compute_aabb",
     "parse_ply_3d", "write_ply_3d", "SortConfig", "SortTrigger", "update_sort_trigger",
     "GaussianSplattingPlugin", "PlanarGaussian3dHandle", "SortedEntries", "SORT_ENTRY_DTYPE",
 ]

@@ -55,6 +55,7 @@ EXPORTED_SYMBOLS = (
     "bgs_set_debug_flags",
     "bgs_get_stats",
     "bgs_radix_sort_pairs",
+    "bgs_hbm_probe",
 )
 
 
@@ -168,6 +169,9 @@ def load() -> ctypes.CDLL:
     lib.bgs_get_stats.restype = ctypes.c_int
     lib.bgs_radix_sort_pairs.argtypes = [vp, ctypes.POINTER(BgsSortEntry), u32, u32]
     lib.bgs_radix_sort_pairs.restype = ctypes.c_int
+    lib.bgs_hbm_probe.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
+                                  ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    lib.bgs_hbm_probe.restype = ctypes.c_int
     _lib = lib
     return lib
 

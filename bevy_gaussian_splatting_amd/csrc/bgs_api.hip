@@ -308,6 +308,12 @@ int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
     if (s->sh_degree > 3) return fail(ctx, BGS_EINVAL, "sh_degree must be 0..3");
     if (s->sort_mode > BGS_SORT_STD) return fail(ctx, BGS_EINVAL, "unknown sort_mode");
     if (s->color_space > BGS_COLOR_LINEAR) return fail(ctx, BGS_EINVAL, "unknown color_space");
+    if (s->rasterize_mode == BGS_RASTERIZE_OPTICAL_FLOW || s->rasterize_mode == BGS_RASTERIZE_VELOCITY)
+        return fail(ctx, BGS_EINVAL,
+                    "rasterize_mode OpticalFlow/Velocity is outside the path (previous-frame transforms / 4D clouds)");
+    if (s->rasterize_mode > BGS_RASTERIZE_VELOCITY) return fail(ctx, BGS_EINVAL, "unknown rasterize_mode");
+    if (s->rasterize_mode == BGS_RASTERIZE_CLASSIFICATION && s->num_classes == 0)
+        return fail(ctx, BGS_EINVAL, "num_classes must be >= 1");
     if (render) {
         const float w = view->viewport[2], h = view->viewport[3];
         if (!(w >= 1.0f) || !(h >= 1.0f) || w > 4096.0f || h > 4096.0f || w != std::floor(w) || h != std::floor(h))
@@ -524,7 +530,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
 
     if (render && scan) {
         const uint32_t coarse_cap = std::max<uint32_t>(n, 1);
-        launch_project_bin(st, fp, cloud->ptrs, draw_list, ctl, bin_status, L.records, L.rects, L.coarse, coarse_cap,
+        launch_project_bin(st, fp, cloud->ptrs, draw_list, L.culled, ctl, bin_status, L.records, L.rects, L.coarse, coarse_cap,
                            sup_shift, /*ticket_slot=*/4, ctx->num_cus * 2);
         mark(3);
         launch_raster_scan(st, fp, L.records, L.rects, L.coarse, coarse_cap, sup_shift, ctl, L.fb,
@@ -532,7 +538,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         mark(6);
     } else if (render) {
         const uint32_t capacity = (uint32_t)std::min<uint64_t>(L.inst_cap, MAX_INSTANCE_CAPACITY);
-        launch_project_emit(st, fp, cloud->ptrs, draw_list, ctl, scan_status, L.records, L.inst[0], capacity,
+        launch_project_emit(st, fp, cloud->ptrs, draw_list, L.culled, ctl, scan_status, L.records, L.inst[0], capacity,
                             /*ticket_slot=*/4, ctx->num_cus * 3);
         mark(3);
         const size_t inst_tiles = (L.scratch_inst_cap + sort_tile_size(true) - 1) / sort_tile_size(true) + 1;
@@ -701,6 +707,10 @@ void bgs_settings_default(bgs_settings* out) {
     out->radix_depth_bits = 32;             // :52-57 default
     out->sh_degree = 3;                     // Cargo.toml default feature sh3
     out->sort_mode = BGS_SORT_RADIX;        // src/sort/mod.rs:60-74
+    out->rasterize_mode = BGS_RASTERIZE_COLOR;  // src/gaussian/settings.rs:40-41
+    out->num_classes = 1;                   // :124
+    for (int i = 0; i < 3; ++i) out->position_max[i] = 1.0f;
+    out->position_min[3] = out->position_max[3] = 1.0f;  // aabb.min().extend(1.0) src/render/mod.rs:1070
 }
 
 void bgs_view_perspective(const float world_from_view[16], float fov_y_radians, float near_plane,
@@ -1007,6 +1017,50 @@ int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries, uint32_t n, uint
     HIP_TRY(ctx, hipMemcpyAsync(L.h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (L.h_ctl->error) return fail(ctx, BGS_EINTERNAL, "device watchdog tripped in radix sort");
+    return BGS_OK;
+}
+
+int bgs_hbm_probe(bgs_ctx* ctx, uint64_t bytes, uint32_t iters, float* copy_gbs, float* triad_gbs) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    bytes &= ~(uint64_t)15;
+    if (bytes < 4096 || iters == 0 || iters > 10000) return fail(ctx, BGS_EINVAL, "bytes >= 4096 and 1 <= iters <= 10000");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    int rc = finish_all(ctx);
+    if (rc != BGS_OK) return rc;
+    char* buf = nullptr;
+    if (hipMalloc((void**)&buf, (size_t)bytes * 3) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, BGS_ENOMEM, "hipMalloc(probe buffers) failed");
+    }
+    hipStream_t st = ctx->lanes[0].stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms_copy = 0.0f, ms_triad = 0.0f;
+    bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    float4 *a = (float4*)buf, *b = (float4*)(buf + bytes), *c = (float4*)(buf + 2 * bytes);
+    const size_t n4 = (size_t)bytes / 16;
+    const int blocks = ctx->num_cus * 16;
+    ok = ok && hipMemsetAsync(buf, 0, (size_t)bytes * 3, st) == hipSuccess;
+    if (ok) {  // warm-up, then `iters` back-to-back repetitions between two events
+        ok = hipMemcpyAsync(a, b, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+        ok = ok && hipEventRecord(e0, st) == hipSuccess;
+        for (uint32_t i = 0; ok && i < iters; ++i)
+            ok = hipMemcpyAsync(a, b, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+        ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(&ms_copy, e0, e1) == hipSuccess;
+    }
+    if (ok) {
+        launch_triad(st, a, b, c, 0.5f, n4, blocks);
+        ok = hipEventRecord(e0, st) == hipSuccess;
+        for (uint32_t i = 0; ok && i < iters; ++i) launch_triad(st, a, b, c, 0.5f, n4, blocks);
+        ok = ok && hipGetLastError() == hipSuccess && hipEventRecord(e1, st) == hipSuccess &&
+             hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms_triad, e0, e1) == hipSuccess;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (!ok) { (void)hipGetLastError(); return fail(ctx, BGS_EHIP, "HBM probe failed"); }
+    if (copy_gbs) *copy_gbs = ms_copy > 0.0f ? (float)(2.0 * (double)bytes * iters / (ms_copy * 1e6)) : 0.0f;
+    if (triad_gbs) *triad_gbs = ms_triad > 0.0f ? (float)(3.0 * (double)bytes * iters / (ms_triad * 1e6)) : 0.0f;
     return BGS_OK;
 }
 

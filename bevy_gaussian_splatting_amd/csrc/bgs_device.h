@@ -35,6 +35,20 @@ struct FrameParams {
     int32_t width, height;      // render target size in pixels
     int32_t tiles_x, tiles_y;
     uint32_t debug;             // experiment switches (bgs_set_debug_flags); 0 in production
+    uint32_t rasterize_mode;    // RasterizeMode discriminant (include/bgs.h)
+    uint32_t num_classes;
+    float pos_min[3], pos_max[3];  // gaussian_uniforms.min / .max (Position mode)
+};
+
+// rasterize_mode values (include/bgs.h)
+constexpr uint32_t RASTERIZE_CLASSIFICATION = 0, RASTERIZE_COLOR = 1, RASTERIZE_DEPTH = 2,
+                   RASTERIZE_NORMAL = 3, RASTERIZE_POSITION = 5;
+
+// Per-splat inputs of the non-Color colour variants (src/render/gaussian.wgsl:312-405).
+struct ColorInputs {
+    float visibility;    // position_visibility.w (Classification: class id + 2)
+    float min_distance;  // Depth: |M * p(sorted[count-1]) - cam|
+    float max_distance;  // Depth: |M * p(sorted[1]) - cam|
 };
 
 // Projected record, one per draw-list rank, stored in front-to-back order.

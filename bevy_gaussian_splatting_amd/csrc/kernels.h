@@ -53,7 +53,7 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
 // Vertex stage in front-to-back order + ordered tile-instance emission
 // (vs_points once per splat, src/render/gaussian.wgsl:184-436).
 void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
-                         const uint2* draw_list, Control* ctl, unsigned long long* scan_status,
+                         const uint2* draw_list, const uint2* culled, Control* ctl, unsigned long long* scan_status,
                          void* records, uint2* instances, uint32_t capacity, uint32_t ticket_slot,
                          int max_blocks);
 
@@ -62,7 +62,7 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
 // tile rectangle overlaps. One pass, no sort, no atomics on the data path: the <= 256 supertiles
 // are the "digits" of the same chained-scan look-back the radix sort uses.
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
-                        const uint2* draw_list, Control* ctl, uint32_t* bin_status, void* records,
+                        const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status, void* records,
                         uint32_t* rects, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
                         uint32_t ticket_slot, int max_blocks);
 
@@ -85,5 +85,9 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
 
 // Rgba8UnormSrgb image of the f32 framebuffer (the reference's render-target format).
 void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* out, uint32_t pixels);
+
+// STREAM-triad on float4: a = b + s * c (HBM ceiling probe, bgs_hbm_probe).
+void launch_triad(hipStream_t stream, float4* a, const float4* b, const float4* c, float s, size_t n4,
+                  int blocks);
 
 }  // namespace bgs

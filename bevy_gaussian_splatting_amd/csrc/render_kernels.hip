@@ -130,10 +130,30 @@ struct ShF16 {
 // vertex stage for one front-to-back rank: load the splat, project, write its record.
 // Returns the packed tile rectangle (RECT_EMPTY if nothing is to be drawn).
 // ---------------------------------------------------------------------------------------
-template <bool F16, bool SURFEL>
+// RASTERIZE_DEPTH normalises by the distances of sorted[count-1] and sorted[1]
+// (src/render/gaussian.wgsl:331-340; count = gaussian_uniforms.count = N). The full sorted list is
+// drawable-prefix ++ culled-tail (see keygen_kernel), so sorted[j] lives in one of the two buffers.
+// Uniform over the launch; every thread reads the same two positions (scalar-cache hits).
+__device__ __forceinline__ ColorInputs frame_color_inputs(const FrameParams& fp, const CloudPtrs& cloud,
+                                                          const uint2* draw_list, const uint2* culled,
+                                                          uint32_t draw_count) {
+    ColorInputs ci{0.0f, 0.0f, 0.0f};
+    if (fp.rasterize_mode == RASTERIZE_DEPTH && fp.n > 0u) {
+        const uint32_t j_first = fp.n > 1u ? 1u : 0u, j_last = fp.n - 1u;
+        const uint32_t i_first = j_first < draw_count ? draw_list[j_first].y : culled[j_first - draw_count].y;
+        const uint32_t i_last = j_last < draw_count ? draw_list[j_last].y : culled[j_last - draw_count].y;
+        const float4 pf = cloud.position_visibility[i_first], pl = cloud.position_visibility[i_last];
+        ci.max_distance = distance_to_camera(fp, V3{pf.x, pf.y, pf.z});
+        ci.min_distance = distance_to_camera(fp, V3{pl.x, pl.y, pl.z});
+    }
+    return ci;
+}
+
+template <bool F16, bool SURFEL, bool ANY_MODE>
 __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const CloudPtrs& cloud,
                                                  const uint2 entry, const uint32_t j,
-                                                 float4* __restrict__ records, bool& visible) {
+                                                 float4* __restrict__ records, ColorInputs ci,
+                                                 bool& visible) {
     const uint32_t si = entry.y;
     const float4 pv = cloud.position_visibility[si];
     float rot[4], so[4];
@@ -151,10 +171,11 @@ __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const Cl
         so[0] = s4.x; so[1] = s4.y; so[2] = s4.z; so[3] = s4.w;
     }
     Projected pr;
+    ci.visibility = pv.w;
     if constexpr (F16)
-        project_splat(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF16{cloud.sh_f16 + (size_t)si * 24u}, pr);
+        project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF16{cloud.sh_f16 + (size_t)si * 24u}, ci, pr);
     else
-        project_splat(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{cloud.sh_f32 + (size_t)si * 48u}, pr);
+        project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{cloud.sh_f32 + (size_t)si * 48u}, ci, pr);
     visible = pr.visible;
     if (!pr.draw) return RECT_EMPTY;
     const uint32_t rect = (uint32_t)pr.tx0 | ((uint32_t)pr.tx1 << 8) | ((uint32_t)pr.ty0 << 16) |
@@ -179,9 +200,10 @@ __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const Cl
 // ---------------------------------------------------------------------------------------
 // BINNING_SORT: project + ordered instance emission
 // ---------------------------------------------------------------------------------------
-template <bool F16, bool SURFEL>
+template <bool F16, bool SURFEL, bool ANY_MODE>
 __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, CloudPtrs cloud,
                                                            const uint2* __restrict__ draw_list,
+                                                           const uint2* __restrict__ culled,
                                                            Control* ctl,
                                                            unsigned long long* scan_status,
                                                            float4* __restrict__ records,
@@ -202,6 +224,8 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
     s_histx[tid] = 0u;
     s_histy[tid] = 0u;
     uint32_t visible_acc = 0u;
+    const ColorInputs ci = ANY_MODE ? frame_color_inputs(fp, cloud, draw_list, culled, count)
+                                    : ColorInputs{0.0f, 0.0f, 0.0f};
 
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
@@ -213,7 +237,7 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
         if (j < count) {
             // the LAST entry of the draw list is drawn on top => it is the front-most
             bool vis;
-            const uint32_t r = project_rank<F16, SURFEL>(fp, cloud, draw_list[count - 1u - j], j, records, vis);
+            const uint32_t r = project_rank<F16, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis);
             visible_acc += vis ? 1u : 0u;
             if (r != RECT_EMPTY) {
                 rect = r;
@@ -305,7 +329,8 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
 }
 
 void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
-                         const uint2* draw_list, Control* ctl, unsigned long long* scan_status,
+                         const uint2* draw_list, const uint2* culled, Control* ctl,
+                         unsigned long long* scan_status,
                          void* records, uint2* instances, uint32_t capacity, uint32_t ticket_slot,
                          int max_blocks) {
     if (fp.n == 0) return;
@@ -313,23 +338,29 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
     const bool surfel = fp.gaussian_mode == 0u && fp.aabb != 0u;
     float4* rec = (float4*)records;
-#define BGS_LAUNCH_PE(F16, SURFEL)                                                              \
-    hipLaunchKernelGGL((project_emit_kernel<F16, SURFEL>), dim3(blocks), dim3(256), 0, stream, fp, \
-                       cloud, draw_list, ctl, scan_status, rec, instances, capacity, ticket_slot)
+    const bool any_mode = fp.rasterize_mode != RASTERIZE_COLOR;
+#define BGS_LAUNCH_PE(F16, SURFEL, ANY)                                                             \
+    hipLaunchKernelGGL((project_emit_kernel<F16, SURFEL, ANY>), dim3(blocks), dim3(256), 0, stream, \
+                       fp, cloud, draw_list, culled, ctl, scan_status, rec, instances, capacity,    \
+                       ticket_slot)
+#define BGS_LAUNCH_PE2(F16, SURFEL) \
+    do { if (any_mode) BGS_LAUNCH_PE(F16, SURFEL, true); else BGS_LAUNCH_PE(F16, SURFEL, false); } while (0)
     if (cloud.is_f16) {
-        if (surfel) BGS_LAUNCH_PE(true, true); else BGS_LAUNCH_PE(true, false);
+        if (surfel) BGS_LAUNCH_PE2(true, true); else BGS_LAUNCH_PE2(true, false);
     } else {
-        if (surfel) BGS_LAUNCH_PE(false, true); else BGS_LAUNCH_PE(false, false);
+        if (surfel) BGS_LAUNCH_PE2(false, true); else BGS_LAUNCH_PE2(false, false);
     }
+#undef BGS_LAUNCH_PE2
 #undef BGS_LAUNCH_PE
 }
 
 // ---------------------------------------------------------------------------------------
 // BINNING_SCAN: project + ordered coarse binning (supertile lists), one pass
 // ---------------------------------------------------------------------------------------
-template <bool F16, bool SURFEL>
+template <bool F16, bool SURFEL, bool ANY_MODE>
 __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudPtrs cloud,
                                                           const uint2* __restrict__ draw_list,
+                                                          const uint2* __restrict__ culled,
                                                           Control* ctl, uint32_t* bin_status,
                                                           float4* __restrict__ records,
                                                           uint32_t* __restrict__ rects,
@@ -351,6 +382,8 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
     const uint32_t num_st = sup_x * sup_y;
     const uint32_t my_sy = (uint32_t)tid / sup_x, my_sx = (uint32_t)tid - my_sy * sup_x;  // thread = supertile
     uint32_t visible_acc = 0u;
+    const ColorInputs ci = ANY_MODE ? frame_color_inputs(fp, cloud, draw_list, culled, count)
+                                    : ColorInputs{0.0f, 0.0f, 0.0f};
 
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
@@ -364,7 +397,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
             if (fp.debug & 1u) {  // ablation: no projection, a fixed 2x1-tile rectangle
                 rect = 0x01000000u | (j & 63u) | (((j & 63u) + 1u) << 8);
             } else {
-                rect = project_rank<F16, SURFEL>(fp, cloud, draw_list[count - 1u - j], j, records, vis);
+                rect = project_rank<F16, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis);
             }
             visible_acc += vis ? 1u : 0u;
             rects[j] = rect;
@@ -428,7 +461,8 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
 }
 
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
-                        const uint2* draw_list, Control* ctl, uint32_t* bin_status, void* records,
+                        const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status,
+                        void* records,
                         uint32_t* rects, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
                         uint32_t ticket_slot, int max_blocks) {
     if (fp.n == 0) return;
@@ -438,15 +472,19 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPt
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup, sup_y = ((uint32_t)fp.tiles_y + sup - 1u) / sup;
     const bool surfel = fp.gaussian_mode == 0u && fp.aabb != 0u;
     float4* rec = (float4*)records;
-#define BGS_LAUNCH_PB(F16, SURFEL)                                                                \
-    hipLaunchKernelGGL((project_bin_kernel<F16, SURFEL>), dim3(blocks), dim3(256), 0, stream, fp,  \
-                       cloud, draw_list, ctl, bin_status, rec, rects, coarse, coarse_cap, sup_shift, \
-                       sup_x, sup_y, ticket_slot)
+    const bool any_mode = fp.rasterize_mode != RASTERIZE_COLOR;
+#define BGS_LAUNCH_PB(F16, SURFEL, ANY)                                                            \
+    hipLaunchKernelGGL((project_bin_kernel<F16, SURFEL, ANY>), dim3(blocks), dim3(256), 0, stream, \
+                       fp, cloud, draw_list, culled, ctl, bin_status, rec, rects, coarse,          \
+                       coarse_cap, sup_shift, sup_x, sup_y, ticket_slot)
+#define BGS_LAUNCH_PB2(F16, SURFEL) \
+    do { if (any_mode) BGS_LAUNCH_PB(F16, SURFEL, true); else BGS_LAUNCH_PB(F16, SURFEL, false); } while (0)
     if (cloud.is_f16) {
-        if (surfel) BGS_LAUNCH_PB(true, true); else BGS_LAUNCH_PB(true, false);
+        if (surfel) BGS_LAUNCH_PB2(true, true); else BGS_LAUNCH_PB2(true, false);
     } else {
-        if (surfel) BGS_LAUNCH_PB(false, true); else BGS_LAUNCH_PB(false, false);
+        if (surfel) BGS_LAUNCH_PB2(false, true); else BGS_LAUNCH_PB2(false, false);
     }
+#undef BGS_LAUNCH_PB2
 #undef BGS_LAUNCH_PB
 }
 

@@ -376,4 +376,22 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
                            n_ptr, hist, status, ticket, error_flag, shift, key_xor);
 }
 
+// ---------------------------------------------------------------------------------------
+// HBM ceiling probe: STREAM triad, 16-byte accesses, grid-stride
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void triad_kernel(float4* __restrict__ a, const float4* __restrict__ b,
+                                                    const float4* __restrict__ c, float s, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n4; i += stride) {
+        const float4 x = b[i], y = c[i];
+        a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+    }
+}
+
+void launch_triad(hipStream_t stream, float4* a, const float4* b, const float4* c, float s, size_t n4,
+                  int blocks) {
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(triad_kernel, dim3(blocks), dim3(256), 0, stream, a, b, c, s, n4);
+}
+
 }  // namespace bgs

@@ -341,6 +341,60 @@ BGS_HD V3 sh_direction(const FrameParams& fp, V3 transformed_position) {
     return world_to_local_direction(rdw, fp.transform);
 }
 
+// ---- colour variants other than RASTERIZE_COLOR (src/render/gaussian.wgsl:312-405) -------------
+BGS_HD float clamp1(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// WGSL smoothstep(low, high, x)
+BGS_HD float smoothstep1(float low, float high, float x) {
+    float t = clamp1((x - low) / (high - low), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+// src/material/depth.wgsl:3-11
+BGS_HD V3 depth_to_rgb(float depth, float min_depth, float max_depth) {
+    float nd = clamp1((depth - min_depth) / (max_depth - min_depth), 0.0f, 1.0f);
+    float r = smoothstep1(0.5f, 1.0f, nd);
+    float g = 1.0f - fabsf(nd - 0.5f) * 2.0f;
+    float b = 1.0f - smoothstep1(0.0f, 0.5f, nd);
+    return V3{r, g, b};
+}
+// bevy_render 0.19 color_operations.wgsl hsv_to_rgb (third-party, restated; hue in radians):
+// k = (n + h / (pi/3)) % 6, n = (5,3,1); rgb = v - v*s*max(0, min(k, min(4-k, 1)))
+BGS_HD float hsv_channel(float n, float h, float s, float v) {
+    float k = fmodf(n + h / 1.047197551f, 6.0f);
+    return v - v * s * fmaxf(0.0f, fminf(k, fminf(4.0f - k, 1.0f)));
+}
+// src/material/classification.wgsl:9-27
+BGS_HD V3 class_to_rgb(const FrameParams& fp, float visualization, V3 sh_color) {
+    if (visualization < 2.0f) return sh_color;
+    float class_idx = visualization - 2.0f;
+    float hue = (class_idx / (float)fp.num_classes) * 6.283185307f;
+    V3 c{hsv_channel(5.0f, hue, 1.0f, 1.0f), hsv_channel(3.0f, hue, 1.0f, 1.0f), hsv_channel(1.0f, hue, 1.0f, 1.0f)};
+    // mix(a, b, 0.5) = a * (1 - 0.5) + b * 0.5
+    return V3{sh_color.x * (1.0f - 0.5f) + c.x * 0.5f, sh_color.y * (1.0f - 0.5f) + c.y * 0.5f,
+              sh_color.z * (1.0f - 0.5f) + c.z * 0.5f};
+}
+// Depth-mode range endpoints: length(transform * vec4(p, 1) - camera) (gaussian.wgsl:329-340)
+BGS_HD float distance_to_camera(const FrameParams& fp, V3 pos) {
+    V4 t = m4_mul_point(fp.transform, pos);
+    V3 d = sub3(V3{t.x, t.y, t.z}, V3{fp.cam[0], fp.cam[1], fp.cam[2]});
+    return sqrtf(dot3(d, d));
+}
+// RASTERIZE_NORMAL (gaussian.wgsl:349-368): third column of L = T*S*R, taken to view space
+BGS_HD V3 normal_rgb(const FrameParams& fp, const float* rot, const float* scale) {
+    M3 R = rotation_matrix(rot);
+    M3 S = scale_matrix(scale, fp.global_scale);
+    M3 T = m3_from_m4(fp.transform);
+    M3 L = m3_mul(m3_mul(T, S), R);
+    const float x = L.m[6], y = L.m[7], z = L.m[8];
+    const float* m = fp.view_from_world;
+    V4 wn;
+    wn.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12] * 0.0f;
+    wn.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * 0.0f;
+    wn.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * 0.0f;
+    wn.w = ((m[3] * x + m[7] * y) + m[11] * z) + m[15] * 0.0f;
+    float len = sqrtf(((wn.x * wn.x + wn.y * wn.y) + wn.z * wn.z) + wn.w * wn.w);
+    return V3{0.5f * (wn.x / len + 1.0f), 0.5f * (wn.y / len + 1.0f), 0.5f * (wn.z / len + 1.0f)};
+}
+
 // src/render/gaussian.wgsl:229-235
 BGS_HD float cutoff_radius(const FrameParams& fp, float opacity) {
     if (!fp.adaptive_radius) return 3.0f;
@@ -420,9 +474,12 @@ struct Projected {
     int tx0, ty0, tx1, ty1;
 };
 
-template <class ShFn>
+// ANY_MODE = false compiles the benchmarked RASTERIZE_COLOR path only (the mode tests fold away and
+// the kernel keeps its register budget); true honours fp.rasterize_mode.
+template <bool ANY_MODE, class ShFn>
 BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const float rot[4],
-                          const float so[4], ShFn sh, Projected& o) {
+                          const float so[4], ShFn sh, const ColorInputs& ci, Projected& o) {
+    const uint32_t mode = ANY_MODE ? fp.rasterize_mode : RASTERIZE_COLOR;
     o.visible = false;
     o.draw = false;
     bool discard_quad = key == 0xFFFFFFFFu;                        // gaussian.wgsl:196
@@ -432,8 +489,9 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
     discard_quad = discard_quad || !in_frustum(projected);         // :211
     if (discard_quad) return;                                      // :214-218
     o.visible = true;
+    const bool sh_color = mode == RASTERIZE_COLOR || mode == RASTERIZE_CLASSIFICATION;
     float shc[48];
-    sh.load_all(shc);
+    if (sh_color) sh.load_all(shc);
 
     const float opacity = so[3];
     const float cutoff = cutoff_radius(fp, opacity);               // :229-235
@@ -477,24 +535,42 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
         }
     }
 
-    // RASTERIZE_COLOR :406-422, get_color src/render/planar.wgsl:334-339
-    V3 dir = sh_direction(fp, tp);
-    float w[16];
-    sh_weights(dir, fp.sh_degree, w);
-    float r = 0.5f, g = 0.5f, b = 0.5f;
-    const int ncoef = fp.sh_degree == 0 ? 1 : (fp.sh_degree == 1 ? 4 : (fp.sh_degree == 2 ? 9 : 16));
+    float r = 0.0f, g = 0.0f, b = 0.0f;                            // var rgb = vec3(0.0)  :312
+    if (sh_color) {
+        // RASTERIZE_COLOR :406-417 / RASTERIZE_CLASSIFICATION :315-328, get_color planar.wgsl:334-339
+        V3 dir = sh_direction(fp, tp);
+        float w[16];
+        sh_weights(dir, fp.sh_degree, w);
+        r = 0.5f; g = 0.5f; b = 0.5f;
+        const int ncoef = fp.sh_degree == 0 ? 1 : (fp.sh_degree == 1 ? 4 : (fp.sh_degree == 2 ? 9 : 16));
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (k < ncoef) {  // coefficients past the requested degree are never touched (may be garbage)
-            r += w[k] * shc[3 * k];
-            g += w[k] * shc[3 * k + 1];
-            b += w[k] * shc[3 * k + 2];
+        for (int k = 0; k < 16; ++k) {
+            if (k < ncoef) {  // coefficients past the requested degree are never touched (may be garbage)
+                r += w[k] * shc[3 * k];
+                g += w[k] * shc[3 * k + 1];
+                b += w[k] * shc[3 * k + 2];
+            }
         }
-    }
-    if (fp.color_space != 1u) {                                    // planar.wgsl:91-106
-        r = srgb_to_linear1(r);
-        g = srgb_to_linear1(g);
-        b = srgb_to_linear1(b);
+        if (fp.color_space != 1u) {                                // planar.wgsl:91-106
+            r = srgb_to_linear1(r);
+            g = srgb_to_linear1(g);
+            b = srgb_to_linear1(b);
+        }
+        if (mode == RASTERIZE_CLASSIFICATION) {
+            V3 c = class_to_rgb(fp, ci.visibility, V3{r, g, b});
+            r = c.x; g = c.y; b = c.z;
+        }
+    } else if (mode == RASTERIZE_DEPTH) {             // :329-347
+        V3 d = sub3(tp, V3{fp.cam[0], fp.cam[1], fp.cam[2]});
+        V3 c = depth_to_rgb(sqrtf(dot3(d, d)), ci.min_distance, ci.max_distance);
+        r = c.x; g = c.y; b = c.z;
+    } else if (mode == RASTERIZE_NORMAL) {            // :348-368
+        V3 c = normal_rgb(fp, rot, so);
+        r = c.x; g = c.y; b = c.z;
+    } else if (mode == RASTERIZE_POSITION) {          // :376-377
+        r = (tp.x - fp.pos_min[0]) / (fp.pos_max[0] - fp.pos_min[0]);
+        g = (tp.y - fp.pos_min[1]) / (fp.pos_max[1] - fp.pos_min[1]);
+        b = (tp.z - fp.pos_min[2]) / (fp.pos_max[2] - fp.pos_min[2]);
     }
     o.color[0] = r; o.color[1] = g; o.color[2] = b;
     o.color[3] = opacity * fp.global_opacity;

@@ -170,6 +170,12 @@ class GaussianSplattingPlugin:
                 keys.shape[0], int(passes)))
         return e
 
+    def hbm_probe(self, nbytes: int = 1 << 29, iters: int = 20):
+        """Measured HBM ceiling: (DtoD-copy GB/s counting read+write, triad GB/s) — for the roofline."""
+        c, t = ctypes.c_float(), ctypes.c_float()
+        self._check(self._lib.bgs_hbm_probe(self._ctx, int(nbytes), int(iters), ctypes.byref(c), ctypes.byref(t)))
+        return float(c.value), float(t.value)
+
     # -- interop / introspection -----------------------------------------------------
     def synchronize(self) -> None:
         self._check(self._lib.bgs_synchronize(self._ctx))

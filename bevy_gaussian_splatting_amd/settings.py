@@ -49,9 +49,18 @@ class GaussianColorSpace(enum.IntEnum):
 
 
 class RasterizeMode(enum.IntEnum):
-    """src/gaussian/settings.rs:36-47. Only Color is on the benchmarked hot path."""
+    """src/gaussian/settings.rs:36-47 (same discriminants). Color is the benchmarked mode;
+    Classification / Depth / Normal / Position are colour-stage variants of the same pipeline
+    (src/render/gaussian.wgsl:312-405). OpticalFlow (needs the previous frame's transforms) and
+    Velocity (4D clouds) are outside the path and rejected by the library."""
 
+    Classification = 0
     Color = 1
+    Depth = 2
+    Normal = 3
+    OpticalFlow = 4
+    Position = 5
+    Velocity = 6
 
 
 class DrawMode(enum.IntEnum):
@@ -120,7 +129,11 @@ class BgsSettings(ctypes.Structure):
         ("radix_depth_bits", ctypes.c_uint32),
         ("sh_degree", ctypes.c_uint32),
         ("sort_mode", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32),
+        ("rasterize_mode", ctypes.c_uint32),
+        ("num_classes", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32 * 3),
+        ("position_min", ctypes.c_float * 4),
+        ("position_max", ctypes.c_float * 4),
     ]
 
 
@@ -155,10 +168,12 @@ class CloudSettings:
     time_stop: float = 1.0
     sh_degree: int = 3
     transform: np.ndarray = field(default_factory=_identity4)
+    # CloudUniform.min / .max = the cloud entity's Aabb (src/render/mod.rs:1070-1071); only read by
+    # RasterizeMode.Position. `compute_aabb(cloud)` gives what the reference would have attached.
+    position_min: tuple = (0.0, 0.0, 0.0)
+    position_max: tuple = (1.0, 1.0, 1.0)
 
     def to_native(self) -> BgsSettings:
-        if self.rasterize_mode != RasterizeMode.Color:
-            raise ValueError("only RasterizeMode.Color is implemented on the hot path")
         if self.draw_mode != DrawMode.All:
             raise ValueError("only DrawMode.All is implemented on the hot path")
         s = BgsSettings()
@@ -176,5 +191,24 @@ class CloudSettings:
         s.radix_depth_bits = int(self.radix_sort_depth_bits)
         s.sh_degree = int(self.sh_degree)
         s.sort_mode = int(self.sort_mode)
-        s.reserved = 0
+        s.rasterize_mode = int(self.rasterize_mode)
+        s.num_classes = int(self.num_classes)
+        s.position_min[:] = [float(v) for v in self.position_min] + [1.0]
+        s.position_max[:] = [float(v) for v in self.position_max] + [1.0]
         return s
+
+
+def compute_aabb(cloud):
+    """(min, max) the reference hands to the shaders for `cloud`: `compute_aabb`
+    (src/gaussian/interface.rs:22-63: position -/+ 0.1 per splat) -> Bevy `Aabb {center,
+    half_extents}` (src/gaussian/cloud.rs:56-59) -> `aabb.min()/max()` = center -/+ half_extents
+    (src/render/mod.rs:1070-1071), all in f32. Returns None for an empty cloud."""
+    if len(cloud) == 0:
+        return None
+    pos = cloud.position_visibility[:, :3]
+    off = np.float32(0.1)
+    mn = (pos - off).min(axis=0).astype(np.float32)
+    mx = (pos + off).max(axis=0).astype(np.float32)
+    center = ((mn + mx) / np.float32(2.0)).astype(np.float32)
+    half = ((mx - mn) / np.float32(2.0)).astype(np.float32)
+    return tuple((center - half).tolist()), tuple((center + half).tolist())

@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define BGS_VERSION_MAJOR 0
-#define BGS_VERSION_MINOR 1
+#define BGS_VERSION_MINOR 2
 
 typedef enum bgs_status {
     BGS_OK = 0,
@@ -78,6 +78,17 @@ typedef struct bgs_view {
 #define BGS_SORT_RAYON 2u /* CPU-sort semantics: key=bits(dist2), descending, no cull    */
 #define BGS_SORT_STD 3u   /* same ordering contract as RAYON (src/sort/std_sort.rs)      */
 
+/* rasterize_mode: discriminants of RasterizeMode (src/gaussian/settings.rs:38-47); selects the
+ * colour the vertex stage gives a splat (src/render/gaussian.wgsl:312-417). OpticalFlow needs the
+ * previous frame's transforms and Velocity a 4D cloud: both are rejected with BGS_EINVAL. */
+#define BGS_RASTERIZE_CLASSIFICATION 0u
+#define BGS_RASTERIZE_COLOR 1u /* default */
+#define BGS_RASTERIZE_DEPTH 2u
+#define BGS_RASTERIZE_NORMAL 3u
+#define BGS_RASTERIZE_OPTICAL_FLOW 4u
+#define BGS_RASTERIZE_POSITION 5u
+#define BGS_RASTERIZE_VELOCITY 6u
+
 /* CloudUniform (src/render/mod.rs:995-1009) + the CloudSettings fields that select the
  * pipeline specialisation (src/gaussian/settings.rs:87-132, src/render/mod.rs:770-896). */
 typedef struct bgs_settings {
@@ -91,7 +102,11 @@ typedef struct bgs_settings {
     uint32_t radix_depth_bits;        /* 16 | 24 | 32 (default 32)     settings.rs:52-77 */
     uint32_t sh_degree;               /* 0..3; reference is compile-time sh3             */
     uint32_t sort_mode;               /* BGS_SORT_RADIX default                          */
-    uint32_t reserved;
+    uint32_t rasterize_mode;          /* BGS_RASTERIZE_COLOR default   settings.rs:38-47 */
+    uint32_t num_classes;             /* default 1 (Classification)    settings.rs:124   */
+    uint32_t reserved[3];
+    float position_min[4];            /* CloudUniform.min/max = the cloud entity's Aabb   */
+    float position_max[4];            /* (src/render/mod.rs:1070-1071); Position mode     */
 } bgs_settings;
 
 /* src/sort/mod.rs:324-329 */
@@ -246,6 +261,12 @@ int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out);
  * kernel on arbitrary keys (ties, all-equal, ragged sizes). */
 int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries_inout, uint32_t n,
                          uint32_t passes);
+
+/* Measured HBM ceiling of this device, for the roofline ("state both" the nominal and
+ * the measured peak): `bytes` per buffer (rounded down to 16), `iters` timed repetitions.
+ * copy_gbs = hipMemcpyDtoD rate counting read + write; triad_gbs = a[i] = b[i] + s * c[i] with
+ * float4 accesses, counting 2 reads + 1 write. Allocates 3 * bytes for the call. */
+int bgs_hbm_probe(bgs_ctx* ctx, uint64_t bytes, uint32_t iters, float* copy_gbs, float* triad_gbs);
 
 #ifdef __cplusplus
 }

@@ -521,9 +521,64 @@ static v3 world_to_local_direction(v3 ray_direction_world, const float* transfor
 
 static const v2 quad_vertices[4] = {{-1.0f, -1.0f}, {-1.0f, 1.0f}, {1.0f, -1.0f}, {1.0f, 1.0f}};
 
-/* src/render/gaussian.wgsl:184-436 (RASTERIZE_COLOR, DrawMode::All, planar f32 storage) */
-int oracle_vs(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_view* view,
-              const bgs_settings* s, oracle_vs_out* o) {
+/* ---- colour variants (src/render/gaussian.wgsl:312-405) ---- */
+static inline float clamp1(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+/* WGSL smoothstep(low, high, x) */
+static inline float smoothstep1(float low, float high, float x) {
+    float t = clamp1((x - low) / (high - low), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+/* src/material/depth.wgsl:3-11 */
+static v3 depth_to_rgb(float depth, float min_depth, float max_depth) {
+    float normalized_depth = clamp1((depth - min_depth) / (max_depth - min_depth), 0.0f, 1.0f);
+    v3 c;
+    c.x = smoothstep1(0.5f, 1.0f, normalized_depth);
+    c.y = 1.0f - fabsf(normalized_depth - 0.5f) * 2.0f;
+    c.z = 1.0f - smoothstep1(0.0f, 0.5f, normalized_depth);
+    return c;
+}
+/* hsv_to_rgb: THIRD PARTY, bevy_render 0.19.0 `color_operations.wgsl` (not in the reference tree;
+ * restated from its published form, the Wikipedia "HSV to RGB alternative" formula with the hue
+ * in radians: k = (n + h/(pi/3)) mod 6 for n = 5,3,1; c = v - v*s*max(0, min(k, 4-k, 1))).
+ * PARITY UNPINNED. Only reached by Classification mode with visibility >= 2. */
+static inline float hsv_channel(float n, float h, float sat, float val) {
+    float k = fmodf(n + h / 1.047197551f, 6.0f);
+    return val - val * sat * fmaxf(0.0f, fminf(k, fminf(4.0f - k, 1.0f)));
+}
+/* src/material/classification.wgsl:9-27 */
+static v3 class_to_rgb(float visualization, v3 sh_color, uint32_t num_classes) {
+    if (visualization < 2.0f) return sh_color;
+    float class_idx = visualization - 2.0f;
+    float hue = (class_idx / (float)num_classes) * 6.283185307f;
+    v3 c = {hsv_channel(5.0f, hue, 1.0f, 1.0f), hsv_channel(3.0f, hue, 1.0f, 1.0f),
+            hsv_channel(1.0f, hue, 1.0f, 1.0f)};
+    v3 r = {sh_color.x * (1.0f - 0.5f) + c.x * 0.5f, sh_color.y * (1.0f - 0.5f) + c.y * 0.5f,
+            sh_color.z * (1.0f - 0.5f) + c.z * 0.5f};              /* mix(a, b, 0.5) */
+    return r;
+}
+
+/* RASTERIZE_DEPTH range (src/render/gaussian.wgsl:331-340): distances of get_entry(count - 1) and
+ * get_entry(1), count = gaussian_uniforms.count = number of splats. With a single splat entry 1
+ * does not exist (out-of-bounds read in the reference); index 0 is used. out = {min, max}. */
+int oracle_depth_range(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                       const bgs_view* view, const bgs_settings* s, float out[2]) {
+    out[0] = out[1] = 0.0f;
+    if (cloud->n == 0) return 0;
+    if (count < cloud->n) return -1;
+    const uint32_t j_first = cloud->n > 1 ? 1u : 0u, j_last = cloud->n - 1u;
+    if (entries[j_first].index >= cloud->n || entries[j_last].index >= cloud->n) return -1;
+    v3 cam = view_world_position(view);
+    v3 max_position = transform_point(s->transform, cloud->position_visibility + 4 * (size_t)entries[j_first].index);
+    v3 min_position = transform_point(s->transform, cloud->position_visibility + 4 * (size_t)entries[j_last].index);
+    v3 dmin = v3sub(min_position, cam), dmax = v3sub(max_position, cam);
+    out[0] = sqrtf(dot3(dmin, dmin));
+    out[1] = sqrtf(dot3(dmax, dmax));
+    return 0;
+}
+
+/* src/render/gaussian.wgsl:184-436 (DrawMode::All, planar f32 storage) */
+static int vs_impl(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_view* view,
+                   const bgs_settings* s, const float depth_range[2], oracle_vs_out* o) {
     memset(o, 0, sizeof *o);
     const uint32_t splat_index = entry.index;
     if (splat_index >= cloud->n) { o->discard = 1; return 0; }
@@ -570,22 +625,62 @@ int oracle_vs(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_view* v
         }
     }
 
-    /* RASTERIZE_COLOR :406-417, get_color src/render/planar.wgsl:334-339 */
     v3 cam = view_world_position(view);
-    v3 ray_direction_world = v3normalize(v3sub(transformed_position, cam));
-    v3 ray_direction_local = world_to_local_direction(ray_direction_world, s->transform);
-    v3 rgb = spherical_harmonics_lookup(
-        ray_direction_local, cloud->spherical_harmonic + 48 * (size_t)splat_index, s->sh_degree);
-    if (s->color_space != BGS_COLOR_LINEAR) {                        /* planar.wgsl:91-106 */
-        rgb.x = srgb_to_linear1(rgb.x);
-        rgb.y = srgb_to_linear1(rgb.y);
-        rgb.z = srgb_to_linear1(rgb.z);
+    v3 rgb = {0.0f, 0.0f, 0.0f};                                     /* :312 */
+    if (s->rasterize_mode == BGS_RASTERIZE_COLOR || s->rasterize_mode == BGS_RASTERIZE_CLASSIFICATION) {
+        /* RASTERIZE_COLOR :406-417 / RASTERIZE_CLASSIFICATION :315-328, get_color planar.wgsl:334-339 */
+        v3 ray_direction_world = v3normalize(v3sub(transformed_position, cam));
+        v3 ray_direction_local = world_to_local_direction(ray_direction_world, s->transform);
+        rgb = spherical_harmonics_lookup(
+            ray_direction_local, cloud->spherical_harmonic + 48 * (size_t)splat_index, s->sh_degree);
+        if (s->color_space != BGS_COLOR_LINEAR) {                    /* planar.wgsl:91-106 */
+            rgb.x = srgb_to_linear1(rgb.x);
+            rgb.y = srgb_to_linear1(rgb.y);
+            rgb.z = srgb_to_linear1(rgb.z);
+        }
+        if (s->rasterize_mode == BGS_RASTERIZE_CLASSIFICATION)
+            rgb = class_to_rgb(pv[3], rgb, s->num_classes);          /* get_visibility(splat_index) */
+    } else if (s->rasterize_mode == BGS_RASTERIZE_DEPTH) {           /* :329-347 */
+        v3 d = v3sub(transformed_position, cam);
+        rgb = depth_to_rgb(sqrtf(dot3(d, d)), depth_range[0], depth_range[1]);
+    } else if (s->rasterize_mode == BGS_RASTERIZE_NORMAL) {          /* :348-368 */
+        m3 R = get_rotation_matrix(rot);
+        m3 S = get_scale_matrix(so, s->global_scale);
+        m3 T = m3_from_m4(s->transform);
+        m3 L = m3_mul(m3_mul(T, S), R);
+        v4 local_normal = {L.m[6], L.m[7], L.m[8], 0.0f};
+        v4 wn = m4_mul_v4(view->view_from_world, local_normal);
+        float len = sqrtf(((wn.x * wn.x + wn.y * wn.y) + wn.z * wn.z) + wn.w * wn.w);
+        rgb.x = 0.5f * (wn.x / len + 1.0f);
+        rgb.y = 0.5f * (wn.y / len + 1.0f);
+        rgb.z = 0.5f * (wn.z / len + 1.0f);
+    } else if (s->rasterize_mode == BGS_RASTERIZE_POSITION) {        /* :376-377 */
+        rgb.x = (transformed_position.x - s->position_min[0]) / (s->position_max[0] - s->position_min[0]);
+        rgb.y = (transformed_position.y - s->position_min[1]) / (s->position_max[1] - s->position_min[1]);
+        rgb.z = (transformed_position.z - s->position_min[2]) / (s->position_max[2] - s->position_min[2]);
+    } else {
+        return -1;                                                   /* OpticalFlow / Velocity: out of scope */
     }
     o->color[0] = rgb.x;
     o->color[1] = rgb.y;
     o->color[2] = rgb.z;
     o->color[3] = opacity * s->global_opacity;                       /* :419-422 */
     return 0;
+}
+
+int oracle_vs(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_view* view,
+              const bgs_settings* s, oracle_vs_out* o) {
+    if (s->rasterize_mode == BGS_RASTERIZE_DEPTH) return -1; /* needs the sorted list: oracle_vs_sorted */
+    const float none[2] = {0.0f, 0.0f};
+    return vs_impl(cloud, entry, view, s, none, o);
+}
+
+int oracle_vs_sorted(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                     uint32_t instance, const bgs_view* view, const bgs_settings* s, oracle_vs_out* o) {
+    float range[2] = {0.0f, 0.0f};
+    if (instance >= count) return -1;
+    if (s->rasterize_mode == BGS_RASTERIZE_DEPTH && oracle_depth_range(cloud, entries, count, view, s, range)) return -1;
+    return vs_impl(cloud, entries[instance], view, s, range, o);
 }
 
 /* ------------------------------------------------------------------------------------
@@ -706,6 +801,11 @@ int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint
     const double W = (double)view->viewport[2], H = (double)view->viewport[3];
     const int32_t rw = x1 - x0, rh = y1 - y0;
 
+    float depth_range[2] = {0.0f, 0.0f};
+    if (s->rasterize_mode == BGS_RASTERIZE_DEPTH && oracle_depth_range(cloud, entries, count, view, s, depth_range))
+        return -3;
+    if (s->rasterize_mode == BGS_RASTERIZE_OPTICAL_FLOW || s->rasterize_mode >= BGS_RASTERIZE_VELOCITY) return -4;
+
     /* vertex stage for every instance, keeping the non-discarded ones in draw order */
     uint8_t* keep = (uint8_t*)calloc(count ? count : 1, 1);
     prim* tmp = (prim*)malloc((size_t)(count ? count : 1) * sizeof(prim));
@@ -713,7 +813,7 @@ int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < (int64_t)count; ++i) {
         prim* p = &tmp[i];
-        oracle_vs(cloud, entries[i], view, s, &p->vs);
+        vs_impl(cloud, entries[i], view, s, depth_range, &p->vs);
         if (p->vs.discard) continue;
         keep[i] = (uint8_t)build_prim(p, x0, y0, x1, y1, W, H);
     }

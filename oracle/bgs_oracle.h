@@ -18,6 +18,9 @@
  *     against a running reference (none can run here). Pinned only by (a) float64
  *     closed-form single-splat cases and (b) the coarse thresholds of
  *     tests/visibility_render.rs:245-274 applied to the oracle's image.
+ *   - RasterizeMode::{Depth, Normal, Position, Classification} colour variants
+ *     (src/render/gaussian.wgsl:312-405): PARITY UNPINNED (closed-form cases only); Classification
+ *     additionally restates bevy_render 0.19.0's hsv_to_rgb, which is not in the reference tree.
  *
  * Arithmetic contract (so "bit-exact sort order" is well defined; WGSL leaves the
  * evaluation order of dot()/matrix products implementation-defined):
@@ -99,6 +102,15 @@ typedef struct oracle_vs_out {
 
 int oracle_vs(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_view* view,
               const bgs_settings* settings, oracle_vs_out* out);
+
+/* Same for instance `instance` of a sorted list; required for RasterizeMode::Depth, whose colour
+ * depends on get_entry(1) and get_entry(count - 1) (src/render/gaussian.wgsl:331-340). */
+int oracle_vs_sorted(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                     uint32_t instance, const bgs_view* view, const bgs_settings* settings,
+                     oracle_vs_out* out);
+/* out = {min_distance, max_distance} of the Depth mode. */
+int oracle_depth_range(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                       const bgs_view* view, const bgs_settings* settings, float out[2]);
 
 /* Draw entries[0..count) in order into the pixel window [x0,x1) x [y0,y1) of the
  * viewport-sized target. rgba_out is (y1-y0)*(x1-x0)*4 floats, row 0 = y0 (top).

@@ -91,6 +91,10 @@ def lib() -> ctypes.CDLL:
         l.oracle_sort.restype = ctypes.c_int
         l.oracle_vs.argtypes = [ctypes.POINTER(_Cloud), _Entry, vp, sp, ctypes.POINTER(VsOut)]
         l.oracle_vs.restype = ctypes.c_int
+        l.oracle_vs_sorted.argtypes = [ctypes.POINTER(_Cloud), ep, u32, u32, vp, sp, ctypes.POINTER(VsOut)]
+        l.oracle_vs_sorted.restype = ctypes.c_int
+        l.oracle_depth_range.argtypes = [ctypes.POINTER(_Cloud), ep, u32, vp, sp, fp]
+        l.oracle_depth_range.restype = ctypes.c_int
         l.oracle_render.argtypes = [ctypes.POINTER(_Cloud), ep, u32, vp, sp, i32, i32, i32, i32, fp, fp]
         l.oracle_render.restype = ctypes.c_int
         l.oracle_decode_f16.argtypes = [u32, up, up, fp, fp, fp]
@@ -182,8 +186,36 @@ def vs(cloud, entry, view: View, settings: CloudSettings) -> VsOut:
     out = VsOut()
     v, s = view.to_native(), settings.to_native()
     e = _Entry(int(entry[0]), int(entry[1]))
-    lib().oracle_vs(ctypes.byref(c), e, ctypes.byref(v), ctypes.byref(s), ctypes.byref(out))
+    rc = lib().oracle_vs(ctypes.byref(c), e, ctypes.byref(v), ctypes.byref(s), ctypes.byref(out))
+    if rc:
+        raise RuntimeError(f"oracle_vs failed: {rc} (RasterizeMode.Depth needs vs_sorted)")
     return out
+
+
+def vs_sorted(cloud, entries: np.ndarray, instance: int, view: View, settings: CloudSettings) -> VsOut:
+    """vs_points for instance `instance` of the sorted list (needed by RasterizeMode.Depth)."""
+    cloud = _as_f32_cloud(cloud)
+    c = _cloud_struct(cloud)
+    e = np.ascontiguousarray(entries, dtype=SORT_ENTRY_DTYPE)
+    out = VsOut()
+    v, s = view.to_native(), settings.to_native()
+    rc = lib().oracle_vs_sorted(ctypes.byref(c), _ep(e), e.shape[0], instance, ctypes.byref(v), ctypes.byref(s),
+                                ctypes.byref(out))
+    if rc:
+        raise RuntimeError(f"oracle_vs_sorted failed: {rc}")
+    return out
+
+
+def depth_range(cloud, entries: np.ndarray, view: View, settings: CloudSettings):
+    cloud = _as_f32_cloud(cloud)
+    c = _cloud_struct(cloud)
+    e = np.ascontiguousarray(entries, dtype=SORT_ENTRY_DTYPE)
+    out = np.zeros(2, np.float32)
+    v, s = view.to_native(), settings.to_native()
+    rc = lib().oracle_depth_range(ctypes.byref(c), _ep(e), e.shape[0], ctypes.byref(v), ctypes.byref(s), _fp(out))
+    if rc:
+        raise RuntimeError(f"oracle_depth_range failed: {rc}")
+    return float(out[0]), float(out[1])
 
 
 def render(cloud, entries: np.ndarray, view: View, settings: CloudSettings, window=None,

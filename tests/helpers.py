@@ -41,6 +41,8 @@ class FrameParamsC(ctypes.Structure):
         ("width", ctypes.c_int32), ("height", ctypes.c_int32),
         ("tiles_x", ctypes.c_int32), ("tiles_y", ctypes.c_int32),
         ("debug", ctypes.c_uint32),
+        ("rasterize_mode", ctypes.c_uint32), ("num_classes", ctypes.c_uint32),
+        ("pos_min", ctypes.c_float * 3), ("pos_max", ctypes.c_float * 3),
     ]
 
 
@@ -81,8 +83,10 @@ def shim() -> ctypes.CDLL:
     l.shim_frame_params_size.restype = ctypes.c_uint32
     l.shim_sort_keys.argtypes = [ctypes.POINTER(FrameParamsC), fp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
     l.shim_sort_keys.restype = None
-    l.shim_project.argtypes = [ctypes.POINTER(FrameParamsC), ctypes.c_uint32, fp, fp, fp, fp, ctypes.POINTER(ShimOut)]
+    l.shim_project.argtypes = [ctypes.POINTER(FrameParamsC), ctypes.c_uint32, fp, fp, fp, fp, fp, ctypes.POINTER(ShimOut)]
     l.shim_project.restype = None
+    l.shim_distance_to_camera.argtypes = [ctypes.POINTER(FrameParamsC), fp]
+    l.shim_distance_to_camera.restype = ctypes.c_float
     assert l.shim_frame_params_size() == ctypes.sizeof(FrameParamsC)
     _shim = l
     return l
@@ -145,12 +149,18 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
     out = ShimOut()
     surfel = settings.gaussian_mode == GaussianMode.Gaussian2d and settings.aabb
     eps = np.float32(1.0 / 65536.0)
+    # Depth mode: range from sorted[count-1] and sorted[1] of the FULL entry list (gaussian.wgsl:331-340)
+    depth_range = np.zeros(2, np.float32)
+    if n > 0:
+        i_first, i_last = int(entries[min(1, n - 1)]["index"]), int(entries[n - 1]["index"])
+        depth_range[0] = shim().shim_distance_to_camera(ctypes.byref(fpc), _fp(cloud.position_visibility[i_last]))
+        depth_range[1] = shim().shim_distance_to_camera(ctypes.byref(fpc), _fp(cloud.position_visibility[i_first]))
     for j in range(count):
         e = entries[count - 1 - j]
         si = int(e["index"])
         shim().shim_project(ctypes.byref(fpc), int(e["key"]), _fp(cloud.position_visibility[si]),
                             _fp(cloud.rotation[si]), _fp(cloud.scale_opacity[si]),
-                            _fp(cloud.spherical_harmonic[si]), ctypes.byref(out))
+                            _fp(cloud.spherical_harmonic[si]), _fp(depth_range), ctypes.byref(out))
         if not out.draw:
             continue
         dx = qx - np.float32(out.cx)

@@ -41,11 +41,17 @@ void shim_sort_keys(const FrameParams* fp, const float* pos_vis, uint32_t n, uin
         keys_out[i] = sort_key(*fp, V3{pos_vis[4 * i], pos_vis[4 * i + 1], pos_vis[4 * i + 2]});
 }
 
+// pos = position_visibility row (4 floats); depth_range = {min_distance, max_distance}
 void shim_project(const FrameParams* fp, uint32_t key, const float* pos, const float* rot,
-                  const float* so, const float* sh48, ShimOut* out) {
+                  const float* so, const float* sh48, const float* depth_range, ShimOut* out) {
     Projected pr;
     memset(&pr, 0, sizeof pr);
-    project_splat(*fp, key, V3{pos[0], pos[1], pos[2]}, rot, so, ShFloat{sh48}, pr);
+    ColorInputs ci{pos[3], depth_range[0], depth_range[1]};
+    // the same dispatch as the launchers: the Color-only instantiation unless another mode is asked for
+    if (fp->rasterize_mode == RASTERIZE_COLOR)
+        project_splat<false>(*fp, key, V3{pos[0], pos[1], pos[2]}, rot, so, ShFloat{sh48}, ci, pr);
+    else
+        project_splat<true>(*fp, key, V3{pos[0], pos[1], pos[2]}, rot, so, ShFloat{sh48}, ci, pr);
     memset(out, 0, sizeof *out);
     out->visible = pr.visible;
     out->draw = pr.draw;
@@ -63,6 +69,10 @@ void shim_project(const FrameParams* fp, uint32_t key, const float* pos, const f
     out->quad_m[2] = pr.quad.m10; out->quad_m[3] = pr.quad.m11;
     out->bounds[0] = pr.quad.minx; out->bounds[1] = pr.quad.maxx;
     out->bounds[2] = pr.quad.miny; out->bounds[3] = pr.quad.maxy;
+}
+
+float shim_distance_to_camera(const FrameParams* fp, const float* pos) {
+    return distance_to_camera(*fp, V3{pos[0], pos[1], pos[2]});
 }
 
 }  // extern "C"

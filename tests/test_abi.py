@@ -27,12 +27,12 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert set(names) == set(_native.EXPORTED_SYMBOLS)
     for n in names:
         assert hasattr(lib, n), f"libbgs.so does not export {n}"
-    assert lib.bgs_version() == (0 << 16) | 1
+    assert lib.bgs_version() == (0 << 16) | 2
 
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(BgsView) == (16 * 4 + 8) * 4
-    assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8) * 4
+    assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8 + 1 + 3 + 8) * 4
     assert ctypes.sizeof(_native.BgsSortEntry) == 8
     assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 4 * 4 + 8 + 8 + 8
     # the ctypes images include natural padding exactly like the C structs
@@ -46,7 +46,7 @@ def test_settings_default_equals_cloud_settings_default():
     py = CloudSettings().to_native()
     for name, _ in BgsSettings._fields_:
         a, b = getattr(s, name), getattr(py, name)
-        if name == "transform":
+        if name in ("transform", "position_min", "position_max", "reserved"):
             assert list(a) == list(b)
         else:
             assert a == b, name

@@ -83,7 +83,8 @@ def test_tile_rect_covers_every_pixel_the_oracle_draws(oracle):
             si = int(ent["index"])
             H.shim().shim_project(ctypes.byref(fpc), int(ent["key"]), H._fp(c.position_visibility[si]),
                                   H._fp(c.rotation[si]), H._fp(c.scale_opacity[si]),
-                                  H._fp(c.spherical_harmonic[si]), ctypes.byref(out))
+                                  H._fp(c.spherical_harmonic[si]), H._fp(np.zeros(2, np.float32)),
+                                  ctypes.byref(out))
             one = np.array([ent], dtype=e.dtype)
             vclear = View(v.world_from_view, v.view_from_world, v.clip_from_view, v.clip_from_world,
                           v.viewport, clear_color=(0, 0, 0, 0))
@@ -96,3 +97,114 @@ def test_tile_rect_covers_every_pixel_the_oracle_draws(oracle):
             assert out.ty0 * 16 <= ys.min() and ys.max() < (out.ty1 + 1) * 16
             checked += 1
         assert checked > 20
+
+
+# ---------------------------------------------------------------------------------------------
+# RasterizeMode colour variants (src/render/gaussian.wgsl:312-405), SURVEY 8(f) item 4
+# ---------------------------------------------------------------------------------------------
+from bevy_gaussian_splatting_amd import RasterizeMode, compute_aabb, PlanarGaussian3d
+
+
+def _mode_settings(mode, c, **kw):
+    mn, mx = compute_aabb(c)
+    return CloudSettings(rasterize_mode=mode, position_min=mn, position_max=mx, num_classes=5, **kw)
+
+
+def _classified(c):
+    c = PlanarGaussian3d(c.position_visibility.copy(), c.spherical_harmonic, c.rotation, c.scale_opacity)
+    c.position_visibility[:, 3] = (np.arange(len(c)) % 8).astype(np.float32)  # 0,1: plain colour; 2..7: classes 0..5
+    return c
+
+
+@pytest.mark.parametrize("mode", [RasterizeMode.Classification, RasterizeMode.Depth, RasterizeMode.Normal,
+                                  RasterizeMode.Position])
+@pytest.mark.parametrize("kw", [{}, {"aabb": True}, {"gaussian_mode": GaussianMode.Gaussian2d, "aabb": True}])
+def test_rasterize_modes_device_math_matches_oracle(oracle, mode, kw):
+    c = _classified(random_gaussians_3d_seeded(3000, 21))
+    v = View.headless(128, 72)
+    tr = transform_from((0.5, -0.25, 0.0), rotation_y(0.3))
+    tr[:3, :3] *= np.float32(1.25)   # Transform::with_scale
+    s = _mode_settings(mode, c, transform=tr, **kw)
+    e = oracle.sort(c, v, s)
+    ref, amb = oracle.render(c, e, v, s, with_ambiguity=True)
+    got = H.emulate_render(c, v, s)
+    ok, err = H.tolerance_mask(ref, got, amb)
+    assert ok.all(), f"{mode.name} {kw}: max err {err.max():.3e}"
+    assert np.abs(ref[..., :3]).max() > 0.05
+    # the variants only change the colour: coverage/alpha is the Color image's
+    ref_color = oracle.render(c, e, v, CloudSettings(transform=s.transform, **kw))
+    assert np.array_equal(ref[..., 3], ref_color[..., 3])
+    if mode == RasterizeMode.Classification:
+        plain = PlanarGaussian3d(c.position_visibility.copy(), c.spherical_harmonic, c.rotation, c.scale_opacity)
+        plain.position_visibility[:, 3] = 1.0   # visibility < 2: class_to_rgb returns the SH colour
+        assert np.array_equal(oracle.render(plain, e, v, s), ref_color)
+
+
+def test_rasterize_mode_closed_forms(oracle):
+    """Per-splat colours against float64 closed forms."""
+    import ctypes
+    n = 5
+    pv = np.array([[0, 0, -6, 1], [1, 0.5, -4, 3], [-1, 0.2, -9, 5.5], [0.3, -0.4, -5, 7], [0, 1, -7, 2]], np.float32)
+    rot = np.tile(np.array([[1, 0, 0, 0]], np.float32), (n, 1))
+    rot[1] = [0.7071068, 0.7071068, 0, 0]      # 90 deg about x
+    so = np.tile(np.array([[0.3, 0.2, 0.1, 0.7]], np.float32), (n, 1))
+    sh = np.zeros((n, 48), np.float32)
+    c = PlanarGaussian3d(pv, sh, rot, so)
+    v = View.perspective(transform_from((0, 0, 0)), 64, 64)
+    mn, mx = compute_aabb(c)
+    assert np.allclose(mn, pv[:, :3].min(0) - 0.1, atol=1e-6) and np.allclose(mx, pv[:, :3].max(0) + 0.1, atol=1e-6)
+    base = dict(position_min=mn, position_max=mx, num_classes=4, sort_mode=SortMode.NONE)
+    e = oracle.sort(c, v, CloudSettings(**base))          # identity order
+    cam = np.zeros(3)
+
+    # Depth: range from entries[n-1] (min) and entries[1] (max); r/g/b ramps of depth.wgsl
+    s = CloudSettings(rasterize_mode=RasterizeMode.Depth, **base)
+    dmin, dmax = np.linalg.norm(pv[n - 1, :3] - cam), np.linalg.norm(pv[1, :3] - cam)
+    assert np.allclose(oracle.depth_range(c, e, v, s), (dmin, dmax), rtol=1e-6)
+    sm = lambda a, b, x: (lambda t: t * t * (3 - 2 * t))(np.clip((x - a) / (b - a), 0, 1))
+    for i in range(n):
+        nd = np.clip((np.linalg.norm(pv[i, :3] - cam) - dmin) / (dmax - dmin), 0, 1)
+        want = (sm(0.5, 1.0, nd), 1 - abs(nd - 0.5) * 2, 1 - sm(0, 0.5, nd))
+        assert np.allclose(list(oracle.vs_sorted(c, e, i, v, s).color)[:3], want, atol=2e-5)
+    with pytest.raises(RuntimeError):
+        oracle.vs(c, e[0], v, s)
+
+    # Normal: third column of T*S*R in view space (camera at origin looking -z => view = world)
+    s = CloudSettings(rasterize_mode=RasterizeMode.Normal, **base)
+    assert np.allclose(list(oracle.vs(c, e[0], v, s).color)[:3], (0.5, 0.5, 1.0), atol=1e-6)   # +z
+    # helpers.wgsl:137-157 feeds the row-major quaternion matrix to WGSL's column-major constructor, so its
+    # third COLUMN is (2(xz - wy), 2(yz + wx), 1 - 2(xx + yy)) = (0, 1, 0) for w = x = 0.7071
+    assert np.allclose(list(oracle.vs(c, e[1], v, s).color)[:3], (0.5, 1.0, 0.5), atol=1e-6)   # +y
+
+    # Position: (p - min) / (max - min)
+    s = CloudSettings(rasterize_mode=RasterizeMode.Position, **base)
+    for i in range(n):
+        want = (pv[i, :3].astype(np.float64) - mn) / (np.array(mx) - mn)
+        assert np.allclose(list(oracle.vs(c, e[i], v, s).color)[:3], want, atol=1e-6)
+
+    # Classification: visibility < 2 -> SH colour (0.5 -> sRGB->linear 0.2140); class k -> 50/50 mix with hue 2*pi*k/num_classes
+    s = CloudSettings(rasterize_mode=RasterizeMode.Classification, **base)
+    lin = ((0.5 + 0.055) / 1.055) ** 2.4
+    assert np.allclose(list(oracle.vs(c, e[0], v, s).color)[:3], (lin,) * 3, atol=1e-6)
+    import colorsys
+    for i, cls in ((1, 1.0), (2, 3.5), (3, 5.0), (4, 0.0)):
+        hue = (cls / 4.0) % 1.0
+        want = 0.5 * lin + 0.5 * np.array(colorsys.hsv_to_rgb(hue, 1.0, 1.0))
+        assert np.allclose(list(oracle.vs(c, e[i], v, s).color)[:3], want, atol=2e-5), (i, cls)
+
+    # the product's arithmetic gives the same per-splat colours
+    for mode in (RasterizeMode.Depth, RasterizeMode.Normal, RasterizeMode.Position, RasterizeMode.Classification):
+        s = CloudSettings(rasterize_mode=mode, **base)
+        fpc = H.frame_params(n, v, s)
+        rng = np.array(oracle.depth_range(c, e, v, s) if mode == RasterizeMode.Depth else (0, 0), np.float32)
+        out = H.ShimOut()
+        drawn = 0
+        for i in range(n):
+            H.shim().shim_project(ctypes.byref(fpc), int(e[i]["key"]), H._fp(pv[i]), H._fp(rot[i]), H._fp(so[i]),
+                                  H._fp(sh[i]), H._fp(rng), ctypes.byref(out))
+            ref = oracle.vs_sorted(c, e, i, v, s)
+            if out.draw:   # (the on-axis splat has a NaN OBB in the reference's own maths: nothing to draw)
+                assert not ref.discard
+                assert np.allclose(list(out.color), list(ref.color), atol=2e-6), (mode, i)
+                drawn += 1
+        assert drawn >= 3

@@ -14,6 +14,7 @@ import helpers as H
 from bevy_gaussian_splatting_amd import (
     CloudSettings, GaussianColorSpace, GaussianMode, PlanarGaussian3d, RadixSortDepthBits, SortMode,
     View, random_gaussians_3d_seeded, transform_from, rotation_y)
+from bevy_gaussian_splatting_amd import RasterizeMode, compute_aabb
 from bevy_gaussian_splatting_amd.multiview import headless_view
 
 pytestmark = pytest.mark.gpu
@@ -515,4 +516,57 @@ def test_ply_loaded_cloud_renders_like_the_oracle(plugin, oracle, binning, tmp_p
         assert np.array_equal(gs["key"], e["key"]) and np.array_equal(gs["index"], e["index"])
         ref, amb = oracle.render(loaded, e, v, s, with_ambiguity=True)
         _assert_image(ref, got, amb, what=f"ply {kw}")
+        h.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# RasterizeMode colour variants (src/render/gaussian.wgsl:312-405)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [RasterizeMode.Classification, RasterizeMode.Depth, RasterizeMode.Normal,
+                                  RasterizeMode.Position])
+def test_rasterize_modes(plugin, oracle, binning, mode):
+    c = random_gaussians_3d_seeded(6000, 23)
+    c.position_visibility[:, 3] = (np.arange(len(c)) % 8).astype(np.float32)   # classes for Classification
+    mn, mx = compute_aabb(c)
+    v = View.headless(160, 90)
+    tr = transform_from((0.5, -0.25, 0.0), rotation_y(0.3))
+    for kw in ({}, {"aabb": True}, {"gaussian_mode": GaussianMode.Gaussian2d, "aabb": True},
+               {"sort_mode": SortMode.Rayon}, {"radix_sort_depth_bits": RadixSortDepthBits.Bits16}):
+        s = CloudSettings(rasterize_mode=mode, position_min=mn, position_max=mx, num_classes=5, transform=tr, **kw)
+        for cloud in ((c, c.to_f16()) if not kw else (c,)):
+            h = plugin.upload(cloud)
+            got = plugin.render(h, v, s)
+            cd = oracle.decode_f16(cloud) if cloud is not c else c
+            e = oracle.sort(cd, v, s)
+            if s.sort_mode == SortMode.Radix:
+                assert (e["key"] == (0xFFFFFFFF >> (32 - int(s.radix_sort_depth_bits)))).any()  # Depth reads the culled tail
+                gs = plugin.sort(h, v, s)
+                assert np.array_equal(gs["index"], e["index"])
+            else:
+                e = plugin.sort(h, v, s)   # unstable-sort contract: draw in the device's (valid) order
+            ref, amb = oracle.render(cd, e, v, s, with_ambiguity=True)
+            _assert_image(ref, got, amb, what=f"{mode.name} {kw}")
+            assert np.abs(got[..., :3]).max() > 0.05
+            h.free()
+
+
+def test_rasterize_mode_edge_cases(plugin, oracle):
+    v = View.headless(64, 64)
+    one = PlanarGaussian3d(np.array([[0.3, 1.2, 0, 1]], np.float32), np.zeros((1, 48), np.float32),
+                           np.array([[1, 0, 0, 0]], np.float32), np.array([[0.5, 0.5, 0.5, 0.9]], np.float32))
+    for mode in (RasterizeMode.Depth, RasterizeMode.Normal, RasterizeMode.Position, RasterizeMode.Classification):
+        s = CloudSettings(rasterize_mode=mode, position_min=(-1, -1, -1), position_max=(1, 2, 1))
+        h = plugin.upload(one)
+        got = plugin.render(h, v, s)     # Depth with one splat: min == max -> 0/0 -> NaN colour, like the oracle
+        e = oracle.sort(one, v, s)
+        ref, amb = oracle.render(one, e, v, s, with_ambiguity=True)
+        assert np.array_equal(np.isnan(ref), np.isnan(got))
+        m = ~np.isnan(ref)
+        ok, err = H.tolerance_mask(np.where(m, ref, 0), np.where(m, got, 0), amb)
+        assert ok.all(), (mode, err.max())
+        h.free()
+    for bad in (RasterizeMode.OpticalFlow, RasterizeMode.Velocity):
+        h = plugin.upload(one)
+        with pytest.raises(Exception, match="rasterize_mode"):
+            plugin.render(h, v, CloudSettings(rasterize_mode=bad))
         h.free()
