@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splats", type=int, default=N_SPLATS)
-    ap.add_argument("--depth", type=int, default=3, help="frames in flight (pipeline lanes, 1..4)")
+    ap.add_argument("--depth", type=int, default=3, help="frames in flight (pipeline lanes, 1..8)")
     args = ap.parse_args()
 
     import torch
@@ -165,7 +165,7 @@ def main():
     handle = plugin.upload(cloud)
     view = headless_view(rank, WIDTH, HEIGHT)  # rank g owns camera g
     settings = CloudSettings()
-    DEPTH = max(1, min(4, args.depth))  # frames in flight (lanes); 1 = a single stream
+    DEPTH = max(1, min(8, args.depth))  # frames in flight (lanes); 1 = a single stream
     plugin.set_async(True)
     plugin.set_pipeline_depth(DEPTH)
     # every kernel of every 4th frame is bracketed by HIP events (a record costs ~4 us of GPU time)

@@ -50,7 +50,7 @@ constexpr uint64_t MAX_INSTANCE_CAPACITY = 1ull << 30;  // look-back words carry
 constexpr uint32_t MAX_SPLATS = (1u << 30) - 1u;
 constexpr int EV_COUNT = BGS_STAGE_COUNT + 1;
 constexpr int EV_RING = 64;   // per-stage timings are averaged over up to this many frames per lane
-constexpr int MAX_LANES = 4;
+constexpr int MAX_LANES = 8;
 
 template <class T>
 T* dev_alloc(size_t count) {
@@ -921,7 +921,7 @@ int bgs_set_async(bgs_ctx* ctx, int enabled) {
 
 int bgs_set_pipeline_depth(bgs_ctx* ctx, uint32_t lanes) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
-    if (lanes < 1 || lanes > (uint32_t)MAX_LANES) return fail(ctx, BGS_EINVAL, "pipeline depth must be 1..4");
+    if (lanes < 1 || lanes > (uint32_t)MAX_LANES) return fail(ctx, BGS_EINVAL, "pipeline depth must be 1..8");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
     int rc = finish_all(ctx);
     if (rc != BGS_OK) return rc;

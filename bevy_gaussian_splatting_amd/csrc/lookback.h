@@ -1,0 +1,85 @@
+// lookback.h — decoupled look-back over the status words of a chained scan (device only).
+//
+// Every tile publishes STATUS_AGGREGATE | total as soon as it knows its local total, then sums
+// its predecessors' words until it meets a STATUS_PREFIX (inclusive prefix). With every tile of a
+// launch resident at once, all aggregates appear at about the same time and a walk that consumes
+// B predecessors per L2 round trip (tau ~ 1 us under load) finishes tile j after ~ j / (2B) round
+// trips, because the prefix frontier and the walkers move towards each other at B tiles per tau.
+// Measured (profiles/r1_v7 timeline): with B = 4 that walk WAS the kernel time of keygen (488
+// tiles, 29 us) and project_bin (470 tiles, 58 us). Hence: a whole wave per hop (64 predecessors)
+// where the block has one chain, and 16 per hop where each thread owns a chain (one per digit).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bgs_device.h"
+
+namespace bgs {
+
+constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 22;  // bounded spin (watchdog, never expected)
+
+__device__ __forceinline__ uint32_t lb_load(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One chain per THREAD (status words `stride` apart): B predecessors per round trip, consumed in
+// order up to the first unpublished word or the first inclusive prefix.
+template <int B>
+__device__ __forceinline__ uint32_t lookback_u32(const uint32_t* chain, uint32_t tile, uint32_t stride,
+                                                 uint32_t* error_flag, uint32_t error_code) {
+    uint32_t excl = 0u, spins = 0u;
+    int p = (int)tile - 1;
+    while (p >= 0) {
+        uint32_t v[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) v[b] = p - b >= 0 ? lb_load(chain + (size_t)(p - b) * stride) : STATUS_PREFIX;
+        int used = 0;
+        bool finished = false;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            if (finished || used != b) continue;
+            const uint32_t flag = v[b] >> STATUS_FLAG_SHIFT;
+            if (flag == 0u) continue;           // not published yet: retry from p - b
+            excl += v[b] & STATUS_VALUE_MASK;
+            used = b + 1;
+            if (flag == 2u) finished = true;    // inclusive prefix: done
+        }
+        if (finished) break;
+        if (used == 0) {
+            if (++spins > LOOKBACK_SPIN_LIMIT) { atomicOr(error_flag, error_code); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        p -= used;
+    }
+    return excl;
+}
+
+// One chain per BLOCK (contiguous status words): called by all 64 lanes of ONE wave; lane l reads
+// predecessor p - l, so a hop covers 64 tiles. Returns the exclusive prefix in every lane.
+__device__ __forceinline__ uint32_t lookback_wave(const uint32_t* chain, uint32_t tile, int lane,
+                                                  uint32_t* error_flag, uint32_t error_code) {
+    uint32_t excl = 0u, spins = 0u;
+    int p = (int)tile - 1;
+    while (p >= 0) {
+        const int idx = p - lane;
+        const uint32_t v = idx >= 0 ? lb_load(chain + idx) : STATUS_PREFIX;
+        const uint32_t flag = v >> STATUS_FLAG_SHIFT;
+        const unsigned long long unpub = __ballot(flag == 0u), pref = __ballot(flag == 2u);
+        const int first_unpub = unpub ? (int)__builtin_ctzll(unpub) : 64;
+        const int first_pref = pref ? (int)__builtin_ctzll(pref) : 64;
+        const bool done = first_pref < first_unpub;
+        const int take = done ? first_pref + 1 : first_unpub;  // lanes [0, take) are consumed
+        uint32_t c = lane < take ? (v & STATUS_VALUE_MASK) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        excl += c;
+        if (done) break;
+        if (take == 0) {
+            if (++spins > LOOKBACK_SPIN_LIMIT) { if (lane == 0) atomicOr(error_flag, error_code); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        p -= take;
+    }
+    return excl;
+}
+
+}  // namespace bgs

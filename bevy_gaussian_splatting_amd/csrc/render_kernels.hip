@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "lookback.h"
 #include "splat_math.h"
 
 namespace bgs {
@@ -43,39 +44,6 @@ constexpr unsigned long long S64_VALUE_MASK = (1ull << S64_FLAG_SHIFT) - 1ull;
 constexpr unsigned long long S64_AGGREGATE = 1ull << S64_FLAG_SHIFT;
 constexpr unsigned long long S64_PREFIX = 2ull << S64_FLAG_SHIFT;
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
-
-// batched decoupled look-back (see sort_kernels.hip): 4 predecessors per L2 round trip
-__device__ __forceinline__ uint32_t lookback_u32(const uint32_t* chain, uint32_t tile, uint32_t stride,
-                                                 uint32_t* error_flag, uint32_t error_code) {
-    uint32_t excl = 0u, spins = 0u;
-    int p = (int)tile - 1;
-    while (p >= 0) {
-        uint32_t v[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            v[b] = p - b >= 0 ? __hip_atomic_load(chain + (size_t)(p - b) * stride, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT)
-                              : STATUS_PREFIX;
-        int used = 0;
-        bool finished = false;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (finished || used != b) continue;
-            const uint32_t flag = v[b] >> STATUS_FLAG_SHIFT;
-            if (flag == 0u) continue;
-            excl += v[b] & STATUS_VALUE_MASK;
-            used = b + 1;
-            if (flag == 2u) finished = true;
-        }
-        if (finished) break;
-        if (used == 0) {
-            if (++spins > SPIN_LIMIT) { atomicOr(error_flag, error_code); break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        p -= used;
-    }
-    return excl;
-}
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -432,11 +400,16 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
             uint32_t excl = 0u;
             if (tile > 0u) {
                 __hip_atomic_store(my_status, STATUS_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                excl = lookback_u32(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u);
+                excl = lookback_u32<16>(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u);
             }
             __hip_atomic_store(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tile == num_tiles - 1u) ctl->coarse_total[tid] = excl + total;
+            // Append the block's hits to this supertile's list in rank order. (Measured alternatives,
+            // same process, dense / sparse workload: this serial bit walk 62.5 / 52.9 us per launch;
+            // rank-centric stores 64.5 / 52.3; a wave-cooperative sweep over all supertile x wave masks
+            // 66.7 / 63.2; no stores at all 51.0 / 50.9 — the ~11 us are the scattered 4-byte stores
+            // themselves, not the loop shape.)
             if (!(fp.debug & 8u)) {  // ablation bit 8: chain but no list writes
                 uint32_t* __restrict__ dst = coarse + (size_t)tid * coarse_cap;
                 uint32_t pos = excl;

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "lookback.h"
 #include "splat_math.h"
 
 namespace bgs {
@@ -57,39 +58,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 }
 
 constexpr int KG_ITEMS = 8;  // splats per thread in keygen
-constexpr uint32_t SPIN_LIMIT = 1u << 22;  // bounded look-back spin (watchdog, never expected)
-
-// Decoupled look-back over predecessor tiles of one chain (status words `stride` apart).
-// With every tile in flight at once a one-hop-at-a-time walk serialises ~tile/2 dependent L2
-// round trips, so 4 predecessors are fetched per round trip and consumed in order.
-__device__ __forceinline__ uint32_t lookback_u32(const uint32_t* chain, uint32_t tile, uint32_t stride,
-                                                 uint32_t* error_flag, uint32_t error_code) {
-    uint32_t excl = 0u, spins = 0u;
-    int p = (int)tile - 1;
-    while (p >= 0) {
-        uint32_t v[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) v[b] = p - b >= 0 ? ld_agent(chain + (size_t)(p - b) * stride) : STATUS_PREFIX;
-        int used = 0;
-        bool finished = false;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (finished || used != b) continue;
-            const uint32_t flag = v[b] >> STATUS_FLAG_SHIFT;
-            if (flag == 0u) continue;           // not published yet: retry from p - b
-            excl += v[b] & STATUS_VALUE_MASK;
-            used = b + 1;
-            if (flag == 2u) finished = true;    // inclusive prefix: done
-        }
-        if (finished) break;
-        if (used == 0) {
-            if (++spins > SPIN_LIMIT) { atomicOr(error_flag, error_code); break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        p -= used;
-    }
-    return excl;
-}
+constexpr int LOOKBACK_BATCH = 16;  // predecessors per round trip of a per-digit chain (lookback.h)
 
 }  // namespace
 
@@ -159,18 +128,20 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
             }
         }
         const uint32_t total = run;
-        if (tid == 0) {
+        if (wave == 0) {  // one chain per block: the whole wave walks it, 64 predecessors per hop
             uint32_t* const my_status = part_status + tile;
             uint32_t excl = 0u;
             if (tile > 0u) {
-                st_agent(my_status, STATUS_AGGREGATE | total);
-                excl = lookback_u32(part_status, tile, 1u, &ctl->error, 8u);
+                if (lane == 0) st_agent(my_status, STATUS_AGGREGATE | total);
+                excl = lookback_wave(part_status, tile, lane, &ctl->error, 8u);
             }
-            st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
-            s_base = excl;
-            if (tile == num_tiles - 1u) {
-                ctl->draw_count = excl + total;
-                ctl->splat_count = fp.n;
+            if (lane == 0) {
+                st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
+                s_base = excl;
+                if (tile == num_tiles - 1u) {
+                    ctl->draw_count = excl + total;
+                    ctl->splat_count = fp.n;
+                }
             }
         }
         __syncthreads();
@@ -323,7 +294,7 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
         uint32_t excl = 0u;
         if (tile > 0u) {
             st_agent(my_status, STATUS_AGGREGATE | total);
-            excl = lookback_u32(status + tid, tile, RADIX_BASE, error_flag, 1u);
+            excl = lookback_u32<LOOKBACK_BATCH>(status + tid, tile, RADIX_BASE, error_flag, 1u);
         }
         st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
 

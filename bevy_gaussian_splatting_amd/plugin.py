@@ -28,8 +28,12 @@ SORT_ENTRY_DTYPE = np.dtype([("key", np.uint32), ("index", np.uint32)])
 
 @dataclass
 class SortedEntries:
-    """src/sort/mod.rs:331-393: `camera_count * entry_count` (key, index) pairs; camera `c`
-    owns `sorted[c * entry_count : (c + 1) * entry_count]` (src/sort/rayon.rs:82-84)."""
+    """src/sort/mod.rs:331-393: `camera_count * entry_count` (key, index) pairs, where the creator
+    passes `entry_count = cloud.len_sqrt_ceil()**2` (src/sort/mod.rs:259-262). Camera `c` owns the
+    chunk `sorted[c * gaussians : (c + 1) * gaussians]` with `gaussians = cloud.len()` — the stride is
+    the CLOUD length, not entry_count, both where the sort writes (`chunks_mut(gaussians).nth(
+    camera_index)`, src/sort/rayon.rs:82-84) and where the draw binds (dynamic offset
+    `camera_index * 8 * cloud.len()`, src/render/mod.rs:1548-1554); the square-padding tail is unused."""
 
     camera_count: int
     entry_count: int
@@ -42,8 +46,22 @@ class SortedEntries:
         s["index"] = np.tile(np.arange(entry_count, dtype=np.uint32), camera_count)
         return SortedEntries(camera_count, entry_count, s)
 
-    def chunk(self, camera_index: int) -> np.ndarray:
-        return self.sorted[camera_index * self.entry_count : (camera_index + 1) * self.entry_count]
+    @staticmethod
+    def for_cloud(camera_count: int, cloud_len: int) -> "SortedEntries":
+        """`auto_insert_sorted_entries` (src/sort/mod.rs:218-268)."""
+        side = int(np.ceil(np.sqrt(np.float32(cloud_len))))
+        return SortedEntries.new(camera_count, side * side)
+
+    def chunk(self, camera_index: int, gaussians: Optional[int] = None) -> np.ndarray:
+        g = self.entry_count if gaussians is None else int(gaussians)
+        if camera_index < 0 or (camera_index + 1) * g > self.sorted.shape[0]:
+            raise IndexError("camera chunk out of range")  # `.nth(camera_index).unwrap()` panics
+        return self.sorted[camera_index * g : (camera_index + 1) * g]
+
+    def resized(self, camera_count: int) -> "SortedEntries":
+        """`update_sorted_entries_sizes` (src/sort/mod.rs:270-296): a camera-count change re-creates
+        the asset (all chunks back to key 1 / identity order)."""
+        return self if camera_count == self.camera_count else SortedEntries.new(camera_count, self.entry_count)
 
 
 class PlanarGaussian3dHandle:
@@ -145,6 +163,32 @@ class GaussianSplattingPlugin:
         self._check(self._lib.bgs_sort(self._ctx, handle._ptr, ctypes.byref(v), ctypes.byref(s), ptr))
         return out
 
+    def sort_cameras(self, handle: PlanarGaussian3dHandle, views, settings: CloudSettings,
+                     sorted_entries: Optional[SortedEntries] = None, camera_indices=None) -> SortedEntries:
+        """Multi-camera entry layout (src/sort/mod.rs:331-393): depth-sort the cloud for each view and
+        store the result in that camera's chunk of one `SortedEntries`. `views[i]` belongs to camera
+        index `camera_indices[i]` (default i = `Camera.order`, src/sort/mod.rs:171-176). Unlike the
+        reference's GPU radix path, which only ever sorts into chunk 0 (TODO at src/sort/mod.rs:427),
+        every camera gets its own order here. Cameras whose trigger does not ask for a sort are simply
+        left out of `views`; their chunks keep their previous content."""
+        views = list(views)
+        idx = list(range(len(views))) if camera_indices is None else [int(i) for i in camera_indices]
+        if len(idx) != len(views):
+            raise ValueError("camera_indices must match views")
+        count = (max(idx) + 1) if idx else 0
+        if sorted_entries is None:
+            sorted_entries = SortedEntries.for_cloud(count, handle.n)
+        if count > sorted_entries.camera_count:
+            raise ValueError("sorted_entries has fewer camera chunks than the camera indices need")
+        for view, ci in zip(views, idx):
+            chunk = sorted_entries.chunk(ci, handle.n)
+            v, s = view.to_native(), settings.to_native()
+            tmp = np.empty(handle.n, dtype=SORT_ENTRY_DTYPE)
+            self._check(self._lib.bgs_sort(self._ctx, handle._ptr, ctypes.byref(v), ctypes.byref(s),
+                                           tmp.ctypes.data_as(ctypes.POINTER(_native.BgsSortEntry))))
+            chunk[:] = tmp
+        return sorted_entries
+
     def render(self, handle: PlanarGaussian3dHandle, view: View, settings: CloudSettings,
                download: bool = True) -> Optional[np.ndarray]:
         """Sort + project + bin + rasterize one view. Returns [H, W, 4] float32
@@ -189,7 +233,7 @@ class GaussianSplattingPlugin:
         self._check(self._lib.bgs_set_profiling_stride(self._ctx, int(every_nth_frame)))
 
     def set_pipeline_depth(self, lanes: int) -> None:
-        """Frames in flight (1..4), each on its own HIP stream; see bgs_set_pipeline_depth."""
+        """Frames in flight (1..8), each on its own HIP stream; see bgs_set_pipeline_depth."""
         self._check(self._lib.bgs_set_pipeline_depth(self._ctx, int(lanes)))
 
     def set_output_srgb8(self, enabled: bool) -> None:

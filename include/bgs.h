@@ -209,7 +209,7 @@ int bgs_framebuffer_srgb8_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes)
  * watchdog check) when the lane is reused. bgs_pipeline_pop completes the OLDEST frame in flight
  * and returns its f32 / sRGB8 framebuffers (valid until that lane is reused, i.e. for depth-1 more
  * enqueues). bgs_framebuffer_device_ptr & co refer to the most recently enqueued frame. */
-int bgs_set_pipeline_depth(bgs_ctx* ctx, uint32_t lanes /* 1..4, default 1 */);
+int bgs_set_pipeline_depth(bgs_ctx* ctx, uint32_t lanes /* 1..8, default 1 */);
 int bgs_pipeline_pop(bgs_ctx* ctx, void** rgba_f32_dptr_or_null, void** rgba8_dptr_or_null);
 int bgs_frames_in_flight(bgs_ctx* ctx, uint32_t* count);
 

@@ -10,7 +10,7 @@ cloud = random_gaussians_3d_seeded(1_000_000, 2)
 p = GaussianSplattingPlugin(0)
 h = p.upload(cloud)
 v = headless_view(0)
-for gs in (1.0, 0.05):
+for gs in (1.0, 0.05, 1.0, 0.05):
     s = CloudSettings(global_scale=gs)
     for flags in flag_sets:
         p.set_debug_flags(flags)

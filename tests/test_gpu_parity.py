@@ -570,3 +570,30 @@ def test_rasterize_mode_edge_cases(plugin, oracle):
         with pytest.raises(Exception, match="rasterize_mode"):
             plugin.render(h, v, CloudSettings(rasterize_mode=bad))
         h.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-camera entry layout (src/sort/mod.rs:331-393)
+# ---------------------------------------------------------------------------------------------
+def test_multi_camera_sorted_entries_layout(plugin, oracle):
+    n = 5003   # not a perfect square: the asset is padded to 71*71 = 5041 entries per camera
+    c = random_gaussians_3d_seeded(n, 31)
+    views = [headless_view(g, 160, 90) for g in range(3)]
+    s = CloudSettings()
+    h = plugin.upload(c)
+    se = plugin.sort_cameras(h, views, s)
+    assert se.camera_count == 3 and se.entry_count == 71 * 71 and se.sorted.shape == (3 * 71 * 71,)
+    for g, v in enumerate(views):
+        ref = oracle.sort(c, v, s)
+        chunk = se.sorted[g * n:(g + 1) * n]     # stride = cloud length, like the reference's draw offset
+        assert np.array_equal(chunk["key"], ref["key"]) and np.array_equal(chunk["index"], ref["index"])
+    assert np.all(se.sorted["key"][3 * n:] == 1)  # padding tail untouched
+    # only camera 1's trigger fires: the other chunks keep their content
+    before = se.sorted.copy()
+    moved = headless_view(5, 160, 90)
+    plugin.sort_cameras(h, [moved], s, sorted_entries=se, camera_indices=[1])
+    assert np.array_equal(se.sorted[:n], before[:n]) and np.array_equal(se.sorted[2 * n:], before[2 * n:])
+    assert np.array_equal(se.sorted[n:2 * n]["index"], oracle.sort(c, moved, s)["index"])
+    with pytest.raises(ValueError):
+        plugin.sort_cameras(h, [moved], s, sorted_entries=se, camera_indices=[3])
+    h.free()

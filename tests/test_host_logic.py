@@ -36,6 +36,15 @@ def test_sorted_entries_initialisation():
     se = SortedEntries.new(3, 5)  # src/sort/mod.rs:347-354
     assert se.sorted.shape == (15,) and np.all(se.sorted["key"] == 1)
     assert se.chunk(2)["index"].tolist() == [0, 1, 2, 3, 4]
+    # auto_insert_sorted_entries sizes the asset with the square-padded length (src/sort/mod.rs:259-262) but the
+    # sort and the draw stride by the CLOUD length (src/sort/rayon.rs:82-84, src/render/mod.rs:1548-1554)
+    se = SortedEntries.for_cloud(2, 10)
+    assert se.entry_count == 16 and se.sorted.shape == (32,)
+    se.chunk(1, 10)["index"][:] = 7
+    assert np.all(se.sorted["index"][10:20] == 7) and se.sorted["index"][9] == 9 and se.sorted["index"][20] == 4
+    with pytest.raises(IndexError):
+        se.chunk(4, 10)
+    assert se.resized(2) is se and se.resized(3).sorted.shape == (48,) and np.all(se.resized(3).sorted["key"] == 1)
 
 
 def test_random_cloud_distributions_and_determinism():
