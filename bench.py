@@ -101,32 +101,58 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
 
 
 def cpu_baseline(cloud, view, settings):
-    """The oracle (C restatement, OpenMP over all host cores) on a bounded sample of the SAME
-    workload: the full 1M-splat sort + the vertex stage for every splat + the raster of the
-    centred 480x270 window (1/16 of the frame), raster time scaled x16."""
+    """The oracle (C restatement, OpenMP) on a bounded sample of the SAME workload:
+    all host cores: the full 1M-splat sort (both reference sorts: the radix semantics and the
+    rayon/std descending-f32 semantics) + the vertex stage for every splat + the raster of the centred
+    480x270 window (1/16 of the frame, time scaled x16); and the same pinned to ONE core with a
+    120x68 window (1/254 of the frame). About 15-25 s of CPU work in total."""
     from oracle import oracle
+    from bevy_gaussian_splatting_amd import CloudSettings, SortMode
 
     oracle.build()
+    all_cores = oracle.max_threads()
+
+    def frame(window_w, window_h):
+        t0 = time.perf_counter()
+        entries = oracle.sort(cloud, view, settings)
+        t_sort = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        oracle.render(cloud, entries, view, settings, window=(0, 0, 1, 1))
+        t_vs = time.perf_counter() - t0
+        x0, y0 = (WIDTH - window_w) // 2, (HEIGHT - window_h) // 2
+        t0 = time.perf_counter()
+        oracle.render(cloud, entries, view, settings, window=(x0, y0, x0 + window_w, y0 + window_h))
+        t_win = max(time.perf_counter() - t0 - t_vs, 1e-6)
+        scale = (WIDTH * HEIGHT) / float(window_w * window_h)
+        return t_sort, t_vs, t_win, scale
+
+    t_sort, t_vs, t_win, scale = frame(480, 270)
     t0 = time.perf_counter()
-    entries = oracle.sort(cloud, view, settings)
-    t_sort = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    oracle.render(cloud, entries, view, settings, window=(0, 0, 1, 1))
-    t_vs = time.perf_counter() - t0
-    x0, y0 = (WIDTH - 480) // 2, (HEIGHT - 270) // 2
-    t0 = time.perf_counter()
-    oracle.render(cloud, entries, view, settings, window=(x0, y0, x0 + 480, y0 + 270))
-    t_win = max(time.perf_counter() - t0 - t_vs, 1e-6)
-    t_frame = t_sort + t_vs + 16.0 * t_win
+    oracle.sort(cloud, view, CloudSettings(sort_mode=SortMode.Rayon))
+    t_sort_std = time.perf_counter() - t0
+    t_frame = t_sort + t_vs + scale * t_win
+
+    oracle.set_threads(1)
+    try:
+        s1, v1, w1, sc1 = frame(120, 68)
+    finally:
+        oracle.set_threads(all_cores)
+    t_frame1 = s1 + v1 + sc1 * w1
     return {
         "value": 1.0 / t_frame,
         "unit": "frames/s",
-        "cores": oracle.max_threads(),
+        "cores": all_cores,
         "kind": "port",
         "sample": ("oracle/bgs_oracle.c (gcc -O2 -fopenmp): full 1M-splat keygen+LSD radix sort "
                    f"({t_sort:.3f}s) + vertex stage of all splats ({t_vs:.3f}s) + raster of the centred "
-                   f"480x270 window ({t_win:.2f}s, scaled x16 to the 1920x1080 frame)"),
+                   f"480x270 window ({t_win:.2f}s, scaled x{scale:.0f} to the 1920x1080 frame)"),
         "sort_msplats_per_s": len(cloud) / t_sort / 1e6,
+        "sort_std_msplats_per_s": len(cloud) / t_sort_std / 1e6,
+        "sort_std_note": "rayon/std semantics (src/sort/rayon.rs:86-104): keygen + descending-f32 comparison sort (qsort, 1 thread)",
+        "one_core": {"value": 1.0 / t_frame1, "unit": "frames/s", "cores": 1,
+                     "sort_msplats_per_s": len(cloud) / s1 / 1e6,
+                     "sample": (f"same, OMP threads = 1: sort {s1:.3f}s + vertex stage {v1:.2f}s + 120x68 window "
+                                f"({w1:.2f}s, scaled x{sc1:.0f})")},
     }
 
 
@@ -330,7 +356,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cloud, view, settings)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)
-            out["cpu_baseline"]["sort_msplats_per_s"] = round(out["cpu_baseline"]["sort_msplats_per_s"], 2)
+            cb = out["cpu_baseline"]
+            cb["sort_msplats_per_s"] = round(cb["sort_msplats_per_s"], 2)
+            cb["sort_std_msplats_per_s"] = round(cb["sort_std_msplats_per_s"], 2)
+            cb["one_core"]["value"] = round(cb["one_core"]["value"], 6)
+            cb["one_core"]["sort_msplats_per_s"] = round(cb["one_core"]["sort_msplats_per_s"], 2)
         else:
             out["cpu_baseline"] = None
     if dist is not None:

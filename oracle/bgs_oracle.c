@@ -1016,6 +1016,14 @@ void oracle_encode_srgb8(const float* rgba, uint32_t n, uint8_t* out) {
     }
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -145,6 +145,8 @@ int oracle_instance_stats(const oracle_cloud* cloud, const bgs_sort_entry* entri
 void oracle_encode_srgb8(const float* rgba, uint32_t n, uint8_t* out);
 
 int oracle_max_threads(void);
+/* OpenMP threads used by keygen / render from now on (bench.py: the pinned 1-core baseline). */
+void oracle_set_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,8 @@ def lib() -> ctypes.CDLL:
         l.oracle_instance_stats.restype = ctypes.c_int
         l.oracle_encode_srgb8.argtypes = [fp, u32, ctypes.POINTER(ctypes.c_uint8)]
         l.oracle_encode_srgb8.restype = None
+        l.oracle_set_threads.argtypes = [ctypes.c_int]
+        l.oracle_set_threads.restype = None
         l.oracle_max_threads.argtypes = []
         l.oracle_max_threads.restype = ctypes.c_int
         _lib = l
@@ -281,3 +283,7 @@ def encode_srgb8(rgba: np.ndarray) -> np.ndarray:
 
 def max_threads() -> int:
     return int(lib().oracle_max_threads())
+
+
+def set_threads(n: int) -> None:
+    lib().oracle_set_threads(int(n))
