@@ -53,13 +53,13 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
     P = WIDTH * HEIGHT
     B = cloud_bytes_per_splat
     if stats.get("binning") == "scan":
-        # I = coarse (supertile) list entries: written once by project_bin (4 B), read once by the
-        # rasteriser (4 B) which also reads each visible record at least once
+        # I = coarse (supertile) list entries (rank + tile rect, 8 B): written once by project_bin, read
+        # once by the rasteriser, which also reads each visible record at least once
         return {
             "keygen": {"bytes": N * 16 + N * 8, "launches": 1},
             "depth_sort": {"bytes": k * D * 16, "launches": max(k, 1)},
-            "project": {"bytes": V * 8 + V * (B - 16) + V * rec_bytes + V * 4 + I * 4, "launches": 1},
-            "raster": {"bytes": I * 4 + V * 4 + V * rec_bytes + P * 16, "launches": 1},
+            "project": {"bytes": V * 8 + V * (B - 16) + V * rec_bytes + I * 8, "launches": 1},
+            "raster": {"bytes": I * 8 + V * rec_bytes + P * 16, "launches": 1},
         }
     return {
         "keygen": {"bytes": N * 16 + N * 8, "launches": 1},

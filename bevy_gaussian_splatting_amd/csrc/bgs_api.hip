@@ -8,7 +8,7 @@
 //   memset(zeroed scratch: Control | look-back words)
 //   keygen                        N x (16 B read, 8 B write) + digit histograms + stable partition
 //   onesweep x places             the V' drawable depth keys, 16 B/pair/pass
-//   project_bin                   V' splats -> records, rects (front-to-back) + ordered coarse lists
+//   project_bin                   V' splats -> records (front-to-back) + ordered coarse lists of (rank, tile rect)
 //   raster_scan                   one wave per 16x16 tile, lazy binning, saturation exit
 //   [encode_srgb8]                optional Rgba8UnormSrgb image (the reference's target format)
 //   copy Control -> pinned host   read when the frame is completed
@@ -79,9 +79,7 @@ struct Lane {
     size_t records_bytes = 0;
     uint2* inst[2] = {nullptr, nullptr};  // BINNING_SORT only
     uint64_t inst_cap = 0;
-    uint32_t* rects = nullptr;   // BINNING_SCAN: packed tile rectangle per rank
-    uint32_t rects_cap = 0;
-    uint32_t* coarse = nullptr;  // BINNING_SCAN: [num_supertiles][coarse_cap] ordered rank lists
+    uint32_t* coarse = nullptr;  // BINNING_SCAN: [num_supertiles][coarse_cap] ordered (rank, tile rect) lists
     size_t coarse_words = 0;
     float4* fb = nullptr;
     size_t fb_pixels = 0;
@@ -172,7 +170,6 @@ void lane_destroy(Lane& L) {
     if (L.culled) (void)hipFree(L.culled);
     for (auto e : L.inst) if (e) (void)hipFree(e);
     if (L.records) (void)hipFree(L.records);
-    if (L.rects) (void)hipFree(L.rects);
     if (L.coarse) (void)hipFree(L.coarse);
     if (L.fb) (void)hipFree(L.fb);
     if (L.fb8) (void)hipFree(L.fb8);
@@ -261,14 +258,9 @@ int ensure_records(bgs_ctx* ctx, Lane& L, size_t bytes) {
 }
 
 int ensure_coarse(bgs_ctx* ctx, Lane& L, uint32_t n, uint32_t num_st) {
-    if (n > L.rects_cap || !L.rects) {
-        if (L.rects) (void)hipFree(L.rects);
-        L.rects = dev_alloc<uint32_t>(n);
-        if (!L.rects) return fail(ctx, BGS_ENOMEM, "hipMalloc(rects) failed");
-        L.rects_cap = n;
-    }
-    // worst case: every rank lands in every supertile list -> num_st * n words (no overflow path)
-    const size_t words = (size_t)num_st * std::max<uint32_t>(n, 1);
+    // worst case: every rank lands in every supertile list -> num_st * n entries of 2 words
+    // (rank, tile rectangle); no overflow path
+    const size_t words = 2 * (size_t)num_st * std::max<uint32_t>(n, 1);
     if (words > L.coarse_words || !L.coarse) {
         if (words * sizeof(uint32_t) > (64ull << 30))
             return fail(ctx, BGS_ECAPACITY, "coarse bin lists would exceed 64 GiB; use bgs_set_binning(ctx, 1)");
@@ -378,8 +370,8 @@ int finish_lane(bgs_ctx* ctx, Lane& L, uint64_t* need_cap) {
         if (render) {
             const uint64_t B = L.pending_is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
             const uint64_t P = (uint64_t)L.pending_w * L.pending_h;
-            if (scan)  // coarse entries: written once (4 B), read by the tiles of their supertile
-                bytes += V * (B - 16) + V * R + V * 8 + I * 4 + I * 4 + P * 16;
+            if (scan)  // coarse entries (rank + tile rect, 8 B): written once, read by the tiles of their supertile
+                bytes += V * (B - 16) + V * R + V * 8 + I * 8 + I * 8 + P * 16;
             else
                 bytes += V * (B - 16) + V * R + I * 8 + 2 * I * 16 + I * (4 + R) + P * 16;
         }
@@ -530,10 +522,10 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
 
     if (render && scan) {
         const uint32_t coarse_cap = std::max<uint32_t>(n, 1);
-        launch_project_bin(st, fp, cloud->ptrs, draw_list, L.culled, ctl, bin_status, L.records, L.rects, L.coarse, coarse_cap,
+        launch_project_bin(st, fp, cloud->ptrs, draw_list, L.culled, ctl, bin_status, L.records, L.coarse, coarse_cap,
                            sup_shift, /*ticket_slot=*/4, ctx->num_cus * 2);
         mark(3);
-        launch_raster_scan(st, fp, L.records, L.rects, L.coarse, coarse_cap, sup_shift, ctl, L.fb,
+        launch_raster_scan(st, fp, L.records, L.coarse, coarse_cap, sup_shift, ctl, L.fb,
                            view->clear_color);
         mark(6);
     } else if (render) {

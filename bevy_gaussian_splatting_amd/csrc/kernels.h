@@ -63,14 +63,14 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
 // are the "digits" of the same chained-scan look-back the radix sort uses.
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status, void* records,
-                        uint32_t* rects, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
+                        uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
                         uint32_t ticket_slot, int max_blocks);
 
 // Tile rasteriser for BINNING_SCAN: walks the supertile's ordered list, keeps the ranks whose
 // rectangle contains this tile (order-preserving ballot compaction), stages their records in LDS
 // and composites front-to-back until the tile saturates.
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* records,
-                        const uint32_t* rects, const uint32_t* coarse, uint32_t coarse_cap,
+                        const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_shift, const Control* ctl, float4* framebuffer,
                         const float clear_color[4]);
 

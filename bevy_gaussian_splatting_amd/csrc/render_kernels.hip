@@ -331,7 +331,6 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
                                                           const uint2* __restrict__ culled,
                                                           Control* ctl, uint32_t* bin_status,
                                                           float4* __restrict__ records,
-                                                          uint32_t* __restrict__ rects,
                                                           uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_shift,
                                                           uint32_t sup_x, uint32_t sup_y,
@@ -341,6 +340,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
     // sup_x + sup_y ballots instead of sup_x * sup_y.
     __shared__ unsigned long long s_xmask[4][32];
     __shared__ unsigned long long s_ymask[4][32];
+    __shared__ uint32_t s_rect[256];  // packed tile rectangle of each of the block's ranks
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
                 rect = project_rank<F16, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis);
             }
             visible_acc += vis ? 1u : 0u;
-            rects[j] = rect;
         }
+        s_rect[tid] = rect;
         if (fp.debug & 2u) { __syncthreads(); continue; }  // ablation: no coarse binning at all
         {
             // supertile bounds of the rectangle; an empty rect has sx0 = 31 > sx1 = 0: no column matches
@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
             // 66.7 / 63.2; no stores at all 51.0 / 50.9 — the ~11 us are the scattered 4-byte stores
             // themselves, not the loop shape.)
             if (!(fp.debug & 8u)) {  // ablation bit 8: chain but no list writes
-                uint32_t* __restrict__ dst = coarse + (size_t)tid * coarse_cap;
+                // entry = (rank, its packed tile rectangle): the rasteriser's candidate scan then is one
+                // coalesced 8-byte stream instead of a rank stream plus a 64-line gather of rects[rank]
+                uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)tid * coarse_cap;
                 uint32_t pos = excl;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
                     while (bits) {
                         const uint32_t l = (uint32_t)__builtin_ctzll(bits);
                         bits &= bits - 1ull;
-                        if (pos < coarse_cap) dst[pos] = rank0 + l;
+                        if (pos < coarse_cap) dst[pos] = make_uint2(rank0 + l, s_rect[w * 64 + (int)l]);
                         ++pos;
                     }
                 }
@@ -435,8 +437,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
 
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status,
-                        void* records,
-                        uint32_t* rects, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
+                        void* records, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
                         uint32_t ticket_slot, int max_blocks) {
     if (fp.n == 0) return;
     uint32_t blocks = (fp.n + 255u) / 256u;
@@ -448,7 +449,7 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPt
     const bool any_mode = fp.rasterize_mode != RASTERIZE_COLOR;
 #define BGS_LAUNCH_PB(F16, SURFEL, ANY)                                                            \
     hipLaunchKernelGGL((project_bin_kernel<F16, SURFEL, ANY>), dim3(blocks), dim3(256), 0, stream, \
-                       fp, cloud, draw_list, culled, ctl, bin_status, rec, rects, coarse,          \
+                       fp, cloud, draw_list, culled, ctl, bin_status, rec, coarse,                 \
                        coarse_cap, sup_shift, sup_x, sup_y, ticket_slot)
 #define BGS_LAUNCH_PB2(F16, SURFEL) \
     do { if (any_mode) BGS_LAUNCH_PB(F16, SURFEL, true); else BGS_LAUNCH_PB(F16, SURFEL, false); } while (0)
@@ -633,7 +634,6 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 // 1024 SIMDs x 8 slots, so at 7 waves/SIMD a second, nearly empty round of waves appears.
 template <int VARIANT>
 __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(FrameParams fp, const float4* __restrict__ records,
-                                                          const uint32_t* __restrict__ rects,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_shift,
                                                           uint32_t sup_x, const Control* __restrict__ ctl,
@@ -654,7 +654,6 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
     const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + (lane >> 4);
     const float qx = (float)px + 0.5f;
     const float aspect = fp.viewport_w / fp.viewport_h;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const float tile_cx = (float)((int)tx * TILE_PX + 8), tile_cy = (float)((int)ty * TILE_PX + 8);
 
     float T[4], cr[4], cg[4], cb[4], qy[4];
@@ -668,24 +667,44 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
 
     const uint32_t st = (ty >> sup_shift) * sup_x + (tx >> sup_shift);
     const uint32_t total = min(ctl->coarse_total[st], coarse_cap);
-    const uint32_t* __restrict__ list = coarse + (size_t)st * coarse_cap;
+    const uint2* __restrict__ list = reinterpret_cast<const uint2*>(coarse) + (size_t)st * coarse_cap;
 
-    // candidate stream: ranks two groups ahead, rectangles one group ahead
-    uint32_t rank_cur = (uint32_t)lane < total ? list[lane] : 0u;
-    uint32_t rank_nxt = (uint32_t)lane + 64u < total ? list[lane + 64] : 0u;
-    uint32_t rect_cur = (uint32_t)lane < total ? rects[rank_cur] : RECT_EMPTY;
+    // candidate stream of (rank, tile rectangle) entries, two groups ahead of the scan
+    uint32_t rank_cur = 0u, rect_cur = RECT_EMPTY, rank_nxt = 0u, rect_nxt = RECT_EMPTY;
+    if ((uint32_t)lane < total) { const uint2 e = list[lane]; rank_cur = e.x; rect_cur = e.y; }
+    if ((uint32_t)lane + 64u < total) { const uint2 e = list[lane + 64]; rank_nxt = e.x; rect_nxt = e.y; }
 
-    for (uint32_t base = 0u; base < total; base += 64u) {
-        const uint32_t i2 = base + 128u + (uint32_t)lane;
-        const uint32_t rank_nn = i2 < total ? list[i2] : 0u;
-        const uint32_t rect_nxt = base + 64u + (uint32_t)lane < total ? rects[rank_nxt] : RECT_EMPTY;
-
-        const bool hit = tx >= (rect_cur & 255u) && tx <= ((rect_cur >> 8) & 255u) &&
+    // Hits are queued across candidate groups and gathered / blended together once FLUSH_AT of them
+    // wait (or the next group would not fit, or the list ends): every gather is a dependent global
+    // load (~2.5 us under load) that nothing hides, and a sparse list yields only a few hits per
+    // group of 64 candidates — 17 gathers per tile on the scene-like workload before, 3 now. A dense
+    // list fills the queue with its first group, so nothing changes there.
+    constexpr uint32_t FLUSH_AT = 32u;
+    uint32_t qn = 0u;  // ranks waiting in s_queue (wave-uniform)
+    uint32_t base = 0u;
+    for (;;) {
+        const bool have = base < total;
+        const bool hit = have && tx >= (rect_cur & 255u) && tx <= ((rect_cur >> 8) & 255u) &&
                          ty >= ((rect_cur >> 16) & 255u) && ty <= (rect_cur >> 24);
         const unsigned long long b = __ballot(hit);
-        const uint32_t cnt = (uint32_t)__popcll(b);
-        if (cnt && !(fp.debug & 32u)) {  // ablation bit 32: candidate scan only
-            if (hit) s_queue[__popcll(b & lanes_below)] = rank_cur;
+        const uint32_t hits = (uint32_t)__popcll(b);
+        const bool fits = qn + hits <= 64u;
+        if (have && fits) {  // queue this group's hits and advance the candidate stream
+            const uint32_t i2 = base + 128u + (uint32_t)lane;
+            uint32_t rank_nn = 0u, rect_nn = RECT_EMPTY;
+            if (i2 < total) { const uint2 e = list[i2]; rank_nn = e.x; rect_nn = e.y; }
+            // hits of lower lanes: v_mbcnt, no 64-bit lane mask to keep in registers
+            if (hit)
+                s_queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = rank_cur;
+            qn += hits;
+            rank_cur = rank_nxt; rect_cur = rect_nxt;
+            rank_nxt = rank_nn; rect_nxt = rect_nn;
+            base += 64u;
+        }
+        const bool end = base >= total;
+        if (qn && (qn >= FLUSH_AT || !fits || end) && !(fp.debug & 32u)) {  // ablation bit 32: scan only
+            const uint32_t cnt = qn;
+            qn = 0u;
             __builtin_amdgcn_wave_barrier();
             if ((uint32_t)lane < cnt) {
                 const float4* src = records + (size_t)s_queue[lane] * REC_V4;
@@ -744,11 +763,10 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
             }
             const bool sat = T[0] < T_EPS && T[1] < T_EPS && T[2] < T_EPS && T[3] < T_EPS;
             if (__all(sat)) break;
-            __builtin_amdgcn_wave_barrier();  // blend reads of s_rec done before the next staging
+            __builtin_amdgcn_wave_barrier();  // blend reads of s_rec / s_queue done before they are rewritten
         }
-        rank_cur = rank_nxt;
-        rank_nxt = rank_nn;
-        rect_cur = rect_nxt;
+        if (fp.debug & 32u) qn = 0u;
+        if (end && qn == 0u) break;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -761,7 +779,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
 }
 
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* records,
-                        const uint32_t* rects, const uint32_t* coarse, uint32_t coarse_cap,
+                        const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_shift, const Control* ctl, float4* framebuffer,
                         const float clear_color[4]) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
@@ -771,7 +789,7 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* r
     const uint32_t sup = 1u << sup_shift;
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
 #define BGS_LAUNCH_RS(V)                                                                          \
-    hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, fp, rec, rects, \
+    hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, fp, rec,        \
                        coarse, coarse_cap, sup_shift, sup_x, ctl, framebuffer, clear)
     if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
