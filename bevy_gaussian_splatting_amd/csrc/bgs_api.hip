@@ -68,7 +68,11 @@ struct Lane {
     uint8_t* scratch = nullptr;
     size_t scratch_bytes = 0;
     size_t off_depth_status = 0, off_scan_status = 0, off_tile_status = 0, off_ranges = 0, off_bin_status = 0,
-           off_part_status = 0;
+           off_part_status = 0, off_ctl1 = 0;
+    uint32_t ctl_parity = 0;  // which of the lane's two Control blocks the next frame uses
+    // true while the scratch region is known to be all zero without a memset: the rasteriser of a
+    // BINNING_SCAN frame zeroes what the frame used (FrameCleanup, kernels.h)
+    bool scratch_clean = false;
     uint32_t scratch_n = 0;         // splat capacity the scratch was laid out for
     uint64_t scratch_inst_cap = 0;  // instance capacity the scratch was laid out for
 
@@ -88,7 +92,8 @@ struct Lane {
     uint32_t fb_w = 0, fb_h = 0;
     bool fb8_valid = false;
 
-    Control* h_ctl = nullptr;  // pinned; filled by a copy enqueued with the frame
+    Control* h_ctl = nullptr;  // pinned; filled by a copy enqueued with the frame, or by the rasteriser
+    Control* h_ctl_dev = nullptr;  // the same memory as the device sees it
     hipEvent_t ev_ring[EV_RING][EV_COUNT] = {};
     uint8_t ev_kind[EV_RING] = {};  // 0 unused, 1 sort-only frame, 2 render/scan, 3 render/sort-binning
     uint32_t ev_head = 0;
@@ -160,6 +165,9 @@ int lane_create(bgs_ctx* ctx, Lane& L) {
     HIP_TRY(ctx, hipHostMalloc(&h, sizeof(Control), hipHostMallocDefault));
     L.h_ctl = (Control*)h;
     std::memset(L.h_ctl, 0, sizeof(Control));
+    void* hd = nullptr;
+    HIP_TRY(ctx, hipHostGetDevicePointer(&hd, h, 0));
+    L.h_ctl_dev = (Control*)hd;
     return BGS_OK;
 }
 
@@ -202,6 +210,8 @@ int ensure_scratch(bgs_ctx* ctx, Lane& L, uint32_t n, uint64_t inst_cap) {
     off += align_up(scan_tiles * MAX_SUPERTILES * sizeof(uint32_t), 256);
     const size_t off_part = off;
     off += align_up((((size_t)n + KEYGEN_TILE - 1) / KEYGEN_TILE + 1) * sizeof(uint32_t), 256);
+    const size_t off_ctl1 = off;  // the lane's second Control block (see FrameCleanup)
+    off += align_up(sizeof(Control), 256);
     if (L.scratch) { (void)hipFree(L.scratch); L.scratch = nullptr; }
     void* p = nullptr;
     if (hipMalloc(&p, off) != hipSuccess) return fail(ctx, BGS_ENOMEM, "hipMalloc(scratch) failed");
@@ -213,6 +223,8 @@ int ensure_scratch(bgs_ctx* ctx, Lane& L, uint32_t n, uint64_t inst_cap) {
     L.off_ranges = off_ranges;
     L.off_bin_status = off_bin;
     L.off_part_status = off_part;
+    L.off_ctl1 = off_ctl1;
+    L.scratch_clean = false;
     L.scratch_n = n;
     L.scratch_inst_cap = inst_cap;
     return BGS_OK;
@@ -336,6 +348,7 @@ int finish_lane(bgs_ctx* ctx, Lane& L, uint64_t* need_cap) {
                                     (size_t)(n - h.draw_count) * sizeof(uint2), hipMemcpyDeviceToDevice, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
     }
+    if (h.error) L.scratch_clean = false;  // do not trust what a tripped frame left behind
     if (h.error)
         return fail(ctx, BGS_EINTERNAL,
                     "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
@@ -476,7 +489,9 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     if ((rc = ensure_scratch(ctx, L, n, L.inst_cap)) != BGS_OK) return rc;
 
     hipStream_t st = L.stream;
-    Control* ctl = (Control*)L.scratch;
+    const bool need_memset = !L.scratch_clean;  // else the previous frame's rasteriser left it zeroed
+    if (need_memset) L.ctl_parity = 0;
+    Control* ctl = (Control*)(L.scratch + (L.ctl_parity ? L.off_ctl1 : 0));
     uint32_t* depth_status = (uint32_t*)(L.scratch + L.off_depth_status);
     unsigned long long* scan_status = (unsigned long long*)(L.scratch + L.off_scan_status);
     uint32_t* tile_status = (uint32_t*)(L.scratch + L.off_tile_status);
@@ -497,7 +512,8 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         if (prof >= 2 || (prof == 1 && (i == 0 || i == last_mark))) (void)hipEventRecord(ev[i], st);
     };
 
-    HIP_TRY(ctx, hipMemsetAsync(L.scratch, 0, L.scratch_bytes, st));
+    if (need_memset) HIP_TRY(ctx, hipMemsetAsync(L.scratch, 0, L.scratch_bytes, st));
+    L.scratch_clean = false;
     mark(0);
     launch_keygen(st, fp, cloud->ptrs.position_visibility, L.entries[0], L.culled, ctl, part_status, places,
                   /*ticket_slot=*/7, ctx->num_cus * 4);
@@ -520,13 +536,24 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     L.last_sorted = draw_list;
     L.last_sorted_n = n;
 
+    bool raster_cleans = false;
     if (render && scan) {
         const uint32_t coarse_cap = std::max<uint32_t>(n, 1);
         launch_project_bin(st, fp, cloud->ptrs, draw_list, L.culled, ctl, bin_status, L.records, L.coarse, coarse_cap,
                            sup_shift, /*ticket_slot=*/4, ctx->num_cus * 2);
         mark(3);
+        FrameCleanup cl{};
+        cl.part_status = part_status;
+        cl.depth_status = depth_status;
+        cl.bin_status = bin_status;
+        cl.other_ctl = (Control*)(L.scratch + (L.ctl_parity ? 0 : L.off_ctl1));
+        cl.host_ctl = L.h_ctl_dev;
+        cl.pass_stride = (uint32_t)(depth_tiles * RADIX_BASE);
+        cl.places = places;
+        cl.depth_tile = sort_tile_size(large);
         launch_raster_scan(st, fp, L.records, L.coarse, coarse_cap, sup_shift, ctl, L.fb,
-                           view->clear_color);
+                           view->clear_color, cl);
+        raster_cleans = fp.tiles_x > 0 && fp.tiles_y > 0;
         mark(6);
     } else if (render) {
         const uint32_t capacity = (uint32_t)std::min<uint64_t>(L.inst_cap, MAX_INSTANCE_CAPACITY);
@@ -550,8 +577,11 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         L.fb8_valid = true;
     }
     HIP_TRY(ctx, hipGetLastError());
-    // the Control block travels back with the frame; it is looked at when the lane is completed
-    HIP_TRY(ctx, hipMemcpyAsync(L.h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+    // the Control block travels back with the frame; it is looked at when the lane is completed.
+    // A BINNING_SCAN frame's rasteriser has already written the counters to L.h_ctl and left the
+    // scratch region zeroed for the next frame.
+    if (raster_cleans) { L.scratch_clean = true; L.ctl_parity ^= 1u; }
+    else HIP_TRY(ctx, hipMemcpyAsync(L.h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
 
     L.pending = true;
     L.pending_render = render;
@@ -992,6 +1022,7 @@ int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries, uint32_t n, uint
     Control* ctl = (Control*)L.scratch;
     uint32_t* depth_status = (uint32_t*)(L.scratch + L.off_depth_status);
     HIP_TRY(ctx, hipMemsetAsync(L.scratch, 0, L.scratch_bytes, st));
+    L.scratch_clean = false;
     HIP_TRY(ctx, hipMemcpyAsync(L.entries[0], entries, (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)&ctl->splat_count, (int)n, 1, st));
     launch_histogram(st, L.entries[0], n, &ctl->hist_depth[0][0], passes);

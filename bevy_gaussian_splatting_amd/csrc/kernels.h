@@ -20,6 +20,25 @@ struct CloudPtrs {
     uint32_t is_f16;
 };
 
+// What the rasteriser of a BINNING_SCAN frame tidies up so that the NEXT frame of the same lane needs
+// neither a memset of the scratch region nor a device-to-host copy of the Control block (each a
+// separate blit kernel with its own launch gap, ~13 us per frame on one stream). Every status word the
+// frame's chained scans used is dead once project_bin has finished, so the raster threads zero them
+// at their start; the lane alternates between two Control blocks, and this frame's rasteriser zeroes
+// the OTHER one (last used by the lane's previous frame) and copies the header + coarse totals of its
+// own, final since project_bin, to pinned host memory. No counters, no atomics (a "last wave done"
+// counter was tried first: 8160 same-address atomics cost 65 us). All-null = no cleanup.
+struct FrameCleanup {
+    uint32_t* part_status;    // keygen chain: ceil(n / KEYGEN_TILE) words used
+    uint32_t* depth_status;   // depth passes: places x [pass_stride words], ceil(D / depth_tile) * 256 used each
+    uint32_t* bin_status;     // project_bin chain: ceil(D / 256) * MAX_SUPERTILES words used
+    Control* other_ctl;       // the lane's other Control block: zeroed here
+    Control* host_ctl;        // pinned host Control (device-visible)
+    uint32_t pass_stride;     // words between the status arrays of consecutive depth passes
+    uint32_t places;
+    uint32_t depth_tile;      // keys per onesweep tile of the depth passes
+};
+
 // Onesweep geometry: 256 threads x KPT keys per tile.
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_KPT_SMALL = 8;   // 2048-pair tiles: more tiles for <= ~4M keys
@@ -71,8 +90,8 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPt
 // and composites front-to-back until the tile saturates.
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
-                        uint32_t sup_shift, const Control* ctl, float4* framebuffer,
-                        const float clear_color[4]);
+                        uint32_t sup_shift, Control* ctl, float4* framebuffer,
+                        const float clear_color[4], const FrameCleanup& cleanup);
 
 // Per-tile [start, end) over the tile-sorted instances; ranges indexed by (ty << 8 | tx).
 void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Control* ctl, uint2* ranges);

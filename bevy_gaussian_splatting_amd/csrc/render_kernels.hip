@@ -636,8 +636,9 @@ template <int VARIANT>
 __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(FrameParams fp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_shift,
-                                                          uint32_t sup_x, const Control* __restrict__ ctl,
-                                                          float4* __restrict__ fb, float4 clear) {
+                                                          uint32_t sup_x, Control* ctl,
+                                                          float4* __restrict__ fb, float4 clear,
+                                                          FrameCleanup cl) {
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     __shared__ float4 s_rec_all[4][64 * REC_V4];
     __shared__ uint32_t s_queue_all[4][64];
@@ -646,7 +647,33 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     const uint32_t nblocks = (ntiles + 3u) / 4u;
     const uint32_t tile = xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
-    if (tile >= ntiles) return;  // whole wave; nothing below synchronises across waves
+    const uint32_t draw_count = ctl->draw_count;
+    if (cl.other_ctl) {
+        // the status words of this frame's chained scans are dead by now: zero the used ones, and
+        // the Control block the lane's next frame will use; report this frame's counters to the host
+        const uint32_t g = blockIdx.x * 256u + (uint32_t)tid, gn = nblocks * 256u;
+        uint32_t* zc = reinterpret_cast<uint32_t*>(cl.other_ctl);
+        for (uint32_t i = g; i < (uint32_t)(sizeof(Control) / 4u); i += gn) zc[i] = 0u;
+        if (blockIdx.x == nblocks - 1u) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
+            uint32_t* host = reinterpret_cast<uint32_t*>(cl.host_ctl);
+            constexpr uint32_t HEADER_WORDS = 8u;  // draw_count .. splat_count
+            constexpr uint32_t COARSE_OFF = (uint32_t)(offsetof(Control, coarse_total) / 4u);
+            if ((uint32_t)tid < HEADER_WORDS) host[tid] = src[tid];
+            host[COARSE_OFF + (uint32_t)tid] = src[COARSE_OFF + (uint32_t)tid];
+        }
+        const uint32_t part_words = (fp.n + KEYGEN_TILE - 1u) / KEYGEN_TILE;
+        for (uint32_t i = g; i < part_words; i += gn) cl.part_status[i] = 0u;
+        const uint32_t depth_v4 = ((draw_count + cl.depth_tile - 1u) / cl.depth_tile) * (RADIX_BASE / 4u);
+        for (uint32_t p = 0u; p < cl.places; ++p) {
+            uint4* dst = reinterpret_cast<uint4*>(cl.depth_status + (size_t)p * cl.pass_stride);
+            for (uint32_t i = g; i < depth_v4; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const uint32_t bin_v4 = ((draw_count + 255u) / 256u) * (MAX_SUPERTILES / 4u);
+        uint4* bdst = reinterpret_cast<uint4*>(cl.bin_status);
+        for (uint32_t i = g; i < bin_v4; i += gn) bdst[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tile < ntiles) {  // whole wave; nothing in here synchronises across waves
     float4* const s_rec = s_rec_all[wave];
     volatile uint32_t* const s_queue = s_queue_all[wave];
 
@@ -776,12 +803,14 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
                 make_float4(fmaf(T[r], clear.x, cr[r]), fmaf(T[r], clear.y, cg[r]), fmaf(T[r], clear.z, cb[r]),
                             fmaf(T[r], clear.w, 1.0f - T[r]));
     }
+    }  // tile < ntiles
+
 }
 
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
-                        uint32_t sup_shift, const Control* ctl, float4* framebuffer,
-                        const float clear_color[4]) {
+                        uint32_t sup_shift, Control* ctl, float4* framebuffer,
+                        const float clear_color[4], const FrameCleanup& cleanup) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4 clear = make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]);
@@ -790,7 +819,7 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* r
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
 #define BGS_LAUNCH_RS(V)                                                                          \
     hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, fp, rec,        \
-                       coarse, coarse_cap, sup_shift, sup_x, ctl, framebuffer, clear)
+                       coarse, coarse_cap, sup_shift, sup_x, ctl, framebuffer, clear, cleanup)
     if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
     else BGS_LAUNCH_RS(RV_SURFEL);
