@@ -134,6 +134,11 @@ struct bgs_ctx {
     bool async_frames = false;
     bool output_srgb8 = false;
 
+    // draw_count of the most recently completed frame: sizes the grids of the next frame's sort passes
+    // (a hint only — the kernels read the real count on the device and loop over tickets if short)
+    uint32_t draw_hint = 0;
+    bool draw_hint_valid = false;
+
     bool have_stats = false;
     bgs_stats stats{};
     uint32_t regrow_count = 0;
@@ -339,6 +344,8 @@ int finish_lane(bgs_ctx* ctx, Lane& L, uint64_t* need_cap) {
     const size_t rec_bytes = L.pending_rec_bytes;
 
     const Control& h = *L.h_ctl;
+    ctx->draw_hint = h.draw_count;
+    ctx->draw_hint_valid = true;
     // after a render only the drawable prefix of the list is materialised (the culled tail stays
     // in its side buffer); bgs_sort appends it so that callers get the reference's full list
     L.last_sorted_n = render ? h.draw_count : n;
@@ -520,7 +527,13 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     mark(1);
     const bool large = n > (4u << 20);
     const size_t depth_tiles = ((size_t)L.scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
-    const int sort_blocks = ctx->num_cus * 4;
+    int sort_blocks = ctx->num_cus * 4;
+    if (ctx->draw_hint_valid) {
+        // only the D drawable entries are sorted, and D is known on the device only; launching a block
+        // per N/tile would start ~6x more blocks than tiles, each queueing for a ticket just to leave
+        const uint64_t want = ((uint64_t)ctx->draw_hint * 5 / 4) / sort_tile_size(large) + 8;
+        sort_blocks = (int)std::min<uint64_t>((uint64_t)sort_blocks, std::max<uint64_t>(want, 32));
+    }
     int cur = 0;
     for (uint32_t p = 0; p < places; ++p) {
         const uint32_t key_xor =

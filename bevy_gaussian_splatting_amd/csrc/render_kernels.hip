@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
     const uint32_t num_st = sup_x * sup_y;
     const uint32_t my_sy = (uint32_t)tid / sup_x, my_sx = (uint32_t)tid - my_sy * sup_x;  // thread = supertile
     uint32_t visible_acc = 0u;
+    const bool single_shot = gridDim.x >= num_tiles;  // one ticket per block (see keygen_kernel)
     const ColorInputs ci = ANY_MODE ? frame_color_inputs(fp, cloud, draw_list, culled, count)
                                     : ColorInputs{0.0f, 0.0f, 0.0f};
 
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
                 }
             }
         }
+        if (single_shot) break;
         __syncthreads();
     }
 #pragma unroll

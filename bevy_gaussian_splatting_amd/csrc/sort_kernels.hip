@@ -88,6 +88,11 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
     const uint32_t per_tile = 256u * KG_ITEMS;
     const uint32_t num_tiles = (fp.n + per_tile - 1u) / per_tile;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    // Tiles are handed out by ticket so that a tile's predecessors in the chained scan are always owned
+    // by running blocks (kernels of several lanes share the chip). Same-address device-scope atomics
+    // retire at ~8 ns each, so when the grid covers every tile a block takes ONE ticket and leaves
+    // after its tile instead of queueing for a second ticket only to be told there is nothing left.
+    const bool single_shot = gridDim.x >= num_tiles;
 
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
                 else culled[i - before] = make_uint2(key[k], i);
             }
         }
+        if (single_shot) break;
         __syncthreads();
     }
     for (uint32_t pl = 0; pl < places; ++pl) {
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
         s_hist_excl[tid] = block_exclusive_scan_256(h, s_tot, total);
     }
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const bool single_shot = gridDim.x >= num_tiles;  // see keygen_kernel
 
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(ticket, 1u);
@@ -327,6 +334,7 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
                 if (dst < n) out[dst] = e;  // always true unless the watchdog tripped
             }
         }
+        if (single_shot) break;
         __syncthreads();
     }
 }
