@@ -540,7 +540,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
             (p + 1 == places && (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD)) ? 0xFFFFFFFFu : 0u;
         // only the V' drawable entries are sorted; the culled tail is already in its final order
         launch_onesweep_pass(st, L.entries[cur], L.entries[cur ^ 1], &ctl->draw_count, n, ctl->hist_depth[p],
-                             depth_status + (size_t)p * depth_tiles * RADIX_BASE, &ctl->ticket[p], &ctl->error,
+                             depth_status + (size_t)p * depth_tiles * RADIX_BASE, &ctl->ticket[p][0], &ctl->error,
                              p * RADIX_BITS, key_xor, large, sort_blocks);
         cur ^= 1;
     }
@@ -576,7 +576,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         const size_t inst_tiles = (L.scratch_inst_cap + sort_tile_size(true) - 1) / sort_tile_size(true) + 1;
         for (uint32_t p = 0; p < 2; ++p)
             launch_onesweep_pass(st, L.inst[p], L.inst[p ^ 1], &ctl->instance_count, capacity, ctl->hist_tile[p],
-                                 tile_status + (size_t)p * inst_tiles * RADIX_BASE, &ctl->ticket[5 + p],
+                                 tile_status + (size_t)p * inst_tiles * RADIX_BASE, &ctl->ticket[5 + p][0],
                                  &ctl->error, p * RADIX_BITS, 0u, true, sort_blocks);
         mark(4);
         launch_tile_ranges(st, L.inst[0], ctl, ranges);
@@ -1044,7 +1044,7 @@ int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries, uint32_t n, uint
     int cur = 0;
     for (uint32_t p = 0; p < passes; ++p) {
         launch_onesweep_pass(st, L.entries[cur], L.entries[cur ^ 1], &ctl->splat_count, n, ctl->hist_depth[p],
-                             depth_status + (size_t)p * depth_tiles * RADIX_BASE, &ctl->ticket[p], &ctl->error,
+                             depth_status + (size_t)p * depth_tiles * RADIX_BASE, &ctl->ticket[p][0], &ctl->error,
                              p * RADIX_BITS, 0u, large, ctx->num_cus * 4);
         cur ^= 1;
     }

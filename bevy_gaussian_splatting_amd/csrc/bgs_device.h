@@ -88,7 +88,11 @@ struct Control {
     uint32_t error;           // device watchdog (bounded spins)
     uint32_t visible_count;   // splats that pass the vertex-stage cull (stats)
     uint32_t splat_count;     // N, parked on the device so the sort kernels read every size the same way
-    uint32_t ticket[16];      // dynamic tile ids: one word per kernel launch of the frame
+    uint32_t pad0[24];        // the read-mostly header owns its 128-byte line (see ticket)
+    // dynamic tile ids, one word per kernel launch of the frame, each in its OWN 128-byte line: every
+    // block of a launch does a returning atomic on its ticket and the L2 retires same-line atomics one
+    // at a time (~8 ns), so a load of draw_count queued behind them on a shared line waited for all.
+    uint32_t ticket[16][32];
     uint32_t hist_depth[4][RADIX_BASE];  // global digit histograms of the depth keys
     uint32_t hist_tile[2][RADIX_BASE];   // digit 0 = tile x, digit 1 = tile y
     uint32_t coarse_total[RADIX_BASE];   // scan binning: entries in each supertile's ordered list

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
                                     : ColorInputs{0.0f, 0.0f, 0.0f};
 
     for (;;) {
-        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
+        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);  // in flight with the count load
     const uint32_t count = ctl->draw_count;
     const uint32_t num_tiles = (count + 255u) / 256u;
     if (num_tiles == 0u) return;
@@ -355,7 +356,6 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
                                     : ColorInputs{0.0f, 0.0f, 0.0f};
 
     for (;;) {
-        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
@@ -371,7 +371,11 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
             visible_acc += vis ? 1u : 0u;
         }
         s_rect[tid] = rect;
-        if (fp.debug & 2u) { __syncthreads(); continue; }  // ablation: no coarse binning at all
+        if (fp.debug & 2u) {  // ablation: no coarse binning at all
+            __syncthreads();
+            if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
+            continue;
+        }
         {
             // supertile bounds of the rectangle; an empty rect has sx0 = 31 > sx1 = 0: no column matches
             const uint32_t sx0 = (rect & 255u) >> sup_shift, sx1 = ((rect >> 8) & 255u) >> sup_shift;
@@ -386,7 +390,11 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
             }
         }
         __syncthreads();
-        if (fp.debug & 4u) { __syncthreads(); continue; }  // ablation: ballots only
+        if (fp.debug & 4u) {  // ablation: ballots only
+            __syncthreads();
+            if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
+            continue;
+        }
         // thread = supertile: lane masks of the 4 waves, chained scan over the blocks, then this
         // thread appends the block's hits to ITS list in rank order (wave 0 lanes first, ...)
         if ((uint32_t)tid < num_st) {
@@ -431,6 +439,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
         }
         if (single_shot) break;
         __syncthreads();
+        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) visible_acc += __shfl_down(visible_acc, off, 64);

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
     const bool single_shot = gridDim.x >= num_tiles;
 
     for (;;) {
-        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot], 1u);
+        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
@@ -238,20 +238,22 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the first ticket, the key count and the global histogram are three independent L2/HBM round
+    // trips: issue them together (taken one after the other they were ~4 us of an ~12 us pass)
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    const uint32_t h = hist[tid];
     const uint32_t n = *n_ptr;
     const uint32_t num_tiles = (n + TILE - 1u) / TILE;
     if (num_tiles == 0u) return;
 
     {   // radix_sort_b: exclusive scan of the global digit histogram, once per block
         uint32_t total;
-        const uint32_t h = hist[tid];
         s_hist_excl[tid] = block_exclusive_scan_256(h, s_tot, total);
     }
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const bool single_shot = gridDim.x >= num_tiles;  // see keygen_kernel
 
     for (;;) {
-        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
 #pragma unroll
         for (int w = 0; w < 4; ++w) s_wave_hist[w][tid] = 0u;
         __syncthreads();
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
         }
         if (single_shot) break;
         __syncthreads();
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     }
 }
 
