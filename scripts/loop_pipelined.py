@@ -8,6 +8,7 @@ depth = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 gs = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 prof = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+flags = int(sys.argv[5], 0) if len(sys.argv) > 5 else 0
 p = GaussianSplattingPlugin(0)
 h = p.upload(random_gaussians_3d_seeded(1_000_000, 2))
 v = headless_view(0)
@@ -15,6 +16,7 @@ s = CloudSettings(global_scale=gs)
 p.set_async(True)
 p.set_pipeline_depth(depth)
 p.set_profiling(prof)
+p.set_debug_flags(flags)
 pv = p.prepare(v, s)
 for _ in range(10):
     p.render(h, pv, download=False)
@@ -24,4 +26,4 @@ for _ in range(frames):
     p.render(h, pv, download=False)
 p.synchronize()
 dt = time.perf_counter() - t0
-print(f"depth {depth} frames {frames}: {frames / dt:.1f} fps, {1e6 * dt / frames:.1f} us/frame")
+print(f"flags {flags:#x} depth {depth} frames {frames}: {frames / dt:.1f} fps, {1e6 * dt / frames:.1f} us/frame")
