@@ -528,7 +528,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     const bool large = n > (4u << 20);
     const size_t depth_tiles = ((size_t)L.scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
     int sort_blocks = ctx->num_cus * 4;
-    if (ctx->draw_hint_valid) {
+    if (ctx->draw_hint_valid && !(ctx->debug_flags & 0x2000u)) {
         // only the D drawable entries are sorted, and D is known on the device only; launching a block
         // per N/tile would start ~6x more blocks than tiles, each queueing for a ticket just to leave
         const uint64_t want = ((uint64_t)ctx->draw_hint * 5 / 4) / sort_tile_size(large) + 8;
@@ -564,9 +564,10 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         cl.pass_stride = (uint32_t)(depth_tiles * RADIX_BASE);
         cl.places = places;
         cl.depth_tile = sort_tile_size(large);
+        if (ctx->debug_flags & 0x1000u) cl = FrameCleanup{};  // experiment: classic memset + copy path
         launch_raster_scan(st, fp, L.records, L.coarse, coarse_cap, sup_shift, ctl, L.fb,
                            view->clear_color, cl);
-        raster_cleans = fp.tiles_x > 0 && fp.tiles_y > 0;
+        raster_cleans = fp.tiles_x > 0 && fp.tiles_y > 0 && cl.other_ctl != nullptr;
         mark(6);
     } else if (render) {
         const uint32_t capacity = (uint32_t)std::min<uint64_t>(L.inst_cap, MAX_INSTANCE_CAPACITY);

@@ -15,14 +15,25 @@
 
 namespace bgs {
 
-constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 22;  // bounded spin (watchdog, never expected)
+constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 21;  // bounded spin (watchdog, never expected): >= 2 s with the back-off
 
 __device__ __forceinline__ uint32_t lb_load(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Spin back-off while a predecessor has not published: s_sleep units are 64 clocks. Thousands of
+// threads poll at once when several chained-scan kernels share the chip (3 lanes x 512 blocks x 135
+// chains on a 5 M-splat frame); without a back-off the device-scope polling loads alone saturate the
+// fabric and starve the very blocks everyone is waiting for (observed: the watchdog bound was reached).
+__device__ __forceinline__ void lb_backoff(uint32_t spins) {
+    if (spins < 8u) __builtin_amdgcn_s_sleep(1);
+    else if (spins < 64u) __builtin_amdgcn_s_sleep(8);
+    else __builtin_amdgcn_s_sleep(32);
+}
+
 // One chain per THREAD (status words `stride` apart): B predecessors per round trip, consumed in
-// order up to the first unpublished word or the first inclusive prefix.
+// order up to the first unpublished word or the first inclusive prefix. While the NEAREST predecessor
+// is unpublished only that one word is polled.
 template <int B>
 __device__ __forceinline__ uint32_t lookback_u32(const uint32_t* chain, uint32_t tile, uint32_t stride,
                                                  uint32_t* error_flag, uint32_t error_code) {
@@ -32,6 +43,11 @@ __device__ __forceinline__ uint32_t lookback_u32(const uint32_t* chain, uint32_t
         uint32_t v[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) v[b] = p - b >= 0 ? lb_load(chain + (size_t)(p - b) * stride) : STATUS_PREFIX;
+        while ((v[0] >> STATUS_FLAG_SHIFT) == 0u) {  // nearest predecessor not there yet: poll it alone
+            if (++spins > LOOKBACK_SPIN_LIMIT) { atomicOr(error_flag, error_code); return excl; }
+            lb_backoff(spins);
+            v[0] = lb_load(chain + (size_t)p * stride);
+        }
         int used = 0;
         bool finished = false;
 #pragma unroll
@@ -44,10 +60,6 @@ __device__ __forceinline__ uint32_t lookback_u32(const uint32_t* chain, uint32_t
             if (flag == 2u) finished = true;    // inclusive prefix: done
         }
         if (finished) break;
-        if (used == 0) {
-            if (++spins > LOOKBACK_SPIN_LIMIT) { atomicOr(error_flag, error_code); break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
         p -= used;
     }
     return excl;
@@ -75,7 +87,7 @@ __device__ __forceinline__ uint32_t lookback_wave(const uint32_t* chain, uint32_
         if (done) break;
         if (take == 0) {
             if (++spins > LOOKBACK_SPIN_LIMIT) { if (lane == 0) atomicOr(error_flag, error_code); break; }
-            __builtin_amdgcn_s_sleep(1);
+            lb_backoff(spins);
         }
         p -= take;
     }

@@ -344,7 +344,6 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);  // in flight with the count load
     const uint32_t count = ctl->draw_count;
     const uint32_t num_tiles = (count + 255u) / 256u;
     if (num_tiles == 0u) return;
@@ -356,6 +355,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
                                     : ColorInputs{0.0f, 0.0f, 0.0f};
 
     for (;;) {
+        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
@@ -373,7 +373,6 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
         s_rect[tid] = rect;
         if (fp.debug & 2u) {  // ablation: no coarse binning at all
             __syncthreads();
-            if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
             continue;
         }
         {
@@ -392,7 +391,6 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
         __syncthreads();
         if (fp.debug & 4u) {  // ablation: ballots only
             __syncthreads();
-            if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
             continue;
         }
         // thread = supertile: lane masks of the 4 waves, chained scan over the blocks, then this
@@ -439,7 +437,6 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
         }
         if (single_shot) break;
         __syncthreads();
-        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) visible_acc += __shfl_down(visible_acc, off, 64);

@@ -240,7 +240,6 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the first ticket, the key count and the global histogram are three independent L2/HBM round
     // trips: issue them together (taken one after the other they were ~4 us of an ~12 us pass)
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     const uint32_t h = hist[tid];
     const uint32_t n = *n_ptr;
     const uint32_t num_tiles = (n + TILE - 1u) / TILE;
@@ -254,6 +253,7 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
     const bool single_shot = gridDim.x >= num_tiles;  // see keygen_kernel
 
     for (;;) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
 #pragma unroll
         for (int w = 0; w < 4; ++w) s_wave_hist[w][tid] = 0u;
         __syncthreads();
@@ -345,7 +345,6 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
         }
         if (single_shot) break;
         __syncthreads();
-        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     }
 }
 
