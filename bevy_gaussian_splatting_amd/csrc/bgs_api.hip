@@ -578,7 +578,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         for (uint32_t p = 0; p < 2; ++p)
             launch_onesweep_pass(st, L.inst[p], L.inst[p ^ 1], &ctl->instance_count, capacity, ctl->hist_tile[p],
                                  tile_status + (size_t)p * inst_tiles * RADIX_BASE, &ctl->ticket[5 + p][0],
-                                 &ctl->error, p * RADIX_BITS, 0u, true, sort_blocks);
+                                 &ctl->error, p * RADIX_BITS, 0u, true, ctx->num_cus * 4);
         mark(4);
         launch_tile_ranges(st, L.inst[0], ctl, ranges);
         mark(5);
