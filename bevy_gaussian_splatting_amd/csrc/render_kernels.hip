@@ -508,6 +508,22 @@ struct StagedRecord {
     }
 };
 
+// OBB records are re-expressed at staging time in the coordinates of the tile that blends them, with
+// the falloff constant folded in, so that the per-pixel work is two fmas, a compare and exp2:
+//   c  = sqrt(4.5 * log2(e))             exp(-4.5 (u^2 + v^2)) = exp2(-(u'^2 + v'^2)),  u' = c u
+//   a0 = (U0', V0', m00', m01'),  a1 = (m10', m11', -, r)   with m' = c m and (U0', V0') = (u', v') at the
+//   centre (ox, oy) of the tile's first pixel;  u' = fma(m01', yl, fma(m00', xl, U0')) for the pixel
+//   (xl, yl) of the tile. Covered <=> max(|u'|, |v'|) <= c.
+// Both rasterisers stage through this function, so their images stay bit-identical.
+constexpr float OBB_C = 2.5479654147f;  // sqrt(4.5 * 1.4426950408889634)
+__device__ __forceinline__ void stage_obb(float4& r0, float4& r1, const float ox, const float oy) {
+    const float m00 = OBB_C * r0.z, m01 = OBB_C * r0.w, m10 = OBB_C * r1.x, m11 = OBB_C * r1.y;
+    const float dx = ox - r0.x, dy = oy - r0.y;
+    r0 = make_float4(fmaf(m01, dy, m00 * dx), fmaf(m11, dy, m10 * dx), m00, m01);
+    r1.x = m10;
+    r1.y = m11;
+}
+
 // fs_main + blend for ONE record and ONE pixel (src/render/gaussian.wgsl:438-505,
 // src/render/mod.rs:944-948), front-to-back form, branch-free:
 //     w = covered && T >= T_EPS ? T * alpha : 0;   C += w * c;   T -= w
@@ -517,22 +533,21 @@ struct StagedRecord {
 template <int VARIANT>
 __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const float qx, const float qy,
                                          const float aspect, float& T, float& cr, float& cg, float& cb) {
-    const float dx = qx - s.a0.x, dy = qy - s.a0.y;
     float alpha, r, g, b;
     bool hit;
     if constexpr (VARIANT == RV_OBB) {
-        // a0 = cx cy m00 m01 | a1 = m10 m11 - r | a2 = g b a rect
-        const float u = fmaf(s.a0.w, dy, s.a0.z * dx);
-        const float v = fmaf(s.a1.y, dy, s.a1.x * dx);
-        hit = fmaxf(fabsf(u), fabsf(v)) <= 1.0f;
+        // staged by stage_obb: a0 = U0' V0' m00' m01' | a1 = m10' m11' - r | a2 = g b a -; here
+        // (qx, qy) is the pixel's position INSIDE the tile (0..15)
+        const float u = fmaf(s.a0.w, qy, fmaf(s.a0.z, qx, s.a0.x));
+        const float v = fmaf(s.a1.y, qy, fmaf(s.a1.x, qx, s.a0.y));
+        hit = fmaxf(fabsf(u), fabsf(v)) <= OBB_C;
         // fs_main OBB: power = -dot(uv,uv) / (2 * (1/3)^2)  (gaussian.wgsl:474-480);
-        // exp(power) = exp2(power * log2(e)), constants folded
-        constexpr float sigma = 1.0f / 3.0f;
-        constexpr float k = -1.0f / (2.0f * sigma * sigma) * 1.4426950408889634f;
-        const float e = __builtin_amdgcn_exp2f(fmaf(u, u, v * v) * k);
+        // exp(power) = exp2(-(u'^2 + v'^2))
+        const float e = __builtin_amdgcn_exp2f(-fmaf(u, u, v * v));
         alpha = fminf(e * s.a2.z, 0.999f);
         r = s.a1.w; g = s.a2.x; b = s.a2.y;
     } else if constexpr (VARIANT == RV_AABB3D) {
+        const float dx = qx - s.a0.x, dy = qy - s.a0.y;
         // a0 = cx cy m00 m11 | a1 = A B C r | a2 = g b a rect
         const float u = s.a0.z * dx, v = s.a0.w * dy;
         hit = fmaxf(fabsf(u), fabsf(v)) <= 1.0f;
@@ -542,6 +557,7 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
         r = s.a1.w; g = s.a2.x; b = s.a2.y;
     } else {
         // a0 = cx cy m00 m11 | a1 = radius mean.xy T0 | a2 = T1..T4 | a3 = T5..T8 | a4 = rgba
+        const float dx = qx - s.a0.x, dy = qy - s.a0.y;
         const float u = s.a0.z * dx, v = s.a0.w * dy;
         hit = fmaxf(fabsf(u), fabsf(v)) <= 1.0f;
         // fs_main GAUSSIAN_2D + USE_AABB (gaussian.wgsl:440-455), aspect = (1, W/H)
@@ -599,7 +615,10 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     const int tid = threadIdx.x;
     const int px = (int)tx * TILE_PX + (tid & 15), py = (int)ty * TILE_PX + (tid >> 4);
     const bool in_image = px < fp.width && py < fp.height;
-    const float qx = (float)px + 0.5f, qy = (float)py + 0.5f;
+    // OBB records are staged tile-local (stage_obb): the pixel is addressed inside its tile
+    const float qx = VARIANT == RV_OBB ? (float)(tid & 15) : (float)px + 0.5f;
+    const float qy = VARIANT == RV_OBB ? (float)(tid >> 4) : (float)py + 0.5f;
+    const float tile_ox = (float)((int)tx * TILE_PX) + 0.5f, tile_oy = (float)((int)ty * TILE_PX) + 0.5f;
     const float aspect = fp.viewport_w / fp.viewport_h;
 
     const uint2 range = ranges[(ty << 8) | tx];
@@ -610,8 +629,16 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
         if ((uint32_t)tid < cnt) {
             const uint32_t rank = instances[base + (uint32_t)tid].y;
             const float4* src = records + (size_t)rank * REC_V4;
+            if constexpr (VARIANT == RV_OBB) {
+                float4 r0 = src[0], r1 = src[1];
+                stage_obb(r0, r1, tile_ox, tile_oy);
+                s_rec[tid * REC_V4 + 0] = r0;
+                s_rec[tid * REC_V4 + 1] = r1;
+                s_rec[tid * REC_V4 + 2] = src[2];
+            } else {
 #pragma unroll
-            for (int v = 0; v < REC_V4; ++v) s_rec[tid * REC_V4 + v] = src[v];
+                for (int v = 0; v < REC_V4; ++v) s_rec[tid * REC_V4 + v] = src[v];
+            }
         }
         __syncthreads();
         if (!__all(T < T_EPS))
@@ -687,15 +714,17 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
 
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
     const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + (lane >> 4);
-    const float qx = (float)px + 0.5f;
+    // OBB records are staged tile-local (stage_obb): pixels are then addressed inside the tile
+    const float qx = VARIANT == RV_OBB ? (float)(lane & 15) : (float)px + 0.5f;
     const float aspect = fp.viewport_w / fp.viewport_h;
     const float tile_cx = (float)((int)tx * TILE_PX + 8), tile_cy = (float)((int)ty * TILE_PX + 8);
+    const float tile_ox = (float)((int)tx * TILE_PX) + 0.5f, tile_oy = (float)((int)ty * TILE_PX) + 0.5f;
 
     float T[4], cr[4], cg[4], cb[4], qy[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int py = py0 + 4 * r;
-        qy[r] = (float)py + 0.5f;
+        qy[r] = VARIANT == RV_OBB ? (float)((lane >> 4) + 4 * r) : (float)py + 0.5f;
         T[r] = (px < fp.width && py < fp.height) ? 1.0f : 0.0f;
         cr[r] = cg[r] = cb[r] = 0.0f;
     }
@@ -748,20 +777,22 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
                 // it misses the tile iff the tile's pixel-centre box lies wholly beyond one of its
                 // two axes (the box's own axes are the rect test). The verdict rides in a spare
                 // dword of the staged record and the blend loop skips rejected records.
-                const float dcx = tile_cx - r0.x, dcy = tile_cy - r0.y;
-                float uc, vc, eu, ev;
+                bool keep;
                 if constexpr (VARIANT == RV_OBB) {
-                    uc = fmaf(r0.w, dcy, r0.z * dcx);
-                    vc = fmaf(r1.y, dcy, r1.x * dcx);
-                    eu = 7.5f * (fabsf(r0.z) + fabsf(r0.w));
-                    ev = 7.5f * (fabsf(r1.x) + fabsf(r1.y));
+                    stage_obb(r0, r1, tile_ox, tile_oy);
+                    // tile centre = first pixel + (7.5, 7.5), half extent 7.5 in both axes
+                    const float uc = fmaf(r0.w, 7.5f, fmaf(r0.z, 7.5f, r0.x));
+                    const float vc = fmaf(r1.y, 7.5f, fmaf(r1.x, 7.5f, r0.y));
+                    const float eu = 7.5f * (fabsf(r0.z) + fabsf(r0.w));
+                    const float ev = 7.5f * (fabsf(r1.x) + fabsf(r1.y));
+                    keep = !(fabsf(uc) - eu > 1.0001f * OBB_C) && !(fabsf(vc) - ev > 1.0001f * OBB_C);
                 } else {  // axis-aligned square: uv = (m00 * dx, m11 * dy)
-                    uc = r0.z * dcx;
-                    vc = r0.w * dcy;
-                    eu = 7.5f * fabsf(r0.z);
-                    ev = 7.5f * fabsf(r0.w);
+                    const float dcx = tile_cx - r0.x, dcy = tile_cy - r0.y;
+                    const float uc = r0.z * dcx, vc = r0.w * dcy;
+                    const float eu = 7.5f * fabsf(r0.z), ev = 7.5f * fabsf(r0.w);
+                    keep = !(fabsf(uc) - eu > 1.0001f) && !(fabsf(vc) - ev > 1.0001f);
                 }
-                const bool keep = (!(fabsf(uc) - eu > 1.0001f) && !(fabsf(vc) - ev > 1.0001f)) || (fp.debug & 64u);
+                keep = keep || (fp.debug & 64u);
                 s_rec[lane * REC_V4 + 0] = r0;
                 if constexpr (VARIANT == RV_OBB) {
                     r1.z = __uint_as_float(keep ? 1u : 0u);  // p[4] is unused by the OBB record
@@ -803,13 +834,20 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
         if (fp.debug & 32u) qn = 0u;
         if (end && qn == 0u) break;
     }
+    {
+        // pixel coordinates are recomputed from an opaque copy of the lane id: keeping the four row
+        // indices alive across the blend loop costs registers the loop needs (they were spilled)
+        int lw = lane;
+        asm volatile("" : "+v"(lw));
+        const int pxw = (int)tx * TILE_PX + (lw & 15), pyw = (int)ty * TILE_PX + (lw >> 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int py = py0 + 4 * r;
-        if (px < fp.width && py < fp.height)
-            fb[(size_t)py * (size_t)fp.width + (size_t)px] =
-                make_float4(fmaf(T[r], clear.x, cr[r]), fmaf(T[r], clear.y, cg[r]), fmaf(T[r], clear.z, cb[r]),
-                            fmaf(T[r], clear.w, 1.0f - T[r]));
+        for (int r = 0; r < 4; ++r) {
+            const int py = pyw + 4 * r;
+            if (pxw < fp.width && py < fp.height)
+                fb[(size_t)py * (size_t)fp.width + (size_t)pxw] =
+                    make_float4(fmaf(T[r], clear.x, cr[r]), fmaf(T[r], clear.y, cg[r]), fmaf(T[r], clear.z, cb[r]),
+                                fmaf(T[r], clear.w, 1.0f - T[r]));
+        }
     }
     }  // tile < ntiles
 
