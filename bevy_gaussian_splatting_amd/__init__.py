@@ -27,6 +27,7 @@ from .settings import (
     compute_aabb,
 )
 from .io_ply import parse_ply_3d, write_ply_3d
+from .io_gcloud import decode_gcloud, encode_gcloud, read_gcloud, write_gcloud
 from .sort_policy import SortConfig, SortTrigger, update_sort_trigger
 from .plugin import (
     GaussianSplattingPlugin,
@@ -41,6 +42,6 @@ __all__ = [
     "SH_COEFF_COUNT", "random_gaussians_3d", "random_gaussians_3d_seeded",
     "CloudSettings", "DrawMode", "GaussianColorSpace", "GaussianMode", "RadixSortDepthBits",
     "RasterizeMode", "ShaderDefines", "SortMode", "compute_aabb",
-    "parse_ply_3d", "write_ply_3d", "SortConfig", "SortTrigger", "update_sort_trigger",
+    "parse_ply_3d", "write_ply_3d", "decode_gcloud", "encode_gcloud", "read_gcloud", "write_gcloud", "SortConfig", "SortTrigger", "update_sort_trigger",
     "GaussianSplattingPlugin", "PlanarGaussian3dHandle", "SortedEntries", "SORT_ENTRY_DTYPE",
 ]

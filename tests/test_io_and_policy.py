@@ -116,3 +116,76 @@ def test_sort_trigger_policy():
     # src/sort/rayon.rs:124-129
     assert after_cpu_sort(SortConfig(1000), 0.1).period_ms == 1000
     assert after_cpu_sort(SortConfig(1000), 0.4).period_ms == 1600
+
+
+# ---------------------------------------------------------------------------------------------
+# .gcloud (FlexBuffers) container: src/io/gcloud/flexbuffers.rs, round trip as in tests/io.rs
+# ---------------------------------------------------------------------------------------------
+import struct
+
+from bevy_gaussian_splatting_amd import decode_gcloud, encode_gcloud, read_gcloud, write_gcloud
+from bevy_gaussian_splatting_amd.io_gcloud import _Builder, flexbuffers_loads
+
+
+def test_gcloud_round_trip(tmp_path):
+    """tests/io.rs:7-17 (`test_codec_3d`): encode -> decode gives the same cloud, bit for bit."""
+    c = random_gaussians_3d_seeded(3000, 9)
+    data = encode_gcloud(c)
+    d = decode_gcloud(data)
+    for k in ("position_visibility", "spherical_harmonic", "rotation", "scale_opacity"):
+        assert np.array_equal(getattr(c, k), getattr(d, k)), k
+    path = os.path.join(tmp_path, "c.gcloud")
+    write_gcloud(c, path)
+    assert open(path, "rb").read() == data and len(read_gcloud(path)) == 3000
+    empty = decode_gcloud(encode_gcloud(PlanarGaussian3d(np.zeros((0, 4)), np.zeros((0, 48)), np.zeros((0, 4)), np.zeros((0, 4)))))
+    assert len(empty) == 0
+    # the logical structure the serde derives produce (src/gaussian/f32.rs, planar_3d.rs:28-54)
+    doc = flexbuffers_loads(encode_gcloud(random_gaussians_3d_seeded(2, 1)))
+    assert sorted(doc) == ["position_visibility", "rotation", "scale_opacity", "spherical_harmonic"]
+    assert sorted(doc["position_visibility"][0]) == ["position", "visibility"] and len(doc["position_visibility"][0]["position"]) == 3
+    assert sorted(doc["scale_opacity"][1]) == ["opacity", "scale"] and len(doc["rotation"][0]["rotation"]) == 4
+    assert len(doc["spherical_harmonic"][0]["coefficients"]) == 48
+
+
+def test_flexbuffers_known_answers_from_the_published_format():
+    """Hand-assembled buffers following google/flatbuffers `flexbuffers.h` (the reader must not depend
+    on what OUR writer emits): scalars, string, typed / fixed / untyped vectors, map, wide offsets."""
+    assert flexbuffers_loads(bytes([13, (1 << 2) | 0, 1])) == 13                                # int8
+    assert flexbuffers_loads(bytes([0x39, 0x30, (2 << 2) | 1, 2])) == 12345                     # uint16
+    assert flexbuffers_loads(struct.pack("<f", 1.5) + bytes([(3 << 2) | 2, 4])) == 1.5           # f32
+    assert flexbuffers_loads(struct.pack("<d", -2.25) + bytes([(3 << 2) | 3, 8])) == -2.25       # f64
+    assert flexbuffers_loads(bytes([2, 0x68, 0x69, 0, 3, (5 << 2) | 0, 1])) == "hi"             # string
+    assert list(flexbuffers_loads(bytes([3, 1, 2, 3, 3, (11 << 2) | 0, 1]))) == [1, 2, 3]       # VECTOR_INT
+    f3 = struct.pack("<3f", 1.0, 2.0, 3.0)                                                     # VECTOR_FLOAT3: no length
+    assert list(flexbuffers_loads(f3 + bytes([12, (21 << 2) | 2, 1]))) == [1.0, 2.0, 3.0]
+    # untyped vector [7, "hi", true]: string first, then [len][elems][types]
+    buf = bytes([2, 0x68, 0x69, 0]) + bytes([3, 7, 5, 1]) + bytes([(1 << 2), (5 << 2), (26 << 2)]) + bytes([6, (10 << 2), 1])
+    assert flexbuffers_loads(buf) == [7, "hi", True]
+    # map {"a": 1}: key, keys vector, then [keys offset][keys width][len][values][types]
+    buf = bytes([0x61, 0, 1, 3, 1, 1, 1, 1, (1 << 2), 2, (9 << 2), 1])
+    assert flexbuffers_loads(buf) == {"a": 1}
+    # a 2-byte-wide vector: offsets and length are uint16
+    vec = struct.pack("<H", 2) + struct.pack("<HH", 300, 400)                                   # [300, 400] as uint16
+    assert list(flexbuffers_loads(vec + bytes([4, (12 << 2) | 1, 1]))) == [300, 400]
+    for bad in (b"", b"\x01", bytes([9, 4, 3]), bytes([200, (5 << 2), 1])):
+        with pytest.raises(ValueError):
+            flexbuffers_loads(bad)
+
+
+def test_flexbuffers_writer_follows_the_builder_algorithm():
+    b = _Builder()
+    assert b.finish(b.uint(13)) == bytes([13, (2 << 2) | 0, 1])
+    b = _Builder()
+    assert b.finish(b.floats([1.0, 2.0, 3.0])) == struct.pack("<3f", 1.0, 2.0, 3.0) + bytes([12, (21 << 2) | 2, 1])
+    b = _Builder()
+    five = b.finish(b.floats([1, 2, 3, 4, 5]))   # longer than 4: typed vector WITH a length word of the element width
+    assert five == struct.pack("<I5f", 5, 1, 2, 3, 4, 5) + bytes([20, (13 << 2) | 2, 1])
+    b = _Builder()
+    m = b.finish(b.map({"b": b.uint(2), "a": b.uint(1)}))   # keys sorted, pooled strings first
+    assert flexbuffers_loads(m) == {"a": 1, "b": 2}
+    assert m[:4] == b"b\x00a\x00" or m[:4] == b"a\x00b\x00"
+    # widths grow with the distance an offset has to span
+    b = _Builder()
+    big = b.finish(b.vector([b.floats(np.arange(100, dtype=np.float32) + i) for i in range(3)]))
+    out = flexbuffers_loads(big)
+    assert [list(v[:2]) for v in out] == [[0.0, 1.0], [1.0, 2.0], [2.0, 3.0]]
