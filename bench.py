@@ -196,8 +196,10 @@ def main():
     DEPTH = max(1, min(8, args.depth))  # frames in flight (lanes); 1 = a single stream
     plugin.set_async(True)
     plugin.set_pipeline_depth(DEPTH)
-    # every kernel of every 4th frame is bracketed by HIP events (a record costs ~4 us of GPU time)
-    plugin.set_profiling_stride(8)
+    # every kernel of every Nth frame is bracketed by HIP events (a record costs ~4 us of GPU time, so
+    # timing every frame would cost ~20 % of the frame rate being measured)
+    STRIDE = 16 if args.steps >= 48 else 8
+    plugin.set_profiling_stride(STRIDE)
 
     def barrier():
         if dist is not None:
@@ -300,7 +302,7 @@ def main():
         sort_bytes = plugin.stats()["algorithmic_bytes"]
 
         # scene-like variant: global_scale = 0.05
-        plugin.set_profiling_stride(8)
+        plugin.set_profiling_stride(STRIDE)
         plugin.set_pipeline_depth(DEPTH)
         s2 = CloudSettings(global_scale=0.05)
         dt2, stage2, st2 = measure(plugin, handle, view, s2, args.steps, args.warmup, depth=DEPTH)

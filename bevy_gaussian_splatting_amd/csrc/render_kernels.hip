@@ -572,7 +572,10 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
         const float cpx = fmaf(huy, hvz, -(hvy * huz));
         const float cpy = fmaf(huz, hvx, -(hvz * hux));
         const float cpz = fmaf(hux, hvy, -(hvx * huy));
-        const float us = cpx / cpz, vs = cpy / cpz;
+        // one reciprocal instead of two IEEE divisions (~20 fewer instructions per pixel; v_rcp_f32 is
+        // good to 1 ulp, far inside the 1e-3 tolerance of the image)
+        const float icz = __builtin_amdgcn_rcpf(cpz);
+        const float us = cpx * icz, vs = cpy * icz;
         const float ddx = s.a1.y - pcx, ddy = s.a1.z - pcy;
         const float s3 = fmaf(us, us, vs * vs);
         const float s2 = 2.0f * fmaf(ddx, ddx, ddy * ddy);
