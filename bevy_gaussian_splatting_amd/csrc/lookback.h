@@ -2,12 +2,12 @@
 //
 // Every tile publishes STATUS_AGGREGATE | total as soon as it knows its local total, then sums
 // its predecessors' words until it meets a STATUS_PREFIX (inclusive prefix). With every tile of a
-// launch resident at once, all aggregates appear at about the same time and a walk that consumes
-// B predecessors per L2 round trip (tau ~ 1 us under load) finishes tile j after ~ j / (2B) round
-// trips, because the prefix frontier and the walkers move towards each other at B tiles per tau.
-// Measured (profiles/r1_v7 timeline): with B = 4 that walk WAS the kernel time of keygen (488
-// tiles, 29 us) and project_bin (470 tiles, 58 us). Hence: a whole wave per hop (64 predecessors)
-// where the block has one chain, and 16 per hop where each thread owns a chain (one per digit).
+// launch resident at once all aggregates appear at about the same time, so a walker consumes B
+// predecessors per L2 round trip (tau ~ 2.5 us for device-scope traffic): a whole wave per hop (64)
+// where the block has one chain, 16 where each thread owns a chain (one per digit / supertile).
+// At ~500 tiles the walk turned out NOT to be what bounds keygen or project_bin (B = 4 -> 16/64 changed
+// nothing measurable); the wide hops are kept for the multi-thousand-tile launches of large clouds.
+// What does matter is how waiting is done: see lb_backoff.
 #pragma once
 #include <hip/hip_runtime.h>
 

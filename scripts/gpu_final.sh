@@ -2,7 +2,7 @@
 # Round-end evidence run: smoke, all GPU tests, bench, other configs, rocprofv3 stats + PMC, timelines.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r1_v8}
+TAG=${1:-r1_final}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
