@@ -198,7 +198,7 @@ def main():
     plugin.set_pipeline_depth(DEPTH)
     # every kernel of every Nth frame is bracketed by HIP events (a record costs ~4 us of GPU time, so
     # timing every frame would cost ~20 % of the frame rate being measured)
-    STRIDE = 16 if args.steps >= 48 else 8
+    STRIDE = 16 if args.steps >= 64 else max(1, min(8, args.steps // 4))
     plugin.set_profiling_stride(STRIDE)
 
     def barrier():
@@ -282,7 +282,7 @@ def main():
                   "stage_ms": {k: round(v, 4) for k, v in stage1.items() if v}}
         dom1 = max(stage1, key=lambda k: stage1[k] / table[k]["launches"] if k in table else 0.0)
         b1 = table[dom1]["bytes"] / table[dom1]["launches"]
-        t1 = stage1[dom1] * 1e-3 / table[dom1]["launches"]
+        t1 = max(stage1[dom1] * 1e-3 / table[dom1]["launches"], 1e-12)
         single["roofline"] = {"bound": "hbm", "kernel": kernel_names[dom1], "achieved": round(b1 / t1 / 1e9, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b1 / t1 / 1e9 / HBM_PEAK_GBS, 4),
                               "launch_ms": round(t1 * 1e3, 4), "bytes_per_launch": int(b1)}
@@ -353,7 +353,7 @@ def main():
                 "value": round(max(args.steps // 3, 3) / dt3, 2), "unit": "frames/s",
                 "tile_instances": st3["instance_count"],
                 "stage_ms": {k: round(v, 4) for k, v in stage3.items()},
-                "GBps": round(st3["algorithmic_bytes"] / (sum(stage3.values()) * 1e-3) / 1e9, 1),
+                "GBps": round(st3["algorithmic_bytes"] / (max(sum(stage3.values()), 1e-9) * 1e-3) / 1e9, 1),
                 "scene_like_value": round(max(args.steps // 3, 3) / dt4, 2),
                 "scene_like_stage_ms": {k: round(v, 4) for k, v in stage4.items()}},
         }
