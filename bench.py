@@ -161,8 +161,8 @@ def cpu_baseline(cloud, view, settings):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splats", type=int, default=N_SPLATS)
     ap.add_argument("--depth", type=int, default=3, help="frames in flight (pipeline lanes, 1..8)")
