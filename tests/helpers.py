@@ -270,3 +270,41 @@ def tolerance_mask(ref: np.ndarray, got: np.ndarray, amb: np.ndarray | None, ato
     if amb is not None:
         lim = lim + amb.astype(np.float64)[..., None]
     return err <= lim, err
+
+
+def random_case(seed: int):
+    """One random (cloud, view, settings) configuration for the randomized parity sweeps: camera pose,
+    field of view, near plane and aspect; model transform with rotation, non-uniform scale and
+    translation; every CloudSettings switch the path honours; clear colour."""
+    import math
+    from bevy_gaussian_splatting_amd import (GaussianColorSpace, RadixSortDepthBits, RasterizeMode,
+                                             compute_aabb, random_gaussians_3d_seeded, transform_from)
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1500, 5000))
+    c = random_gaussians_3d_seeded(n, 100 + seed)
+    c.position_visibility[:, 3] = rng.integers(0, 7, n).astype(np.float32)
+    w, h = int(rng.integers(40, 200)), int(rng.integers(40, 140))
+    ang = rng.uniform(-math.pi, math.pi)
+    axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+    q = (*(np.sin(ang / 2) * axis), math.cos(ang / 2))
+    cam = transform_from(tuple(rng.uniform(-8, 8, 3)), q)
+    clear = tuple(rng.uniform(0, 1, 4)) if rng.random() < 0.5 else (0.0, 0.0, 0.0, 1.0)
+    v = View.perspective(cam, w, h, fov_y=float(rng.uniform(0.4, 1.6)), near=float(rng.uniform(0.05, 0.5)),
+                         clear_color=clear)
+    ang2 = rng.uniform(-math.pi, math.pi)
+    ax2 = rng.normal(size=3); ax2 /= np.linalg.norm(ax2)
+    tr = transform_from(tuple(rng.uniform(-3, 3, 3)), (*(np.sin(ang2 / 2) * ax2), math.cos(ang2 / 2)))
+    tr[:3, :3] = tr[:3, :3] @ np.diag(rng.uniform(0.5, 1.8, 3).astype(np.float32))
+    mn, mx = compute_aabb(c)
+    mode = [RasterizeMode.Color] * 3 + [RasterizeMode.Depth, RasterizeMode.Normal, RasterizeMode.Position,
+                                        RasterizeMode.Classification]
+    s = CloudSettings(
+        aabb=bool(rng.random() < 0.4),
+        gaussian_mode=GaussianMode.Gaussian2d if rng.random() < 0.3 else GaussianMode.Gaussian3d,
+        global_opacity=float(rng.uniform(0.3, 2.0)), global_scale=float(rng.choice([0.05, 0.3, 1.0, 1.5])),
+        opacity_adaptive_radius=bool(rng.random() < 0.7),
+        color_space=GaussianColorSpace.LinRec709Display if rng.random() < 0.3 else GaussianColorSpace.SrgbRec709Display,
+        radix_sort_depth_bits=RadixSortDepthBits(int(rng.choice([16, 24, 32]))),
+        sh_degree=int(rng.integers(0, 4)), rasterize_mode=mode[int(rng.integers(0, len(mode)))],
+        num_classes=int(rng.integers(1, 6)), position_min=mn, position_max=mx, transform=tr)
+    return c, v, s

@@ -612,3 +612,23 @@ def test_multi_camera_sorted_entries_layout(plugin, oracle):
     with pytest.raises(ValueError):
         plugin.sort_cameras(h, [moved], s, sorted_entries=se, camera_indices=[3])
     h.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# randomized sweep over camera / transform / settings combinations
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_configurations(plugin, oracle, seed):
+    c, v, s = H.random_case(seed)
+    cloud = c.to_f16() if seed % 4 == 3 else c
+    cd = oracle.decode_f16(cloud) if cloud is not c else c
+    plugin.set_binning("sort" if seed % 6 == 5 else "scan")
+    h = plugin.upload(cloud)
+    got = plugin.render(h, v, s)
+    gs = plugin.sort(h, v, s)
+    plugin.set_binning("scan")
+    e = oracle.sort(cd, v, s)
+    assert np.array_equal(gs["key"], e["key"]) and np.array_equal(gs["index"], e["index"])
+    ref, amb = oracle.render(cd, e, v, s, with_ambiguity=True)
+    _assert_image(ref, got, amb, frac_slack=0.01, what=f"seed {seed}: {s}")
+    h.free()
