@@ -11,8 +11,8 @@ already resident in HBM (uploaded once before the timed region, like the referen
 upload). Workload = BASELINE.json configs[1]: 1M random 3DGS splats (the reference's own
 `random_gaussians_3d` distributions), f32 planar cloud, SH degree 3, `CloudSettings::default()`,
 examples/headless.rs camera. With N > 1 ranks every rank renders ITS camera (camera g = the
-headless camera yawed g*45 degrees) of the replicated cloud and rank 0 gathers the N framebuffers
-over RCCL each step (weak scaling: per-GPU work fixed).
+headless camera yawed g*45 degrees) of the replicated cloud and rank 0 gathers every rank's frames
+over RCCL, asynchronously, 8 frames per collective (weak scaling: per-GPU work fixed).
 
 Prints ONE JSON line on rank 0. `value` = whole-job frames/s. Extra objects:
   roofline      dominant kernel of the timed region, algorithmic bytes per launch / average launch
@@ -43,6 +43,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 N_SPLATS = 1_000_000
 SEED = 2
 WIDTH, HEIGHT = 1920, 1080
+GATHER_BATCH = 8  # frames per framebuffer gather (N > 1)
 
 
 def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) -> dict:
@@ -88,6 +89,8 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
         if gather is not None:
             while plugin.frames_in_flight():
                 gather(*plugin.pipeline_pop())
+            if hasattr(gather, "flush"):
+                gather.flush()  # the last (partial) batch and every outstanding collective
         plugin.synchronize()  # also checks the device watchdog word of every frame
 
     run(warmup)
@@ -208,19 +211,23 @@ def main():
 
     gather_ms = [0.0]
     gather = None
+    batcher = None
     if dist is not None:
         # the gathered frame is the reference's colour-attachment format (Rgba8UnormSrgb, 8.3 MB at
-        # 1080p); the f32 target stays on its GPU
-        from bevy_gaussian_splatting_amd.multiview import device_ptr_as_tensor
+        # 1080p); the f32 target stays on its GPU. One collective per GATHER_BATCH frames, asynchronous
+        # and double-buffered (BatchedFrameGather): a per-frame gather would be bound by the collective's
+        # latency at these frame rates.
+        from bevy_gaussian_splatting_amd.multiview import BatchedFrameGather, device_ptr_as_tensor
         plugin.set_output_srgb8(True)
-        recv = [torch.empty((HEIGHT, WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(world)] if rank == 0 else None
+        batcher = BatchedFrameGather((HEIGHT, WIDTH, 4), torch.uint8, f"cuda:{local_rank}", batch=GATHER_BATCH)
 
         def gather(f32_ptr, srgb8_ptr):
             t = device_ptr_as_tensor(srgb8_ptr, (HEIGHT, WIDTH, 4), "|u1", f"cuda:{local_rank}")
             t0 = time.perf_counter()
-            dist.gather(t, gather_list=recv, dst=0)
-            torch.cuda.current_stream().synchronize()  # the lane may be reused once its frame was sent
+            batcher.push(t)  # the lane may be reused once push returns
             gather_ms[0] += (time.perf_counter() - t0) * 1e3
+
+        gather.flush = batcher.flush
 
     # ---- headline: reference distribution, CloudSettings::default() -------------------------
     dt, stage_ms, st = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, DEPTH)
@@ -337,7 +344,9 @@ def main():
                       "effective_pct_measured_peak": round(100 * eff_gbs / measured, 2) if measured else None,
                       "visible_splats": st["visible_count"], "tile_instances": st["instance_count"],
                       "gather_ms_per_step": round(gather_ms[0] / max(args.steps + args.warmup, 1), 4),
-                      "gathered_format": "Rgba8UnormSrgb" if world > 1 else None},
+                      "gathered_format": "Rgba8UnormSrgb" if world > 1 else None,
+                      "gather_batch_frames": GATHER_BATCH if world > 1 else None,
+                      "frames_gathered_on_rank0": batcher.frames_received if batcher is not None else None},
             "stages": stages,
             "sort_msplats_per_s": round(args.splats / (sort_dev_ms * 1e-3) / 1e6, 1) if sort_dev_ms > 0 else None,
             "sort": {"device_ms": round(sort_dev_ms, 4), "wall_ms": round(sort_wall * 1e3, 4),

@@ -53,6 +53,82 @@ def gather_framebuffers(local, dst: int = 0, group=None):
     return None
 
 
+class BatchedFrameGather:
+    """Gather frames to rank `dst` in batches: one collective per `batch` frames, asynchronous and
+    double-buffered, so that neither the collective's latency (~100 us per call) nor its transfer time
+    (8.3 MB per 1080p Rgba8UnormSrgb frame per xGMI link) stalls the renderer. `push(frame)` copies the
+    frame into the current staging batch (the caller may reuse the frame's memory as soon as push
+    returns); a full batch is sent with `gather(..., async_op=True)` while the other staging buffer
+    fills. `flush()` sends a partial batch and waits for everything. On `dst`, `on_batch(list of
+    per-rank [count, ...] tensors)` is called for every completed batch (default: count frames).
+    Works on any backend (nccl == RCCL on ROCm; gloo in the CPU tests)."""
+
+    def __init__(self, shape, dtype, device, batch: int = 8, dst: int = 0, group=None, on_batch=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist, self.torch = dist, torch
+        self.group, self.dst = group, dst
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.batch = max(1, int(batch))
+        self.stage = [torch.empty((self.batch, *shape), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [[torch.empty_like(self.stage[0]) for _ in range(self.world)] if self.rank == dst else None
+                     for _ in range(2)]
+        self.work = [None, None]
+        self.count_in_flight = [0, 0]
+        self.pushed = 0
+        self.frames_received = 0  # on dst: frames of all ranks that have arrived
+        self.on_batch = on_batch
+        self._is_cuda = torch.device(device).type == "cuda"
+
+    def _complete(self, s: int) -> None:
+        if self.work[s] is None:
+            return
+        self.work[s].wait()
+        if self._is_cuda:
+            self.torch.cuda.current_stream().synchronize()
+        self.work[s] = None
+        if self.rank == self.dst:
+            k = self.count_in_flight[s]
+            self.frames_received += k * self.world
+            if self.on_batch is not None:
+                self.on_batch([t[:k] for t in self.recv[s]])
+
+    def _send(self, s: int, count: int) -> None:
+        self.count_in_flight[s] = count
+        if not self.active:
+            self.frames_received += count
+            if self.on_batch is not None:
+                self.on_batch([self.stage[s][:count]])
+            return
+        self.work[s] = self.dist.gather(self.stage[s], gather_list=self.recv[s], dst=self.dst, group=self.group,
+                                        async_op=True)
+
+    def push(self, frame) -> None:
+        s, slot = (self.pushed // self.batch) % 2, self.pushed % self.batch
+        if slot == 0:
+            self._complete(s)  # the staging buffer is about to be overwritten
+        self.stage[s][slot].copy_(frame)
+        if self._is_cuda:
+            self.torch.cuda.current_stream().synchronize()  # the caller's frame memory may now be reused
+        self.pushed += 1
+        if slot == self.batch - 1:
+            self._send(s, self.batch)
+
+    def flush(self) -> None:
+        s, slot = (self.pushed // self.batch) % 2, self.pushed % self.batch
+        if slot:
+            self._send(s, slot)
+            self.pushed += self.batch - slot  # keep the batch phase of every rank aligned
+            self._complete(1 - s)  # completion in send order: the other buffer went out first
+            self._complete(s)
+        else:
+            self._complete(s)      # buffer s would be filled next, so it holds the older batch
+            self._complete(1 - s)
+
+
 class _DeviceArray:
     """Zero-copy view of a raw device pointer for torch (CUDA array interface v2)."""
 

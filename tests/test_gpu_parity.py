@@ -494,6 +494,23 @@ def test_pipelined_frames_and_srgb8_output(plugin, oracle):
                 assert np.array_equal(f, r)
                 exp = oracle.encode_srgb8(r)
                 assert np.abs(u.astype(np.int16) - exp.astype(np.int16)).max() <= 1
+        # bench.py's N > 1 consumer: popped frames staged into batches (here on one rank, no collective)
+        from bevy_gaussian_splatting_amd.multiview import BatchedFrameGather
+        batches = []
+        bg = BatchedFrameGather((180, 320, 4), torch.uint8, "cuda:0", batch=3,
+                                on_batch=lambda per_rank: batches.append(per_rank[0].cpu().numpy().copy()))
+        plugin.set_pipeline_depth(3)
+        for v in views:
+            plugin.render(h, v, s, download=False)
+            if plugin.frames_in_flight() >= 3:
+                bg.push(device_ptr_as_tensor(plugin.pipeline_pop()[1], (180, 320, 4), "|u1", "cuda:0"))
+        while plugin.frames_in_flight():
+            bg.push(device_ptr_as_tensor(plugin.pipeline_pop()[1], (180, 320, 4), "|u1", "cuda:0"))
+        bg.flush()
+        staged = np.concatenate(batches)
+        assert bg.frames_received == len(views) and staged.shape[0] == len(views)
+        for u, (_, u_ref) in zip(staged, got):
+            assert np.array_equal(u, u_ref)
         # more frames than lanes without popping: older frames are completed when their lane is reused
         plugin.set_pipeline_depth(3)
         for v in views:

@@ -77,3 +77,47 @@ def test_views_shard_one_per_rank_and_gather_to_rank0():
             assert np.array_equal(gathered[r][k], ref)
     # different cameras really produce different images
     assert not np.array_equal(gathered[0][0], gathered[1][0])
+
+
+def _batched_worker(rank, world, port, frames, batch, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bevy_gaussian_splatting_amd.multiview import BatchedFrameGather
+
+    got = []
+    g = BatchedFrameGather((4, 6, 4), torch.uint8, "cpu", batch=batch,
+                           on_batch=lambda per_rank: got.append([t.clone() for t in per_rank]))
+    frame = torch.empty((4, 6, 4), dtype=torch.uint8)
+    for i in range(frames):
+        frame.fill_((17 * rank + i) % 251)   # the SAME buffer is overwritten every frame, like a lane's
+        g.push(frame)
+    g.flush()
+    if rank == 0:
+        q.put((g.frames_received, [[t.numpy() for t in b] for b in got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("frames,batch", [(11, 4), (8, 4), (3, 8)])
+def test_batched_asynchronous_frame_gather(frames, batch):
+    """bench.py's gather for N > 1: one collective per `batch` frames, double-buffered; every frame of
+    every rank arrives once, in order, including the partial last batch."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batched_worker, args=(r, world, port, frames, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    received, batches = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert received == frames * world
+    for r in range(world):
+        seq = np.concatenate([b[r] for b in batches])
+        assert seq.shape == (frames, 4, 6, 4)
+        assert [int(f[0, 0, 0]) for f in seq] == [(17 * r + i) % 251 for i in range(frames)]
