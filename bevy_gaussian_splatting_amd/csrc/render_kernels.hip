@@ -438,9 +438,17 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
         if (single_shot) break;
         __syncthreads();
     }
+    // one atomic per BLOCK: same-address atomics retire one at a time (~8 ns), and a launch's last
+    // waves all arrive here together
+    __shared__ uint32_t s_vis[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) visible_acc += __shfl_down(visible_acc, off, 64);
-    if (lane == 0 && visible_acc) atomicAdd(&ctl->visible_count, visible_acc);
+    if (lane == 0) s_vis[wave] = visible_acc;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t v = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
+        if (v) atomicAdd(&ctl->visible_count, v);
+    }
 }
 
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
