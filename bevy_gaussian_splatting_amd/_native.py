@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "bgs_sorted_entries_device_ptr",
     "bgs_set_output_srgb8",
     "bgs_framebuffer_srgb8_device_ptr",
+    "bgs_set_srgb8_target",
     "bgs_set_pipeline_depth",
     "bgs_pipeline_pop",
     "bgs_frames_in_flight",
@@ -147,6 +148,8 @@ def load() -> ctypes.CDLL:
     lib.bgs_set_output_srgb8.restype = ctypes.c_int
     lib.bgs_framebuffer_srgb8_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
     lib.bgs_framebuffer_srgb8_device_ptr.restype = ctypes.c_int
+    lib.bgs_set_srgb8_target.argtypes = [vp, vp]
+    lib.bgs_set_srgb8_target.restype = ctypes.c_int
     lib.bgs_set_pipeline_depth.argtypes = [vp, u32]
     lib.bgs_set_pipeline_depth.restype = ctypes.c_int
     lib.bgs_pipeline_pop.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]

@@ -88,6 +88,7 @@ struct Lane {
     float4* fb = nullptr;
     size_t fb_pixels = 0;
     uint32_t* fb8 = nullptr;     // Rgba8UnormSrgb image (optional)
+    uint32_t* fb8_out = nullptr; // where the last frame's sRGB8 image went (fb8 or a caller's target)
     size_t fb8_pixels = 0;
     uint32_t fb_w = 0, fb_h = 0;
     bool fb8_valid = false;
@@ -133,6 +134,7 @@ struct bgs_ctx {
     uint32_t frame_counter = 0;
     bool async_frames = false;
     bool output_srgb8 = false;
+    uint32_t* next_srgb8_target = nullptr;  // bgs_set_srgb8_target: one-shot destination of the next frame
 
     // draw_count of the most recently completed frame: sizes the grids of the next frame's sort passes
     // (a hint only — the kernels read the real count on the device and loop over tickets if short)
@@ -586,10 +588,12 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         mark(6);
     }
     L.fb8_valid = false;
-    if (render && ctx->output_srgb8) {
-        launch_encode_srgb8(st, L.fb, L.fb8, (uint32_t)fp.width * (uint32_t)fp.height);
+    if (render && (ctx->output_srgb8 || ctx->next_srgb8_target)) {
+        L.fb8_out = ctx->next_srgb8_target ? ctx->next_srgb8_target : L.fb8;
+        launch_encode_srgb8(st, L.fb, L.fb8_out, (uint32_t)fp.width * (uint32_t)fp.height);
         L.fb8_valid = true;
     }
+    ctx->next_srgb8_target = nullptr;
     HIP_TRY(ctx, hipGetLastError());
     // the Control block travels back with the frame; it is looked at when the lane is completed.
     // A BINNING_SCAN frame's rasteriser has already written the counters to L.h_ctl and left the
@@ -892,9 +896,9 @@ int bgs_framebuffer_srgb8_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes)
         int rc = finish_lane(ctx, L, nullptr);
         if (rc != BGS_OK) return rc;
     }
-    if (!L.fb8 || !L.fb8_valid)
+    if (!L.fb8_out || !L.fb8_valid)
         return fail(ctx, BGS_EINVAL, "no Rgba8UnormSrgb frame: call bgs_set_output_srgb8(ctx, 1) before rendering");
-    *dptr = L.fb8;
+    *dptr = L.fb8_out;
     if (bytes) *bytes = (uint64_t)L.fb_w * L.fb_h * 4u;
     return BGS_OK;
 }
@@ -910,7 +914,7 @@ int bgs_pipeline_pop(bgs_ctx* ctx, void** rgba_f32, void** rgba8) {
     int rc = finish_lane(ctx, L, nullptr);
     if (rc != BGS_OK) return rc;
     if (rgba_f32) *rgba_f32 = L.fb;
-    if (rgba8) *rgba8 = L.fb8_valid ? L.fb8 : nullptr;
+    if (rgba8) *rgba8 = L.fb8_valid ? L.fb8_out : nullptr;
     return BGS_OK;
 }
 
@@ -966,6 +970,12 @@ int bgs_set_pipeline_depth(bgs_ctx* ctx, uint32_t lanes) {
     ctx->depth = (int)lanes;
     ctx->next = 0;
     ctx->recent = 0;
+    return BGS_OK;
+}
+
+int bgs_set_srgb8_target(bgs_ctx* ctx, void* device_ptr) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    ctx->next_srgb8_target = (uint32_t*)device_ptr;
     return BGS_OK;
 }
 

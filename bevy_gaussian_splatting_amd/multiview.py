@@ -78,7 +78,8 @@ class BatchedFrameGather:
                      for _ in range(2)]
         self.work = [None, None]
         self.count_in_flight = [0, 0]
-        self.pushed = 0
+        self.pushed = 0   # frames complete in their slot
+        self.issued = 0   # slots handed out by next_target()
         self.frames_received = 0  # on dst: frames of all ranks that have arrived
         self.on_batch = on_batch
         self._is_cuda = torch.device(device).type == "cuda"
@@ -106,6 +107,23 @@ class BatchedFrameGather:
         self.work[s] = self.dist.gather(self.stage[s], gather_list=self.recv[s], dst=self.dst, group=self.group,
                                         async_op=True)
 
+    # -- zero-copy interface: the producer writes each frame straight into its slot -------------
+    def next_target(self):
+        """Slot ([*shape] tensor view) the NEXT frame to be enqueued must be written to (e.g. via
+        `plugin.set_srgb8_target(slot.data_ptr())`). Frames may be enqueued up to `batch` ahead of
+        `frame_completed()` calls."""
+        s, slot = (self.issued // self.batch) % 2, self.issued % self.batch
+        if slot == 0:
+            self._complete(s)  # the previous gather out of this staging buffer must have finished
+        self.issued += 1
+        return self.stage[s][slot]
+
+    def frame_completed(self) -> None:
+        """The oldest outstanding frame (in `next_target` order) is now complete in its slot."""
+        self.pushed += 1
+        if self.pushed % self.batch == 0:
+            self._send((self.pushed // self.batch - 1) % 2, self.batch)
+
     def push(self, frame) -> None:
         s, slot = (self.pushed // self.batch) % 2, self.pushed % self.batch
         if slot == 0:
@@ -114,6 +132,7 @@ class BatchedFrameGather:
         if self._is_cuda:
             self.torch.cuda.current_stream().synchronize()  # the caller's frame memory may now be reused
         self.pushed += 1
+        self.issued = self.pushed
         if slot == self.batch - 1:
             self._send(s, self.batch)
 
@@ -122,6 +141,7 @@ class BatchedFrameGather:
         if slot:
             self._send(s, slot)
             self.pushed += self.batch - slot  # keep the batch phase of every rank aligned
+            self.issued = self.pushed
             self._complete(1 - s)  # completion in send order: the other buffer went out first
             self._complete(s)
         else:

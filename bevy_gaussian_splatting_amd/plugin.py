@@ -259,6 +259,10 @@ class GaussianSplattingPlugin:
         """Also produce every frame as Rgba8UnormSrgb (the reference's target format)."""
         self._check(self._lib.bgs_set_output_srgb8(self._ctx, 1 if enabled else 0))
 
+    def set_srgb8_target(self, device_ptr: Optional[int]) -> None:
+        """The next `render` writes its Rgba8UnormSrgb image to this device address (one-shot)."""
+        self._check(self._lib.bgs_set_srgb8_target(self._ctx, ctypes.c_void_p(device_ptr or 0)))
+
     def framebuffer_srgb8_device_ptr(self):
         p = ctypes.c_void_p()
         nbytes = ctypes.c_uint64()

@@ -201,6 +201,12 @@ int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes);
  * RGB -> sRGB transfer -> unorm8, alpha linear, 4 bytes per pixel R,G,B,A. Default off. */
 int bgs_set_output_srgb8(bgs_ctx* ctx, int enabled);
 int bgs_framebuffer_srgb8_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes);
+/* The NEXT bgs_render writes its Rgba8UnormSrgb image (width * height * 4 bytes) to this caller-owned
+ * device memory instead of the lane's own buffer (one-shot; NULL cancels). Lets a consumer that ships
+ * frames in batches (the multi-GPU gather) have each frame land in its slot of the batch with no copy
+ * and no extra synchronisation. Implies srgb8 output for that frame; bgs_pipeline_pop /
+ * bgs_framebuffer_srgb8_device_ptr then return this pointer for it. */
+int bgs_set_srgb8_target(bgs_ctx* ctx, void* device_ptr);
 
 /* Frame pipelining. A single stream of this path's kernels is latency bound at 1M splats, so the
  * context can keep up to 4 frames in flight on separate HIP streams ("lanes", each with its own

@@ -511,6 +511,24 @@ def test_pipelined_frames_and_srgb8_output(plugin, oracle):
         assert bg.frames_received == len(views) and staged.shape[0] == len(views)
         for u, (_, u_ref) in zip(staged, got):
             assert np.array_equal(u, u_ref)
+        # ... and the zero-copy variant: every frame is rendered straight into its slot of the batch
+        # (bgs_set_srgb8_target), nothing is copied on pop
+        batches2 = []
+        bg2 = BatchedFrameGather((180, 320, 4), torch.uint8, "cuda:0", batch=3,
+                                 on_batch=lambda per_rank: batches2.append(per_rank[0].cpu().numpy().copy()))
+        plugin.set_output_srgb8(False)
+        for v in views:
+            plugin.set_srgb8_target(bg2.next_target().data_ptr())
+            plugin.render(h, v, s, download=False)
+            if plugin.frames_in_flight() >= 3:
+                plugin.pipeline_pop()
+                bg2.frame_completed()
+        while plugin.frames_in_flight():
+            plugin.pipeline_pop()
+            bg2.frame_completed()
+        bg2.flush()
+        assert np.array_equal(np.concatenate(batches2), staged)
+        plugin.set_output_srgb8(True)
         # more frames than lanes without popping: older frames are completed when their lane is reused
         plugin.set_pipeline_depth(3)
         for v in views:

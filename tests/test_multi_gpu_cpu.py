@@ -79,7 +79,7 @@ def test_views_shard_one_per_rank_and_gather_to_rank0():
     assert not np.array_equal(gathered[0][0], gathered[1][0])
 
 
-def _batched_worker(rank, world, port, frames, batch, q):
+def _batched_worker(rank, world, port, frames, batch, zero_copy, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -89,10 +89,24 @@ def _batched_worker(rank, world, port, frames, batch, q):
     got = []
     g = BatchedFrameGather((4, 6, 4), torch.uint8, "cpu", batch=batch,
                            on_batch=lambda per_rank: got.append([t.clone() for t in per_rank]))
-    frame = torch.empty((4, 6, 4), dtype=torch.uint8)
-    for i in range(frames):
-        frame.fill_((17 * rank + i) % 251)   # the SAME buffer is overwritten every frame, like a lane's
-        g.push(frame)
+    if zero_copy:
+        # producer writes straight into the slot (bgs_set_srgb8_target), up to 3 frames ahead of completion
+        pending = []
+        for i in range(frames):
+            slot = g.next_target()
+            pending.append((slot, (17 * rank + i) % 251))
+            if len(pending) == 3:
+                t, val = pending.pop(0)
+                t.fill_(val)
+                g.frame_completed()
+        for t, val in pending:
+            t.fill_(val)
+            g.frame_completed()
+    else:
+        frame = torch.empty((4, 6, 4), dtype=torch.uint8)
+        for i in range(frames):
+            frame.fill_((17 * rank + i) % 251)   # the SAME buffer is overwritten every frame, like a lane's
+            g.push(frame)
     g.flush()
     if rank == 0:
         q.put((g.frames_received, [[t.numpy() for t in b] for b in got]))
@@ -101,15 +115,16 @@ def _batched_worker(rank, world, port, frames, batch, q):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("zero_copy", [False, True])
 @pytest.mark.parametrize("frames,batch", [(11, 4), (8, 4), (3, 8)])
-def test_batched_asynchronous_frame_gather(frames, batch):
+def test_batched_asynchronous_frame_gather(frames, batch, zero_copy):
     """bench.py's gather for N > 1: one collective per `batch` frames, double-buffered; every frame of
     every rank arrives once, in order, including the partial last batch."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_batched_worker, args=(r, world, port, frames, batch, q)) for r in range(world)]
+    procs = [ctx.Process(target=_batched_worker, args=(r, world, port, frames, batch, zero_copy, q)) for r in range(world)]
     for p in procs:
         p.start()
     received, batches = q.get(timeout=240)
