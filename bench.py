@@ -238,6 +238,8 @@ def main():
     # with a consumer popping frames the host waits for the oldest frame while the others run, so one
     # more lane keeps DEPTH frames on the GPU (measured on one rank: 9.3 k fps with 3 lanes, 10.8 k with 4)
     lanes = min(8, DEPTH + 1) if gather is not None else DEPTH
+    if os.environ.get("BGS_BENCH_LANES"):
+        lanes = max(1, min(8, int(os.environ["BGS_BENCH_LANES"])))  # experiment override
     plugin.set_pipeline_depth(lanes)
     dt, stage_ms, st = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, lanes)
     if dist is not None:
