@@ -15,11 +15,11 @@ headless camera yawed g*45 degrees) of the replicated cloud and rank 0 gathers e
 over RCCL, asynchronously, 8 frames per collective (weak scaling: per-GPU work fixed).
 
 Prints ONE JSON line on rank 0. `value` = whole-job frames/s. Extra objects:
-  roofline      dominant kernel of the timed region, algorithmic bytes per launch / average launch
-                duration measured live with HIP events on the library's own streams (bgs_get_stats);
-                with frames pipelined on several streams that duration includes the other frames'
-                kernels sharing the chip, so `single_stream.roofline` has the un-overlapped figure
-                and `frame` the whole-frame effective rate (algorithmic bytes x frames/s).
+  roofline      dominant kernel of the hot path, algorithmic bytes per launch / average launch duration
+                measured live with HIP events on the library's own stream (bgs_get_stats) on frames
+                that are not overlapped with other frames; `in_flight` has the same for the pipelined
+                timed region, where an event interval also contains the wait for the other lanes'
+                kernels; `frame` has the whole-frame effective rate (algorithmic bytes x frames/s).
                 `measured_peak` = this device's DtoD-copy / triad ceiling (bgs_hbm_probe).
   cpu_baseline  the oracle ("port": C restatement, OpenMP) timed on this host on a bounded sample
   stages        per-stage ms / algorithmic GB/s / %peak, V, I
@@ -304,6 +304,31 @@ def main():
         single["roofline"] = {"bound": "hbm", "kernel": kernel_names[dom1], "achieved": round(b1 / t1 / 1e9, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b1 / t1 / 1e9 / HBM_PEAK_GBS, 4),
                               "launch_ms": round(t1 * 1e3, 4), "bytes_per_launch": int(b1)}
+        # The roofline object: the dominant kernel of the hot path, its duration measured live with HIP
+        # events on frames that are NOT overlapped with other frames (this agrees with the rocprofv3
+        # kernel durations under profiles/). Inside the pipelined timed region an event interval also
+        # contains the time a kernel waits for the other lanes' kernels, which is reported as `in_flight`.
+        roofline_main = dict(single["roofline"])
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                roofline_main["traffic"] = json.load(f)["kernels"][roofline_main["kernel"]]["hbm_bytes_per_launch"]
+        except Exception:
+            roofline_main["traffic"] = None
+        roofline_main["measured_peak"] = roofline["measured_peak"]
+        roofline_main["frac_of_measured"] = round(roofline_main["achieved"] / measured, 4) if measured else None
+        roofline_main["measured_on"] = "single-stream frames (HIP events, every kernel of every Nth frame)"
+        # the kernel is VALU-issue bound, not HBM bound: its vector instruction count (SQ_INSTS_VALU from the
+        # committed PMC pass) against what 1024 SIMDs issue at 4 clocks per wave64 fp32 instruction, 2.4 GHz max clock
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                wi = json.load(f)["kernels"][roofline_main["kernel"]].get("valu_wave_instructions")
+            if wi:
+                min_ms = wi * 4.0 / (4 * 256) / 2.4e9 * 1e3
+                roofline_main["valu"] = {"wave_instructions_per_launch": int(wi), "issue_bound_ms": round(min_ms, 4),
+                                         "frac_of_issue_peak": round(min_ms / roofline_main["launch_ms"], 3)}
+        except Exception:
+            pass
+        roofline_main["in_flight"] = roofline
 
         # "Msplats/s sorted": keygen + depth sort only (blocking calls, every one timed)
         plugin.set_profiling_stride(1)
@@ -347,7 +372,7 @@ def main():
                        "parallelism": f"views{world}", "sort": "radix32", "global_scale": 1.0,
                        "frames_in_flight": DEPTH, "lanes": lanes},
             "single_stream": single,
-            "roofline": roofline,
+            "roofline": roofline_main,
             "frame": {"device_ms": round(frame_ms, 4), "algorithmic_GB": round(frame_bytes / 1e9, 4),
                       "GBps": round(frame_gbs, 1), "pct_hbm_peak": round(100 * frame_gbs / HBM_PEAK_GBS, 2),
                       "effective_GBps": round(eff_gbs, 1),
