@@ -2,12 +2,13 @@
 //
 // Every tile publishes STATUS_AGGREGATE | total as soon as it knows its local total, then sums
 // its predecessors' words until it meets a STATUS_PREFIX (inclusive prefix). With every tile of a
-// launch resident at once all aggregates appear at about the same time, so a walker consumes B
-// predecessors per L2 round trip (tau ~ 2.5 us for device-scope traffic): a whole wave per hop (64)
-// where the block has one chain, 16 where each thread owns a chain (one per digit / supertile).
-// At ~500 tiles the walk turned out NOT to be what bounds keygen or project_bin (B = 4 -> 16/64 changed
-// nothing measurable); the wide hops are kept for the multi-thousand-tile launches of large clouds.
-// What does matter is how waiting is done: see lb_backoff.
+// launch resident at once all aggregates appear at about the same time, and a walker consumes B
+// predecessors per L2 round trip: a whole wave per hop (64) where the block has one chain (keygen: one
+// poller wave per block), 4 where each thread owns a chain (one per digit / supertile; 16 beyond ~1000
+// tiles). Wider is NOT better for the per-thread chains: a prefix is usually met within a few words
+// and every extra word polled by 256 threads x hundreds of blocks is fabric traffic (one depth pass at
+// 74 tiles: 11.6 us with 4 words per hop, 12.4 with 16, 16.4 with 64).
+// What matters most is how waiting is done: see lb_backoff.
 #pragma once
 #include <hip/hip_runtime.h>
 
