@@ -341,6 +341,9 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
     __shared__ unsigned long long s_xmask[4][32];
     __shared__ unsigned long long s_ymask[4][32];
     __shared__ uint32_t s_rect[256];  // packed tile rectangle of each of the block's ranks
+    __shared__ uint32_t s_excl[MAX_SUPERTILES];  // list offset of the block's first hit, per supertile
+    __shared__ unsigned long long s_m[4][MAX_SUPERTILES];  // hit mask of each rank-wave, per supertile
+    __shared__ uint32_t s_block_hits;  // list entries this block appends (picks the append strategy)
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
             visible_acc += vis ? 1u : 0u;
         }
         s_rect[tid] = rect;
+        if (tid == 0) s_block_hits = 0u;
         if (fp.debug & 2u) {  // ablation: no coarse binning at all
             __syncthreads();
             continue;
@@ -413,26 +417,53 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
             __hip_atomic_store(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tile == num_tiles - 1u) ctl->coarse_total[tid] = excl + total;
-            // Append the block's hits to this supertile's list in rank order. (Measured alternatives,
-            // same process, dense / sparse workload: this serial bit walk 62.5 / 52.9 us per launch;
-            // rank-centric stores 64.5 / 52.3; a wave-cooperative sweep over all supertile x wave masks
-            // 66.7 / 63.2; no stores at all 51.0 / 50.9 — the ~11 us are the scattered 4-byte stores
-            // themselves, not the loop shape.)
-            if (!(fp.debug & 8u)) {  // ablation bit 8: chain but no list writes
-                // entry = (rank, its packed tile rectangle): the rasteriser's candidate scan then is one
-                // coalesced 8-byte stream instead of a rank stream plus a 64-line gather of rects[rank]
-                uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)tid * coarse_cap;
-                uint32_t pos = excl;
+            s_excl[tid] = excl;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s_m[w][tid] = m[w];
+            if (total) atomicAdd(&s_block_hits, total);
+        }
+        __syncthreads();
+        // Append the block's hits to the supertile lists in rank order. On the dense workload the cost of
+        // this step is the stores themselves (1.78 M scattered 8-byte stores: 16 us of this kernel,
+        // whether one thread walks a supertile's up-to-256 hit bits or the walk is split four ways), so a
+        // block with many hits makes them contiguous: wave v takes supertiles v, v+4, ...; for each of the
+        // block's four rank-waves, lane l owns hit bit l and the set lanes store to consecutive list slots
+        // (11.6 us). That sweep costs ~9 us even when the lists are short, so a block with few hits (the
+        // scene-like workload: ~2 per supertile) lets one thread per supertile walk its bits (2 us).
+        // entry = (rank, its packed tile rectangle): the rasteriser's candidate scan then is one coalesced
+        // 8-byte stream instead of a rank stream plus a 64-line gather of rects[rank].
+        if (fp.debug & 8u) {
+            // ablation bit 8: chain but no list writes
+        } else if (s_block_hits >= 8u * num_st) {
+            const uint32_t r0 = s_rect[lane], r1 = s_rect[64 + lane], r2 = s_rect[128 + lane], r3 = s_rect[192 + lane];
+            const uint32_t rr[4] = {r0, r1, r2, r3};
+            for (uint32_t st = (uint32_t)wave; st < num_st; st += 4u) {
+                const unsigned long long m0 = s_m[0][st], m1 = s_m[1][st], m2 = s_m[2][st], m3 = s_m[3][st];
+                uint32_t pos = s_excl[st];
+                uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)st * coarse_cap;
+                const unsigned long long mm[4] = {m0, m1, m2, m3};
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    unsigned long long bits = m[w];
-                    const uint32_t rank0 = tile * 256u + (uint32_t)w * 64u;
-                    while (bits) {
-                        const uint32_t l = (uint32_t)__builtin_ctzll(bits);
-                        bits &= bits - 1ull;
-                        if (pos < coarse_cap) dst[pos] = make_uint2(rank0 + l, s_rect[w * 64 + (int)l]);
-                        ++pos;
-                    }
+                    const unsigned long long m = mm[w];
+                    const uint32_t at = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (((m >> lane) & 1ull) && at < coarse_cap)
+                        dst[at] = make_uint2(tile * 256u + (uint32_t)(w * 64 + lane), rr[w]);
+                    pos += (uint32_t)__popcll(m);
+                }
+            }
+        } else if ((uint32_t)tid < num_st) {
+            uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)tid * coarse_cap;
+            uint32_t pos = s_excl[tid];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long bits = s_m[w][tid];
+                const uint32_t rank0 = tile * 256u + (uint32_t)w * 64u;
+                while (bits) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(bits);
+                    bits &= bits - 1ull;
+                    if (pos < coarse_cap) dst[pos] = make_uint2(rank0 + l, s_rect[w * 64 + (int)l]);
+                    ++pos;
                 }
             }
         }
