@@ -554,8 +554,15 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     bool raster_cleans = false;
     if (render && scan) {
         const uint32_t coarse_cap = std::max<uint32_t>(n, 1);
+        // grid: one block per 256-rank tile of the D drawable entries when that fits the chip (every block
+        // then takes exactly one ticket); D is only known on the device, so the previous frame's count
+        // sizes it (3 blocks of 163 VGPRs fit a CU)
+        int bin_blocks = ctx->num_cus * 3;
+        if (ctx->draw_hint_valid && !(ctx->debug_flags & 0x2000u))
+            bin_blocks = (int)std::min<uint64_t>((uint64_t)bin_blocks,
+                                                 std::max<uint64_t>(((uint64_t)ctx->draw_hint * 33 / 32) / 256 + 8, 32));
         launch_project_bin(st, fp, cloud->ptrs, draw_list, L.culled, ctl, bin_status, L.records, L.coarse, coarse_cap,
-                           sup_shift, /*ticket_slot=*/4, ctx->num_cus * 2);
+                           sup_shift, /*ticket_slot=*/4, bin_blocks);
         mark(3);
         FrameCleanup cl{};
         cl.part_status = part_status;
