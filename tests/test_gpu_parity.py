@@ -667,3 +667,23 @@ def test_randomized_configurations(plugin, oracle, seed):
     ref, amb = oracle.render(cd, e, v, s, with_ambiguity=True)
     _assert_image(ref, got, amb, frac_slack=0.01, what=f"seed {seed}: {s}")
     h.free()
+
+
+def test_maximum_viewport_4096_square(plugin, oracle):
+    """Largest target the ABI accepts: 256 x 256 tiles, 16 x 16 = 256 supertiles (every thread of the
+    binning block owns one), 16.7 M pixels. Oracle-checked crops at three places incl. the far corner."""
+    c = random_gaussians_3d_seeded(150_000, 51)
+    v = View.headless(4096, 4096)
+    for kw in ({"global_scale": 0.2}, {"global_scale": 0.2, "aabb": True}):
+        s = CloudSettings(**kw)
+        h = plugin.upload(c)
+        got = plugin.render(h, v, s)
+        assert got.shape == (4096, 4096, 4) and np.isfinite(got).all()
+        e = oracle.sort(c, v, s)
+        for (x0, y0) in ((0, 0), (2040, 2040), (4096 - 40, 4096 - 40)):
+            win = (x0, y0, x0 + 40, y0 + 40)
+            ref, amb = oracle.render(c, e, v, s, window=win, with_ambiguity=True)
+            _assert_image(ref, got[y0:y0 + 40, x0:x0 + 40], amb, frac_slack=0.01, what=f"4096^2 {kw} {win}")
+        h.free()
+    with pytest.raises(Exception):
+        plugin.render(plugin.upload(random_gaussians_3d_seeded(10, 1)), View.headless(4097, 64), CloudSettings())
