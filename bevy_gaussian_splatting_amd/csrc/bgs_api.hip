@@ -323,6 +323,7 @@ int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
         return fail(ctx, BGS_EINVAL,
                     "rasterize_mode OpticalFlow/Velocity is outside the path (previous-frame transforms / 4D clouds)");
     if (s->rasterize_mode > BGS_RASTERIZE_VELOCITY) return fail(ctx, BGS_EINVAL, "unknown rasterize_mode");
+    if (s->draw_mode > BGS_DRAW_HIGHLIGHT_SELECTED) return fail(ctx, BGS_EINVAL, "unknown draw_mode");
     if (s->rasterize_mode == BGS_RASTERIZE_CLASSIFICATION && s->num_classes == 0)
         return fail(ctx, BGS_EINVAL, "num_classes must be >= 1");
     if (render) {
@@ -556,7 +557,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         const uint32_t coarse_cap = std::max<uint32_t>(n, 1);
         // grid: one block per 256-rank tile of the D drawable entries when that fits the chip (every block
         // then takes exactly one ticket); D is only known on the device, so the previous frame's count
-        // sizes it (3 blocks of 163 VGPRs fit a CU)
+        // sizes it (two 172-VGPR blocks are resident per CU; a third of the grid may queue behind them)
         int bin_blocks = ctx->num_cus * 3;
         if (ctx->draw_hint_valid && !(ctx->debug_flags & 0x2000u))
             bin_blocks = (int)std::min<uint64_t>((uint64_t)bin_blocks,

@@ -38,6 +38,7 @@ struct FrameParams {
     uint32_t rasterize_mode;    // RasterizeMode discriminant (include/bgs.h)
     uint32_t num_classes;
     float pos_min[3], pos_max[3];  // gaussian_uniforms.min / .max (Position mode)
+    uint32_t draw_mode;            // 0 All, 1 Selected, 2 HighlightSelected
 };
 
 // rasterize_mode values (include/bgs.h)

@@ -43,6 +43,7 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     fp.debug = 0;
     fp.rasterize_mode = s->rasterize_mode;
     fp.num_classes = s->num_classes;
+    fp.draw_mode = s->draw_mode;
     for (int i = 0; i < 3; ++i) {
         fp.pos_min[i] = s->position_min[i];
         fp.pos_max[i] = s->position_max[i];

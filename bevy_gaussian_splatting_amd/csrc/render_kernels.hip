@@ -306,7 +306,7 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
     const bool surfel = fp.gaussian_mode == 0u && fp.aabb != 0u;
     float4* rec = (float4*)records;
-    const bool any_mode = fp.rasterize_mode != RASTERIZE_COLOR;
+    const bool any_mode = fp.rasterize_mode != RASTERIZE_COLOR || fp.draw_mode != 0u;
 #define BGS_LAUNCH_PE(F16, SURFEL, ANY)                                                             \
     hipLaunchKernelGGL((project_emit_kernel<F16, SURFEL, ANY>), dim3(blocks), dim3(256), 0, stream, \
                        fp, cloud, draw_list, culled, ctl, scan_status, rec, instances, capacity,    \
@@ -494,7 +494,7 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPt
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup, sup_y = ((uint32_t)fp.tiles_y + sup - 1u) / sup;
     const bool surfel = fp.gaussian_mode == 0u && fp.aabb != 0u;
     float4* rec = (float4*)records;
-    const bool any_mode = fp.rasterize_mode != RASTERIZE_COLOR;
+    const bool any_mode = fp.rasterize_mode != RASTERIZE_COLOR || fp.draw_mode != 0u;
 #define BGS_LAUNCH_PB(F16, SURFEL, ANY)                                                            \
     hipLaunchKernelGGL((project_bin_kernel<F16, SURFEL, ANY>), dim3(blocks), dim3(256), 0, stream, \
                        fp, cloud, draw_list, culled, ctl, bin_status, rec, coarse,                 \

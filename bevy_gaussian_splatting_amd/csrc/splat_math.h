@@ -487,6 +487,7 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
     V3 tp{t4.x, t4.y, t4.z};
     V4 projected = world_to_clip(fp, tp);                          // :210
     discard_quad = discard_quad || !in_frustum(projected);         // :211
+    if (ANY_MODE && fp.draw_mode == 1u) discard_quad = discard_quad || ci.visibility < 0.5f;  // DRAW_SELECTED :203-205
     if (discard_quad) return;                                      // :214-218
     o.visible = true;
     const bool sh_color = mode == RASTERIZE_COLOR || mode == RASTERIZE_CLASSIFICATION;
@@ -574,6 +575,9 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
     }
     o.color[0] = r; o.color[1] = g; o.color[2] = b;
     o.color[3] = opacity * fp.global_opacity;
+    if (ANY_MODE && fp.draw_mode == 2u && ci.visibility > 0.5f) {  // HIGHLIGHT_SELECTED :423-427
+        o.color[0] = 0.3f; o.color[1] = 1.0f; o.color[2] = 0.1f; o.color[3] = 1.0f;
+    }
     o.draw = true;
 }
 

@@ -64,9 +64,12 @@ class RasterizeMode(enum.IntEnum):
 
 
 class DrawMode(enum.IntEnum):
-    """src/gaussian/settings.rs:6-12. Only All is on the hot path."""
+    """src/gaussian/settings.rs:6-12; shader defs DRAW_SELECTED / HIGHLIGHT_SELECTED
+    (src/render/mod.rs:889-893, src/render/gaussian.wgsl:203-205,423-427)."""
 
     All = 0
+    Selected = 1
+    HighlightSelected = 2
 
 
 @dataclass(frozen=True)
@@ -131,7 +134,8 @@ class BgsSettings(ctypes.Structure):
         ("sort_mode", ctypes.c_uint32),
         ("rasterize_mode", ctypes.c_uint32),
         ("num_classes", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32 * 3),
+        ("draw_mode", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32 * 2),
         ("position_min", ctypes.c_float * 4),
         ("position_max", ctypes.c_float * 4),
     ]
@@ -174,8 +178,6 @@ class CloudSettings:
     position_max: tuple = (1.0, 1.0, 1.0)
 
     def to_native(self) -> BgsSettings:
-        if self.draw_mode != DrawMode.All:
-            raise ValueError("only DrawMode.All is implemented on the hot path")
         s = BgsSettings()
         m = np.asarray(self.transform, dtype=np.float32)
         if m.shape != (4, 4):
@@ -193,6 +195,7 @@ class CloudSettings:
         s.sort_mode = int(self.sort_mode)
         s.rasterize_mode = int(self.rasterize_mode)
         s.num_classes = int(self.num_classes)
+        s.draw_mode = int(self.draw_mode)
         s.position_min[:] = [float(v) for v in self.position_min] + [1.0]
         s.position_max[:] = [float(v) for v in self.position_max] + [1.0]
         return s

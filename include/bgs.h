@@ -89,6 +89,12 @@ typedef struct bgs_view {
 #define BGS_RASTERIZE_POSITION 5u
 #define BGS_RASTERIZE_VELOCITY 6u
 
+/* draw_mode: src/gaussian/settings.rs:6-12 -> DRAW_SELECTED / HIGHLIGHT_SELECTED shader defs
+ * (src/render/mod.rs:889-893; src/render/gaussian.wgsl:203-205, 423-427) */
+#define BGS_DRAW_ALL 0u
+#define BGS_DRAW_SELECTED 1u           /* splats with visibility < 0.5 are not drawn         */
+#define BGS_DRAW_HIGHLIGHT_SELECTED 2u /* splats with visibility > 0.5 drawn (0.3, 1, 0.1, 1) */
+
 /* CloudUniform (src/render/mod.rs:995-1009) + the CloudSettings fields that select the
  * pipeline specialisation (src/gaussian/settings.rs:87-132, src/render/mod.rs:770-896). */
 typedef struct bgs_settings {
@@ -104,7 +110,8 @@ typedef struct bgs_settings {
     uint32_t sort_mode;               /* BGS_SORT_RADIX default                          */
     uint32_t rasterize_mode;          /* BGS_RASTERIZE_COLOR default   settings.rs:38-47 */
     uint32_t num_classes;             /* default 1 (Classification)    settings.rs:124   */
-    uint32_t reserved[3];
+    uint32_t draw_mode;               /* BGS_DRAW_ALL default          settings.rs:6-12  */
+    uint32_t reserved[2];
     float position_min[4];            /* CloudUniform.min/max = the cloud entity's Aabb   */
     float position_max[4];            /* (src/render/mod.rs:1070-1071); Position mode     */
 } bgs_settings;

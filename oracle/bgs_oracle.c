@@ -590,6 +590,7 @@ static int vs_impl(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_vi
     v3 transformed_position = transform_point(s->transform, pv);     /* :198-200 */
     v4 projected_position = world_to_clip(view, transformed_position); /* :210 */
     discard_quad |= !in_frustum(projected_position);                 /* :211 */
+    if (s->draw_mode == BGS_DRAW_SELECTED) discard_quad |= pv[3] < 0.5f; /* DRAW_SELECTED :203-205 */
     o->projected[0] = projected_position.x;
     o->projected[1] = projected_position.y;
     o->projected[2] = projected_position.z;
@@ -665,6 +666,9 @@ static int vs_impl(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_vi
     o->color[1] = rgb.y;
     o->color[2] = rgb.z;
     o->color[3] = opacity * s->global_opacity;                       /* :419-422 */
+    if (s->draw_mode == BGS_DRAW_HIGHLIGHT_SELECTED && pv[3] > 0.5f) { /* HIGHLIGHT_SELECTED :423-427 */
+        o->color[0] = 0.3f; o->color[1] = 1.0f; o->color[2] = 0.1f; o->color[3] = 1.0f;
+    }
     return 0;
 }
 

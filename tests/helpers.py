@@ -43,6 +43,7 @@ class FrameParamsC(ctypes.Structure):
         ("debug", ctypes.c_uint32),
         ("rasterize_mode", ctypes.c_uint32), ("num_classes", ctypes.c_uint32),
         ("pos_min", ctypes.c_float * 3), ("pos_max", ctypes.c_float * 3),
+        ("draw_mode", ctypes.c_uint32),
     ]
 
 
@@ -277,7 +278,7 @@ def random_case(seed: int):
     field of view, near plane and aspect; model transform with rotation, non-uniform scale and
     translation; every CloudSettings switch the path honours; clear colour."""
     import math
-    from bevy_gaussian_splatting_amd import (GaussianColorSpace, RadixSortDepthBits, RasterizeMode,
+    from bevy_gaussian_splatting_amd import (DrawMode, GaussianColorSpace, RadixSortDepthBits, RasterizeMode,
                                              compute_aabb, random_gaussians_3d_seeded, transform_from)
     rng = np.random.default_rng(seed)
     n = int(rng.integers(1500, 5000))
@@ -306,5 +307,6 @@ def random_case(seed: int):
         color_space=GaussianColorSpace.LinRec709Display if rng.random() < 0.3 else GaussianColorSpace.SrgbRec709Display,
         radix_sort_depth_bits=RadixSortDepthBits(int(rng.choice([16, 24, 32]))),
         sh_degree=int(rng.integers(0, 4)), rasterize_mode=mode[int(rng.integers(0, len(mode)))],
-        num_classes=int(rng.integers(1, 6)), position_min=mn, position_max=mx, transform=tr)
+        num_classes=int(rng.integers(1, 6)), position_min=mn, position_max=mx, transform=tr,
+        draw_mode=DrawMode(int(rng.choice([0, 0, 0, 1, 2]))))
     return c, v, s

@@ -48,7 +48,7 @@ void shim_project(const FrameParams* fp, uint32_t key, const float* pos, const f
     memset(&pr, 0, sizeof pr);
     ColorInputs ci{pos[3], depth_range[0], depth_range[1]};
     // the same dispatch as the launchers: the Color-only instantiation unless another mode is asked for
-    if (fp->rasterize_mode == RASTERIZE_COLOR)
+    if (fp->rasterize_mode == RASTERIZE_COLOR && fp->draw_mode == 0u)
         project_splat<false>(*fp, key, V3{pos[0], pos[1], pos[2]}, rot, so, ShFloat{sh48}, ci, pr);
     else
         project_splat<true>(*fp, key, V3{pos[0], pos[1], pos[2]}, rot, so, ShFloat{sh48}, ci, pr);

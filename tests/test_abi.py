@@ -32,7 +32,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(BgsView) == (16 * 4 + 8) * 4
-    assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8 + 1 + 3 + 8) * 4
+    assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8 + 1 + 1 + 2 + 8) * 4
     assert ctypes.sizeof(_native.BgsSortEntry) == 8
     assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 4 * 4 + 8 + 8 + 8
     # the ctypes images include natural padding exactly like the C structs

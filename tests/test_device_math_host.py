@@ -221,3 +221,31 @@ def test_randomized_configurations_device_math(oracle, seed):
     got = H.emulate_render(c, v, s)
     ok, err = H.tolerance_mask(ref, got, amb)
     assert ok.all(), f"seed {seed}: max err {err.max():.3e} settings {s}"
+
+
+def test_draw_modes_device_math_matches_oracle(oracle):
+    """DrawMode::Selected / HighlightSelected (src/render/gaussian.wgsl:203-205, 423-427)."""
+    from bevy_gaussian_splatting_amd import DrawMode
+    c = _classified(random_gaussians_3d_seeded(3000, 27))
+    c.position_visibility[:, 3] = (np.arange(len(c)) % 3 == 0).astype(np.float32)   # every third splat selected
+    v = View.headless(128, 72)
+    base = oracle.render(c, oracle.sort(c, v, CloudSettings()), v, CloudSettings())
+    for dm in (DrawMode.Selected, DrawMode.HighlightSelected):
+        for kw in ({}, {"aabb": True}):
+            s = CloudSettings(draw_mode=dm, **kw)
+            e = oracle.sort(c, v, s)
+            ref, amb = oracle.render(c, e, v, s, with_ambiguity=True)
+            got = H.emulate_render(c, v, s)
+            ok, err = H.tolerance_mask(ref, got, amb)
+            assert ok.all(), f"{dm.name} {kw}: max err {err.max():.3e}"
+        assert not np.allclose(ref, base)
+    # closed forms: Selected draws exactly the selected subset; Highlight recolours it (0.3, 1, 0.1) at opacity 1
+    s = CloudSettings(draw_mode=DrawMode.Selected)
+    e = oracle.sort(c, v, s)
+    sel = c.position_visibility[e["index"], 3] > 0.5
+    only = oracle.render(c, e[sel], v, CloudSettings())
+    assert np.array_equal(oracle.render(c, e, v, s), only)
+    hs = CloudSettings(draw_mode=DrawMode.HighlightSelected)
+    drawn = [i for i in range(0, 3000, 3) if not oracle.vs(c, (0, i), v, hs).discard][:5]
+    for i in drawn:
+        assert list(oracle.vs(c, (0, i), v, hs).color) == pytest.approx([0.3, 1.0, 0.1, 1.0])

@@ -687,3 +687,24 @@ def test_maximum_viewport_4096_square(plugin, oracle):
         h.free()
     with pytest.raises(Exception):
         plugin.render(plugin.upload(random_gaussians_3d_seeded(10, 1)), View.headless(4097, 64), CloudSettings())
+
+
+def test_draw_modes(plugin, oracle, binning):
+    """DrawMode::Selected / HighlightSelected (src/render/gaussian.wgsl:203-205, 423-427)."""
+    from bevy_gaussian_splatting_amd import DrawMode
+    c = random_gaussians_3d_seeded(8000, 29)
+    c.position_visibility[:, 3] = (np.arange(len(c)) % 3 == 0).astype(np.float32)
+    v = View.headless(192, 108)
+    for dm in (DrawMode.Selected, DrawMode.HighlightSelected):
+        for kw in ({}, {"aabb": True}, {"gaussian_mode": GaussianMode.Gaussian2d, "aabb": True}):
+            s = CloudSettings(draw_mode=dm, **kw)
+            for cloud in (c, c.to_f16()) if not kw else (c,):
+                h = plugin.upload(cloud)
+                got = plugin.render(h, v, s)
+                cd = oracle.decode_f16(cloud) if cloud is not c else c
+                e = oracle.sort(cd, v, s)
+                ref, amb = oracle.render(cd, e, v, s, with_ambiguity=True)
+                _assert_image(ref, got, amb, what=f"{dm.name} {kw}")
+                vis, _ = oracle.instance_stats(cd, e, v, s)
+                assert plugin.stats()["visible_count"] == vis
+                h.free()
