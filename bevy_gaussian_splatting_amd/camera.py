@@ -15,6 +15,8 @@ import ctypes
 import math
 from dataclasses import dataclass, field
 
+from typing import Optional
+
 import numpy as np
 
 
@@ -28,6 +30,9 @@ class BgsView(ctypes.Structure):
         ("clip_from_world", ctypes.c_float * 16),
         ("viewport", ctypes.c_float * 4),
         ("clear_color", ctypes.c_float * 4),
+        ("previous_clip_from_world", ctypes.c_float * 16),
+        ("delta_time", ctypes.c_float),
+        ("reserved", ctypes.c_float * 3),
     ]
 
 
@@ -87,6 +92,10 @@ class View:
     clip_from_world: np.ndarray
     viewport: tuple  # x, y, w, h
     clear_color: tuple = (0.0, 0.0, 0.0, 1.0)  # examples/headless.rs:70
+    # RasterizeMode.OpticalFlow: last frame's clip_from_world (None = camera did not move) and the
+    # frame time in seconds (Bevy `globals.delta_time`)
+    previous_clip_from_world: Optional[np.ndarray] = None
+    delta_time: float = 1.0 / 60.0
     camera: GaussianCamera = field(default_factory=GaussianCamera)
 
     @property
@@ -139,4 +148,7 @@ class View:
             getattr(v, name)[:] = m.T.reshape(16).tolist()  # column-major
         v.viewport[:] = [float(c) for c in self.viewport]
         v.clear_color[:] = [float(c) for c in self.clear_color]
+        prev = self.clip_from_world if self.previous_clip_from_world is None else self.previous_clip_from_world
+        v.previous_clip_from_world[:] = np.asarray(prev, dtype=np.float32).T.reshape(16).tolist()
+        v.delta_time = float(self.delta_time)
         return v

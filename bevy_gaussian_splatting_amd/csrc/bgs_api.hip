@@ -319,9 +319,10 @@ int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
     if (s->sh_degree > 3) return fail(ctx, BGS_EINVAL, "sh_degree must be 0..3");
     if (s->sort_mode > BGS_SORT_STD) return fail(ctx, BGS_EINVAL, "unknown sort_mode");
     if (s->color_space > BGS_COLOR_LINEAR) return fail(ctx, BGS_EINVAL, "unknown color_space");
-    if (s->rasterize_mode == BGS_RASTERIZE_OPTICAL_FLOW || s->rasterize_mode == BGS_RASTERIZE_VELOCITY)
-        return fail(ctx, BGS_EINVAL,
-                    "rasterize_mode OpticalFlow/Velocity is outside the path (previous-frame transforms / 4D clouds)");
+    if (s->rasterize_mode == BGS_RASTERIZE_VELOCITY)
+        return fail(ctx, BGS_EINVAL, "rasterize_mode Velocity is outside the path (4D clouds only)");
+    if (s->rasterize_mode == BGS_RASTERIZE_OPTICAL_FLOW && !(view->delta_time > 0.0f))
+        return fail(ctx, BGS_EINVAL, "rasterize_mode OpticalFlow needs bgs_view.delta_time > 0");
     if (s->rasterize_mode > BGS_RASTERIZE_VELOCITY) return fail(ctx, BGS_EINVAL, "unknown rasterize_mode");
     if (s->draw_mode > BGS_DRAW_HIGHLIGHT_SELECTED) return fail(ctx, BGS_EINVAL, "unknown draw_mode");
     if (s->rasterize_mode == BGS_RASTERIZE_CLASSIFICATION && s->num_classes == 0)
@@ -781,6 +782,8 @@ void bgs_view_perspective(const float world_from_view[16], float fov_y_radians, 
     out->viewport[2] = (float)width;
     out->viewport[3] = (float)height;
     out->clear_color[3] = 1.0f;  // opaque black, examples/headless.rs:70
+    std::memcpy(out->previous_clip_from_world, out->clip_from_world, sizeof out->clip_from_world);
+    out->delta_time = 1.0f / 60.0f;
 }
 
 static int upload_plane(bgs_ctx* ctx, const void* host, size_t bytes, void** dev) {

@@ -39,11 +39,13 @@ struct FrameParams {
     uint32_t num_classes;
     float pos_min[3], pos_max[3];  // gaussian_uniforms.min / .max (Position mode)
     uint32_t draw_mode;            // 0 All, 1 Selected, 2 HighlightSelected
+    float prev_clip_from_world[16];  // previous_view_uniforms.clip_from_world (OpticalFlow)
+    float delta_time;                // globals.delta_time
 };
 
 // rasterize_mode values (include/bgs.h)
 constexpr uint32_t RASTERIZE_CLASSIFICATION = 0, RASTERIZE_COLOR = 1, RASTERIZE_DEPTH = 2,
-                   RASTERIZE_NORMAL = 3, RASTERIZE_POSITION = 5;
+                   RASTERIZE_NORMAL = 3, RASTERIZE_OPTICAL_FLOW = 4, RASTERIZE_POSITION = 5;
 
 // Per-splat inputs of the non-Color colour variants (src/render/gaussian.wgsl:312-405).
 struct ColorInputs {

@@ -372,6 +372,22 @@ BGS_HD V3 class_to_rgb(const FrameParams& fp, float visualization, V3 sh_color) 
     return V3{sh_color.x * (1.0f - 0.5f) + c.x * 0.5f, sh_color.y * (1.0f - 0.5f) + c.y * 0.5f,
               sh_color.z * (1.0f - 0.5f) + c.z * 0.5f};
 }
+// RASTERIZE_OPTICAL_FLOW (gaussian.wgsl:369-375; src/material/optical_flow.wgsl:16-53). For a 3D cloud
+// previous_transformed_position == transformed_position (gaussian.wgsl:201), so the flow is the
+// camera's. hsv_to_rgb is bevy_render's (third party, restated: see hsv_channel).
+BGS_HD V3 optical_flow_rgb(const FrameParams& fp, V3 tp) {
+    const float* c = fp.clip_from_world;
+    const float* q = fp.prev_clip_from_world;
+    V4 a = m4_mul_point(c, tp), b = m4_mul_point(q, tp);
+    const float mx = (a.x / a.w - b.x / b.w) * 0.5f, my = (a.y / a.w - b.y / b.w) * -0.5f;
+    const float fx = mx / fp.delta_time, fy = my / fp.delta_time;
+    const float radius = sqrtf(fx * fx + fy * fy);
+    float angle = atan2f(fy, fx);
+    if (angle < 0.0f) angle += 6.283185307f;
+    const float m = clamp1(radius, 0.0f, 1.0f);
+    return V3{hsv_channel(5.0f, angle, m, 1.0f), hsv_channel(3.0f, angle, m, 1.0f), hsv_channel(1.0f, angle, m, 1.0f)};
+}
+
 // Depth-mode range endpoints: length(transform * vec4(p, 1) - camera) (gaussian.wgsl:329-340)
 BGS_HD float distance_to_camera(const FrameParams& fp, V3 pos) {
     V4 t = m4_mul_point(fp.transform, pos);
@@ -567,6 +583,9 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
         r = c.x; g = c.y; b = c.z;
     } else if (mode == RASTERIZE_NORMAL) {            // :348-368
         V3 c = normal_rgb(fp, rot, so);
+        r = c.x; g = c.y; b = c.z;
+    } else if (mode == RASTERIZE_OPTICAL_FLOW) {                   // :369-375
+        V3 c = optical_flow_rgb(fp, tp);
         r = c.x; g = c.y; b = c.z;
     } else if (mode == RASTERIZE_POSITION) {          // :376-377
         r = (tp.x - fp.pos_min[0]) / (fp.pos_max[0] - fp.pos_min[0]);

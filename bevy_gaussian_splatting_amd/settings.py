@@ -51,8 +51,8 @@ class GaussianColorSpace(enum.IntEnum):
 class RasterizeMode(enum.IntEnum):
     """src/gaussian/settings.rs:36-47 (same discriminants). Color is the benchmarked mode;
     Classification / Depth / Normal / Position are colour-stage variants of the same pipeline
-    (src/render/gaussian.wgsl:312-405). OpticalFlow (needs the previous frame's transforms) and
-    Velocity (4D clouds) are outside the path and rejected by the library."""
+    (src/render/gaussian.wgsl:312-405); OpticalFlow reads the previous frame's clip_from_world and the
+    frame time from the View. Velocity (4D clouds only) is outside the path and rejected by the library."""
 
     Classification = 0
     Color = 1

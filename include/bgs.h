@@ -64,6 +64,11 @@ typedef struct bgs_view {
     float clip_from_world[16]; /* also used as unjittered_clip_from_world (no TAA)   */
     float viewport[4];         /* x, y, width, height in pixels (View.viewport)      */
     float clear_color[4];      /* linear RGBA the target is cleared to before draws  */
+    /* RasterizeMode::OpticalFlow only (src/material/optical_flow.wgsl:16-53): the PREVIOUS frame's
+     * clip_from_world (Bevy's previous_view_uniforms) and globals.delta_time in seconds */
+    float previous_clip_from_world[16];
+    float delta_time;
+    float reserved[3];
 } bgs_view;
 
 /* gaussian_mode: src/gaussian/settings.rs:17-22 */
@@ -80,7 +85,7 @@ typedef struct bgs_view {
 
 /* rasterize_mode: discriminants of RasterizeMode (src/gaussian/settings.rs:38-47); selects the
  * colour the vertex stage gives a splat (src/render/gaussian.wgsl:312-417). OpticalFlow needs the
- * previous frame's transforms and Velocity a 4D cloud: both are rejected with BGS_EINVAL. */
+ * previous frame's clip_from_world + delta_time in bgs_view. Velocity needs a 4D cloud: BGS_EINVAL. */
 #define BGS_RASTERIZE_CLASSIFICATION 0u
 #define BGS_RASTERIZE_COLOR 1u /* default */
 #define BGS_RASTERIZE_DEPTH 2u

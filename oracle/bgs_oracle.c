@@ -655,6 +655,19 @@ static int vs_impl(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_vi
         rgb.x = 0.5f * (wn.x / len + 1.0f);
         rgb.y = 0.5f * (wn.y / len + 1.0f);
         rgb.z = 0.5f * (wn.z / len + 1.0f);
+    } else if (s->rasterize_mode == BGS_RASTERIZE_OPTICAL_FLOW) {    /* :369-375, optical_flow.wgsl:16-53 */
+        v4 wp = {transformed_position.x, transformed_position.y, transformed_position.z, 1.0f};
+        v4 a = m4_mul_v4(view->clip_from_world, wp);           /* unjittered_clip_from_world */
+        v4 b = m4_mul_v4(view->previous_clip_from_world, wp);  /* previous position == position for 3D clouds (:201) */
+        float mx = (a.x / a.w - b.x / b.w) * 0.5f, my = (a.y / a.w - b.y / b.w) * -0.5f;
+        float fx = mx / view->delta_time, fy = my / view->delta_time;
+        float radius = sqrtf(fx * fx + fy * fy);
+        float angle = atan2f(fy, fx);
+        if (angle < 0.0f) angle += 6.283185307f;
+        float m = clamp1(radius, 0.0f, 1.0f);
+        rgb.x = hsv_channel(5.0f, angle, m, 1.0f);
+        rgb.y = hsv_channel(3.0f, angle, m, 1.0f);
+        rgb.z = hsv_channel(1.0f, angle, m, 1.0f);
     } else if (s->rasterize_mode == BGS_RASTERIZE_POSITION) {        /* :376-377 */
         rgb.x = (transformed_position.x - s->position_min[0]) / (s->position_max[0] - s->position_min[0]);
         rgb.y = (transformed_position.y - s->position_min[1]) / (s->position_max[1] - s->position_min[1]);
@@ -808,7 +821,7 @@ int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint
     float depth_range[2] = {0.0f, 0.0f};
     if (s->rasterize_mode == BGS_RASTERIZE_DEPTH && oracle_depth_range(cloud, entries, count, view, s, depth_range))
         return -3;
-    if (s->rasterize_mode == BGS_RASTERIZE_OPTICAL_FLOW || s->rasterize_mode >= BGS_RASTERIZE_VELOCITY) return -4;
+    if (s->rasterize_mode >= BGS_RASTERIZE_VELOCITY) return -4;
 
     /* vertex stage for every instance, keeping the non-discarded ones in draw order */
     uint8_t* keep = (uint8_t*)calloc(count ? count : 1, 1);

@@ -44,6 +44,7 @@ class FrameParamsC(ctypes.Structure):
         ("rasterize_mode", ctypes.c_uint32), ("num_classes", ctypes.c_uint32),
         ("pos_min", ctypes.c_float * 3), ("pos_max", ctypes.c_float * 3),
         ("draw_mode", ctypes.c_uint32),
+        ("prev_clip_from_world", ctypes.c_float * 16), ("delta_time", ctypes.c_float),
     ]
 
 
@@ -298,7 +299,11 @@ def random_case(seed: int):
     tr[:3, :3] = tr[:3, :3] @ np.diag(rng.uniform(0.5, 1.8, 3).astype(np.float32))
     mn, mx = compute_aabb(c)
     mode = [RasterizeMode.Color] * 3 + [RasterizeMode.Depth, RasterizeMode.Normal, RasterizeMode.Position,
-                                        RasterizeMode.Classification]
+                                        RasterizeMode.Classification, RasterizeMode.OpticalFlow]
+    if rng.random() < 0.7:   # the camera moved since the previous frame (OpticalFlow)
+        prev = transform_from(tuple(np.asarray(cam[:3, 3]) + rng.uniform(-0.05, 0.05, 3)), q)
+        v.previous_clip_from_world = View.perspective(prev, w, h, fov_y=0.9, near=0.1).clip_from_world
+        v.delta_time = float(rng.uniform(0.004, 0.05))
     s = CloudSettings(
         aabb=bool(rng.random() < 0.4),
         gaussian_mode=GaussianMode.Gaussian2d if rng.random() < 0.3 else GaussianMode.Gaussian3d,

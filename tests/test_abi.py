@@ -31,7 +31,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_the_header():
-    assert ctypes.sizeof(BgsView) == (16 * 4 + 8) * 4
+    assert ctypes.sizeof(BgsView) == (16 * 4 + 8 + 16 + 4) * 4
     assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8 + 1 + 1 + 2 + 8) * 4
     assert ctypes.sizeof(_native.BgsSortEntry) == 8
     assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 4 * 4 + 8 + 8 + 8
@@ -59,7 +59,9 @@ def test_view_perspective_matches_python_mirror():
     wfv = v.to_native().world_from_view
     lib.bgs_view_perspective(wfv, ctypes.c_float(np.pi / 4), ctypes.c_float(0.1), 1920, 1080, ctypes.byref(out))
     ref = v.to_native()
-    for name in ("world_from_view", "view_from_world", "clip_from_view", "clip_from_world", "viewport", "clear_color"):
+    assert abs(out.delta_time - 1 / 60) < 1e-7
+    for name in ("world_from_view", "view_from_world", "clip_from_view", "clip_from_world", "viewport", "clear_color",
+                 "previous_clip_from_world"):
         assert np.allclose(list(getattr(out, name)), list(getattr(ref, name)), rtol=1e-5, atol=1e-6), name
 
 

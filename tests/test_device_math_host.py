@@ -117,11 +117,13 @@ def _classified(c):
 
 
 @pytest.mark.parametrize("mode", [RasterizeMode.Classification, RasterizeMode.Depth, RasterizeMode.Normal,
-                                  RasterizeMode.Position])
+                                  RasterizeMode.Position, RasterizeMode.OpticalFlow])
 @pytest.mark.parametrize("kw", [{}, {"aabb": True}, {"gaussian_mode": GaussianMode.Gaussian2d, "aabb": True}])
 def test_rasterize_modes_device_math_matches_oracle(oracle, mode, kw):
     c = _classified(random_gaussians_3d_seeded(3000, 21))
     v = View.headless(128, 72)
+    v.previous_clip_from_world = View.headless(128, 72, yaw=0.003).clip_from_world   # the camera turned a little
+    v.delta_time = 1.0 / 120.0
     tr = transform_from((0.5, -0.25, 0.0), rotation_y(0.3))
     tr[:3, :3] *= np.float32(1.25)   # Transform::with_scale
     s = _mode_settings(mode, c, transform=tr, **kw)
@@ -192,8 +194,25 @@ def test_rasterize_mode_closed_forms(oracle):
         want = 0.5 * lin + 0.5 * np.array(colorsys.hsv_to_rgb(hue, 1.0, 1.0))
         assert np.allclose(list(oracle.vs(c, e[i], v, s).color)[:3], want, atol=2e-5), (i, cls)
 
+    # OpticalFlow: previous position == position for a 3D cloud, so a camera that did not move gives zero flow =
+    # hsv(angle 0, saturation 0, value 1) = white; a moved camera gives hue = direction, saturation = min(|flow|, 1)
+    s = CloudSettings(rasterize_mode=RasterizeMode.OpticalFlow, **base)
+    assert list(oracle.vs(c, e[1], v, s).color)[:3] == pytest.approx([1.0, 1.0, 1.0])
+    import copy, colorsys, math
+    v2 = copy.copy(v)
+    v2.previous_clip_from_world = View.perspective(transform_from((0.02, -0.01, 0)), 64, 64).clip_from_world
+    v2.delta_time = 0.05
+    for i in (1, 2, 3):
+        p4 = np.append(pv[i, :3].astype(np.float64), 1.0)
+        a, b = np.asarray(v2.clip_from_world, np.float64) @ p4, np.asarray(v2.previous_clip_from_world, np.float64) @ p4
+        flow = (a[:2] / a[3] - b[:2] / b[3]) * np.array([0.5, -0.5]) / v2.delta_time
+        ang = math.atan2(flow[1], flow[0]) % (2 * math.pi)
+        want = colorsys.hsv_to_rgb(ang / (2 * math.pi), min(np.linalg.norm(flow), 1.0), 1.0)
+        assert list(oracle.vs(c, e[i], v2, s).color)[:3] == pytest.approx(want, abs=3e-4)
+
     # the product's arithmetic gives the same per-splat colours
-    for mode in (RasterizeMode.Depth, RasterizeMode.Normal, RasterizeMode.Position, RasterizeMode.Classification):
+    for mode in (RasterizeMode.Depth, RasterizeMode.Normal, RasterizeMode.Position, RasterizeMode.Classification,
+                 RasterizeMode.OpticalFlow):
         s = CloudSettings(rasterize_mode=mode, **base)
         fpc = H.frame_params(n, v, s)
         rng = np.array(oracle.depth_range(c, e, v, s) if mode == RasterizeMode.Depth else (0, 0), np.float32)

@@ -573,12 +573,14 @@ def test_ply_loaded_cloud_renders_like_the_oracle(plugin, oracle, binning, tmp_p
 # RasterizeMode colour variants (src/render/gaussian.wgsl:312-405)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", [RasterizeMode.Classification, RasterizeMode.Depth, RasterizeMode.Normal,
-                                  RasterizeMode.Position])
+                                  RasterizeMode.Position, RasterizeMode.OpticalFlow])
 def test_rasterize_modes(plugin, oracle, binning, mode):
     c = random_gaussians_3d_seeded(6000, 23)
     c.position_visibility[:, 3] = (np.arange(len(c)) % 8).astype(np.float32)   # classes for Classification
     mn, mx = compute_aabb(c)
     v = View.headless(160, 90)
+    v.previous_clip_from_world = View.headless(160, 90, yaw=0.002).clip_from_world   # the camera turned a little
+    v.delta_time = 1.0 / 144.0
     tr = transform_from((0.5, -0.25, 0.0), rotation_y(0.3))
     for kw in ({}, {"aabb": True}, {"gaussian_mode": GaussianMode.Gaussian2d, "aabb": True},
                {"sort_mode": SortMode.Rayon}, {"radix_sort_depth_bits": RadixSortDepthBits.Bits16}):
@@ -615,7 +617,7 @@ def test_rasterize_mode_edge_cases(plugin, oracle):
         ok, err = H.tolerance_mask(np.where(m, ref, 0), np.where(m, got, 0), amb)
         assert ok.all(), (mode, err.max())
         h.free()
-    for bad in (RasterizeMode.OpticalFlow, RasterizeMode.Velocity):
+    for bad in (RasterizeMode.Velocity,):
         h = plugin.upload(one)
         with pytest.raises(Exception, match="rasterize_mode"):
             plugin.render(h, v, CloudSettings(rasterize_mode=bad))
