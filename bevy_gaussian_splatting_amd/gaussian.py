@@ -234,3 +234,33 @@ def test_model(seed: int = 0) -> PlanarGaussian3d:
                 )
     gs.append(gs[0])
     return PlanarGaussian3d.from_interleaved(gs)
+
+
+def compute_covariance_3d(rotation, scale) -> np.ndarray:
+    """CPU twin of the shader's covariance (src/gaussian/covariance.rs:4-41): `S = diag(scale)`, `R` from
+    the [w, x, y, z] quaternion with glam's column constructor, `M = S * R`, `Sigma = M^T * M`; returns the
+    six unique entries [xx, xy, xz, yy, yz, zz] in float32 (what `Covariance3dOpacity::from`,
+    src/gaussian/f32.rs:238-251, stores when the `precompute_covariance_3d` feature is on).
+    Accepts one splat ([4], [3]) or planes ([n, 4], [n, 3])."""
+    q = np.atleast_2d(np.asarray(rotation, np.float32))
+    sc = np.atleast_2d(np.asarray(scale, np.float32))[:, :3]
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    one, two = np.float32(1.0), np.float32(2.0)
+    # columns of R (Mat3::from_cols)
+    c0 = np.stack([one - two * (y * y + z * z), two * (x * y - r * z), two * (x * z + r * y)], 1)
+    c1 = np.stack([two * (x * y + r * z), one - two * (x * x + z * z), two * (y * z - r * x)], 1)
+    c2 = np.stack([two * (x * z - r * y), two * (y * z + r * x), one - two * (x * x + y * y)], 1)
+    R = np.stack([c0, c1, c2], 2).astype(np.float32)              # R[n, row, col]
+    M = (sc[:, :, None] * R).astype(np.float32)                   # S * R: row i scaled by scale_i
+    Sigma = np.einsum("nki,nkj->nij", M, M).astype(np.float32)    # M^T * M
+    out = np.stack([Sigma[:, 0, 0], Sigma[:, 0, 1], Sigma[:, 0, 2], Sigma[:, 1, 1], Sigma[:, 1, 2], Sigma[:, 2, 2]], 1)
+    return out[0] if np.asarray(rotation).ndim == 1 else out
+
+
+def covariance_3d_opacity(cloud: "PlanarGaussian3d") -> np.ndarray:
+    """`Covariance3dOpacity` plane ([n, 8] float32: cov3d[6], opacity, pad) of a cloud
+    (src/gaussian/f32.rs:218-251)."""
+    out = np.zeros((len(cloud), 8), np.float32)
+    out[:, :6] = compute_covariance_3d(cloud.rotation, cloud.scale_opacity[:, :3])
+    out[:, 6] = cloud.scale_opacity[:, 3]
+    return out

@@ -102,3 +102,25 @@ def test_view_assignment():
     assert v.camera.order == 2 and np.allclose(v.world_position, [0, 1.5, 5])
     fwd = v.world_from_view[:3, :3] @ np.array([0, 0, -1], np.float32)
     assert np.allclose(fwd, [-1, 0, 0], atol=1e-6)  # yawed 90 degrees about +Y
+
+
+def test_compute_covariance_3d_cpu_twin():
+    """src/gaussian/covariance.rs:4-41 and Covariance3dOpacity::from (src/gaussian/f32.rs:238-251)."""
+    from bevy_gaussian_splatting_amd import compute_covariance_3d, covariance_3d_opacity
+    assert np.allclose(compute_covariance_3d([1, 0, 0, 0], [2, 3, 4]), [4, 0, 0, 9, 0, 16])
+    # a rotation leaves the trace (sum of squared scales) alone; Sigma = R^T S^2 R with the reference's R
+    q = np.array([0.5, 0.5, 0.5, 0.5], np.float32)
+    cov = compute_covariance_3d(q, [1, 2, 3])
+    assert np.isclose(cov[0] + cov[3] + cov[5], 14.0)
+    c = random_gaussians_3d_seeded(500, 3)
+    planes = compute_covariance_3d(c.rotation, c.scale_opacity[:, :3])
+    for i in (0, 7, 499):
+        r, x, y, z = c.rotation[i].astype(np.float64)
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y + r * z), 2 * (x * z - r * y)],
+                      [2 * (x * y - r * z), 1 - 2 * (x * x + z * z), 2 * (y * z + r * x)],
+                      [2 * (x * z + r * y), 2 * (y * z - r * x), 1 - 2 * (x * x + y * y)]])   # rows = from_cols columns^T
+        M = np.diag(c.scale_opacity[i, :3].astype(np.float64)) @ R
+        S = M.T @ M
+        assert np.allclose(planes[i], [S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]], rtol=1e-5, atol=1e-6)
+    co = covariance_3d_opacity(c)
+    assert co.shape == (500, 8) and np.array_equal(co[:, 6], c.scale_opacity[:, 3]) and np.all(co[:, 7] == 0)
