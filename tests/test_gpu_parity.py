@@ -81,10 +81,10 @@ def test_sort_collisions_ties_by_index(plugin, oracle):
 
 
 @pytest.mark.parametrize("n,passes", [(0, 4), (1, 1), (255, 2), (2048, 4), (2049, 3), (300_001, 4),
-                                      (5_000_001, 2), (5_000_001, 4)])
+                                      (5_000_001, 2), (5_000_001, 4), (67_108_867, 4)])
 def test_onesweep_kernel_on_arbitrary_keys(plugin, n, passes):
-    """The radix kernel itself (both tile sizes: > 4M pairs uses 4096-pair tiles) on adversarial
-    keys: random with many ties, all-equal, already sorted, reversed."""
+    """The radix kernel itself (both tile sizes: > 4M pairs uses 4096-pair tiles; 2^26 + 3 pairs =
+    16 385 tiles per pass) on adversarial keys: random with many ties, all-equal, already sorted, reversed."""
     rng = np.random.default_rng(n + passes)
     mask = np.uint32((1 << (8 * passes)) - 1) if passes < 4 else np.uint32(0xFFFFFFFF)
     variants = [rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32) & mask]
@@ -378,6 +378,46 @@ def test_full_size_f16_5m_sort_and_crop(plugin, oracle):
         plugin.synchronize()
         from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
         assert np.array_equal(framebuffer_as_tensor(plugin, 1080, 1920).cpu().numpy(), got)
+    plugin.set_async(False)
+    plugin.set_pipeline_depth(1)
+    h.free()
+
+
+def test_cloud_past_2pow24_splats_f16(plugin, oracle):
+    """Beyond BASELINE's largest config: 16.8 M + 4133 splats (f16 planes, 2.1 GB) — splat indices no
+    longer fit an f32 mantissa, keygen runs 4097 tiles, every chained scan carries > 2^24 counts.
+    Sort bit-exact, crop within tolerance, pipelined frames identical."""
+    n = (1 << 24) + 4133
+    rng = np.random.default_rng(77)
+    pv = np.empty((n, 4), np.float32)
+    pv[:, :3] = rng.uniform(-20.0, 20.0, size=(n, 3)).astype(np.float32)
+    pv[:, 3] = 1.0
+    small = random_gaussians_3d_seeded(1 << 16, 5).to_f16()
+    reps = (n + (1 << 16) - 1) >> 16
+    sh = np.tile(small.spherical_harmonic, (reps, 1))[:n]
+    rso = np.tile(small.rotation_scale_opacity, (reps, 1))[:n]
+    from bevy_gaussian_splatting_amd.gaussian import PlanarGaussian3dF16
+    c = PlanarGaussian3dF16(pv, sh, rso)
+    v = View.headless(1920, 1080)
+    s = CloudSettings(global_scale=0.03)
+    h = plugin.upload(c)
+    got = plugin.render(h, v, s)
+    assert np.isfinite(got).all()
+    es = plugin.sort(h, v, s)
+    dec = oracle.decode_f16(c)
+    e = oracle.sort(dec, v, s)
+    assert np.array_equal(es["key"], e["key"]) and np.array_equal(es["index"], e["index"])
+    assert int(es["index"].max()) == n - 1
+    win = (944, 524, 976, 556)
+    ref, amb = oracle.render(dec, e, v, s, window=win, with_ambiguity=True)
+    _assert_image(ref, got[524:556, 944:976], amb, frac_slack=0.01, what="16.8M f16 crop")
+    plugin.set_async(True)
+    plugin.set_pipeline_depth(3)
+    for _ in range(6):
+        plugin.render(h, v, s, download=False)
+    plugin.synchronize()
+    from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
+    assert np.array_equal(framebuffer_as_tensor(plugin, 1080, 1920).cpu().numpy(), got)
     plugin.set_async(False)
     plugin.set_pipeline_depth(1)
     h.free()
