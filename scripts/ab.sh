@@ -1,0 +1,13 @@
+#!/bin/bash
+# same-box A/B of prebuilt library variants: ab/*.so are swapped in for libbgs.so one after another
+R=$GRAFT_REPO_ROOT
+cp $R/bevy_gaussian_splatting_amd/csrc/libbgs.so /tmp/libbgs_orig.so
+for rep in 1 2; do
+for v in $R/ab/*.so; do
+  cp $v $R/bevy_gaussian_splatting_amd/csrc/libbgs.so
+  echo "== $(basename $v) rep $rep"
+  python $R/scripts/loop_pipelined.py 1 ${1:-400} ${2:-1.0}
+  python $R/scripts/loop_pipelined.py 3 ${1:-400} ${2:-1.0}
+done
+done
+cp /tmp/libbgs_orig.so $R/bevy_gaussian_splatting_amd/csrc/libbgs.so
