@@ -57,6 +57,9 @@ EXPORTED_SYMBOLS = (
     "bgs_get_stats",
     "bgs_radix_sort_pairs",
     "bgs_hbm_probe",
+    "bgs_set_pipeline_streams",
+    "bgs_set_graphs",
+    "bgs_graph_counters",
 )
 
 
@@ -175,6 +178,12 @@ def load() -> ctypes.CDLL:
     lib.bgs_hbm_probe.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
                                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.bgs_hbm_probe.restype = ctypes.c_int
+    lib.bgs_set_pipeline_streams.argtypes = [vp, u32]
+    lib.bgs_set_pipeline_streams.restype = ctypes.c_int
+    lib.bgs_set_graphs.argtypes = [vp, ctypes.c_int]
+    lib.bgs_set_graphs.restype = ctypes.c_int
+    lib.bgs_graph_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.bgs_graph_counters.restype = ctypes.c_int
     _lib = lib
     return lib
 

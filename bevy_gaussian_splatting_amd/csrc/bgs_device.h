@@ -15,7 +15,8 @@ constexpr uint32_t SORT_NONE = 0, SORT_RADIX = 1, SORT_RAYON = 2, SORT_STD = 3;
 
 // Everything the per-splat stages read that is constant over a frame: the used parts of
 // Bevy's View uniform (src/render/bindings.wgsl:3-9) and CloudUniform
-// (src/render/mod.rs:995-1009). Passed to kernels by value.
+// (src/render/mod.rs:995-1009). The frame's first kernel gets it by value and leaves a
+// copy in device memory for the others (kernels.h, KeygenLaunch).
 struct FrameParams {
     float transform[16];        // gaussian_uniforms.transform, column-major
     float view_from_world[16];
@@ -41,7 +42,10 @@ struct FrameParams {
     uint32_t draw_mode;            // 0 All, 1 Selected, 2 HighlightSelected
     float prev_clip_from_world[16];  // previous_view_uniforms.clip_from_world (OpticalFlow)
     float delta_time;                // globals.delta_time
+    float clear[4];                  // the camera's clear colour (premultiplied RGBA)
+    uint64_t srgb8_target;           // device address the frame's Rgba8UnormSrgb image goes to; 0 = the lane's own
 };
+static_assert(sizeof(FrameParams) % 8 == 0 && sizeof(FrameParams) / 4 <= 256, "keygen copies it with one block");
 
 // rasterize_mode values (include/bgs.h)
 constexpr uint32_t RASTERIZE_CLASSIFICATION = 0, RASTERIZE_COLOR = 1, RASTERIZE_DEPTH = 2,

@@ -46,6 +46,8 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     fp.draw_mode = s->draw_mode;
     memcpy(fp.prev_clip_from_world, view->previous_clip_from_world, sizeof fp.prev_clip_from_world);
     fp.delta_time = view->delta_time;
+    memcpy(fp.clear, view->clear_color, sizeof fp.clear);
+    fp.srgb8_target = 0;
     for (int i = 0; i < 3; ++i) {
         fp.pos_min[i] = s->position_min[i];
         fp.pos_max[i] = s->position_max[i];

@@ -49,9 +49,26 @@ inline uint32_t sort_tile_size(bool large) { return SORT_THREADS * (large ? SORT
 // partition: drawable entries -> `entries` (index order), culled-sentinel entries -> `culled`
 // (index order); ctl->draw_count = number of drawable entries. part_status: zeroed chain words,
 // one per 2048-splat tile.
-void launch_keygen(hipStream_t stream, const FrameParams& fp, const float4* position_visibility,
-                   uint2* entries, uint2* culled, Control* ctl, uint32_t* part_status,
-                   uint32_t places, uint32_t ticket_slot, int max_blocks);
+// fp_out (device): the kernel also leaves a copy of `fp` there for the kernels behind it, which take
+// FrameParams by pointer — so one node of a captured frame carries everything that changes per frame.
+struct KeygenLaunch {
+    FrameParams fp;
+    const float4* pos;
+    uint2* entries;
+    uint2* culled;
+    Control* ctl;
+    uint32_t* part_status;
+    uint32_t places;
+    uint32_t ticket_slot;
+    FrameParams* fp_out;
+    // filled by prepare(): the launch geometry and the argument vector (points into this object)
+    const void* func;
+    uint32_t blocks;
+    void* argv[9];
+    bool prepare(int max_blocks);  // false: nothing to launch (n == 0)
+    hipError_t launch(hipStream_t stream);
+    hipError_t update_node(hipGraphExec_t exec, hipGraphNode_t node);  // same launch, as a graph node update
+};
 constexpr uint32_t KEYGEN_TILE = 2048;
 
 // Standalone digit histograms of existing pairs (used by bgs_radix_sort_pairs).
@@ -80,7 +97,8 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
 // appended, in rank order, to the list of each supertile (2^sup_shift x 2^sup_shift tiles) its
 // tile rectangle overlaps. One pass, no sort, no atomics on the data path: the <= 256 supertiles
 // are the "digits" of the same chained-scan look-back the radix sort uses.
-void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
+// d_fp: the device copy of `fp` the kernel reads (written by this frame's keygen).
+void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status, void* records,
                         uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
                         uint32_t ticket_slot, int max_blocks);
@@ -88,10 +106,10 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPt
 // Tile rasteriser for BINNING_SCAN: walks the supertile's ordered list, keeps the ranks whose
 // rectangle contains this tile (order-preserving ballot compaction), stages their records in LDS
 // and composites front-to-back until the tile saturates.
-void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* records,
+void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_shift, Control* ctl, float4* framebuffer,
-                        const float clear_color[4], const FrameCleanup& cleanup);
+                        const FrameCleanup& cleanup);
 
 // Per-tile [start, end) over the tile-sorted instances; ranges indexed by (ty << 8 | tx).
 void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Control* ctl, uint2* ranges);
@@ -103,7 +121,9 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
                    const float clear_color[4]);
 
 // Rgba8UnormSrgb image of the f32 framebuffer (the reference's render-target format).
-void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* out, uint32_t pixels);
+// The destination is d_fp->srgb8_target when that is non-zero, else default_out.
+void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* default_out, uint32_t pixels,
+                         const FrameParams* d_fp);
 
 // STREAM-triad on float4: a = b + s * c (HBM ceiling probe, bgs_hbm_probe).
 void launch_triad(hipStream_t stream, float4* a, const float4* b, const float4* c, float s, size_t n4,

@@ -326,7 +326,7 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
 // BINNING_SCAN: project + ordered coarse binning (supertile lists), one pass
 // ---------------------------------------------------------------------------------------
 template <bool F16, bool SURFEL, bool ANY_MODE>
-__global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudPtrs cloud,
+__global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __restrict__ fpp, CloudPtrs cloud,
                                                           const uint2* __restrict__ draw_list,
                                                           const uint2* __restrict__ culled,
                                                           Control* ctl, uint32_t* bin_status,
@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
                                                           uint32_t coarse_cap, uint32_t sup_shift,
                                                           uint32_t sup_x, uint32_t sup_y,
                                                           uint32_t ticket_slot) {
+    const FrameParams fp = *fpp;  // left in device memory by the frame's keygen (kernels.h, KeygenLaunch)
     // A rank overlaps supertile (sx, sy) iff sx is in its x-range AND sy is in its y-range, so the
     // per-supertile lane masks factor into sup_x column masks and sup_y row masks per wave:
     // sup_x + sup_y ballots instead of sup_x * sup_y.
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(FrameParams fp, CloudP
     }
 }
 
-void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
+void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status,
                         void* records, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
                         uint32_t ticket_slot, int max_blocks) {
@@ -497,7 +498,7 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const CloudPt
     const bool any_mode = fp.rasterize_mode != RASTERIZE_COLOR || fp.draw_mode != 0u;
 #define BGS_LAUNCH_PB(F16, SURFEL, ANY)                                                            \
     hipLaunchKernelGGL((project_bin_kernel<F16, SURFEL, ANY>), dim3(blocks), dim3(256), 0, stream, \
-                       fp, cloud, draw_list, culled, ctl, bin_status, rec, coarse,                 \
+                       d_fp, cloud, draw_list, culled, ctl, bin_status, rec, coarse,               \
                        coarse_cap, sup_shift, sup_x, sup_y, ticket_slot)
 #define BGS_LAUNCH_PB2(F16, SURFEL) \
     do { if (any_mode) BGS_LAUNCH_PB(F16, SURFEL, true); else BGS_LAUNCH_PB(F16, SURFEL, false); } while (0)
@@ -711,12 +712,13 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 // __launch_bounds__(256, 8): 8 waves/SIMD (<= 64 VGPRs). A 1080p frame is 8160 one-wave tiles for
 // 1024 SIMDs x 8 slots, so at 7 waves/SIMD a second, nearly empty round of waves appears.
 template <int VARIANT>
-__global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(FrameParams fp, const float4* __restrict__ records,
+__global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_shift,
                                                           uint32_t sup_x, Control* ctl,
-                                                          float4* __restrict__ fb, float4 clear,
+                                                          float4* __restrict__ fb,
                                                           FrameCleanup cl) {
+    const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     __shared__ float4 s_rec_all[4][64 * REC_V4];
     __shared__ uint32_t s_queue_all[4][64];
@@ -888,27 +890,26 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
             const int py = pyw + 4 * r;
             if (pxw < fp.width && py < fp.height)
                 fb[(size_t)py * (size_t)fp.width + (size_t)pxw] =
-                    make_float4(fmaf(T[r], clear.x, cr[r]), fmaf(T[r], clear.y, cg[r]), fmaf(T[r], clear.z, cb[r]),
-                                fmaf(T[r], clear.w, 1.0f - T[r]));
+                    make_float4(fmaf(T[r], fp.clear[0], cr[r]), fmaf(T[r], fp.clear[1], cg[r]),
+                                fmaf(T[r], fp.clear[2], cb[r]), fmaf(T[r], fp.clear[3], 1.0f - T[r]));
         }
     }
     }  // tile < ntiles
 
 }
 
-void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const void* records,
+void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_shift, Control* ctl, float4* framebuffer,
-                        const float clear_color[4], const FrameCleanup& cleanup) {
+                        const FrameCleanup& cleanup) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
-    const float4 clear = make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]);
     const float4* rec = (const float4*)records;
     const uint32_t sup = 1u << sup_shift;
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
 #define BGS_LAUNCH_RS(V)                                                                          \
-    hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, fp, rec,        \
-                       coarse, coarse_cap, sup_shift, sup_x, ctl, framebuffer, clear, cleanup)
+    hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,      \
+                       coarse, coarse_cap, sup_shift, sup_x, ctl, framebuffer, cleanup)
     if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
     else BGS_LAUNCH_RS(RV_SURFEL);
@@ -948,7 +949,10 @@ __device__ __forceinline__ float srgb_oetf(float x) {
     return x <= 0.0031308f ? 12.92f * x : fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)), -0.055f);
 }
 __global__ __launch_bounds__(256) void encode_srgb8_kernel(const float4* __restrict__ fb,
-                                                           uint32_t* __restrict__ out, uint32_t n) {
+                                                           uint32_t* __restrict__ default_out, uint32_t n,
+                                                           const FrameParams* __restrict__ fpp) {
+    // the frame's own destination (bgs_set_srgb8_target) travels in FrameParams
+    uint32_t* __restrict__ out = fpp->srgb8_target ? reinterpret_cast<uint32_t*>(fpp->srgb8_target) : default_out;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const float4 c = fb[i];
         out[i] = unorm8(srgb_oetf(c.x)) | (unorm8(srgb_oetf(c.y)) << 8) | (unorm8(srgb_oetf(c.z)) << 16) |
@@ -956,11 +960,12 @@ __global__ __launch_bounds__(256) void encode_srgb8_kernel(const float4* __restr
     }
 }
 
-void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* out, uint32_t pixels) {
+void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* default_out, uint32_t pixels,
+                         const FrameParams* d_fp) {
     if (pixels == 0) return;
     uint32_t blocks = (pixels + 255u) / 256u;
     if (blocks > 2048u) blocks = 2048u;
-    hipLaunchKernelGGL(encode_srgb8_kernel, dim3(blocks), dim3(256), 0, stream, framebuffer, out, pixels);
+    hipLaunchKernelGGL(encode_srgb8_kernel, dim3(blocks), dim3(256), 0, stream, framebuffer, default_out, pixels, d_fp);
 }
 
 }  // namespace bgs

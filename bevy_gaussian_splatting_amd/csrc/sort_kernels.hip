@@ -75,13 +75,18 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
                                                      uint2* __restrict__ entries,
                                                      uint2* __restrict__ culled, Control* ctl,
                                                      uint32_t* part_status, uint32_t places,
-                                                     uint32_t ticket_slot) {
+                                                     uint32_t ticket_slot, FrameParams* fp_out) {
     __shared__ uint32_t s_hist[4][RADIX_BASE];
     __shared__ uint32_t s_cnt[KG_ITEMS][4];  // drawable per (row, wave)
     __shared__ uint32_t s_keys[256 * KG_ITEMS];  // the tile's drawable keys, compacted (for the histograms)
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The frame's first kernel is the only one that receives FrameParams by value: it leaves a copy
+    // in device memory for the kernels behind it, so that a captured frame (hipGraph) is re-aimed at
+    // a new view by updating this one node's arguments.
+    if (fp_out && blockIdx.x == 0 && (uint32_t)tid < (uint32_t)(sizeof(FrameParams) / 4u))
+        reinterpret_cast<uint32_t*>(fp_out)[tid] = reinterpret_cast<const uint32_t*>(&fp)[tid];
 #pragma unroll
     for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
     const uint32_t sentinel = KEY_CULLED >> fp.key_shift;
@@ -185,22 +190,33 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
     }
 }
 
-void launch_keygen(hipStream_t stream, const FrameParams& fp, const float4* pos, uint2* entries,
-                   uint2* culled, Control* ctl, uint32_t* part_status, uint32_t places,
-                   uint32_t ticket_slot, int max_blocks) {
-    if (fp.n == 0) return;
+bool KeygenLaunch::prepare(int max_blocks) {
+    if (fp.n == 0) return false;
     // 4096-splat tiles once there are enough splats to fill the chip with them: half the tickets and
     // chain hops (measured at 1 M splats: 30.8 -> 27.3 us)
     const bool wide = fp.n >= (1u << 19);
     const uint32_t per_block = 256u * (wide ? 16u : 8u);
-    uint32_t blocks = (fp.n + per_block - 1) / per_block;
+    blocks = (fp.n + per_block - 1) / per_block;
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
-    if (wide)
-        hipLaunchKernelGGL(keygen_kernel<16>, dim3(blocks), dim3(256), 0, stream, fp, pos, entries, culled, ctl,
-                           part_status, places, ticket_slot);
-    else
-        hipLaunchKernelGGL(keygen_kernel<8>, dim3(blocks), dim3(256), 0, stream, fp, pos, entries, culled, ctl,
-                           part_status, places, ticket_slot);
+    func = wide ? reinterpret_cast<const void*>(&keygen_kernel<16>) : reinterpret_cast<const void*>(&keygen_kernel<8>);
+    argv[0] = &fp; argv[1] = &pos; argv[2] = &entries; argv[3] = &culled; argv[4] = &ctl;
+    argv[5] = &part_status; argv[6] = &places; argv[7] = &ticket_slot; argv[8] = &fp_out;
+    return true;
+}
+
+hipError_t KeygenLaunch::launch(hipStream_t stream) {
+    return hipLaunchKernel(func, dim3(blocks), dim3(256), argv, 0, stream);
+}
+
+hipError_t KeygenLaunch::update_node(hipGraphExec_t exec, hipGraphNode_t node) {
+    hipKernelNodeParams np{};
+    np.func = const_cast<void*>(func);
+    np.gridDim = dim3(blocks);
+    np.blockDim = dim3(256);
+    np.sharedMemBytes = 0;
+    np.kernelParams = argv;
+    np.extra = nullptr;
+    return hipGraphExecKernelNodeSetParams(exec, node, &np);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -239,6 +239,20 @@ class GaussianSplattingPlugin:
         self._check(self._lib.bgs_hbm_probe(self._ctx, int(nbytes), int(iters), ctypes.byref(c), ctypes.byref(t)))
         return float(c.value), float(t.value)
 
+    def set_pipeline_streams(self, streams: int) -> None:
+        """HIP streams the lanes are multiplexed onto (0 = one per lane); see bgs_set_pipeline_streams."""
+        self._check(self._lib.bgs_set_pipeline_streams(self._ctx, int(streams)))
+
+    def set_graphs(self, enabled: bool) -> None:
+        """Replay steady-state async frames from a captured hipGraph (default on; bgs_set_graphs)."""
+        self._check(self._lib.bgs_set_graphs(self._ctx, 1 if enabled else 0))
+
+    def graph_counters(self) -> tuple:
+        """(frames captured into a graph, frames replayed from one) since the plugin was created."""
+        c, r = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._lib.bgs_graph_counters(self._ctx, ctypes.byref(c), ctypes.byref(r)))
+        return int(c.value), int(r.value)
+
     # -- interop / introspection -----------------------------------------------------
     def synchronize(self) -> None:
         self._check(self._lib.bgs_synchronize(self._ctx))

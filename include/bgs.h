@@ -288,6 +288,26 @@ int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries_inout, uint32_t n
  * float4 accesses, counting 2 reads + 1 write. Allocates 3 * bytes for the call. */
 int bgs_hbm_probe(bgs_ctx* ctx, uint64_t bytes, uint32_t iters, float* copy_gbs, float* triad_gbs);
 
+/* Streams the lanes run on: lane i uses stream i % min(streams, depth); 0 = one stream per lane.
+ * Default 3. With fewer streams than lanes (depth 6 on 3 streams) a stream already holds the next
+ * frame of a sibling lane while one executes, so it never idles between frames waiting for the
+ * host, and no more than `streams` frames compete for the chip at a time (measured on the headline
+ * workload: 11.8 k frames/s with 3 lanes on 3 streams, 12.7 k with 6 lanes on 3 streams; more than 3
+ * concurrent frames is slower). Completes the frames in flight. */
+int bgs_set_pipeline_streams(bgs_ctx* ctx, uint32_t streams);
+
+/* Frame graphs (opt-in, default off). An asynchronous BINNING_SCAN frame (bgs_set_async) in the
+ * steady state is replayed from a hipGraph captured once per (lane, parity): the frame's first kernel
+ * receives the new view/settings as its arguments (one graph-node update) and leaves them in device
+ * memory for the kernels behind it. A replay costs the host ~10 us instead of ~19 us for 7 direct
+ * launches, but runs ~5 % slower on the GPU than the same launches issued directly (measured), so it
+ * is meant for hosts short of CPU time. The graph is rebuilt when anything else a launch depends on
+ * changes (cloud, buffers, viewport size, pipeline variant, grid sizes, debug flags); frames whose
+ * stages are timed with events (bgs_set_profiling) are always launched directly. */
+int bgs_set_graphs(bgs_ctx* ctx, int enabled);
+/* How many frames were captured into a graph / replayed from one since bgs_create. */
+int bgs_graph_counters(bgs_ctx* ctx, uint64_t* captures, uint64_t* replays);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevy_gaussian_splatting_amd import (CloudSettings, GaussianMode, GaussianSplattingPlugin, View,
                                          random_gaussians_3d_seeded)
 
-def run(p, h, v, s, steps=40, warm=6, depth=3):
+def run(p, h, v, s, steps=40, warm=6, depth=6):
     p.set_async(True); p.set_pipeline_depth(depth); p.set_profiling_stride(4)
     for _ in range(warm): p.render(h, v, s, download=False)
     p.synchronize()

@@ -45,6 +45,7 @@ class FrameParamsC(ctypes.Structure):
         ("pos_min", ctypes.c_float * 3), ("pos_max", ctypes.c_float * 3),
         ("draw_mode", ctypes.c_uint32),
         ("prev_clip_from_world", ctypes.c_float * 16), ("delta_time", ctypes.c_float),
+        ("clear", ctypes.c_float * 4), ("srgb8_target", ctypes.c_uint64),
     ]
 
 

@@ -371,6 +371,7 @@ def test_full_size_f16_5m_sort_and_crop(plugin, oracle):
     # spin back-off the polling loads starved the blocks everybody waited for and the device watchdog
     # tripped (seen at depth 3); the pipelined frames must complete and equal the blocking one.
     plugin.set_async(True)
+    plugin.set_pipeline_streams(0)  # one stream per lane: all `depth` frames compete for the chip
     for depth in (3, 6):
         plugin.set_pipeline_depth(depth)
         for _ in range(3 * depth):
@@ -378,6 +379,11 @@ def test_full_size_f16_5m_sort_and_crop(plugin, oracle):
         plugin.synchronize()
         from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
         assert np.array_equal(framebuffer_as_tensor(plugin, 1080, 1920).cpu().numpy(), got)
+    plugin.set_pipeline_streams(3)  # the default: 6 lanes on 3 streams
+    for _ in range(12):
+        plugin.render(h, v, s, download=False)
+    plugin.synchronize()
+    assert np.array_equal(framebuffer_as_tensor(plugin, 1080, 1920).cpu().numpy(), got)
     plugin.set_async(False)
     plugin.set_pipeline_depth(1)
     h.free()
@@ -465,6 +471,69 @@ def test_async_frames_match_synchronous_frames(plugin, oracle):
     finally:
         plugin.set_async(False)
     h.free()
+
+
+def test_frame_graphs_follow_changing_inputs(plugin):
+    """With bgs_set_graphs, async frames without stage timing replay a captured hipGraph:
+    only keygen's node is updated per frame. Every frame of a sequence in which the view, the
+    settings, the viewport, the pipeline variant, the cloud and the clear colour change must be
+    bit-identical to the same frame launched directly (blocking call), and steady stretches must
+    actually be replays."""
+    from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
+    clouds = [random_gaussians_3d_seeded(40_000, 61), random_gaussians_3d_seeded(25_000, 62)]
+    handles = [plugin.upload(c) for c in clouds]
+
+    def view(i, w=320, h=192):
+        v = headless_view(i % 8, w, h)
+        v.clear_color = (0.1 * (i % 3), 0.05, 0.2, 0.5 if i % 2 else 0.0)
+        return v
+
+    steps = []  # (cloud index, view, settings)
+    for i in range(6):   # moving camera, same everything else: replays
+        steps.append((0, view(i), CloudSettings(global_scale=0.5)))
+    for i in range(4):   # FrameParams-only settings changes: still replays
+        steps.append((0, view(i), CloudSettings(global_scale=0.3 + 0.1 * i, global_opacity=0.7, sh_degree=i % 4)))
+    steps.append((0, view(1, 256, 144), CloudSettings(global_scale=0.5)))              # viewport: recapture
+    steps.append((0, view(2, 256, 144), CloudSettings(global_scale=0.5)))
+    steps.append((0, view(3), CloudSettings(global_scale=0.5, aabb=True)))              # raster variant
+    steps.append((0, view(4), CloudSettings(global_scale=0.5, rasterize_mode=RasterizeMode.Normal)))  # any_mode
+    steps.append((0, view(5), CloudSettings(global_scale=0.5, radix_sort_depth_bits=RadixSortDepthBits.Bits16)))
+    steps.append((1, view(6), CloudSettings(global_scale=0.5)))                        # another cloud
+    steps.append((1, view(7), CloudSettings(global_scale=0.5, sort_mode=SortMode.Rayon)))
+    for i in range(4):
+        steps.append((0, view(i + 3), CloudSettings(global_scale=0.5)))
+
+    direct = [plugin.render(handles[ci], v, s) for ci, v, s in steps]  # blocking: launched directly
+    plugin.set_profiling(0)
+    plugin.set_async(True)
+    plugin.set_graphs(True)
+    try:
+        for depth in (1, 2, 3):
+            plugin.set_pipeline_depth(depth)
+            c0, r0 = plugin.graph_counters()
+            for k, (ci, v, s) in enumerate(steps):
+                plugin.render(handles[ci], v, s, download=False)
+                plugin.synchronize()
+                got = framebuffer_as_tensor(plugin, v.height, v.width).cpu().numpy()
+                assert np.array_equal(got, direct[k]), f"depth {depth} step {k}"
+            c1, r1 = plugin.graph_counters()
+            assert c1 > c0 and r1 - r0 >= 4, (depth, c1 - c0, r1 - r0)
+        # graphs off: same images, nothing captured or replayed
+        plugin.set_graphs(False)
+        c0, r0 = plugin.graph_counters()
+        for k in (0, 5, 12):
+            ci, v, s = steps[k]
+            plugin.render(handles[ci], v, s, download=False)
+            plugin.synchronize()
+            assert np.array_equal(framebuffer_as_tensor(plugin, v.height, v.width).cpu().numpy(), direct[k])
+        assert plugin.graph_counters() == (c0, r0)
+    finally:
+        plugin.set_graphs(False)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.set_profiling(2)
+    for h in handles:
+        h.free()
 
 
 def test_framebuffer_zero_copy_tensor_and_rccl_gather_single_rank(plugin):
