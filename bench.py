@@ -240,13 +240,21 @@ def main():
         gather.before_render = lambda: plugin.set_srgb8_target(batcher.next_target().data_ptr())
 
     # ---- headline: reference distribution, CloudSettings::default() -------------------------
-    # with a consumer popping frames the host waits for the oldest frame while the others run, so one
-    # more lane keeps DEPTH frames on the GPU (measured on one rank: 9.3 k fps with 3 lanes, 10.8 k with 4)
-    lanes = min(8, DEPTH + 1) if gather is not None else DEPTH
+    # with a consumer popping frames the host waits for the oldest frame while the others run: 8 lanes on
+    # 4 streams keep the GPU fed meanwhile (one rank driving this path without peers: 11.8 k frames/s;
+    # 10.6 k with 6 lanes on 3 streams, 10.0 k with 8 on 3)
+    lanes, streams = (8, 4) if gather is not None else (DEPTH, args.streams)
     if os.environ.get("BGS_BENCH_LANES"):
         lanes = max(1, min(8, int(os.environ["BGS_BENCH_LANES"])))  # experiment override
+    if os.environ.get("BGS_BENCH_STREAMS"):
+        streams = max(0, min(8, int(os.environ["BGS_BENCH_STREAMS"])))
     plugin.set_pipeline_depth(lanes)
-    dt, stage_ms, st = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, lanes)
+    plugin.set_pipeline_streams(streams)
+    # the headline region runs without stage events (each record is a packet on the stream; timing every
+    # 16th frame cost ~5 % of the rate being measured); the per-stage numbers come from separate passes
+    plugin.set_profiling(0)
+    dt, _, _ = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, lanes)
+    plugin.set_profiling(2)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -256,6 +264,8 @@ def main():
     # ---- side measurements on rank 0 (outside the timed region) -----------------------------
     out = None
     if rank == 0:
+        # per-stage times with the frames overlapped as in the headline region (every STRIDE-th frame timed)
+        _, stage_ms, st = measure(plugin, handle, view, settings, max(args.steps // 2, 4 * STRIDE), 4, depth=lanes)
         table = stage_table(st, 240)
         stages = {}
         for name, info in table.items():
@@ -352,6 +362,7 @@ def main():
         # scene-like variant: global_scale = 0.05
         plugin.set_profiling_stride(STRIDE)
         plugin.set_pipeline_depth(DEPTH)
+        plugin.set_pipeline_streams(max(0, min(8, args.streams)))
         s2 = CloudSettings(global_scale=0.05)
         dt2, stage2, st2 = measure(plugin, handle, view, s2, args.steps, args.warmup, depth=DEPTH)
         ms2 = sum(stage2.values())
@@ -375,7 +386,7 @@ def main():
                                    "distributions), 1920x1080, SH degree 3, CloudSettings::default(), "
                                    "examples/headless.rs camera; one camera per GPU",
                        "parallelism": f"views{world}", "sort": "radix32", "global_scale": 1.0,
-                       "frames_in_flight": DEPTH, "lanes": lanes, "streams": args.streams},
+                       "frames_in_flight": lanes, "lanes": lanes, "streams": streams},
             "single_stream": single,
             "roofline": roofline_main,
             "frame": {"device_ms": round(frame_ms, 4), "algorithmic_GB": round(frame_bytes / 1e9, 4),

@@ -5,14 +5,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevy_gaussian_splatting_amd import (CloudSettings, GaussianMode, GaussianSplattingPlugin, View,
                                          random_gaussians_3d_seeded)
 
-def run(p, h, v, s, steps=40, warm=6, depth=6):
-    p.set_async(True); p.set_pipeline_depth(depth); p.set_profiling_stride(4)
+def run(p, h, v, s, steps=60, warm=8, depth=6):
+    # throughput with `depth` lanes (on the default 3 streams), no stage events in the timed loop
+    p.set_async(True); p.set_pipeline_depth(depth); p.set_profiling(0)
     for _ in range(warm): p.render(h, v, s, download=False)
     p.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps): p.render(h, v, s, download=False)
     p.synchronize()
     dt = time.perf_counter() - t0
+    p.set_profiling(2); p.set_profiling_stride(4)
+    for _ in range(8): p.render(h, v, s, download=False)
+    p.synchronize()
     st = p.stats()
     p.set_pipeline_depth(1)
     for _ in range(warm): p.render(h, v, s, download=False)

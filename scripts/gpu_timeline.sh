@@ -1,18 +1,18 @@
 #!/bin/bash
-# rocprofv3 kernel timelines of the pipelined loop (depth 1 and 3) -> gpurun_out/timeline_depth*.json
+# rocprofv3 kernel timelines of the pipelined loop (depth 1, 3 and 6 — the last on 3 streams) -> gpurun_out/timeline_depth*.json
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp
-for d in 1 3; do
+for d in 1 3 6; do
   rm -rf /tmp/tl$d
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl$d -o t -- python $R/scripts/loop_pipelined.py $d 60 ${1:-1.0} > /tmp/tl$d.out 2>/tmp/tl$d.err
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl$d -o t -- python $R/scripts/loop_pipelined.py $d 60 ${1:-1.0} 0 0 3 > /tmp/tl$d.out 2>/tmp/tl$d.err
   cat /tmp/tl$d.out
   for f in $(find /tmp/tl$d -name "*kernel_trace.csv"); do python $R/scripts/timeline_analysis.py $f 150 > $R/gpurun_out/timeline_depth$d.json; done
 done
 python - <<'PY'
 import json, os
-for d in (1, 3):
+for d in (1, 3, 6):
     p = f"{os.environ['GRAFT_REPO_ROOT']}/gpurun_out/timeline_depth{d}.json"
     if os.path.exists(p):
         t = json.load(open(p))
