@@ -7,7 +7,7 @@ for v in $R/ab/*.so; do
   cp $v $R/bevy_gaussian_splatting_amd/csrc/libbgs.so
   echo "== $(basename $v) rep $rep"
   python $R/scripts/loop_pipelined.py 1 ${1:-400} ${2:-1.0}
-  python $R/scripts/loop_pipelined.py 3 ${1:-400} ${2:-1.0}
+  python $R/scripts/loop_pipelined.py 6 ${1:-400} ${2:-1.0} 0 0 3
 done
 done
 cp /tmp/libbgs_orig.so $R/bevy_gaussian_splatting_amd/csrc/libbgs.so
