@@ -68,6 +68,7 @@ struct GraphKey {
     uint32_t n, is_f16, places, sort_mode, gaussian_mode, aabb, any_mode, srgb8, debug_flags;
     int32_t width, height;
     int32_t sort_blocks, bin_blocks, keygen_blocks;
+    uint32_t sup_edge;
 };
 struct FrameGraph {
     hipGraph_t graph = nullptr;
@@ -164,6 +165,7 @@ struct bgs_ctx {
     // kernels read the real count on the device and loop over tickets if the grid is short.
     uint32_t draw_hint = 0;
     bool draw_hint_valid = false;
+    bool sup_fine = false;   // supertile edge rule of the next frames (see enqueue_frame)
     bool use_graphs = false;  // async BINNING_SCAN frames replay a captured hipGraph (bgs_set_graphs)
     uint64_t graph_captures = 0, graph_replays = 0;
 
@@ -425,6 +427,13 @@ int finish_lane(bgs_ctx* ctx, Lane& L, uint64_t* need_cap) {
         if (need_cap) *need_cap = total;
         return BGS_OK;
     }
+    if (render && scan && h.visible_count > 0) {
+        // list entries per visible splat: ~1.2 when splats are smaller than a supertile, 15-20 when they
+        // span many; thresholds far apart so that the rule does not flip on a moving camera
+        const uint64_t v = h.visible_count;
+        if (!ctx->sup_fine && total < 3 * v) ctx->sup_fine = true;
+        else if (ctx->sup_fine && total > 8 * v) ctx->sup_fine = false;
+    }
 
     bgs_stats& stt = L.result;
     std::memset(&stt, 0, sizeof stt);
@@ -535,16 +544,33 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     if ((rc = lane_create(ctx, L)) != BGS_OK) return rc;
     if ((rc = ensure_entries(ctx, L, n)) != BGS_OK) return rc;
     const bool scan = ctx->binning == BINNING_SCAN;
-    // supertile edge (in tiles): smallest power of two that keeps the coarse bins <= 256
-    uint32_t sup_shift = 3;
-    while ((((uint32_t)fp.tiles_x + (1u << sup_shift) - 1) >> sup_shift) *
-               (((uint32_t)fp.tiles_y + (1u << sup_shift) - 1) >> sup_shift) > MAX_SUPERTILES)
-        ++sup_shift;
-    const uint32_t num_st = (((uint32_t)fp.tiles_x + (1u << sup_shift) - 1) >> sup_shift) *
-                            (((uint32_t)fp.tiles_y + (1u << sup_shift) - 1) >> sup_shift);
+    // Supertile edge (in tiles). Two candidates: the smallest power of two >= 8 that keeps the coarse bins
+    // <= 256 and <= 32 per axis (8 at 1080p: 135 bins) and the smallest edge >= 3/4 of it that does
+    // (6 at 1080p: 240 bins).
+    // Small splats want the fine one — every tile scans its supertile's whole list, and the lists are
+    // 1.8x shorter (scene-like frame: 91.7 -> 87.9 us) — splats that span many supertiles the coarse one
+    // (1.5x fewer list entries to append; dense frame: 79.2 vs 86.4 us). Images do not depend on it; the
+    // choice follows the entries-per-splat ratio of the last completed frame (ctx->sup_fine).
+    // Debug flags: 0x8000 forces the coarse edge, 0x10000 the fine one.
+    auto bins = [&](uint32_t e, uint32_t& bx, uint32_t& by) {
+        bx = ((uint32_t)fp.tiles_x + e - 1) / e;
+        by = ((uint32_t)fp.tiles_y + e - 1) / e;
+        return bx * by <= MAX_SUPERTILES && bx <= MAX_SUPERTILES_PER_AXIS && by <= MAX_SUPERTILES_PER_AXIS;
+    };
+    uint32_t edge_c = 8, cbx = 0, cby = 0, edge_f = 1, fbx = 0, fby = 0;
+    while (!bins(edge_c, cbx, cby)) edge_c *= 2;
+    // the fine edge stays within 3/4 of the coarse one: the entries-per-splat statistic then differs by
+    // < 1.8x between the two rules, less than the gap between the switching thresholds (no flip-flop)
+    edge_f = (3 * edge_c + 3) / 4;
+    while (!bins(edge_f, fbx, fby)) ++edge_f;
+    if (edge_f >= edge_c) { edge_f = edge_c; fbx = cbx; fby = cby; }
+    const bool fine = (ctx->debug_flags & 0x10000u) || (ctx->sup_fine && !(ctx->debug_flags & 0x8000u));
+    const uint32_t sup_edge = fine ? edge_f : edge_c, sup_bx = fine ? fbx : cbx, sup_by = fine ? fby : cby;
+    const uint32_t num_st_alloc = std::max(fbx * fby, cbx * cby);  // lists are sized for either rule
+    const uint32_t num_st = sup_bx * sup_by;
     if (render) {
         if (scan) {
-            if ((rc = ensure_coarse(ctx, L, n, num_st)) != BGS_OK) return rc;
+            if ((rc = ensure_coarse(ctx, L, n, num_st_alloc)) != BGS_OK) return rc;
         } else {
             if ((rc = ensure_instances(ctx, L, std::max<uint64_t>(L.inst_cap, MIN_INSTANCE_CAPACITY))) != BGS_OK) return rc;
         }
@@ -643,9 +669,9 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         mark(2);
         if (render && scan) {
             launch_project_bin(st, fp, L.d_fp, cloud->ptrs, draw_list, L.culled, ctl, bin_status, L.records, L.coarse,
-                               coarse_cap, sup_shift, /*ticket_slot=*/4, bin_blocks);
+                               coarse_cap, sup_edge, /*ticket_slot=*/4, bin_blocks);
             mark(3);
-            launch_raster_scan(st, fp, L.d_fp, L.records, L.coarse, coarse_cap, sup_shift, ctl, L.fb, cl);
+            launch_raster_scan(st, fp, L.d_fp, L.records, L.coarse, coarse_cap, sup_edge, ctl, L.fb, cl);
             mark(6);
         } else if (render) {
             const uint32_t capacity = (uint32_t)std::min<uint64_t>(L.inst_cap, MAX_INSTANCE_CAPACITY);
@@ -699,6 +725,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         key.sort_blocks = sort_blocks;
         key.bin_blocks = bin_blocks;
         key.keygen_blocks = (int32_t)kg.blocks;
+        key.sup_edge = sup_edge;
         FrameGraph& G = L.graph[L.ctl_parity];
         if (G.exec && std::memcmp(&G.key, &key, sizeof key) == 0) {
             HIP_TRY(ctx, kg.update_node(G.exec, G.keygen_node));

@@ -108,6 +108,14 @@ struct Control {
 // packed tile rectangle x0 | x1 << 8 | y0 << 16 | y1 << 24 (inclusive); x0 > x1 = touches no tile
 constexpr uint32_t RECT_EMPTY = 0x000000FFu;
 constexpr uint32_t MAX_SUPERTILES = 256;  // coarse bins ride the 256-wide chained scan
+constexpr uint32_t MAX_SUPERTILES_PER_AXIS = 32;  // column / row masks of project_bin
+// Supertiles are squares of E x E tiles, E any integer (6 at 1080p: 20 x 12 = 240 bins): tile / E as
+// (tile * M) >> 16 with M = 65536 / E + 1, exact for tile < 256 and E <= 32.
+inline uint32_t supertile_mul(uint32_t edge) { return 65536u / edge + 1u; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t supertile_div(uint32_t tile, uint32_t mul) { return (tile * mul) >> 16; }
 
 // binning modes (bgs_set_binning)
 constexpr uint32_t BINNING_SCAN = 0;  // ordered coarse lists + lazy per-tile scan (default)

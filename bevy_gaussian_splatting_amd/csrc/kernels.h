@@ -94,13 +94,13 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
                          int max_blocks);
 
 // Vertex stage in front-to-back order + ORDERED coarse binning (BINNING_SCAN): every rank is
-// appended, in rank order, to the list of each supertile (2^sup_shift x 2^sup_shift tiles) its
+// appended, in rank order, to the list of each supertile (sup_edge x sup_edge tiles) its
 // tile rectangle overlaps. One pass, no sort, no atomics on the data path: the <= 256 supertiles
 // are the "digits" of the same chained-scan look-back the radix sort uses.
 // d_fp: the device copy of `fp` the kernel reads (written by this frame's keygen).
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status, void* records,
-                        uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
+                        uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_edge,
                         uint32_t ticket_slot, int max_blocks);
 
 // Tile rasteriser for BINNING_SCAN: walks the supertile's ordered list, keeps the ranks whose
@@ -108,7 +108,7 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
 // and composites front-to-back until the tile saturates.
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
-                        uint32_t sup_shift, Control* ctl, float4* framebuffer,
+                        uint32_t sup_edge, Control* ctl, float4* framebuffer,
                         const FrameCleanup& cleanup);
 
 // Per-tile [start, end) over the tile-sorted instances; ranges indexed by (ty << 8 | tx).

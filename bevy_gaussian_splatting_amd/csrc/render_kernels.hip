@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
                                                           Control* ctl, uint32_t* bin_status,
                                                           float4* __restrict__ records,
                                                           uint32_t* __restrict__ coarse,
-                                                          uint32_t coarse_cap, uint32_t sup_shift,
+                                                          uint32_t coarse_cap, uint32_t sup_mul,
                                                           uint32_t sup_x, uint32_t sup_y,
                                                           uint32_t ticket_slot) {
     const FrameParams fp = *fpp;  // left in device memory by the frame's keygen (kernels.h, KeygenLaunch)
@@ -381,9 +381,10 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
             continue;
         }
         {
-            // supertile bounds of the rectangle; an empty rect has sx0 = 31 > sx1 = 0: no column matches
-            const uint32_t sx0 = (rect & 255u) >> sup_shift, sx1 = ((rect >> 8) & 255u) >> sup_shift;
-            const uint32_t sy0 = ((rect >> 16) & 255u) >> sup_shift, sy1 = (rect >> 24) >> sup_shift;
+            // supertile bounds of the rectangle; an empty rect has x0 = 255 > x1 = 0, so sx0 > sx1: no column matches
+            // tile / supertile edge by reciprocal multiply (exact for tiles < 256, supertile_div)
+            const uint32_t sx0 = supertile_div(rect & 255u, sup_mul), sx1 = supertile_div((rect >> 8) & 255u, sup_mul);
+            const uint32_t sy0 = supertile_div((rect >> 16) & 255u, sup_mul), sy1 = supertile_div(rect >> 24, sup_mul);
             for (uint32_t c = 0u; c < sup_x; ++c) {
                 const unsigned long long b = __ballot(c >= sx0 && c <= sx1);
                 if (lane == 0) s_xmask[wave][c] = b;
@@ -486,12 +487,12 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
 
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status,
-                        void* records, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_shift,
+                        void* records, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_edge,
                         uint32_t ticket_slot, int max_blocks) {
     if (fp.n == 0) return;
     uint32_t blocks = (fp.n + 255u) / 256u;
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
-    const uint32_t sup = 1u << sup_shift;
+    const uint32_t sup = sup_edge, sup_mul = supertile_mul(sup_edge);
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup, sup_y = ((uint32_t)fp.tiles_y + sup - 1u) / sup;
     const bool surfel = fp.gaussian_mode == 0u && fp.aabb != 0u;
     float4* rec = (float4*)records;
@@ -499,7 +500,7 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
 #define BGS_LAUNCH_PB(F16, SURFEL, ANY)                                                            \
     hipLaunchKernelGGL((project_bin_kernel<F16, SURFEL, ANY>), dim3(blocks), dim3(256), 0, stream, \
                        d_fp, cloud, draw_list, culled, ctl, bin_status, rec, coarse,               \
-                       coarse_cap, sup_shift, sup_x, sup_y, ticket_slot)
+                       coarse_cap, sup_mul, sup_x, sup_y, ticket_slot)
 #define BGS_LAUNCH_PB2(F16, SURFEL) \
     do { if (any_mode) BGS_LAUNCH_PB(F16, SURFEL, true); else BGS_LAUNCH_PB(F16, SURFEL, false); } while (0)
     if (cloud.is_f16) {
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 template <int VARIANT>
 __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
-                                                          uint32_t coarse_cap, uint32_t sup_shift,
+                                                          uint32_t coarse_cap, uint32_t sup_mul,
                                                           uint32_t sup_x, Control* ctl,
                                                           float4* __restrict__ fb,
                                                           FrameCleanup cl) {
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
         cr[r] = cg[r] = cb[r] = 0.0f;
     }
 
-    const uint32_t st = (ty >> sup_shift) * sup_x + (tx >> sup_shift);
+    const uint32_t st = supertile_div(ty, sup_mul) * sup_x + supertile_div(tx, sup_mul);
     const uint32_t total = min(ctl->coarse_total[st], coarse_cap);
     const uint2* __restrict__ list = reinterpret_cast<const uint2*>(coarse) + (size_t)st * coarse_cap;
 
@@ -900,16 +901,16 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
 
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
-                        uint32_t sup_shift, Control* ctl, float4* framebuffer,
+                        uint32_t sup_edge, Control* ctl, float4* framebuffer,
                         const FrameCleanup& cleanup) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4* rec = (const float4*)records;
-    const uint32_t sup = 1u << sup_shift;
+    const uint32_t sup = sup_edge, sup_mul = supertile_mul(sup_edge);
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
 #define BGS_LAUNCH_RS(V)                                                                          \
     hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,      \
-                       coarse, coarse_cap, sup_shift, sup_x, ctl, framebuffer, cleanup)
+                       coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, cleanup)
     if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
     else BGS_LAUNCH_RS(RV_SURFEL);

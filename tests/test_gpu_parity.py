@@ -473,6 +473,29 @@ def test_async_frames_match_synchronous_frames(plugin, oracle):
     h.free()
 
 
+@pytest.mark.parametrize("size", [(1920, 1080), (1000, 600), (250, 130), (4096, 2304)])
+def test_supertile_edge_does_not_change_the_image(plugin, size):
+    """The coarse-bin (supertile) edge is a performance choice made from the previous frame's list
+    statistics — 6 or 8 tiles at 1080p, 13 or 16 at 4096x2304 (division by reciprocal multiply):
+    the forced-fine, forced-coarse and automatic frames must be bit-identical, for splats smaller and
+    larger than a supertile."""
+    c = random_gaussians_3d_seeded(60_000, 71)
+    h = plugin.upload(c)
+    v = View.headless(*size)
+    try:
+        for gs in (0.05, 1.0):
+            s = CloudSettings(global_scale=gs)
+            imgs = []
+            for flags in (0x8000, 0x10000, 0, 0):   # coarse, fine, automatic (twice: the rule may have flipped)
+                plugin.set_debug_flags(flags)
+                imgs.append(plugin.render(h, v, s))
+            for k in (1, 2, 3):
+                assert np.array_equal(imgs[0], imgs[k]), (size, gs, k)
+    finally:
+        plugin.set_debug_flags(0)
+    h.free()
+
+
 def test_frame_graphs_follow_changing_inputs(plugin):
     """With bgs_set_graphs, async frames without stage timing replay a captured hipGraph:
     only keygen's node is updated per frame. Every frame of a sequence in which the view, the
@@ -517,7 +540,7 @@ def test_frame_graphs_follow_changing_inputs(plugin):
                 got = framebuffer_as_tensor(plugin, v.height, v.width).cpu().numpy()
                 assert np.array_equal(got, direct[k]), f"depth {depth} step {k}"
             c1, r1 = plugin.graph_counters()
-            assert c1 > c0 and r1 - r0 >= 4, (depth, c1 - c0, r1 - r0)
+            assert c1 > c0 and r1 - r0 >= 2, (depth, c1 - c0, r1 - r0)  # (the supertile rule may re-capture too)
         # graphs off: same images, nothing captured or replayed
         plugin.set_graphs(False)
         c0, r0 = plugin.graph_counters()
