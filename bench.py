@@ -341,6 +341,19 @@ def main():
                 min_ms = wi * 4.0 / (4 * 256) / 2.4e9 * 1e3
                 roofline_main["valu"] = {"wave_instructions_per_launch": int(wi), "issue_bound_ms": round(min_ms, 4),
                                          "frac_of_issue_peak": round(min_ms / roofline_main["launch_ms"], 3)}
+            # the whole frame against the same bound: every kernel's vector instructions x its launches per
+            # frame, at the frame rate of the timed region — the chip-wide VALU-issue utilisation
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                kk = json.load(f)["kernels"]
+            per_frame = {"keygen_kernel": 1, "onesweep_kernel": st["depth_passes"], "project_bin_kernel": 1,
+                         "raster_scan_kernel": 1}
+            if scan_mode and all(kk.get(k, {}).get("valu_wave_instructions") for k in per_frame):
+                fw = sum(kk[k]["valu_wave_instructions"] * m for k, m in per_frame.items())
+                frame_issue_ms = fw * 4.0 / (4 * 256) / 2.4e9 * 1e3
+                roofline_main["valu"]["frame"] = {
+                    "wave_instructions_per_frame": int(fw), "issue_bound_ms": round(frame_issue_ms, 4),
+                    "ms_per_frame": round(1e3 * dt / args.steps, 4),
+                    "frac_of_issue_peak": round(frame_issue_ms / (1e3 * dt / args.steps), 3)}
         except Exception:
             pass
         roofline_main["in_flight"] = roofline
