@@ -82,6 +82,8 @@ def shim() -> ctypes.CDLL:
     l.shim_fill_params.argtypes = [ctypes.c_uint32, ctypes.POINTER(BgsView), ctypes.POINTER(BgsSettings),
                                    ctypes.POINTER(FrameParamsC)]
     l.shim_fill_params.restype = None
+    l.shim_supertile_div.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    l.shim_supertile_div.restype = ctypes.c_uint32
     l.shim_frame_params_size.argtypes = []
     l.shim_frame_params_size.restype = ctypes.c_uint32
     l.shim_sort_keys.argtypes = [ctypes.POINTER(FrameParamsC), fp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]

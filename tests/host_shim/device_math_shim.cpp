@@ -35,6 +35,9 @@ void shim_fill_params(uint32_t n, const bgs_view* view, const bgs_settings* s, F
 
 uint32_t shim_frame_params_size(void) { return (uint32_t)sizeof(FrameParams); }
 
+// supertile index of a tile for a supertile edge (bgs_device.h: reciprocal multiply)
+uint32_t shim_supertile_div(uint32_t tile, uint32_t edge) { return supertile_div(tile, supertile_mul(edge)); }
+
 // keys exactly as keygen_kernel stores them (before any final-pass un-inversion)
 void shim_sort_keys(const FrameParams* fp, const float* pos_vis, uint32_t n, uint32_t* keys_out) {
     for (uint32_t i = 0; i < n; ++i)

@@ -268,3 +268,12 @@ def test_draw_modes_device_math_matches_oracle(oracle):
     drawn = [i for i in range(0, 3000, 3) if not oracle.vs(c, (0, i), v, hs).discard][:5]
     for i in drawn:
         assert list(oracle.vs(c, (0, i), v, hs).color) == pytest.approx([0.3, 1.0, 0.1, 1.0])
+
+
+def test_supertile_index_by_reciprocal_multiply_is_exact():
+    """bgs_device.h supertile_div: tile / edge as (tile * (65536 / edge + 1)) >> 16 for every tile index a
+    packed rectangle can hold (< 256) and every supertile edge the library can choose (<= 32)."""
+    l = H.shim()
+    for edge in range(1, 33):
+        for tile in range(256):
+            assert l.shim_supertile_div(tile, edge) == tile // edge, (tile, edge)
