@@ -719,6 +719,20 @@ static float surfel_fragment_power(const float* l2p, v2 pixel_coord, v2 mean_2d)
     return -sigmas;
 }
 
+/* The same expression in double: where the f32 evaluation above is ill-conditioned (hu x hv cancels when
+ * the pixel's ray grazes the surfel plane) ANY f32 evaluation — the reference's WGSL under its
+ * compiler's contraction rules included — scatters around this value, and the distance between the
+ * two feeds the ambiguity bound of the pixel. */
+static double surfel_fragment_power_d(const float* l2p, double px, double py, double mx, double my) {
+    const double dx = mx - px, dy = my - py;
+    const double hux = px * l2p[6] - l2p[0], huy = px * l2p[7] - l2p[1], huz = px * l2p[8] - l2p[2];
+    const double hvx = py * l2p[6] - l2p[3], hvy = py * l2p[7] - l2p[4], hvz = py * l2p[8] - l2p[5];
+    const double cx = huy * hvz - hvy * huz, cy = huz * hvx - hvz * hux, cz = hux * hvy - hvx * huy;
+    const double us = cx / cz, vs = cy / cz;
+    const double s3 = us * us + vs * vs, s2 = 2.0 * (dx * dx + dy * dy);
+    return -0.5 * (s3 < s2 ? s3 : s2);   /* NaN s3 (cz == 0) selects s2, like fminf above */
+}
+
 /* src/render/gaussian.wgsl:438-505. Returns 0 if the fragment is discarded. `power_out`
  * is reported for the ambiguity bound. */
 static int fs_main(const oracle_vs_out* in, v2 uv, v2 major_minor, const bgs_view* view,
@@ -881,6 +895,34 @@ int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint
                 float power = 0.0f;
                 const int drawn = fs_main(vs, uv, mm, view, s, src, &power);
                 float* dst = row + 4 * (size_t)(x - x0);
+                if (arow && s->aabb && s->gaussian_mode == BGS_GAUSSIAN_2D) {
+                    /* conditioning of the surfel intersection at this pixel (see surfel_fragment_power_d) */
+                    const double asp = (double)view->viewport[2] / (double)view->viewport[3];
+                    const double pcx = (double)uv.x * vs->radius[0] + vs->mean_2d[0];
+                    const double pcy = (double)uv.y * vs->radius[1] * asp + vs->mean_2d[1];
+                    const double pd = surfel_fragment_power_d(vs->local_to_pixel, pcx, pcy, vs->mean_2d[0], vs->mean_2d[1]);
+                    const double op = fabs((double)vs->color[3]);
+                    const double a32 = power > 0.0f ? 0.0 : fmin(exp((double)power) * op, 0.999);
+                    const double a64 = pd > 0.0 ? 0.0 : fmin(exp(pd) * op, 0.999);
+                    double da = fabs(a32 - a64);
+                    /* ... and its sensitivity to a 2-ulp change of the pixel coordinate, which is what one
+                     * rounding of pcx * T2 amounts to in any f32 evaluation order */
+                    for (int k = 0; k < 4; ++k) {
+                        const double ex = (k & 1) ? 1.0 + 0x1p-22 : 1.0 - 0x1p-22;
+                        const double ey = (k & 2) ? 1.0 + 0x1p-22 : 1.0 - 0x1p-22;
+                        const double pk = surfel_fragment_power_d(vs->local_to_pixel, pcx * ex, pcy * ey, vs->mean_2d[0],
+                                                                  vs->mean_2d[1]);
+                        const double ak = pk > 0.0 ? 0.0 : fmin(exp(pk) * op, 0.999);
+                        if (fabs(ak - a64) > da) da = fabs(ak - a64);
+                    }
+                    if (da > 1e-6) {
+                        float cm = fmaxf(fmaxf(fabsf(vs->color[0]), fabsf(vs->color[1])),
+                                         fmaxf(fabsf(vs->color[2]), 1.0f));
+                        float dm = fmaxf(fmaxf(fabsf(dst[0]), fabsf(dst[1])),
+                                         fmaxf(fabsf(dst[2]), fabsf(dst[3])));
+                        arow[x - x0] += (float)(4.0 * da) * (cm + dm);
+                    }
+                }
                 if (arow) {
                     int ambiguous = near_edge;
                     if (s->aabb && fabsf(power) < 1e-5f) ambiguous = 1;

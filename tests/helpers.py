@@ -277,18 +277,23 @@ def tolerance_mask(ref: np.ndarray, got: np.ndarray, amb: np.ndarray | None, ato
     return err <= lim, err
 
 
-def random_case(seed: int):
+def random_case(seed: int, medium: bool = False):
     """One random (cloud, view, settings) configuration for the randomized parity sweeps: camera pose,
     field of view, near plane and aspect; model transform with rotation, non-uniform scale and
-    translation; every CloudSettings switch the path honours; clear colour."""
+    translation; every CloudSettings switch the path honours; clear colour. `medium`: 40-250 k splats
+    and viewports up to 1280x720 (many tiles and supertiles, ticket loops) instead of a few thousand
+    splats in a thumbnail."""
     import math
     from bevy_gaussian_splatting_amd import (DrawMode, GaussianColorSpace, RadixSortDepthBits, RasterizeMode,
                                              compute_aabb, random_gaussians_3d_seeded, transform_from)
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(1500, 5000))
+    n = int(rng.integers(40_000, 250_000)) if medium else int(rng.integers(1500, 5000))
     c = random_gaussians_3d_seeded(n, 100 + seed)
     c.position_visibility[:, 3] = rng.integers(0, 7, n).astype(np.float32)
-    w, h = int(rng.integers(40, 200)), int(rng.integers(40, 140))
+    if medium:
+        w, h = int(rng.integers(300, 1281)), int(rng.integers(200, 721))
+    else:
+        w, h = int(rng.integers(40, 200)), int(rng.integers(40, 140))
     ang = rng.uniform(-math.pi, math.pi)
     axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
     q = (*(np.sin(ang / 2) * axis), math.cos(ang / 2))

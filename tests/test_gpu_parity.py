@@ -804,6 +804,29 @@ def test_randomized_configurations(plugin, oracle, seed):
     h.free()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BGS_RANDOM_MEDIUM_SEEDS", "3"))))
+def test_randomized_configurations_medium(plugin, oracle, seed):
+    """The same sweep at 40-250 k splats and up to 1280x720: many tiles and supertiles, ticket loops, both
+    supertile rules (BGS_RANDOM_MEDIUM_SEEDS=N widens it; a 60-seed run is in profiles/)."""
+    c, v, s = H.random_case(1000 + seed, medium=True)
+    if os.environ.get("BGS_RANDOM_FORCE_SURFEL"):   # every seed on the 2DGS surfel (aabb) fragment path
+        s.aabb, s.gaussian_mode = True, GaussianMode.Gaussian2d
+    if s.global_scale > 1.0:
+        s.global_scale = 0.3     # keeps the f64 oracle raster of a 1 Mpx frame in seconds
+    cloud = c.to_f16() if seed % 4 == 3 else c
+    cd = oracle.decode_f16(cloud) if cloud is not c else c
+    plugin.set_binning("sort" if seed % 6 == 5 else "scan")
+    h = plugin.upload(cloud)
+    got = plugin.render(h, v, s)
+    gs = plugin.sort(h, v, s)
+    plugin.set_binning("scan")
+    e = oracle.sort(cd, v, s)
+    assert np.array_equal(gs["key"], e["key"]) and np.array_equal(gs["index"], e["index"])
+    ref, amb = oracle.render(cd, e, v, s, with_ambiguity=True)
+    _assert_image(ref, got, amb, frac_slack=0.01, what=f"medium seed {seed}: {s}")
+    h.free()
+
+
 def test_maximum_viewport_4096_square(plugin, oracle):
     """Largest target the ABI accepts: 256 x 256 tiles, 16 x 16 = 256 supertiles (every thread of the
     binning block owns one), 16.7 M pixels. Oracle-checked crops at three places incl. the far corner."""
