@@ -57,6 +57,7 @@ EXPORTED_SYMBOLS = (
     "bgs_get_stats",
     "bgs_radix_sort_pairs",
     "bgs_hbm_probe",
+    "bgs_download",
     "bgs_set_pipeline_streams",
     "bgs_set_graphs",
     "bgs_graph_counters",
@@ -178,6 +179,8 @@ def load() -> ctypes.CDLL:
     lib.bgs_hbm_probe.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
                                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.bgs_hbm_probe.restype = ctypes.c_int
+    lib.bgs_download.argtypes = [vp, vp, vp, ctypes.c_uint64]
+    lib.bgs_download.restype = ctypes.c_int
     lib.bgs_set_pipeline_streams.argtypes = [vp, u32]
     lib.bgs_set_pipeline_streams.restype = ctypes.c_int
     lib.bgs_set_graphs.argtypes = [vp, ctypes.c_int]

@@ -1162,6 +1162,13 @@ int bgs_set_srgb8_target(bgs_ctx* ctx, void* device_ptr) {
     return BGS_OK;
 }
 
+int bgs_download(bgs_ctx* ctx, const void* device_ptr, void* host_out, uint64_t bytes) {
+    if (!ctx || !device_ptr || !host_out) return fail(ctx, BGS_EINVAL, "NULL argument");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    if (bytes) HIP_TRY(ctx, hipMemcpy(host_out, device_ptr, (size_t)bytes, hipMemcpyDeviceToHost));
+    return BGS_OK;
+}
+
 int bgs_set_output_srgb8(bgs_ctx* ctx, int enabled) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     ctx->output_srgb8 = enabled != 0;

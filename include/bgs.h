@@ -219,10 +219,14 @@ int bgs_framebuffer_srgb8_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes)
  * and no extra synchronisation. Implies srgb8 output for that frame; bgs_pipeline_pop /
  * bgs_framebuffer_srgb8_device_ptr then return this pointer for it. */
 int bgs_set_srgb8_target(bgs_ctx* ctx, void* device_ptr);
+/* Copy `bytes` from device memory this library handed out (a framebuffer, an sRGB8 image, the sorted
+ * entries) to host memory, for hosts that do not link the HIP runtime themselves. Blocking. The
+ * memory must belong to a COMPLETED frame: after a blocking call, bgs_pipeline_pop or bgs_synchronize. */
+int bgs_download(bgs_ctx* ctx, const void* device_ptr, void* host_out, uint64_t bytes);
 
 /* Frame pipelining. A single stream of this path's kernels is latency bound at 1M splats, so the
- * context can keep up to 4 frames in flight on separate HIP streams ("lanes", each with its own
- * per-frame buffers): with bgs_set_async(1), successive bgs_render(..., NULL) calls go round-robin
+ * context can keep up to 8 frames in flight ("lanes", each with its own per-frame buffers, run on a
+ * few shared HIP streams, see bgs_set_pipeline_streams): with bgs_set_async(1), successive bgs_render(..., NULL) calls go round-robin
  * over the lanes and overlap on the GPU. A lane's previous frame is completed (stream wait +
  * watchdog check) when the lane is reused. bgs_pipeline_pop completes the OLDEST frame in flight
  * and returns its f32 / sRGB8 framebuffers (valid until that lane is reused, i.e. for depth-1 more
