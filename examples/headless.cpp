@@ -8,6 +8,8 @@
 // Flags follow the reference's GaussianSplattingViewer args (src/utils.rs): --gaussian-count, --seed,
 // --width, --height; plus --frames, --output-dir, --depth (lanes in flight), and two hooks for the parity
 // test: --cloud <file> (u32 n, then the four f32 planes) and --dump-f32 <file> (the last frame, RGBA f32).
+// --input-cloud <file.ply> loads an INRIA .ply (the reference viewer's --input-cloud), --f16 uploads the cloud
+// in the f16 planar format.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -15,7 +17,7 @@
 #include <string>
 #include <sys/stat.h>
 
-#include "../include/bgs.hpp"
+#include "../include/bgs_host.hpp"
 
 namespace {
 
@@ -98,7 +100,8 @@ bgs::PlanarGaussian3d read_planes(const std::string& path) {
 int main(int argc, char** argv) {
     uint32_t count = 10000, width = 1920, height = 1080, frames = 40, depth = 6;
     uint64_t seed = 0;
-    std::string out_dir = "headless_output", cloud_path, dump_path;
+    std::string out_dir = "headless_output", cloud_path, dump_path, ply_path;
+    bool f16 = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string {
@@ -114,13 +117,22 @@ int main(int argc, char** argv) {
         else if (a == "--output-dir") out_dir = next();
         else if (a == "--cloud") cloud_path = next();
         else if (a == "--dump-f32") dump_path = next();
+        else if (a == "--input-cloud") ply_path = next();
+        else if (a == "--f16") f16 = true;
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
     }
     try {
         bgs::GaussianSplattingPlugin plugin(0);
-        const bgs::PlanarGaussian3d cloud =
-            cloud_path.empty() ? bgs::PlanarGaussian3d::random(count, seed) : read_planes(cloud_path);
-        bgs::PlanarGaussian3dHandle handle = plugin.upload(cloud);
+        bgs::PlanarGaussian3d cloud;
+        if (!ply_path.empty()) {
+            std::ifstream in(ply_path, std::ios::binary);
+            if (!in) throw std::runtime_error("cannot open " + ply_path);
+            cloud = bgs::parse_ply_3d(in);
+        } else {
+            cloud = cloud_path.empty() ? bgs::PlanarGaussian3d::random(count, seed) : read_planes(cloud_path);
+        }
+        bgs::PlanarGaussian3dHandle handle =
+            f16 ? bgs::upload(plugin, bgs::PlanarGaussian3dF16::from_f32(cloud)) : plugin.upload(cloud);
         const bgs::View view = bgs::View::headless(width, height);  // Camera3d at (0, 1.5, 5), black clear colour
         const bgs::CloudSettings settings;                          // CloudSettings::default()
         const bgs_settings native = settings.to_native();

@@ -308,6 +308,8 @@ class GaussianSplattingPlugin {
         return st;
     }
     bgs_ctx* native() { return ctx_; }
+    // wrap a cloud uploaded through the C ABI directly (e.g. bgs_cloud_upload_f16) into an owning handle
+    PlanarGaussian3dHandle adopt(bgs_cloud* cloud) { return PlanarGaussian3dHandle(ctx_, cloud); }
 
   private:
     void check(int rc, const char* what) {

@@ -1,0 +1,272 @@
+// bgs_host.hpp — the callers and data formats either side of the hot path (SURVEY section 8 f), in C++17 above
+// include/bgs.hpp: the f16 planar cloud (src/gaussian/f16.rs), the sort trigger / throttle policy
+// (src/sort/mod.rs:76-86,143-194, src/sort/rayon.rs:124-129) and the INRIA `.ply` loader
+// (src/io/ply.rs:23-132, with the reference's quirks). Header-only; tests/test_cpp_host.py checks each
+// against the Python mirror, which is pinned by known answers.
+#ifndef BGS_HOST_HPP
+#define BGS_HOST_HPP
+
+#include <algorithm>
+#include <istream>
+#include <map>
+#include <optional>
+#include <sstream>
+
+#include "bgs.hpp"
+
+namespace bgs {
+
+// ---- f16 storage ------------------------------------------------------------------------------
+// IEEE round-to-nearest-even f32 -> f16 (what `half::f16::from_f32` does, src/gaussian/f16.rs:244-252)
+inline uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t mag = x & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u) return (uint16_t)(sign | (mag > 0x7F800000u ? 0x7E00u | ((mag >> 13) & 0x3FFu) : 0x7C00u));
+    if (mag >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);  // rounds to infinity
+    if (mag < 0x33000001u) return (uint16_t)sign;               // rounds to zero (<= 2^-25)
+    int32_t exp = (int32_t)(mag >> 23) - 127;
+    uint32_t man = (mag & 0x7FFFFFu) | 0x800000u;
+    uint32_t shift, half_bits;
+    if (exp < -14) {  // subnormal half
+        shift = (uint32_t)(13 + (-14 - exp));
+        half_bits = 0;
+    } else {
+        shift = 13;
+        half_bits = (uint32_t)(exp + 15) << 10;
+        man &= 0x7FFFFFu;
+    }
+    uint32_t q = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) ++q;
+    return (uint16_t)(sign | (half_bits + q));  // a mantissa carry moves into the exponent, as it must
+}
+inline uint32_t pack_f32s_to_u32(float upper, float lower) {
+    return ((uint32_t)f32_to_f16(upper) << 16) | (uint32_t)f32_to_f16(lower);
+}
+
+// position_visibility stays f32; spherical_harmonic[n][24] u32 with the EVEN coefficient in the low
+// half (src/render/planar.wgsl:117-130); rotation_scale_opacity[n][4] u32 = [rot0|rot1], [rot2|rot3],
+// [s0|s1], [s2|opacity], first value in the high half (src/gaussian/f16.rs:29-55).
+struct PlanarGaussian3dF16 {
+    std::vector<std::array<float, 4>> position_visibility;
+    std::vector<std::array<uint32_t, SH_COEFF_COUNT / 2>> spherical_harmonic;
+    std::vector<std::array<uint32_t, 4>> rotation_scale_opacity;
+    size_t size() const { return position_visibility.size(); }
+
+    static PlanarGaussian3dF16 from_f32(const PlanarGaussian3d& c) {
+        PlanarGaussian3dF16 o;
+        const size_t n = c.size();
+        o.position_visibility = c.position_visibility;
+        o.spherical_harmonic.resize(n);
+        o.rotation_scale_opacity.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            for (int k = 0; k < SH_COEFF_COUNT / 2; ++k)
+                o.spherical_harmonic[i][k] = pack_f32s_to_u32(c.spherical_harmonic[i][2 * k + 1], c.spherical_harmonic[i][2 * k]);
+            const auto& r = c.rotation[i];
+            const auto& s = c.scale_opacity[i];
+            o.rotation_scale_opacity[i] = {pack_f32s_to_u32(r[0], r[1]), pack_f32s_to_u32(r[2], r[3]),
+                                           pack_f32s_to_u32(s[0], s[1]), pack_f32s_to_u32(s[2], s[3])};
+        }
+        return o;
+    }
+};
+
+inline PlanarGaussian3dHandle upload(GaussianSplattingPlugin& plugin, const PlanarGaussian3dF16& c);
+
+// ---- when to re-sort ----------------------------------------------------------------------------
+struct SortConfig {  // src/sort/mod.rs:76-86
+    int64_t period_ms = 1000;
+};
+struct SortTrigger {  // src/sort/mod.rs:143-150, one per GaussianCamera
+    size_t camera_index = 0;
+    bool needs_sort = false;
+    std::array<float, 3> last_camera_position{0.0f, 0.0f, 0.0f};
+    std::optional<double> last_sort_time;  // seconds
+};
+// src/sort/mod.rs:164-193 for one camera; `now` in seconds (injected so the policy is testable)
+inline void update_sort_trigger(SortTrigger& t, const std::array<float, 3>& camera_position, int64_t camera_order,
+                                const SortConfig& config, double now) {
+    if (!t.last_sort_time) {
+        if (camera_order < 0) throw Error(BGS_EINVAL, "camera order must be a non-negative index into gaussian cameras");
+        t.camera_index = (size_t)camera_order;
+        t.needs_sort = true;
+        t.last_sort_time = now;
+        return;
+    }
+    if ((now - *t.last_sort_time) * 1000.0 < (double)config.period_ms) return;
+    if (t.last_camera_position != camera_position) {
+        t.needs_sort = true;
+        t.last_sort_time = now;
+        t.last_camera_position = camera_position;
+    }
+}
+// src/sort/rayon.rs:124-129: the CPU sorts stretch the period to at least 4x the measured sort time
+inline void after_cpu_sort(SortConfig& config, double sort_duration_s) {
+    config.period_ms = std::max({config.period_ms, config.period_ms * 4 / 5, (int64_t)4 * (int64_t)(sort_duration_s * 1000.0)});
+}
+
+// ---- INRIA .ply -> PlanarGaussian3d ---------------------------------------------------------------
+constexpr float MAX_SIZE_VARIANCE = 4.0f;  // src/io/ply.rs:21
+
+namespace ply_detail {
+struct Prop { std::string name; char kind; int bytes; bool list; };  // kind: 'i' 'u' 'f'
+inline bool scalar_type(const std::string& t, char& kind, int& bytes) {
+    static const std::map<std::string, std::pair<char, int>> types = {
+        {"char", {'i', 1}}, {"int8", {'i', 1}}, {"uchar", {'u', 1}}, {"uint8", {'u', 1}}, {"short", {'i', 2}},
+        {"int16", {'i', 2}}, {"ushort", {'u', 2}}, {"uint16", {'u', 2}}, {"int", {'i', 4}}, {"int32", {'i', 4}},
+        {"uint", {'u', 4}}, {"uint32", {'u', 4}}, {"float", {'f', 4}}, {"float32", {'f', 4}}, {"double", {'f', 8}},
+        {"float64", {'f', 8}}};
+    const auto it = types.find(t);
+    if (it == types.end()) return false;
+    kind = it->second.first;
+    bytes = it->second.second;
+    return true;
+}
+inline float sigmoid(float x) { return 1.0f / (1.0f + std::exp(-x)); }  // src/io/ply.rs:40-42
+}  // namespace ply_detail
+
+// src/io/ply.rs:76-132. Only `float` properties reach the splat; required: x y z f_dc_0..2 scale_0 scale_1
+// opacity rot_0..3; opacity is a logit; f_rest_i -> coefficient (i % 15) + 1 of channel i / 16 (the
+// reference's mapping, reproduced literally); scale clamped to mean +- 4 in log space, then exp;
+// rotation normalised; padded with Gaussian3d::default() to a multiple of 32 (a whole block if aligned).
+inline PlanarGaussian3d parse_ply_3d(std::istream& in) {
+    using namespace ply_detail;
+    std::string line;
+    if (!std::getline(in, line) || line.substr(0, 3) != "ply") throw Error(BGS_EINVAL, "not a PLY file");
+    std::string format;
+    struct Element { std::string name; size_t count; std::vector<Prop> props; };
+    std::vector<Element> elements;
+    for (;;) {
+        if (!std::getline(in, line)) throw Error(BGS_EINVAL, "unexpected end of PLY header");
+        std::istringstream ls(line);
+        std::vector<std::string> tok;
+        for (std::string t; ls >> t;) tok.push_back(t);
+        if (tok.empty() || tok[0] == "comment" || tok[0] == "obj_info") continue;
+        if (tok[0] == "format" && tok.size() > 1) format = tok[1];
+        else if (tok[0] == "element" && tok.size() > 2) elements.push_back({tok[1], (size_t)std::stoull(tok[2]), {}});
+        else if (tok[0] == "property" && tok.size() > 2 && !elements.empty()) {
+            if (tok[1] == "list" && tok.size() > 4) elements.back().props.push_back({tok[4], 'l', 0, true});
+            else {
+                Prop p{tok[2], 'f', 4, false};
+                if (!scalar_type(tok[1], p.kind, p.bytes)) throw Error(BGS_EINVAL, "unknown PLY property type " + tok[1]);
+                elements.back().props.push_back(p);
+            }
+        } else if (tok[0] == "end_header") break;
+    }
+    const bool ascii = format == "ascii", le = format == "binary_little_endian", be = format == "binary_big_endian";
+    if (!ascii && !le && !be) throw Error(BGS_EINVAL, "unsupported PLY format " + format);
+
+    std::map<std::string, std::vector<float>> cols;  // float properties of the vertex element
+    std::vector<std::string> rest_order;             // f_rest_* in file order
+    size_t n = 0;
+    for (const Element& e : elements) {
+        const bool vertex = e.name == "vertex";
+        if (vertex) {
+            for (const char* r : {"x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2", "scale_0", "scale_1", "opacity", "rot_0",
+                                  "rot_1", "rot_2", "rot_3"})
+                if (std::none_of(e.props.begin(), e.props.end(), [&](const Prop& p) { return p.name == r; }))
+                    throw Error(BGS_EINVAL, "missing required properties");  // ply.rs:93-98
+            cols.clear();
+            rest_order.clear();
+            n = e.count;
+            for (const Prop& p : e.props)
+                if (!p.list && p.kind == 'f' && p.bytes == 4) {
+                    cols[p.name].assign(n, 0.0f);
+                    if (p.name.rfind("f_rest_", 0) == 0) rest_order.push_back(p.name);
+                }
+        }
+        if (ascii) {
+            for (size_t r = 0; r < e.count; ++r) {
+                if (!std::getline(in, line)) throw Error(BGS_EINVAL, "truncated PLY payload");
+                std::istringstream ls(line);
+                for (const Prop& p : e.props) {
+                    double v = 0.0;
+                    ls >> v;
+                    if (p.list) { for (long k = (long)v; k > 0; --k) { double skip; ls >> skip; } continue; }
+                    if (vertex && p.kind == 'f' && p.bytes == 4) cols[p.name][r] = (float)v;
+                }
+            }
+        } else {
+            size_t stride = 0;
+            for (const Prop& p : e.props) {
+                if (p.list) throw Error(BGS_EINVAL, "list properties in a binary vertex element are not supported");
+                stride += (size_t)p.bytes;
+            }
+            std::vector<char> raw(stride * e.count);
+            in.read(raw.data(), (std::streamsize)raw.size());
+            if ((size_t)in.gcount() != raw.size()) throw Error(BGS_EINVAL, "truncated PLY payload");
+            if (!vertex) continue;
+            size_t off = 0;
+            for (const Prop& p : e.props) {
+                if (p.kind == 'f' && p.bytes == 4) {
+                    std::vector<float>& col = cols[p.name];
+                    for (size_t r = 0; r < e.count; ++r) {
+                        unsigned char b[4];
+                        std::memcpy(b, raw.data() + r * stride + off, 4);
+                        if (be) std::swap(b[0], b[3]), std::swap(b[1], b[2]);
+                        std::memcpy(&col[r], b, 4);
+                    }
+                }
+                off += (size_t)p.bytes;
+            }
+        }
+    }
+
+    auto col = [&](const std::string& name) -> const std::vector<float>* {
+        const auto it = cols.find(name);
+        return it == cols.end() ? nullptr : &it->second;
+    };
+    const size_t pad = 32 - (n % 32);  // ply.rs:127-129
+    PlanarGaussian3d c;
+    c.resize(n + pad);
+    for (size_t i = 0; i < n + pad; ++i) {
+        c.position_visibility[i] = {0.0f, 0.0f, 0.0f, 1.0f};  // PositionVisibility::default
+        c.spherical_harmonic[i].fill(0.0f);
+        c.rotation[i] = {0.0f, 0.0f, 0.0f, 0.0f};
+        c.scale_opacity[i] = {0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const char* pos_names[4] = {"x", "y", "z", "visibility"};
+    for (int k = 0; k < 4; ++k)
+        if (const auto* v = col(pos_names[k])) for (size_t i = 0; i < n; ++i) c.position_visibility[i][k] = (*v)[i];
+    for (int k = 0; k < 3; ++k) {
+        if (const auto* v = col("f_dc_" + std::to_string(k))) for (size_t i = 0; i < n; ++i) c.spherical_harmonic[i][k] = (*v)[i];
+        if (const auto* v = col("scale_" + std::to_string(k))) for (size_t i = 0; i < n; ++i) c.scale_opacity[i][k] = (*v)[i];
+    }
+    if (const auto* v = col("opacity")) for (size_t i = 0; i < n; ++i) c.scale_opacity[i][3] = sigmoid((*v)[i]);
+    for (int k = 0; k < 4; ++k)
+        if (const auto* v = col("rot_" + std::to_string(k))) for (size_t i = 0; i < n; ++i) c.rotation[i][k] = (*v)[i];
+    constexpr int PER_CHANNEL = SH_COEFF_COUNT / 3;  // 16
+    for (const std::string& name : rest_order) {
+        const int idx = std::stoi(name.substr(7));
+        const int channel = idx / PER_CHANNEL, coefficient = (idx % (PER_CHANNEL - 1)) + 1;
+        const int slot = coefficient * 3 + channel;
+        if (slot < SH_COEFF_COUNT) {
+            const auto& v = *col(name);
+            for (size_t i = 0; i < n; ++i) c.spherical_harmonic[i][slot] = v[i];
+        }
+    }
+    for (size_t i = 0; i < n; ++i) {  // ply.rs:103-125
+        auto& so = c.scale_opacity[i];
+        const float mean = ((so[0] + so[1]) + so[2]) / 3.0f;
+        for (int k = 0; k < 3; ++k) so[k] = std::exp(std::min(std::max(so[k], mean - MAX_SIZE_VARIANCE), mean + MAX_SIZE_VARIANCE));
+        auto& r = c.rotation[i];
+        const float norm = std::sqrt(((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]) + r[3] * r[3]);
+        for (int k = 0; k < 4; ++k) r[k] = r[k] / norm;
+    }
+    return c;
+}
+
+// ---- f16 upload -------------------------------------------------------------------------------
+inline PlanarGaussian3dHandle upload(GaussianSplattingPlugin& plugin, const PlanarGaussian3dF16& c) {
+    bgs_cloud* cloud = nullptr;
+    const int rc = bgs_cloud_upload_f16(plugin.native(), (uint32_t)c.size(), c.size() ? c.position_visibility[0].data() : nullptr,
+                                        c.size() ? c.spherical_harmonic[0].data() : nullptr,
+                                        c.size() ? c.rotation_scale_opacity[0].data() : nullptr, &cloud);
+    if (rc != BGS_OK) throw Error(rc, std::string("bgs_cloud_upload_f16: ") + bgs_last_error(plugin.native()));
+    return plugin.adopt(cloud);
+}
+
+}  // namespace bgs
+#endif  // BGS_HOST_HPP

@@ -1,0 +1,82 @@
+// Test driver for include/bgs_host.hpp (no GPU needed for these subcommands): tests/test_cpp_host.py
+// compares every output with the Python mirror.
+//   host_tool ply <in.ply> <out.bin>        parse_ply_3d -> u32 n + the four f32 planes
+//   host_tool f16 <planes.bin> <out.bin>    PlanarGaussian3dF16::from_f32 -> pv f32, sh u32[n][24], rso u32[n][4]
+//   host_tool half <in.f32> <out.u16>       f32_to_f16 of every value
+//   host_tool trigger <period_ms>           stdin: "t x y z order" per line -> "camera_index needs_sort" per line
+//   host_tool settings                      sizeof / defaults of CloudSettings::to_native()
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "../../include/bgs_host.hpp"
+
+static void write_planes(const std::string& path, const bgs::PlanarGaussian3d& c) {
+    std::ofstream f(path, std::ios::binary);
+    const uint32_t n = (uint32_t)c.size();
+    f.write((const char*)&n, 4);
+    f.write((const char*)c.position_visibility.data(), (std::streamsize)n * 16);
+    f.write((const char*)c.spherical_harmonic.data(), (std::streamsize)n * bgs::SH_COEFF_COUNT * 4);
+    f.write((const char*)c.rotation.data(), (std::streamsize)n * 16);
+    f.write((const char*)c.scale_opacity.data(), (std::streamsize)n * 16);
+}
+
+static bgs::PlanarGaussian3d read_planes(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    uint32_t n = 0;
+    f.read((char*)&n, 4);
+    bgs::PlanarGaussian3d c;
+    c.resize(n);
+    f.read((char*)c.position_visibility.data(), (std::streamsize)n * 16);
+    f.read((char*)c.spherical_harmonic.data(), (std::streamsize)n * bgs::SH_COEFF_COUNT * 4);
+    f.read((char*)c.rotation.data(), (std::streamsize)n * 16);
+    f.read((char*)c.scale_opacity.data(), (std::streamsize)n * 16);
+    return c;
+}
+
+int main(int argc, char** argv) {
+    const std::string cmd = argc > 1 ? argv[1] : "";
+    try {
+        if (cmd == "ply" && argc == 4) {
+            std::ifstream in(argv[2], std::ios::binary);
+            write_planes(argv[3], bgs::parse_ply_3d(in));
+        } else if (cmd == "f16" && argc == 4) {
+            const auto h = bgs::PlanarGaussian3dF16::from_f32(read_planes(argv[2]));
+            std::ofstream f(argv[3], std::ios::binary);
+            f.write((const char*)h.position_visibility.data(), (std::streamsize)h.size() * 16);
+            f.write((const char*)h.spherical_harmonic.data(), (std::streamsize)h.size() * 96);
+            f.write((const char*)h.rotation_scale_opacity.data(), (std::streamsize)h.size() * 16);
+        } else if (cmd == "half" && argc == 4) {
+            std::ifstream in(argv[2], std::ios::binary);
+            std::ofstream out(argv[3], std::ios::binary);
+            float v;
+            while (in.read((char*)&v, 4)) {
+                const uint16_t h = bgs::f32_to_f16(v);
+                out.write((const char*)&h, 2);
+            }
+        } else if (cmd == "trigger" && argc == 3) {
+            bgs::SortConfig config{std::stoll(argv[2])};
+            bgs::SortTrigger t;
+            double now;
+            float x, y, z;
+            long order;
+            while (std::cin >> now >> x >> y >> z >> order) {
+                t.needs_sort = false;
+                bgs::update_sort_trigger(t, {x, y, z}, order, config, now);
+                std::printf("%zu %d\n", t.camera_index, t.needs_sort ? 1 : 0);
+            }
+        } else if (cmd == "settings") {
+            const bgs_settings s = bgs::CloudSettings().to_native();
+            bgs_settings d;
+            bgs_settings_default(&d);
+            std::printf("%zu %d\n", sizeof(bgs_settings), std::memcmp(&s, &d, sizeof s) == 0 ? 1 : 0);
+        } else {
+            std::fprintf(stderr, "usage: host_tool ply|f16|half|trigger|settings ...\n");
+            return 2;
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "host_tool: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -84,3 +84,155 @@ def test_cpp_example_matches_the_python_mirror(tmp_path):
     srgb = device_ptr_as_tensor(ptr, (360, 640, 4), "|u1", "cuda:0").cpu().numpy()
     assert np.array_equal(_decode_png_rgba8(tmp_path / "0.png"), srgb)
     h.free()
+
+    # the f16 planar format through the C++ packers and bgs_cloud_upload_f16
+    r = subprocess.run([EXAMPLE, "--cloud", str(planes), "--f16", "--width", "640", "--height", "360", "--frames", "4",
+                        "--output-dir", str(tmp_path), "--dump-f32", str(tmp_path / "frame16.f32")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    h16 = p.upload(c.to_f16())
+    assert np.array_equal(np.fromfile(tmp_path / "frame16.f32", np.float32).reshape(360, 640, 4),
+                          p.render(h16, v, CloudSettings()))
+    h16.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# include/bgs_host.hpp (f16 packing, sort policy, .ply loader) against the Python mirror — CPU only
+# ---------------------------------------------------------------------------------------------
+TOOL = os.path.join(ROOT, "tests", "cpp", "host_tool")
+
+
+@pytest.fixture(scope="module")
+def host_tool():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "bevy_gaussian_splatting_amd", "csrc"), "-j4"], check=True,
+                   capture_output=True)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-o", TOOL, os.path.join(ROOT, "tests", "cpp", "host_tool.cpp"),
+                    "-L" + os.path.join(ROOT, "bevy_gaussian_splatting_amd", "csrc"), "-lbgs",
+                    "-Wl,-rpath," + os.path.join(ROOT, "bevy_gaussian_splatting_amd", "csrc")], check=True)
+    return TOOL
+
+
+def _write_planes(path, c):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(c)))
+        for a in (c.position_visibility, c.spherical_harmonic, c.rotation, c.scale_opacity):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+
+
+def _read_planes(path):
+    raw = open(path, "rb").read()
+    (n,) = struct.unpack("<I", raw[:4])
+    a = np.frombuffer(raw, np.float32, offset=4)
+    pv, sh, rot, so = np.split(a, np.cumsum([4 * n, 48 * n, 4 * n]))
+    return pv.reshape(n, 4), sh.reshape(n, 48), rot.reshape(n, 4), so.reshape(n, 4)
+
+
+def test_cpp_settings_defaults_are_the_c_abi_defaults(host_tool):
+    out = subprocess.run([host_tool, "settings"], capture_output=True, text=True, check=True).stdout.split()
+    from bevy_gaussian_splatting_amd.settings import BgsSettings
+    import ctypes
+    assert int(out[0]) == ctypes.sizeof(BgsSettings) and out[1] == "1"
+
+
+def test_cpp_f32_to_f16_is_ieee_round_to_nearest_even(host_tool, tmp_path):
+    rng = np.random.default_rng(5)
+    bits = np.concatenate([
+        rng.integers(0, 1 << 32, 400_000, dtype=np.uint64).astype(np.uint32),               # anything, NaNs included
+        (np.arange(0, 1 << 16, dtype=np.uint32) << np.uint32(13)) + np.uint32(0x38000000),   # around every normal half
+        (np.arange(0, 1 << 16, dtype=np.uint32) << np.uint32(13)) + np.uint32(0x38000FFF),
+        (np.arange(0, 1 << 16, dtype=np.uint32) << np.uint32(13)) + np.uint32(0x38001000),   # exact ties
+        (np.arange(0, 1 << 16, dtype=np.uint32) << np.uint32(13)) + np.uint32(0x38001001),
+        np.arange(0x33000000 - 64, 0x38800000, 4099, dtype=np.uint32),                       # the subnormal-half range
+        np.array([0, 0x80000000, 0x7F800000, 0xFF800000, 0x477FE000, 0x477FEFFF, 0x477FF000, 0x33000000, 0x33000001],
+                 np.uint32)])
+    vals = bits.view(np.float32)
+    vals.tofile(tmp_path / "in.f32")
+    subprocess.run([host_tool, "half", str(tmp_path / "in.f32"), str(tmp_path / "out.u16")], check=True)
+    got = np.fromfile(tmp_path / "out.u16", np.uint16)
+    with np.errstate(over="ignore", invalid="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    nan = np.isnan(vals)
+    assert np.array_equal(got[~nan], want[~nan])
+    assert ((got[nan] & 0x7C00) == 0x7C00).all() and ((got[nan] & 0x03FF) != 0).all()   # NaN stays NaN
+
+
+def test_cpp_f16_cloud_packing_matches_the_python_mirror(host_tool, tmp_path):
+    from bevy_gaussian_splatting_amd import random_gaussians_3d_seeded
+    c = random_gaussians_3d_seeded(3000, 12)
+    _write_planes(tmp_path / "c.bin", c)
+    subprocess.run([host_tool, "f16", str(tmp_path / "c.bin"), str(tmp_path / "h.bin")], check=True)
+    raw = open(tmp_path / "h.bin", "rb").read()
+    n = len(c)
+    pv = np.frombuffer(raw, np.float32, 4 * n).reshape(n, 4)
+    sh = np.frombuffer(raw, np.uint32, 24 * n, offset=16 * n).reshape(n, 24)
+    rso = np.frombuffer(raw, np.uint32, 4 * n, offset=16 * n + 96 * n).reshape(n, 4)
+    h = c.to_f16()
+    assert np.array_equal(pv, h.position_visibility) and np.array_equal(sh, h.spherical_harmonic)
+    assert np.array_equal(rso, h.rotation_scale_opacity)
+
+
+def test_cpp_sort_trigger_policy_matches_the_python_mirror(host_tool):
+    from bevy_gaussian_splatting_amd.sort_policy import SortConfig, SortTrigger, update_sort_trigger
+    rng = np.random.default_rng(3)
+    t, lines, want = 0.0, [], []
+    trig, cfg = SortTrigger(), SortConfig(period_ms=250)
+    pos = np.zeros(3, np.float32)
+    for k in range(200):
+        t += float(rng.choice([0.01, 0.1, 0.3]))
+        if rng.random() < 0.4:
+            pos = rng.integers(-3, 4, 3).astype(np.float32)
+        lines.append(f"{t!r} {pos[0]} {pos[1]} {pos[2]} {k % 3}")
+        trig.needs_sort = False
+        update_sort_trigger(trig, pos, k % 3, cfg, now=lambda: t)
+        want.append(f"{trig.camera_index} {int(trig.needs_sort)}")
+    out = subprocess.run([host_tool, "trigger", "250"], input="\n".join(lines) + "\n", capture_output=True, text=True,
+                         check=True).stdout.split("\n")
+    assert out[:len(want)] == want
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_cpp_ply_loader_matches_the_python_mirror(host_tool, tmp_path, fmt):
+    from bevy_gaussian_splatting_amd.io_ply import parse_ply_3d
+    rng = np.random.default_rng(17)
+    n = 100 if fmt == "ascii" else 1000
+    names = ["x", "y", "z", "nx", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)] + \
+            ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3", "label"]
+    types = {nme: "float" for nme in names}
+    types["label"] = "uchar"          # a non-float property: ignored by the loader
+    cols = {nme: rng.normal(0, 2, n).astype(np.float32) for nme in names}
+    cols["scale_2"] = cols["scale_2"] + np.float32(9.0)   # the +-4 clamp around the mean bites
+    cols["label"] = rng.integers(0, 255, n).astype(np.uint8)
+    header = "ply\nformat %s 1.0\ncomment made by the test\nelement vertex %d\n" % (fmt, n)
+    header += "".join(f"property {types[nme]} {nme}\n" for nme in names) + "end_header\n"
+    path = tmp_path / "c.ply"
+    with open(path, "wb") as f:
+        f.write(header.encode())
+        if fmt == "ascii":
+            for r in range(n):
+                f.write((" ".join(repr(float(cols[nme][r])) if types[nme] == "float" else str(int(cols[nme][r]))
+                                  for nme in names) + "\n").encode())
+        else:
+            order = "<" if fmt == "binary_little_endian" else ">"
+            rec = np.zeros(n, np.dtype([(nme, order + ("f4" if types[nme] == "float" else "u1")) for nme in names]))
+            for nme in names:
+                rec[nme] = cols[nme]
+            f.write(rec.tobytes())
+    subprocess.run([host_tool, "ply", str(path), str(tmp_path / "out.bin")], check=True)
+    pv, sh, rot, so = _read_planes(tmp_path / "out.bin")
+    ref = parse_ply_3d(str(path))
+    assert len(pv) == len(ref) == n + (32 - n % 32)
+    assert np.array_equal(pv, ref.position_visibility) and np.array_equal(sh, ref.spherical_harmonic)
+    # exp / sigmoid / sqrt come from libm here and from numpy there: equal to a few ulp
+    assert np.allclose(rot, ref.rotation, rtol=3e-7, atol=0, equal_nan=True)
+    assert np.allclose(so, ref.scale_opacity, rtol=1e-6, atol=0)
+
+
+def test_cpp_ply_loader_rejects_what_the_reference_rejects(host_tool, tmp_path):
+    bad = tmp_path / "bad.ply"
+    bad.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nend_header\n0 0\n")
+    r = subprocess.run([host_tool, "ply", str(bad), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "missing required properties" in r.stderr
+    notply = tmp_path / "not.ply"
+    notply.write_bytes(b"hello\n")
+    r = subprocess.run([host_tool, "ply", str(notply), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "not a PLY file" in r.stderr
