@@ -111,8 +111,8 @@ def cpu_baseline(cloud, view, settings):
     """The oracle (C restatement, OpenMP) on a bounded sample of the SAME workload:
     all host cores: the full 1M-splat sort (both reference sorts: the radix semantics and the
     rayon/std descending-f32 semantics) + the vertex stage for every splat + the raster of the centred
-    480x270 window (1/16 of the frame, time scaled x16); and the same pinned to ONE core with a
-    120x68 window (1/254 of the frame). About 15-25 s of CPU work in total."""
+    WHOLE 1920x1080 frame (no scaling); and the same pinned to ONE core with the centred 480x270
+    window (1/16 of the frame, time scaled x16). About 15-20 s of CPU work in total."""
     from oracle import oracle
     from bevy_gaussian_splatting_amd import CloudSettings, SortMode
 
@@ -133,7 +133,7 @@ def cpu_baseline(cloud, view, settings):
         scale = (WIDTH * HEIGHT) / float(window_w * window_h)
         return t_sort, t_vs, t_win, scale
 
-    t_sort, t_vs, t_win, scale = frame(480, 270)
+    t_sort, t_vs, t_win, scale = frame(WIDTH, HEIGHT)
     t0 = time.perf_counter()
     oracle.sort(cloud, view, CloudSettings(sort_mode=SortMode.Rayon))
     t_sort_std = time.perf_counter() - t0
@@ -141,7 +141,7 @@ def cpu_baseline(cloud, view, settings):
 
     oracle.set_threads(1)
     try:
-        s1, v1, w1, sc1 = frame(120, 68)
+        s1, v1, w1, sc1 = frame(480, 270)
     finally:
         oracle.set_threads(all_cores)
     t_frame1 = s1 + v1 + sc1 * w1
@@ -152,13 +152,13 @@ def cpu_baseline(cloud, view, settings):
         "kind": "port",
         "sample": ("oracle/bgs_oracle.c (gcc -O2 -fopenmp): full 1M-splat keygen+LSD radix sort "
                    f"({t_sort:.3f}s) + vertex stage of all splats ({t_vs:.3f}s) + raster of the centred "
-                   f"480x270 window ({t_win:.2f}s, scaled x{scale:.0f} to the 1920x1080 frame)"),
+                   f"whole {WIDTH}x{HEIGHT} frame ({t_win:.2f}s)"),
         "sort_msplats_per_s": len(cloud) / t_sort / 1e6,
         "sort_std_msplats_per_s": len(cloud) / t_sort_std / 1e6,
         "sort_std_note": "rayon/std semantics (src/sort/rayon.rs:86-104): keygen + descending-f32 comparison sort (qsort, 1 thread)",
         "one_core": {"value": 1.0 / t_frame1, "unit": "frames/s", "cores": 1,
                      "sort_msplats_per_s": len(cloud) / s1 / 1e6,
-                     "sample": (f"same, OMP threads = 1: sort {s1:.3f}s + vertex stage {v1:.2f}s + 120x68 window "
+                     "sample": (f"same, OMP threads = 1: sort {s1:.3f}s + vertex stage {v1:.2f}s + centred 480x270 window "
                                 f"({w1:.2f}s, scaled x{sc1:.0f})")},
     }
 
