@@ -110,7 +110,7 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
 def cpu_baseline(cloud, view, settings):
     """The oracle (C restatement, OpenMP) on a bounded sample of the SAME workload:
     all host cores: the full 1M-splat sort (both reference sorts: the radix semantics and the
-    rayon/std descending-f32 semantics) + the vertex stage for every splat + the raster of the centred
+    rayon/std descending-f32 semantics) + the vertex stage for every splat + the raster of the
     WHOLE 1920x1080 frame (no scaling); and the same pinned to ONE core with the centred 480x270
     window (1/16 of the frame, time scaled x16). About 15-20 s of CPU work in total."""
     from oracle import oracle
@@ -151,7 +151,7 @@ def cpu_baseline(cloud, view, settings):
         "cores": all_cores,
         "kind": "port",
         "sample": ("oracle/bgs_oracle.c (gcc -O2 -fopenmp): full 1M-splat keygen+LSD radix sort "
-                   f"({t_sort:.3f}s) + vertex stage of all splats ({t_vs:.3f}s) + raster of the centred "
+                   f"({t_sort:.3f}s) + vertex stage of all splats ({t_vs:.3f}s) + raster of the "
                    f"whole {WIDTH}x{HEIGHT} frame ({t_win:.2f}s)"),
         "sort_msplats_per_s": len(cloud) / t_sort / 1e6,
         "sort_std_msplats_per_s": len(cloud) / t_sort_std / 1e6,
