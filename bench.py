@@ -74,7 +74,7 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
 
 def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=None, depth=1):
     """W untimed + K timed steps. A step ENQUEUES one frame: the scan pipeline needs no host round
-    trip, and the context keeps `depth` frames in flight on separate HIP streams (lanes). With a
+    trip, and the context keeps `depth` frames in flight (lanes, multiplexed onto a few HIP streams). With a
     `gather` callback (N > 1 ranks) the oldest frame is popped and handed to it as soon as `depth`
     frames are in flight, so gathers overlap the following frames. The closing synchronize waits for
     everything, so dt covers exactly K complete frames (and their gathers). Returns (seconds,

@@ -266,7 +266,8 @@ class GaussianSplattingPlugin:
         self._check(self._lib.bgs_set_profiling_stride(self._ctx, int(every_nth_frame)))
 
     def set_pipeline_depth(self, lanes: int) -> None:
-        """Frames in flight (1..8), each on its own HIP stream; see bgs_set_pipeline_depth."""
+        """Frames in flight (1..8 lanes = per-frame buffer sets, multiplexed onto set_pipeline_streams() HIP
+        streams); see bgs_set_pipeline_depth."""
         self._check(self._lib.bgs_set_pipeline_depth(self._ctx, int(lanes)))
 
     def set_output_srgb8(self, enabled: bool) -> None:

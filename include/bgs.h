@@ -23,7 +23,7 @@
  *   - all matrices are column-major float[16] (glam / WGSL convention): m[4*c + r];
  *   - host pointers are borrowed for the duration of the call only;
  *   - device memory is owned by the library behind opaque handles;
- *   - a bgs_ctx binds one HIP device and one HIP stream and is NOT re-entrant
+ *   - a bgs_ctx binds one HIP device (and a few HIP streams of its own) and is NOT re-entrant
  *     (matches Bevy: one render thread); distinct contexts are independent.
  *   - there is NO CPU fallback: without a usable HIP device bgs_create fails with
  *     BGS_EHIP.
