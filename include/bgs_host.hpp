@@ -1,6 +1,7 @@
 // bgs_host.hpp — the callers and data formats either side of the hot path (SURVEY section 8 f), in C++17 above
 // include/bgs.hpp: the f16 planar cloud (src/gaussian/f16.rs), the sort trigger / throttle policy
-// (src/sort/mod.rs:76-86,143-194, src/sort/rayon.rs:124-129) and the INRIA `.ply` loader
+// (src/sort/mod.rs:76-86,143-194, src/sort/rayon.rs:124-129), the multi-camera SortedEntries asset
+// (src/sort/mod.rs:331-393), compute_aabb (src/gaussian/interface.rs:22-63) and the INRIA `.ply` loader
 // (src/io/ply.rs:23-132, with the reference's quirks). Header-only; tests/test_cpp_host.py checks each
 // against the Python mirror, which is pinned by known answers.
 #ifndef BGS_HOST_HPP
@@ -105,6 +106,71 @@ inline void update_sort_trigger(SortTrigger& t, const std::array<float, 3>& came
 // src/sort/rayon.rs:124-129: the CPU sorts stretch the period to at least 4x the measured sort time
 inline void after_cpu_sort(SortConfig& config, double sort_duration_s) {
     config.period_ms = std::max({config.period_ms, config.period_ms * 4 / 5, (int64_t)4 * (int64_t)(sort_duration_s * 1000.0)});
+}
+
+// ---- multi-camera sorted-entry asset ---------------------------------------------------------------
+// src/sort/mod.rs:331-393: camera_count * entry_count (key, index) pairs, created with
+// entry_count = len_sqrt_ceil(cloud)^2 (:259-262), every chunk initialised to key 1 / identity order
+// (:347-354). Camera c owns sorted[c * gaussians, (c + 1) * gaussians) with gaussians = cloud.len() — the
+// stride is the CLOUD length both where the sorts write (src/sort/rayon.rs:82-84) and where the draw binds
+// (src/render/mod.rs:1548-1554); the square-padding tail is unused.
+struct SortedEntries {
+    size_t camera_count = 0, entry_count = 0;
+    std::vector<bgs_sort_entry> sorted;
+
+    static SortedEntries create(size_t camera_count, size_t entry_count) {
+        SortedEntries s;
+        s.camera_count = camera_count;
+        s.entry_count = entry_count;
+        s.sorted.resize(camera_count * entry_count);
+        for (size_t c = 0; c < camera_count; ++c)
+            for (size_t i = 0; i < entry_count; ++i) s.sorted[c * entry_count + i] = bgs_sort_entry{1u, (uint32_t)i};
+        return s;
+    }
+    static SortedEntries for_cloud(size_t camera_count, size_t cloud_len) {  // auto_insert_sorted_entries, :218-268
+        const size_t side = (size_t)std::ceil(std::sqrt((float)cloud_len));
+        return create(camera_count, side * side);
+    }
+    // [begin, end) of camera `camera_index`'s chunk; throws where the reference's `.nth().unwrap()` panics
+    std::pair<bgs_sort_entry*, bgs_sort_entry*> chunk(size_t camera_index, size_t gaussians) {
+        if ((camera_index + 1) * gaussians > sorted.size()) throw Error(BGS_EINVAL, "camera chunk out of range");
+        return {sorted.data() + camera_index * gaussians, sorted.data() + (camera_index + 1) * gaussians};
+    }
+    // update_sorted_entries_sizes (:270-296): a camera-count change re-creates the asset
+    void resize_cameras(size_t cameras) {
+        if (cameras != camera_count) *this = create(cameras, entry_count);
+    }
+};
+
+// Every camera gets its own order (the reference's radix path only ever fills chunk 0, src/sort/mod.rs:427).
+inline void sort_cameras(GaussianSplattingPlugin& plugin, const PlanarGaussian3dHandle& h, const std::vector<View>& cameras,
+                         const CloudSettings& s, SortedEntries& out) {
+    out.resize_cameras(cameras.size());
+    const bgs_settings ns = s.to_native();
+    for (size_t c = 0; c < cameras.size(); ++c) {
+        auto range = out.chunk(c, h.size());
+        const int rc = bgs_sort(plugin.native(), h.get(), &cameras[c].native, &ns, range.first);
+        if (rc != BGS_OK) throw Error(rc, std::string("bgs_sort: ") + bgs_last_error(plugin.native()));
+    }
+}
+
+// (min, max) the reference hands to the shaders for a cloud: compute_aabb (src/gaussian/interface.rs:22-63,
+// position -/+ 0.1 per splat) -> Bevy Aabb {center, half_extents} (src/gaussian/cloud.rs:56-59) ->
+// aabb.min() / max() = center -/+ half_extents (src/render/mod.rs:1070-1071), all in f32.
+inline bool compute_aabb(const PlanarGaussian3d& c, std::array<float, 3>& mn_out, std::array<float, 3>& mx_out) {
+    if (c.size() == 0) return false;
+    std::array<float, 3> mn{INFINITY, INFINITY, INFINITY}, mx{-INFINITY, -INFINITY, -INFINITY};
+    for (const auto& p : c.position_visibility)
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], p[k] - 0.1f);
+            mx[k] = std::max(mx[k], p[k] + 0.1f);
+        }
+    for (int k = 0; k < 3; ++k) {
+        const float center = (mn[k] + mx[k]) / 2.0f, half = (mx[k] - mn[k]) / 2.0f;
+        mn_out[k] = center - half;
+        mx_out[k] = center + half;
+    }
+    return true;
 }
 
 // ---- INRIA .ply -> PlanarGaussian3d ---------------------------------------------------------------

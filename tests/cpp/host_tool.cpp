@@ -4,6 +4,8 @@
 //   host_tool f16 <planes.bin> <out.bin>    PlanarGaussian3dF16::from_f32 -> pv f32, sh u32[n][24], rso u32[n][4]
 //   host_tool half <in.f32> <out.u16>       f32_to_f16 of every value
 //   host_tool trigger <period_ms>           stdin: "t x y z order" per line -> "camera_index needs_sort" per line
+//   host_tool entries <cams> <len> <out>    SortedEntries::for_cloud, chunk, resize_cameras
+//   host_tool aabb <planes.bin>             compute_aabb
 //   host_tool settings                      sizeof / defaults of CloudSettings::to_native()
 #include <cstdio>
 #include <fstream>
@@ -65,6 +67,22 @@ int main(int argc, char** argv) {
                 bgs::update_sort_trigger(t, {x, y, z}, order, config, now);
                 std::printf("%zu %d\n", t.camera_index, t.needs_sort ? 1 : 0);
             }
+        } else if (cmd == "entries" && argc == 5) {   // entries <cameras> <cloud_len> <out.bin>: for_cloud + a resize
+            bgs::SortedEntries e = bgs::SortedEntries::for_cloud(std::stoul(argv[2]), std::stoul(argv[3]));
+            auto r = e.chunk(e.camera_count - 1, std::stoul(argv[3]));
+            r.first[0].key = 77u;                      // a write through the last camera's chunk
+            std::ofstream f(argv[4], std::ios::binary);
+            const uint64_t hdr[2] = {e.camera_count, e.entry_count};
+            f.write((const char*)hdr, 16);
+            f.write((const char*)e.sorted.data(), (std::streamsize)(e.sorted.size() * 8));
+            bool threw = false;
+            try { e.chunk(e.camera_count, e.entry_count); } catch (const bgs::Error&) { threw = true; }
+            e.resize_cameras(e.camera_count + 1);
+            std::printf("%d %zu %u\n", threw ? 1 : 0, e.sorted.size(), e.sorted[0].key);
+        } else if (cmd == "aabb" && argc == 3) {
+            std::array<float, 3> mn, mx;
+            const bool ok = bgs::compute_aabb(read_planes(argv[2]), mn, mx);
+            std::printf("%d %.9g %.9g %.9g %.9g %.9g %.9g\n", ok ? 1 : 0, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]);
         } else if (cmd == "settings") {
             const bgs_settings s = bgs::CloudSettings().to_native();
             bgs_settings d;

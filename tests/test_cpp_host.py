@@ -236,3 +236,31 @@ def test_cpp_ply_loader_rejects_what_the_reference_rejects(host_tool, tmp_path):
     notply.write_bytes(b"hello\n")
     r = subprocess.run([host_tool, "ply", str(notply), str(tmp_path / "o.bin")], capture_output=True, text=True)
     assert r.returncode == 1 and "not a PLY file" in r.stderr
+
+
+def test_cpp_sorted_entries_layout_matches_the_python_mirror(host_tool, tmp_path):
+    from bevy_gaussian_splatting_amd.plugin import SortedEntries
+    from bevy_gaussian_splatting_amd import SORT_ENTRY_DTYPE
+    cams, n = 3, 1000
+    out = subprocess.run([host_tool, "entries", str(cams), str(n), str(tmp_path / "e.bin")], capture_output=True, text=True,
+                         check=True).stdout.split()
+    raw = open(tmp_path / "e.bin", "rb").read()
+    camera_count, entry_count = struct.unpack("<QQ", raw[:16])
+    got = np.frombuffer(raw, SORT_ENTRY_DTYPE, offset=16)
+    ref = SortedEntries.for_cloud(cams, n)
+    ref.chunk(cams - 1, n)["key"][0] = 77
+    assert (camera_count, entry_count) == (ref.camera_count, ref.entry_count) == (3, 32 * 32)
+    assert np.array_equal(got, ref.sorted)
+    # out-of-range chunk throws; a camera-count change re-creates the asset (key back to 1)
+    assert out == ["1", str((cams + 1) * entry_count), "1"]
+
+
+def test_cpp_compute_aabb_matches_the_python_mirror(host_tool, tmp_path):
+    from bevy_gaussian_splatting_amd import compute_aabb, random_gaussians_3d_seeded
+    c = random_gaussians_3d_seeded(5000, 21)
+    _write_planes(tmp_path / "c.bin", c)
+    out = subprocess.run([host_tool, "aabb", str(tmp_path / "c.bin")], capture_output=True, text=True, check=True).stdout.split()
+    mn, mx = compute_aabb(c)
+    assert out[0] == "1"
+    assert np.array_equal(np.array(out[1:4], np.float32), np.array(mn, np.float32))
+    assert np.array_equal(np.array(out[4:7], np.float32), np.array(mx, np.float32))
