@@ -95,6 +95,9 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
                 gather.flush()  # the last (partial) batch and every outstanding collective
         plugin.synchronize()  # also checks the device watchdog word of every frame
 
+    # every lane allocates its buffers on its first frame: done before the W warm-up steps, so that a short
+    # --warmup (fewer steps than lanes) does not leave allocations inside the timed region
+    run(depth)
     run(warmup)
     if barrier:
         barrier()

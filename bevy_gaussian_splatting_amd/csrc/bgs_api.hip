@@ -671,7 +671,8 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
             launch_project_bin(st, fp, L.d_fp, cloud->ptrs, draw_list, L.culled, ctl, bin_status, L.records, L.coarse,
                                coarse_cap, sup_edge, /*ticket_slot=*/4, bin_blocks);
             mark(3);
-            launch_raster_scan(st, fp, L.d_fp, L.records, L.coarse, coarse_cap, sup_edge, ctl, L.fb, cl);
+            launch_raster_scan(st, fp, L.d_fp, L.records, L.coarse, coarse_cap, sup_edge, ctl, L.fb, L.fb8,
+                               want_srgb8 && !(ctx->debug_flags & 0x40000u), cl);
             mark(6);
         } else if (render) {
             const uint32_t capacity = (uint32_t)std::min<uint64_t>(L.inst_cap, MAX_INSTANCE_CAPACITY);
@@ -689,7 +690,9 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
             launch_raster(st, fp, L.records, L.inst[0], ranges, L.fb, view->clear_color);
             mark(6);
         }
-        if (want_srgb8)
+        // BINNING_SCAN frames get their sRGB8 image from the rasteriser itself (debug flag 0x40000: from the
+        // separate encode pass, for A/B runs)
+        if (want_srgb8 && !(render && scan && !(ctx->debug_flags & 0x40000u)))
             launch_encode_srgb8(st, L.fb, L.fb8, (uint32_t)fp.width * (uint32_t)fp.height, L.d_fp);
         return hipGetLastError();
     };

@@ -105,11 +105,12 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
 
 // Tile rasteriser for BINNING_SCAN: walks the supertile's ordered list, keeps the ranks whose
 // rectangle contains this tile (order-preserving ballot compaction), stages their records in LDS
-// and composites front-to-back until the tile saturates.
+// and composites front-to-back until the tile saturates. With want_srgb8 it also writes the frame as
+// Rgba8UnormSrgb (to d_fp->srgb8_target, else srgb8_default): no separate encode pass for this path.
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
-                        uint32_t sup_edge, Control* ctl, float4* framebuffer,
-                        const FrameCleanup& cleanup);
+                        uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
+                        bool want_srgb8, const FrameCleanup& cleanup);
 
 // Per-tile [start, end) over the tile-sorted instances; ranges indexed by (ty << 8 | tx).
 void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Control* ctl, uint2* ranges);

@@ -637,6 +637,20 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
     }
 }
 
+// Rgba8UnormSrgb packing of one premultiplied linear pixel (shared by the rasteriser's fused output and
+// encode_srgb8_kernel, so both give the same bytes)
+__device__ __forceinline__ uint32_t unorm8(float x) {
+    x = fminf(fmaxf(x, 0.0f), 1.0f);  // NaN -> 0
+    return (uint32_t)(x * 255.0f + 0.5f);
+}
+__device__ __forceinline__ float srgb_oetf(float x) {
+    x = fminf(fmaxf(x, 0.0f), 1.0f);
+    return x <= 0.0031308f ? 12.92f * x : fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)), -0.055f);
+}
+__device__ __forceinline__ uint32_t pack_srgb8(const float4 c) {
+    return unorm8(srgb_oetf(c.x)) | (unorm8(srgb_oetf(c.y)) << 8) | (unorm8(srgb_oetf(c.z)) << 16) | (unorm8(c.w) << 24);
+}
+
 // XCD-aware work order: workgroup b runs on XCD b % 8 (observed dispatch, a speed assumption
 // only); give each XCD a contiguous band of work items so neighbouring tiles, which share records
 // and coarse lists, share an L2.
@@ -718,6 +732,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
                                                           uint32_t coarse_cap, uint32_t sup_mul,
                                                           uint32_t sup_x, Control* ctl,
                                                           float4* __restrict__ fb,
+                                                          uint32_t* __restrict__ fb8_default, uint32_t want_srgb8,
                                                           FrameCleanup cl) {
     const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
@@ -889,10 +904,16 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int py = pyw + 4 * r;
-            if (pxw < fp.width && py < fp.height)
-                fb[(size_t)py * (size_t)fp.width + (size_t)pxw] =
-                    make_float4(fmaf(T[r], fp.clear[0], cr[r]), fmaf(T[r], fp.clear[1], cg[r]),
-                                fmaf(T[r], fp.clear[2], cb[r]), fmaf(T[r], fp.clear[3], 1.0f - T[r]));
+            if (pxw < fp.width && py < fp.height) {
+                const float4 c = make_float4(fmaf(T[r], fp.clear[0], cr[r]), fmaf(T[r], fp.clear[1], cg[r]),
+                                             fmaf(T[r], fp.clear[2], cb[r]), fmaf(T[r], fp.clear[3], 1.0f - T[r]));
+                const size_t at = (size_t)py * (size_t)fp.width + (size_t)pxw;
+                fb[at] = c;
+                // the frame in the reference's target format too, here instead of in a separate pass over
+                // the 33 MB f32 image (the frame's own destination travels in FrameParams)
+                if (want_srgb8)
+                    (fp.srgb8_target ? reinterpret_cast<uint32_t*>(fp.srgb8_target) : fb8_default)[at] = pack_srgb8(c);
+            }
         }
     }
     }  // tile < ntiles
@@ -901,8 +922,8 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
 
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
-                        uint32_t sup_edge, Control* ctl, float4* framebuffer,
-                        const FrameCleanup& cleanup) {
+                        uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
+                        bool want_srgb8, const FrameCleanup& cleanup) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4* rec = (const float4*)records;
@@ -910,7 +931,7 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
 #define BGS_LAUNCH_RS(V)                                                                          \
     hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,      \
-                       coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, cleanup)
+                       coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, want_srgb8 ? 1u : 0u, cleanup)
     if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
     else BGS_LAUNCH_RS(RV_SURFEL);
@@ -941,14 +962,6 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
 // Linear RGB -> sRGB OETF -> unorm8 (round to nearest); alpha is linear. 33 MB read, 8 MB write.
 // Used for the multi-GPU framebuffer gather (8.3 MB per 1080p frame instead of 33 MB).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t unorm8(float x) {
-    x = fminf(fmaxf(x, 0.0f), 1.0f);  // NaN -> 0
-    return (uint32_t)(x * 255.0f + 0.5f);
-}
-__device__ __forceinline__ float srgb_oetf(float x) {
-    x = fminf(fmaxf(x, 0.0f), 1.0f);
-    return x <= 0.0031308f ? 12.92f * x : fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)), -0.055f);
-}
 __global__ __launch_bounds__(256) void encode_srgb8_kernel(const float4* __restrict__ fb,
                                                            uint32_t* __restrict__ default_out, uint32_t n,
                                                            const FrameParams* __restrict__ fpp) {
@@ -956,8 +969,7 @@ __global__ __launch_bounds__(256) void encode_srgb8_kernel(const float4* __restr
     uint32_t* __restrict__ out = fpp->srgb8_target ? reinterpret_cast<uint32_t*>(fpp->srgb8_target) : default_out;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const float4 c = fb[i];
-        out[i] = unorm8(srgb_oetf(c.x)) | (unorm8(srgb_oetf(c.y)) << 8) | (unorm8(srgb_oetf(c.z)) << 16) |
-                 (unorm8(c.w) << 24);
+        out[i] = pack_srgb8(c);
     }
 }
 

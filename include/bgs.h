@@ -267,7 +267,8 @@ int bgs_set_binning(bgs_ctx* ctx, uint32_t mode);
  * of kernels off and produce WRONG images; 0x1000 (per-frame memset + Control copy instead of the
  * rasteriser's in-kernel clean-up), 0x2000 (no draw-count hint for the sort grids), 0x4000 (no
  * hipGraph replay even when bgs_set_graphs is on), 0x8000 / 0x10000 (force the coarse / the fine
- * supertile edge instead of choosing by the last frame's list statistics) keep images correct and
+ * supertile edge instead of choosing by the last frame's list statistics), 0x40000 (sRGB8 image from the
+ * separate encode pass instead of the rasteriser's fused output) keep images correct and
  * exist for A/B timing. Production code leaves this at 0. */
 int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags);
 
