@@ -338,7 +338,9 @@ int ensure_coarse(bgs_ctx* ctx, Lane& L, uint32_t n, uint32_t num_st) {
             return fail(ctx, BGS_ECAPACITY, "coarse bin lists would exceed 64 GiB; use bgs_set_binning(ctx, 1)");
         if (L.coarse) (void)hipFree(L.coarse);
         L.coarse = dev_alloc<uint32_t>(words);
-        if (!L.coarse) return fail(ctx, BGS_ENOMEM, "hipMalloc(coarse lists) failed");
+        if (!L.coarse)
+            return fail(ctx, BGS_ENOMEM, "hipMalloc(coarse lists) failed: " + std::to_string((words * sizeof(uint32_t)) >> 20) +
+                                             " MiB per lane (8 B x supertiles x splats); fewer lanes (bgs_set_pipeline_depth) need less");
         L.coarse_words = words;
     }
     return BGS_OK;
