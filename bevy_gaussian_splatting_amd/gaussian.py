@@ -113,8 +113,9 @@ class PlanarGaussian3d:
 def _pack_f32s_to_u32(upper: np.ndarray, lower: np.ndarray) -> np.ndarray:
     """src/gaussian/f16.rs:244-252: IEEE round-to-nearest-even f32->f16, first argument in
     the high half."""
-    u = np.asarray(upper, dtype=np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
-    l = np.asarray(lower, dtype=np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
+    with np.errstate(over="ignore"):  # values beyond the half range become +-inf, as in the reference
+        u = np.asarray(upper, dtype=np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
+        l = np.asarray(lower, dtype=np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
     return (u << np.uint32(16)) | l
 
 
