@@ -124,6 +124,8 @@ def test_sort_trigger_policy():
 import struct
 
 from bevy_gaussian_splatting_amd import decode_gcloud, encode_gcloud, read_gcloud, write_gcloud
+from struct import error as struct_error
+
 from bevy_gaussian_splatting_amd.io_gcloud import _Builder, flexbuffers_loads
 
 
@@ -145,6 +147,59 @@ def test_gcloud_round_trip(tmp_path):
     assert sorted(doc["position_visibility"][0]) == ["position", "visibility"] and len(doc["position_visibility"][0]["position"]) == 3
     assert sorted(doc["scale_opacity"][1]) == ["opacity", "scale"] and len(doc["rotation"][0]["rotation"]) == 4
     assert len(doc["spherical_harmonic"][0]["coefficients"]) == 48
+
+
+def test_gcloud_fast_path_equals_the_general_reader_and_falls_back():
+    """decode_gcloud's vectorised path (no Python object per splat) must give exactly what the general
+    FlexBuffers reader gives, for every shape the writer or serde may produce, and must hand anything
+    irregular to the general reader instead of guessing."""
+    from bevy_gaussian_splatting_amd.io_gcloud import _decode_gcloud_fast, _Irregular
+    planes = ("position_visibility", "spherical_harmonic", "rotation", "scale_opacity")
+
+    def same(a, b):
+        return all(np.array_equal(getattr(a, k), getattr(b, k)) for k in planes)
+
+    for n in (0, 1, 2, 31, 700, 5000):       # key-vector offsets cross the 1 / 2 byte widths on the way
+        c = random_gaussians_3d_seeded(n, 40 + n)
+        data = encode_gcloud(c)
+        fast, general = _decode_gcloud_fast(data), decode_gcloud(data, fast=False)
+        assert same(fast, general) and same(fast, c)
+        assert fast.position_visibility.dtype == np.float32 and len(fast) == n
+
+    # structs as sequences in declaration order (serde accepts both) and untyped float vectors
+    b = _Builder()
+    c = random_gaussians_3d_seeded(40, 3)
+    pv, sh, rot, so = c.position_visibility, c.spherical_harmonic, c.rotation, c.scale_opacity
+    seq = b.map({
+        "position_visibility": b.vector([b.vector([b.floats(pv[i, :3]), b.f32(pv[i, 3])]) for i in range(40)]),
+        "spherical_harmonic": b.vector([b.vector([b.floats(sh[i])]) for i in range(40)]),
+        "rotation": b.vector([b.vector([b.floats(rot[i])]) for i in range(40)]),
+        "scale_opacity": b.vector([b.vector([b.floats(so[i, :3]), b.f32(so[i, 3])]) for i in range(40)]),
+    })
+    data = b.finish(seq)
+    assert same(_decode_gcloud_fast(data), c) and same(decode_gcloud(data, fast=False), c)
+
+    # irregular: one struct lacks a field (serde default) -> the fast path declines, the result is still right
+    b = _Builder()
+    items = [b.map({"position": b.floats(pv[i, :3]), "visibility": b.f32(pv[i, 3])}) for i in range(39)]
+    items.append(b.map({"position": b.floats(pv[39, :3])}))
+    data = b.finish(b.map({
+        "position_visibility": b.vector(items),
+        "spherical_harmonic": b.vector([b.map({"coefficients": b.floats(sh[i])}) for i in range(40)]),
+        "rotation": b.vector([b.map({"rotation": b.floats(rot[i])}) for i in range(40)]),
+        "scale_opacity": b.vector([b.map({"scale": b.floats(so[i, :3]), "opacity": b.f32(so[i, 3])}) for i in range(40)]),
+    }))
+    with pytest.raises(_Irregular):
+        _decode_gcloud_fast(data)
+    d = decode_gcloud(data)
+    want = pv.copy(); want[39, 3] = 1.0      # PositionVisibility::default().visibility
+    assert np.array_equal(d.position_visibility, want) and np.array_equal(d.rotation, rot)
+
+    # garbage and truncation: an error from the general reader, never a crash or a silent cloud
+    good = encode_gcloud(random_gaussians_3d_seeded(50, 1))
+    for bad in (b"", b"\x00", good[: len(good) // 2], good[:-1], bytes(reversed(good))):
+        with pytest.raises((ValueError, IndexError, KeyError, TypeError, OverflowError, struct_error)):
+            decode_gcloud(bad)
 
 
 def test_flexbuffers_known_answers_from_the_published_format():
