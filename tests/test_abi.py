@@ -87,3 +87,20 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "bgs_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_header_is_plain_c_and_the_cpp_layer_is_standard_cpp17(tmp_path):
+    """include/bgs.h must compile as strict C99 (it is the FFI surface a Rust / cgo / ctypes binding reads)
+    and include/bgs.hpp + bgs_host.hpp as warning-free C++17 with no HIP headers on the include path."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = tmp_path / "abi.c"
+    c.write_text('#include "bgs.h"\nint main(void) { bgs_settings s; bgs_settings_default(&s); '
+                 "return (int)sizeof(bgs_view) == 0; }\n")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                    "-c", str(c), "-o", str(tmp_path / "abi.o")], check=True)
+    cpp = tmp_path / "host.cpp"
+    cpp.write_text('#include "bgs_host.hpp"\nint main() { bgs::CloudSettings s; return (int)s.to_native().sh_degree - 3; }\n')
+    subprocess.run(["g++", "-std=c++17", "-pedantic", "-Wall", "-Wextra", "-Wshadow", "-Werror", "-I",
+                    os.path.join(root, "include"), "-c", str(cpp), "-o", str(tmp_path / "host.o")], check=True)
