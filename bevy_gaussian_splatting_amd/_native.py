@@ -61,6 +61,7 @@ EXPORTED_SYMBOLS = (
     "bgs_set_pipeline_streams",
     "bgs_set_graphs",
     "bgs_graph_counters",
+    "bgs_reset_adaptive_state",
 )
 
 
@@ -75,7 +76,7 @@ class BgsStats(ctypes.Structure):
         ("splat_count", ctypes.c_uint32),
         ("visible_count", ctypes.c_uint32),
         ("draw_count", ctypes.c_uint32),
-        ("pad", ctypes.c_uint32),
+        ("sort_path", ctypes.c_uint32),
         ("instance_count", ctypes.c_uint64),
         ("instance_capacity", ctypes.c_uint64),
         ("tiles_x", ctypes.c_uint32),
@@ -86,7 +87,7 @@ class BgsStats(ctypes.Structure):
         ("regrow_count", ctypes.c_uint32),
         ("binning_mode", ctypes.c_uint32),
         ("frames_averaged", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32),
+        ("list_capacity", ctypes.c_uint32),
     ]
 
 
@@ -187,6 +188,8 @@ def load() -> ctypes.CDLL:
     lib.bgs_set_graphs.restype = ctypes.c_int
     lib.bgs_graph_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.bgs_graph_counters.restype = ctypes.c_int
+    lib.bgs_reset_adaptive_state.argtypes = [vp]
+    lib.bgs_reset_adaptive_state.restype = ctypes.c_int
     _lib = lib
     return lib
 

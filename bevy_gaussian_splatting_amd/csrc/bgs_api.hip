@@ -64,11 +64,15 @@ T* dev_alloc(size_t count) {
 // KeygenLaunch): compared bytewise, any difference rebuilds the graph.
 struct GraphKey {
     const void* cloud[6];
-    const void* bufs[10];
+    const void* bufs[11];
     uint32_t n, is_f16, places, sort_mode, gaussian_mode, aabb, any_mode, srgb8, debug_flags;
     int32_t width, height;
     int32_t sort_blocks, bin_blocks, keygen_blocks;
     uint32_t sup_edge;
+    // the offsets baked into the nodes depend on the scratch layout and the list capacity, not only on
+    // the base pointers (a re-allocation may return the same address)
+    uint64_t scratch_bytes, scratch_inst_cap;
+    uint32_t scratch_n, coarse_cap, sort_path;
 };
 struct FrameGraph {
     hipGraph_t graph = nullptr;
@@ -105,7 +109,8 @@ struct Lane {
     uint2* inst[2] = {nullptr, nullptr};  // BINNING_SORT only
     uint64_t inst_cap = 0;
     uint32_t* coarse = nullptr;  // BINNING_SCAN: [num_supertiles][coarse_cap] ordered (rank, tile rect) lists
-    size_t coarse_words = 0;
+    size_t coarse_entries = 0;   // 8-byte entries allocated (all lists together)
+    uint2* bucket_slots = nullptr;  // bucket sort: [BUCKET_COUNT][BUCKET_CAP] pairs (64 MB), allocated on first use
     float4* fb = nullptr;
     size_t fb_pixels = 0;
     uint32_t* fb8 = nullptr;     // Rgba8UnormSrgb image (optional)
@@ -122,7 +127,15 @@ struct Lane {
     uint32_t frames_timed = 0;  // timed frames since the last stats read-back
 
     bool pending = false;  // a frame is enqueued whose Control block has not been checked yet
-    bool pending_render = false, pending_scan = false;
+    bool pending_render = false, pending_scan = false, pending_bucket = false;
+    uint32_t pending_coarse_cap = 0;
+    // what the pending frame was enqueued with: a frame whose data-dependent capacities turn out too
+    // small (coarse lists, bucket sort, tile instances) is re-run on its lane when it is completed
+    const bgs_cloud* in_cloud = nullptr;
+    bgs_view in_view{};
+    bgs_settings in_settings{};
+    uint32_t* in_srgb8_target = nullptr;
+    bool in_allow_graph = false;
     uint32_t pending_n = 0, pending_places = 0, pending_num_st = 0, pending_rec_bytes = 0, pending_is_f16 = 0;
     uint32_t pending_w = 0, pending_h = 0, pending_tx = 0, pending_ty = 0;
     uint64_t seq = 0;  // enqueue sequence number (to find the oldest pending lane)
@@ -166,6 +179,16 @@ struct bgs_ctx {
     uint32_t draw_hint = 0;
     bool draw_hint_valid = false;
     bool sup_fine = false;   // supertile edge rule of the next frames (see enqueue_frame)
+    // Bucket sort (one launch instead of four digit passes) is used while the last completed frame's
+    // drawable key range is known, the draw count fits the bucket geometry, and it has not just failed.
+    bool key_range_valid = false;
+    uint32_t key_lo = 0, key_hi = 0;  // drawable key range of the most recently completed frame
+    uint32_t bucket_block = 0;        // frames to stay on the onesweep passes after a bucket-sort overflow
+    uint64_t bucket_frames = 0, onesweep_frames = 0;
+    // entries per supertile list the next frames allocate (grown from the longest list seen; a frame whose
+    // lists overflow is re-run): the worst case is n entries in each of up to 256 lists (1.9 GB per lane at
+    // 1 M splats), the real lists of a frame hold ~1 % of that
+    uint32_t coarse_cap_hint = 0;
     bool use_graphs = false;  // async BINNING_SCAN frames replay a captured hipGraph (bgs_set_graphs)
     uint64_t graph_captures = 0, graph_replays = 0;
 
@@ -239,6 +262,7 @@ void lane_destroy(Lane& L) {
     for (auto e : L.inst) if (e) (void)hipFree(e);
     if (L.records) (void)hipFree(L.records);
     if (L.coarse) (void)hipFree(L.coarse);
+    if (L.bucket_slots) (void)hipFree(L.bucket_slots);
     if (L.fb) (void)hipFree(L.fb);
     if (L.fb8) (void)hipFree(L.fb8);
     if (L.h_ctl) (void)hipHostFree(L.h_ctl);
@@ -329,20 +353,42 @@ int ensure_records(bgs_ctx* ctx, Lane& L, size_t bytes) {
     return BGS_OK;
 }
 
-int ensure_coarse(bgs_ctx* ctx, Lane& L, uint32_t n, uint32_t num_st) {
-    // worst case: every rank lands in every supertile list -> num_st * n entries of 2 words
-    // (rank, tile rectangle); no overflow path
-    const size_t words = 2 * (size_t)num_st * std::max<uint32_t>(n, 1);
-    if (words > L.coarse_words || !L.coarse) {
-        if (words * sizeof(uint32_t) > (64ull << 30))
+uint32_t pow2_ceil(uint64_t v) {
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return (uint32_t)std::min<uint64_t>(p, 1ull << 31);
+}
+
+// Supertile lists: `num_st` lists of `cap` (rank, tile rect) entries each. `cap` follows the longest list
+// seen so far (ctx->coarse_cap_hint, never more than n: a list holds each rank at most once); a frame
+// that overflows a list is detected when it completes (coarse_total > cap) and re-run with larger lists.
+int ensure_coarse(bgs_ctx* ctx, Lane& L, uint32_t n, uint32_t num_st, uint32_t* cap_out) {
+    const uint32_t n1 = std::max<uint32_t>(n, 1);
+    if (ctx->coarse_cap_hint == 0)
+        ctx->coarse_cap_hint = (ctx->debug_flags & 0x100000u) ? 64u : std::max<uint32_t>(pow2_ceil(n1 / 16u), 4096u);
+    const uint32_t want = std::min<uint32_t>(n1, ctx->coarse_cap_hint);
+    const size_t need = (size_t)num_st * want;
+    if (need > L.coarse_entries || !L.coarse) {
+        if (need * 8u > (64ull << 30))
             return fail(ctx, BGS_ECAPACITY, "coarse bin lists would exceed 64 GiB; use bgs_set_binning(ctx, 1)");
         if (L.coarse) (void)hipFree(L.coarse);
-        L.coarse = dev_alloc<uint32_t>(words);
+        L.coarse = nullptr;
+        L.coarse_entries = 0;
+        L.coarse = dev_alloc<uint32_t>(2 * need);
         if (!L.coarse)
-            return fail(ctx, BGS_ENOMEM, "hipMalloc(coarse lists) failed: " + std::to_string((words * sizeof(uint32_t)) >> 20) +
-                                             " MiB per lane (8 B x supertiles x splats); fewer lanes (bgs_set_pipeline_depth) need less");
-        L.coarse_words = words;
+            return fail(ctx, BGS_ENOMEM, "hipMalloc(coarse lists) failed: " + std::to_string((need * 8u) >> 20) +
+                                             " MiB per lane (8 B x supertiles x longest list); fewer lanes (bgs_set_pipeline_depth) need less");
+        L.coarse_entries = need;
     }
+    // everything that is allocated is used (a lane that grew for an earlier frame keeps its longer lists)
+    *cap_out = (uint32_t)std::min<size_t>(L.coarse_entries / num_st, n1);
+    return BGS_OK;
+}
+
+int ensure_bucket_slots(bgs_ctx* ctx, Lane& L) {
+    if (L.bucket_slots) return BGS_OK;
+    L.bucket_slots = dev_alloc<uint2>((size_t)BUCKET_COUNT * BUCKET_CAP);
+    if (!L.bucket_slots) return fail(ctx, BGS_ENOMEM, "hipMalloc(bucket sort slots) failed");
     return BGS_OK;
 }
 
@@ -390,83 +436,133 @@ int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
     return BGS_OK;
 }
 
-// Complete the frame pending on a lane: wait for its stream, check the watchdog / overflow words of
-// the Control copy that travelled with the frame, fill the context's stats.
-int finish_lane(bgs_ctx* ctx, Lane& L, uint64_t* need_cap) {
-    if (need_cap) *need_cap = 0;
-    if (!L.pending) return BGS_OK;
-    hipStream_t st = L.stream;
-    HIP_TRY(ctx, hipEventSynchronize(L.done));  // not the stream: a sibling lane's frame may be queued behind
-    L.pending = false;
-    const bool render = L.pending_render, scan = L.pending_scan;
-    const uint32_t n = L.pending_n, places = L.pending_places, num_st = L.pending_num_st;
-    const size_t rec_bytes = L.pending_rec_bytes;
+int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s,
+                  bool render, bool allow_graph);
 
-    const Control& h = *L.h_ctl;
-    if (!ctx->draw_hint_valid || h.draw_count > ctx->draw_hint || (uint64_t)h.draw_count * 2 < ctx->draw_hint) {
-        ctx->draw_hint = (uint32_t)std::min<uint64_t>((uint64_t)h.draw_count + h.draw_count / 8 + 1024, 0xFFFFFFFFull);
-        ctx->draw_hint_valid = true;
-    }
-    // after a render only the drawable prefix of the list is materialised (the culled tail stays
-    // in its side buffer); bgs_sort appends it so that callers get the reference's full list
-    L.last_sorted_n = render ? h.draw_count : n;
-    if (!render && h.draw_count < n) {
-        // bgs_sort contract: one contiguous list, culled entries last (ascending index)
-        HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint2*>(L.last_sorted) + h.draw_count, L.culled,
-                                    (size_t)(n - h.draw_count) * sizeof(uint2), hipMemcpyDeviceToDevice, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-    }
-    if (h.error) L.scratch_clean = false;  // do not trust what a tripped frame left behind
-    if (h.error)
-        return fail(ctx, BGS_EINTERNAL,
-                    "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
-    uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
-    if (render && scan) {
-        total = 0;
-        for (uint32_t i = 0; i < num_st; ++i) total += h.coarse_total[i];
-    }
-    if (render && h.overflow) {
-        if (need_cap) *need_cap = total;
-        return BGS_OK;
-    }
-    if (render && scan && h.visible_count > 0) {
-        // list entries per visible splat: ~1.2 when splats are smaller than a supertile, 15-20 when they
-        // span many; thresholds far apart so that the rule does not flip on a moving camera
-        const uint64_t v = h.visible_count;
-        if (!ctx->sup_fine && total < 3 * v) ctx->sup_fine = true;
-        else if (ctx->sup_fine && total > 8 * v) ctx->sup_fine = false;
-    }
+// Complete the frame pending on a lane: wait for it, check the watchdog word of the Control copy that
+// travelled with the frame, and RE-RUN the frame on its lane if a data-dependent capacity turned out too
+// small (a supertile list, the bucket sort's geometry, the tile-instance buffer): nobody has seen the
+// frame's output yet, so the caller just gets the correct frame a little later. Fills the lane's stats.
+int finish_lane(bgs_ctx* ctx, Lane& L) {
+    for (int attempt = 0; L.pending; ++attempt) {
+        hipStream_t st = L.stream;
+        HIP_TRY(ctx, hipEventSynchronize(L.done));  // not the stream: a sibling lane's frame may be queued behind
+        L.pending = false;
+        const bool render = L.pending_render, scan = L.pending_scan;
+        const uint32_t n = L.pending_n, places = L.pending_places, num_st = L.pending_num_st;
+        const size_t rec_bytes = L.pending_rec_bytes;
 
-    bgs_stats& stt = L.result;
-    std::memset(&stt, 0, sizeof stt);
-    stt.regrow_count = ctx->regrow_count;
-    stt.splat_count = n;
-    stt.visible_count = render ? h.visible_count : h.draw_count;
-    stt.draw_count = h.draw_count;
-    stt.instance_count = render ? total : 0;
-    stt.instance_capacity = L.inst_cap;
-    stt.tiles_x = render ? L.pending_tx : 0;
-    stt.tiles_y = render ? L.pending_ty : 0;
-    stt.depth_passes = places;
-    stt.tile_passes = (render && !scan) ? 2 : 0;
-    stt.binning_mode = scan ? BINNING_SCAN : BINNING_SORT;
-    {
-        // SURVEY 8(d) algorithmic bytes. SURVEY's bytes_sort is N*16 + N*8 + k*N*16; the partition
-        // in keygen means only the D drawable pairs go through the k passes, so that is counted.
-        const uint64_t N = n, k = places, D = h.draw_count;
-        uint64_t bytes = N * 16 + N * 8 + k * D * 16;
-        if (render) {
-            const uint64_t B = L.pending_is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
-            const uint64_t P = (uint64_t)L.pending_w * L.pending_h;
-            if (scan)  // coarse entries (rank + tile rect, 8 B): written once, read by the tiles of their supertile
-                bytes += V * (B - 16) + V * R + V * 8 + I * 8 + I * 8 + P * 16;
-            else
-                bytes += V * (B - 16) + V * R + I * 8 + 2 * I * 16 + I * (4 + R) + P * 16;
+        const Control& h = *L.h_ctl;
+        if (h.error) {
+            // nothing a tripped frame left behind is trusted: not its counters, not the scratch region
+            L.scratch_clean = false;
+            ctx->draw_hint_valid = false;
+            ctx->key_range_valid = false;
+            return fail(ctx, BGS_EINTERNAL,
+                        "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
         }
-        stt.algorithmic_bytes = bytes;
+        if (!ctx->draw_hint_valid || h.draw_count > ctx->draw_hint || (uint64_t)h.draw_count * 2 < ctx->draw_hint) {
+            ctx->draw_hint = (uint32_t)std::min<uint64_t>((uint64_t)h.draw_count + h.draw_count / 8 + 1024, 0xFFFFFFFFull);
+            ctx->draw_hint_valid = true;
+        }
+        if (places == 4 && h.draw_count > 0 && h.key_max >= ~h.key_min_inv) {
+            ctx->key_lo = ~h.key_min_inv;
+            ctx->key_hi = h.key_max;
+            ctx->key_range_valid = true;
+        }
+
+        // ---- capacities that depend on the data ----
+        bool rerun = false;
+        if (L.pending_bucket && h.sort_overflow) {
+            ctx->bucket_block = 256;  // stay on the digit passes for a while: the keys do not suit the buckets
+            rerun = true;
+        }
+        uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
+        if (render && scan) {
+            total = 0;
+            uint32_t longest = 0;
+            for (uint32_t i = 0; i < num_st; ++i) {
+                total += h.coarse_total[i];
+                longest = std::max(longest, h.coarse_total[i]);
+            }
+            const uint32_t want = pow2_ceil((uint64_t)longest + longest / 4);
+            if (want > ctx->coarse_cap_hint) ctx->coarse_cap_hint = want;  // the next allocations
+            if (longest > L.pending_coarse_cap) rerun = true;              // this frame dropped entries
+        }
+        if (render && !scan && h.overflow) {
+            // BINNING_SORT overflow: grow to the next power of two with 25 % headroom
+            if (total > MAX_INSTANCE_CAPACITY)
+                return fail(ctx, BGS_ECAPACITY,
+                            "frame needs " + std::to_string(total) + " tile instances, above the 2^30 limit");
+            uint64_t cap = MIN_INSTANCE_CAPACITY;
+            while (cap < total + total / 4) cap <<= 1;
+            cap = std::min(cap, MAX_INSTANCE_CAPACITY);
+            int rc = ensure_instances(ctx, L, cap);
+            if (rc != BGS_OK) return rc;
+            rerun = true;
+        }
+        if (rerun) {
+            if (attempt >= 8) return fail(ctx, BGS_ECAPACITY, "frame kept overflowing its buffers");
+            ctx->regrow_count += 1;
+            uint32_t* const next_target = ctx->next_srgb8_target;  // belongs to a frame not enqueued yet
+            ctx->next_srgb8_target = L.in_srgb8_target;
+            int rc = enqueue_frame(ctx, L, L.in_cloud, &L.in_view, &L.in_settings, render, L.in_allow_graph);
+            ctx->next_srgb8_target = next_target;
+            if (rc != BGS_OK) return rc;
+            continue;
+        }
+
+        // after a render only the drawable prefix of the list is materialised (the culled tail stays
+        // in its side buffer); bgs_sort appends it so that callers get the reference's full list
+        L.last_sorted_n = render ? h.draw_count : n;
+        if (!render && h.draw_count < n) {
+            // bgs_sort contract: one contiguous list, culled entries last (ascending index)
+            HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint2*>(L.last_sorted) + h.draw_count, L.culled,
+                                        (size_t)(n - h.draw_count) * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+        }
+        if (render && scan && h.visible_count > 0) {
+            // list entries per visible splat: ~1.2 when splats are smaller than a supertile, 15-20 when they
+            // span many; thresholds far apart so that the rule does not flip on a moving camera
+            const uint64_t v = h.visible_count;
+            if (!ctx->sup_fine && total < 3 * v) ctx->sup_fine = true;
+            else if (ctx->sup_fine && total > 8 * v) ctx->sup_fine = false;
+        }
+
+        bgs_stats& stt = L.result;
+        std::memset(&stt, 0, sizeof stt);
+        stt.regrow_count = ctx->regrow_count;
+        stt.splat_count = n;
+        stt.visible_count = render ? h.visible_count : h.draw_count;
+        stt.draw_count = h.draw_count;
+        stt.sort_path = L.pending_bucket ? 1u : 0u;
+        stt.list_capacity = (render && scan) ? L.pending_coarse_cap : 0u;
+        stt.instance_count = render ? total : 0;
+        stt.instance_capacity = L.inst_cap;
+        stt.tiles_x = render ? L.pending_tx : 0;
+        stt.tiles_y = render ? L.pending_ty : 0;
+        stt.depth_passes = places;
+        stt.tile_passes = (render && !scan) ? 2 : 0;
+        stt.binning_mode = scan ? BINNING_SCAN : BINNING_SORT;
+        {
+            // SURVEY 8(d) algorithmic bytes. SURVEY's bytes_sort is N*16 + N*8 + k*N*16; the partition
+            // in keygen means only the D drawable pairs go through the k passes, so that is counted
+            // (the bucket sort moves each drawable pair twice: scatter + gather, sorted write: k = 1.5).
+            const uint64_t N = n, k = places, D = h.draw_count;
+            uint64_t bytes = N * 16 + N * 8 + (L.pending_bucket ? D * 24 : k * D * 16);
+            if (render) {
+                const uint64_t B = L.pending_is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
+                const uint64_t P = (uint64_t)L.pending_w * L.pending_h;
+                if (scan)  // coarse entries (rank + tile rect, 8 B): written once, read by the tiles of their supertile
+                    bytes += V * (B - 16) + V * R + V * 8 + I * 8 + I * 8 + P * 16;
+                else
+                    bytes += V * (B - 16) + V * R + I * 8 + 2 * I * 16 + I * (4 + R) + P * 16;
+            }
+            stt.algorithmic_bytes = bytes;
+        }
+        L.has_result = true;
+        L.result_kind = (uint8_t)(!render ? 1 : (scan ? 2 : 3));
     }
-    L.has_result = true;
-    L.result_kind = (uint8_t)(!render ? 1 : (scan ? 2 : 3));
     return BGS_OK;
 }
 
@@ -477,7 +573,7 @@ int finish_all(bgs_ctx* ctx) {
         for (int i = 0; i < MAX_LANES; ++i)
             if (ctx->lanes[i].pending && (best < 0 || ctx->lanes[i].seq < ctx->lanes[best].seq)) best = i;
         if (best < 0) return BGS_OK;
-        int rc = finish_lane(ctx, ctx->lanes[best], nullptr);
+        int rc = finish_lane(ctx, ctx->lanes[best]);
         if (rc != BGS_OK) return rc;
     }
 }
@@ -532,7 +628,7 @@ int collect_stats(bgs_ctx* ctx) {
 
 // Enqueue one frame on lane L. Returns without waiting; the caller decides when to finish the lane.
 int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s,
-                  bool render, bool allow_graph = false) {
+                  bool render, bool allow_graph) {
     FrameParams fp{};
     fill_frame_params(cloud->ptrs.n, view, s, fp);
     fp.debug = ctx->debug_flags;
@@ -546,6 +642,37 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     if ((rc = lane_create(ctx, L)) != BGS_OK) return rc;
     if ((rc = ensure_entries(ctx, L, n)) != BGS_OK) return rc;
     const bool scan = ctx->binning == BINNING_SCAN;
+    // what finish_lane re-runs the frame with (view / settings may already live in the lane: a re-run)
+    L.in_cloud = cloud;
+    if (view != &L.in_view) L.in_view = *view;
+    if (s != &L.in_settings) L.in_settings = *s;
+    L.in_srgb8_target = render ? ctx->next_srgb8_target : nullptr;
+    L.in_allow_graph = allow_graph;
+
+    // Depth-sort path. The bucket sort needs 32-bit keys (shorter keys are mostly ties, which it ranks
+    // quadratically), a draw count that fits its geometry (a bucket holds <= BUCKET_CAP pairs) and the key
+    // range of a recent frame; it is checked on the device and the frame re-run with the digit passes when
+    // it does not work out (then bucket_block keeps the following frames on the passes for a while).
+    // Debug flags: 0x80000 never, 0x200000 also with a guessed range (no completed frame yet).
+    bool bucket = places == 4 && n > 0 && !(ctx->debug_flags & 0x80000u) && ctx->bucket_block == 0 &&
+                  ((ctx->key_range_valid && ctx->draw_hint_valid) || (ctx->debug_flags & 0x200000u)) &&
+                  (!ctx->draw_hint_valid || ctx->draw_hint <= BUCKET_COUNT * 128u);
+    if (ctx->bucket_block > 0 && places == 4) ctx->bucket_block -= 1;
+    if (bucket) {
+        // 1/16 of the span as a margin on both sides; keys outside fall into the first / last bucket
+        const uint64_t lo0 = ctx->key_range_valid ? ctx->key_lo : 0u, hi0 = ctx->key_range_valid ? ctx->key_hi : 0xFFFFFFFFull;
+        const uint64_t margin = (hi0 - lo0) / 16 + 1;
+        const uint64_t lo = lo0 > margin ? lo0 - margin : 0, hi = std::min<uint64_t>(hi0 + margin, 0xFFFFFFFFull);
+        uint32_t shift = 0;
+        while (((hi - lo) >> shift) >= BUCKET_COUNT) ++shift;
+        fp.sort_path = 1u;
+        fp.bucket_lo = (uint32_t)lo;
+        fp.bucket_shift = shift;
+        if ((rc = ensure_bucket_slots(ctx, L)) != BGS_OK) return rc;
+        ctx->bucket_frames += 1;
+    } else if (places > 0) {
+        ctx->onesweep_frames += 1;
+    }
     // Supertile edge (in tiles). Two candidates: the smallest power of two >= 8 that keeps the coarse bins
     // <= 256 and <= 32 per axis (8 at 1080p: 135 bins) and the smallest edge >= 3/4 of it that does
     // (6 at 1080p: 240 bins).
@@ -568,11 +695,11 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     if (edge_f >= edge_c) { edge_f = edge_c; fbx = cbx; fby = cby; }
     const bool fine = (ctx->debug_flags & 0x10000u) || (ctx->sup_fine && !(ctx->debug_flags & 0x8000u));
     const uint32_t sup_edge = fine ? edge_f : edge_c, sup_bx = fine ? fbx : cbx, sup_by = fine ? fby : cby;
-    const uint32_t num_st_alloc = std::max(fbx * fby, cbx * cby);  // lists are sized for either rule
     const uint32_t num_st = sup_bx * sup_by;
+    uint32_t coarse_cap = 1;  // entries per supertile list
     if (render) {
         if (scan) {
-            if ((rc = ensure_coarse(ctx, L, n, num_st_alloc)) != BGS_OK) return rc;
+            if ((rc = ensure_coarse(ctx, L, n, num_st, &coarse_cap)) != BGS_OK) return rc;
         } else {
             if ((rc = ensure_instances(ctx, L, std::max<uint64_t>(L.inst_cap, MIN_INSTANCE_CAPACITY))) != BGS_OK) return rc;
         }
@@ -616,6 +743,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     kg.places = places;
     kg.ticket_slot = 7;
     kg.fp_out = L.d_fp;
+    kg.bucket_slots = L.bucket_slots;
     const bool have_keygen = kg.prepare(ctx->num_cus * 4);
     const bool large = n > (4u << 20);
     const size_t depth_tiles = ((size_t)L.scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
@@ -633,7 +761,9 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     int bin_blocks = ctx->num_cus * 3;
     if (hinted)
         bin_blocks = (int)std::min<uint64_t>((uint64_t)bin_blocks, std::max<uint64_t>((uint64_t)ctx->draw_hint / 256 + 8, 32));
-    const uint32_t coarse_cap = std::max<uint32_t>(n, 1);
+    // bucket sort grid: one workgroup per chunk of ~BUCKET_HALF..BUCKET_CHUNK pairs (grid-stride beyond)
+    const int bucket_blocks = (int)std::min<uint64_t>((uint64_t)ctx->num_cus * 2,
+                                                      (ctx->draw_hint_valid ? ctx->draw_hint : n) / BUCKET_HALF + 8);
     const bool want_srgb8 = render && (ctx->output_srgb8 || ctx->next_srgb8_target);
     uint2* const draw_list = L.entries[places & 1u];  // the passes ping-pong from entries[0]
     FrameCleanup cl{};
@@ -644,7 +774,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         cl.other_ctl = (Control*)(L.scratch + (L.ctl_parity ? 0 : L.off_ctl1));
         cl.host_ctl = L.h_ctl_dev;
         cl.pass_stride = (uint32_t)(depth_tiles * RADIX_BASE);
-        cl.places = places;
+        cl.places = bucket ? 0u : places;  // the bucket sort has no look-back words (its counters live in Control)
         cl.depth_tile = sort_tile_size(large);
         if (ctx->debug_flags & 0x1000u) cl = FrameCleanup{};  // experiment: classic memset + copy path
     }
@@ -659,7 +789,11 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         }
         mark(1);
         int cur = 0;
-        for (uint32_t p = 0; p < places; ++p) {
+        if (bucket)
+            launch_bucket_sort(st, L.bucket_slots, draw_list, ctl,
+                               (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD) ? 0xFFFFFFFFu : 0u,
+                               bucket_blocks);
+        for (uint32_t p = 0; p < (bucket ? 0u : places); ++p) {
             const uint32_t key_xor =
                 (p + 1 == places && (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD)) ? 0xFFFFFFFFu : 0u;
             // only the V' drawable entries are sorted; the culled tail is already in its final order
@@ -713,8 +847,8 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         const void* planes[6] = {cloud->ptrs.position_visibility, cloud->ptrs.sh_f32, cloud->ptrs.rotation,
                                  cloud->ptrs.scale_opacity, cloud->ptrs.sh_f16, cloud->ptrs.rot_scale_opacity_f16};
         std::memcpy(key.cloud, planes, sizeof planes);
-        const void* bufs[10] = {L.entries[0], L.entries[1], L.culled, L.records, L.coarse, L.fb, L.fb8, L.scratch, L.d_fp,
-                                L.h_ctl_dev};
+        const void* bufs[11] = {L.entries[0], L.entries[1], L.culled, L.records, L.coarse, L.fb, L.fb8, L.scratch, L.d_fp,
+                                L.h_ctl_dev, L.bucket_slots};
         std::memcpy(key.bufs, bufs, sizeof bufs);
         key.n = n;
         key.is_f16 = cloud->ptrs.is_f16;
@@ -731,6 +865,11 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         key.bin_blocks = bin_blocks;
         key.keygen_blocks = (int32_t)kg.blocks;
         key.sup_edge = sup_edge;
+        key.scratch_bytes = L.scratch_bytes;
+        key.scratch_inst_cap = L.scratch_inst_cap;
+        key.scratch_n = L.scratch_n;
+        key.coarse_cap = coarse_cap;
+        key.sort_path = bucket ? 1u : 0u;
         FrameGraph& G = L.graph[L.ctl_parity];
         if (G.exec && std::memcmp(&G.key, &key, sizeof key) == 0) {
             HIP_TRY(ctx, kg.update_node(G.exec, G.keygen_node));
@@ -777,6 +916,8 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     L.pending = true;
     L.pending_render = render;
     L.pending_scan = scan;
+    L.pending_bucket = bucket;
+    L.pending_coarse_cap = coarse_cap;
     L.pending_n = n;
     L.pending_places = places;
     L.pending_num_st = num_st;
@@ -801,26 +942,12 @@ int run(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_se
         Lane& L = ctx->lanes[0];
         ctx->recent = 0;
         ctx->regrow_count = 0;
-        for (int attempt = 0; attempt < 8; ++attempt) {
-            if ((rc = enqueue_frame(ctx, L, cloud, view, s, render)) != BGS_OK) return rc;
-            uint64_t need = 0;
-            if ((rc = finish_lane(ctx, L, &need)) != BGS_OK) return rc;
-            if (!need) return BGS_OK;
-            // BINNING_SORT overflow: grow to the next power of two with 25 % headroom and re-run
-            uint64_t cap = MIN_INSTANCE_CAPACITY;
-            while (cap < need + need / 4) cap <<= 1;
-            if (need > MAX_INSTANCE_CAPACITY)
-                return fail(ctx, BGS_ECAPACITY,
-                            "frame needs " + std::to_string(need) + " tile instances, above the 2^30 limit");
-            cap = std::min(cap, MAX_INSTANCE_CAPACITY);
-            if ((rc = ensure_instances(ctx, L, cap)) != BGS_OK) return rc;
-            ctx->regrow_count += 1;
-        }
-        return fail(ctx, BGS_ECAPACITY, "instance buffer kept overflowing");
+        if ((rc = enqueue_frame(ctx, L, cloud, view, s, render, false)) != BGS_OK) return rc;
+        return finish_lane(ctx, L);  // re-runs the frame itself if a capacity was too small
     }
     // async frame: next lane of the ring; completing its previous occupant first
     Lane& L = ctx->lanes[ctx->next];
-    if (L.pending && (rc = finish_lane(ctx, L, nullptr)) != BGS_OK) return rc;
+    if (L.pending && (rc = finish_lane(ctx, L)) != BGS_OK) return rc;
     if ((rc = enqueue_frame(ctx, L, cloud, view, s, render, /*allow_graph=*/true)) != BGS_OK) return rc;
     ctx->recent = ctx->next;
     ctx->next = (ctx->next + 1) % ctx->depth;
@@ -1021,8 +1148,11 @@ void bgs_cloud_free(bgs_ctx* ctx, bgs_cloud* cloud) {
     if (!cloud) return;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
-        for (auto& L : ctx->lanes)
+        (void)finish_all(ctx);  // frames in flight may still be re-run with this cloud (finish_lane)
+        for (auto& L : ctx->lanes) {
             if (L.stream) (void)hipStreamSynchronize(L.stream);
+            if (L.in_cloud == cloud) L.in_cloud = nullptr;
+        }
     }
     for (auto p : cloud->allocs) if (p) (void)hipFree(p);
     delete cloud;
@@ -1046,7 +1176,7 @@ int bgs_render(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const
     if (rc != BGS_OK) return rc;
     if (rgba_host_out) {
         Lane& L = ctx->lanes[ctx->recent];
-        if (L.pending && (rc = finish_lane(ctx, L, nullptr)) != BGS_OK) return rc;
+        if (L.pending && (rc = finish_lane(ctx, L)) != BGS_OK) return rc;
         HIP_TRY(ctx, hipMemcpy(rgba_host_out, L.fb, (size_t)L.fb_w * L.fb_h * sizeof(float4), hipMemcpyDeviceToHost));
     }
     return BGS_OK;
@@ -1056,7 +1186,7 @@ int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes) {
     if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
     Lane& L = ctx->lanes[ctx->recent];
     if (L.pending) {
-        int rc = finish_lane(ctx, L, nullptr);
+        int rc = finish_lane(ctx, L);
         if (rc != BGS_OK) return rc;
     }
     if (!L.fb) return fail(ctx, BGS_EINVAL, "no frame has been rendered yet");
@@ -1069,7 +1199,7 @@ int bgs_framebuffer_srgb8_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes)
     if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
     Lane& L = ctx->lanes[ctx->recent];
     if (L.pending) {
-        int rc = finish_lane(ctx, L, nullptr);
+        int rc = finish_lane(ctx, L);
         if (rc != BGS_OK) return rc;
     }
     if (!L.fb8_out || !L.fb8_valid)
@@ -1087,7 +1217,7 @@ int bgs_pipeline_pop(bgs_ctx* ctx, void** rgba_f32, void** rgba8) {
         if (ctx->lanes[i].pending && (best < 0 || ctx->lanes[i].seq < ctx->lanes[best].seq)) best = i;
     if (best < 0) return fail(ctx, BGS_EINVAL, "no frame in flight");
     Lane& L = ctx->lanes[best];
-    int rc = finish_lane(ctx, L, nullptr);
+    int rc = finish_lane(ctx, L);
     if (rc != BGS_OK) return rc;
     if (rgba_f32) *rgba_f32 = L.fb;
     if (rgba8) *rgba8 = L.fb8_valid ? L.fb8_out : nullptr;
@@ -1106,7 +1236,7 @@ int bgs_sorted_entries_device_ptr(bgs_ctx* ctx, void** dptr, uint32_t* n) {
     if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
     Lane& L = ctx->lanes[ctx->recent];
     if (L.pending) {
-        int rc = finish_lane(ctx, L, nullptr);
+        int rc = finish_lane(ctx, L);
         if (rc != BGS_OK) return rc;
     }
     if (!L.last_sorted) return fail(ctx, BGS_EINVAL, "no sort has been run yet");
@@ -1213,6 +1343,19 @@ int bgs_set_binning(bgs_ctx* ctx, uint32_t mode) {
 int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     ctx->debug_flags = flags;
+    return BGS_OK;
+}
+
+int bgs_reset_adaptive_state(bgs_ctx* ctx) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    int rc = finish_all(ctx);
+    if (rc != BGS_OK) return rc;
+    ctx->draw_hint_valid = false;
+    ctx->key_range_valid = false;
+    ctx->bucket_block = 0;
+    ctx->sup_fine = false;
+    ctx->coarse_cap_hint = 0;
     return BGS_OK;
 }
 

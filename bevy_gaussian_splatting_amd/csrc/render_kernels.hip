@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
         if (blockIdx.x == nblocks - 1u) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
             uint32_t* host = reinterpret_cast<uint32_t*>(cl.host_ctl);
-            constexpr uint32_t HEADER_WORDS = 8u;  // draw_count .. splat_count
+            constexpr uint32_t HEADER_WORDS = CONTROL_HEADER_WORDS;  // draw_count .. bucket_max
             constexpr uint32_t COARSE_OFF = (uint32_t)(offsetof(Control, coarse_total) / 4u);
             if ((uint32_t)tid < HEADER_WORDS) host[tid] = src[tid];
             host[COARSE_OFF + (uint32_t)tid] = src[COARSE_OFF + (uint32_t)tid];

@@ -58,6 +58,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 }
 
 
+// key-range bucket of a depth key: monotone (non-decreasing) in the key for every lo / shift
+__device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t lo, uint32_t shift) {
+    const uint32_t d = key > lo ? key - lo : 0u;
+    return min(d >> shift, BUCKET_COUNT - 1u);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -70,15 +76,22 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 // `entries` and into the digit histograms. sorted(drawable) ++ culled is bit-identical to the
 // reference's full stable sort. The ordered split is a chained scan over 2048-splat tiles.
 // ---------------------------------------------------------------------------------------
-template <int KG_ITEMS>  // splats per thread
+// BUCKET (fp.sort_path == 1): instead of the index-ordered list + digit histograms that the onesweep
+// passes need, the drawable pairs are scattered into BUCKET_COUNT key-range buckets (fixed slot regions of
+// BUCKET_CAP pairs, a returning atomic per pair on the bucket's counter; order inside a bucket is
+// arbitrary — bucket_sort_kernel orders by (key, index), which is what "stable" means for these pairs).
+template <int KG_ITEMS, bool BUCKET>  // splats per thread
 __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
                                                      uint2* __restrict__ entries,
                                                      uint2* __restrict__ culled, Control* ctl,
                                                      uint32_t* part_status, uint32_t places,
-                                                     uint32_t ticket_slot, FrameParams* fp_out) {
-    __shared__ uint32_t s_hist[4][RADIX_BASE];
+                                                     uint32_t ticket_slot, FrameParams* fp_out,
+                                                     uint2* __restrict__ bucket_slots) {
+    __shared__ uint32_t s_hist[BUCKET ? 1 : 4][RADIX_BASE];
     __shared__ uint32_t s_cnt[KG_ITEMS][4];  // drawable per (row, wave)
-    __shared__ uint32_t s_keys[256 * KG_ITEMS];  // the tile's drawable keys, compacted (for the histograms)
+    __shared__ uint32_t s_keys[256 * KG_ITEMS];  // the tile's drawable keys, compacted (for the histograms / the scatter)
+    __shared__ uint32_t s_idx[BUCKET ? 256 * KG_ITEMS : 1];  // their splat indices (BUCKET)
+    __shared__ uint32_t s_minmax[2][4];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,8 +100,11 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
     // a new view by updating this one node's arguments.
     if (fp_out && blockIdx.x == 0 && (uint32_t)tid < (uint32_t)(sizeof(FrameParams) / 4u))
         reinterpret_cast<uint32_t*>(fp_out)[tid] = reinterpret_cast<const uint32_t*>(&fp)[tid];
+    if constexpr (!BUCKET) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
+        for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
+    }
+    uint32_t kmin_inv = 0u, kmax = 0u;  // over this block's drawable keys (~min so that 0 = nothing seen)
     const uint32_t sentinel = KEY_CULLED >> fp.key_shift;
     const uint32_t per_tile = 256u * KG_ITEMS;
     const uint32_t num_tiles = (fp.n + per_tile - 1u) / per_tile;
@@ -148,7 +164,12 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
         // compacted, a tile's ~600 keys are 3 rows.
 #pragma unroll
         for (int k = 0; k < KG_ITEMS; ++k)
-            if (draw[k]) s_keys[off[k] + below[k]] = key[k];
+            if (draw[k]) {
+                s_keys[off[k] + below[k]] = key[k];
+                if constexpr (BUCKET) s_idx[off[k] + below[k]] = base + (uint32_t)k * 256u + (uint32_t)tid;
+                kmin_inv = max(kmin_inv, ~key[k]);
+                kmax = max(kmax, key[k]);
+            }
         if (wave == 0) {  // one chain per block: the whole wave walks it, 64 predecessors per hop
             uint32_t* const my_status = part_status + tile;
             uint32_t excl = 0u;
@@ -166,10 +187,31 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
             }
         }
         __syncthreads();
-        for (uint32_t j = (uint32_t)tid; j < total; j += 256u) {
-            const uint32_t kk = s_keys[j];
-            for (uint32_t pl = 0; pl < places; ++pl)
-                atomicAdd(&s_hist[pl][(kk >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
+        if constexpr (BUCKET) {
+            // the tile's ~12 % drawable pairs, compacted: full waves of returning atomics, all of a thread's
+            // atomics in flight before the first slot is written
+            constexpr int ROUNDS = KG_ITEMS;
+            uint32_t bk[ROUNDS], at[ROUNDS];
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const uint32_t j = (uint32_t)r * 256u + (uint32_t)tid;
+                if (j < total) {
+                    bk[r] = bucket_of(s_keys[j], fp.bucket_lo, fp.bucket_shift);
+                    at[r] = atomicAdd(&ctl->bucket_count[bk[r]], 1u);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const uint32_t j = (uint32_t)r * 256u + (uint32_t)tid;
+                if (j < total && at[r] < BUCKET_CAP)  // a full bucket is seen by bucket_sort_kernel (count > cap)
+                    bucket_slots[(size_t)bk[r] * BUCKET_CAP + at[r]] = make_uint2(s_keys[j], s_idx[j]);
+            }
+        } else {
+            for (uint32_t j = (uint32_t)tid; j < total; j += 256u) {
+                const uint32_t kk = s_keys[j];
+                for (uint32_t pl = 0; pl < places; ++pl)
+                    atomicAdd(&s_hist[pl][(kk >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
+            }
         }
         const uint32_t vis_base = s_base;
 #pragma unroll
@@ -177,16 +219,32 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
             const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
             if (i < fp.n) {
                 const uint32_t before = vis_base + off[k] + below[k];  // drawable entries before i
-                if (draw[k]) entries[before] = make_uint2(key[k], i);
+                if (draw[k]) { if constexpr (!BUCKET) entries[before] = make_uint2(key[k], i); }
                 else culled[i - before] = make_uint2(key[k], i);
             }
         }
         if (single_shot) break;
         __syncthreads();
     }
-    for (uint32_t pl = 0; pl < places; ++pl) {
-        const uint32_t v = s_hist[pl][tid];
-        if (v) atomicAdd(&ctl->hist_depth[pl][tid], v);
+    if constexpr (!BUCKET) {
+        for (uint32_t pl = 0; pl < places; ++pl) {
+            const uint32_t v = s_hist[pl][tid];
+            if (v) atomicAdd(&ctl->hist_depth[pl][tid], v);
+        }
+    }
+    // range of the drawable keys: the bucket range of the NEXT frames (two atomics per block)
+#pragma unroll
+    for (int off2 = 32; off2 > 0; off2 >>= 1) {
+        kmin_inv = max(kmin_inv, (uint32_t)__shfl_xor((int)kmin_inv, off2, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off2, 64));
+    }
+    if (lane == 0) { s_minmax[0][wave] = kmin_inv; s_minmax[1][wave] = kmax; }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t a = max(max(s_minmax[0][0], s_minmax[0][1]), max(s_minmax[0][2], s_minmax[0][3]));
+        const uint32_t b = max(max(s_minmax[1][0], s_minmax[1][1]), max(s_minmax[1][2], s_minmax[1][3]));
+        if (a) atomicMax(&ctl->key_min_inv, a);
+        if (b) atomicMax(&ctl->key_max, b);
     }
 }
 
@@ -198,9 +256,12 @@ bool KeygenLaunch::prepare(int max_blocks) {
     const uint32_t per_block = 256u * (wide ? 16u : 8u);
     blocks = (fp.n + per_block - 1) / per_block;
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
-    func = wide ? reinterpret_cast<const void*>(&keygen_kernel<16>) : reinterpret_cast<const void*>(&keygen_kernel<8>);
+    if (fp.sort_path == 1u)
+        func = wide ? reinterpret_cast<const void*>(&keygen_kernel<16, true>) : reinterpret_cast<const void*>(&keygen_kernel<8, true>);
+    else
+        func = wide ? reinterpret_cast<const void*>(&keygen_kernel<16, false>) : reinterpret_cast<const void*>(&keygen_kernel<8, false>);
     argv[0] = &fp; argv[1] = &pos; argv[2] = &entries; argv[3] = &culled; argv[4] = &ctl;
-    argv[5] = &part_status; argv[6] = &places; argv[7] = &ticket_slot; argv[8] = &fp_out;
+    argv[5] = &part_status; argv[6] = &places; argv[7] = &ticket_slot; argv[8] = &fp_out; argv[9] = &bucket_slots;
     return true;
 }
 
@@ -398,6 +459,193 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
     else
         hipLaunchKernelGGL(onesweep_kernel<SORT_KPT_SMALL>, dim3(blocks), dim3(256), 0, stream, in, out,
                            n_ptr, hist, status, ticket, error_flag, shift, key_xor);
+}
+
+// ---------------------------------------------------------------------------------------
+// Bucket sort: ONE launch instead of the digit passes, for draw lists that fit the bucket geometry
+// (bgs_device.h). A digit pass over ~10^5 pairs is a chain of dependent L2 round trips (ticket -> load ->
+// look-back -> scatter, ~11 us whatever its bandwidth) and 32-bit keys need four of them; here keygen has
+// already scattered the pairs into BUCKET_COUNT key-range buckets, so the rest of the sort is local:
+//   0. every workgroup scans the 4096 bucket counts (16 KB out of L2): exclusive prefix P[b]
+//   1. chunk c = the non-empty buckets with floor(P[b] / BUCKET_HALF) == c: consecutive buckets holding at
+//      most BUCKET_HALF + BUCKET_CAP pairs; its output offset is P[first bucket]. No workgroup waits for
+//      another one.
+//   2. gather the chunk's pairs (bucket regions are contiguous: coalesced per bucket)
+//   3. counting sort in LDS on BUCKET_FINE fine key ranges of the chunk's own [min, max] (returning LDS
+//      atomics: order inside a fine bucket is arbitrary)
+//   4. rank every pair among the handful that share its fine bucket by (key, index) and write it to
+//      out[P[first] + rank] — ascending key, ties by ascending index: the order of the stable LSD passes.
+// Order never depends on the bucket range, balance does: a bucket over capacity, or a key value repeated
+// more than BUCKET_FINE_MAX times (step 4 is quadratic in the ties), sets ctl->sort_overflow and the host
+// re-runs the frame with the onesweep passes.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restrict__ slots,
+                                                          uint2* __restrict__ out, Control* ctl,
+                                                          uint32_t key_xor) {
+    constexpr uint32_t NB = BUCKET_COUNT, BPT = NB / 256u;   // buckets per thread (contiguous)
+    constexpr uint32_t EPT = BUCKET_CHUNK / 256u;            // pairs per thread (strided)
+    constexpr uint32_t NF = BUCKET_FINE, FPT = NF / 256u;    // fine buckets per thread (contiguous)
+    static_assert(BPT == 16 && (NF & (NF - 1u)) == 0u, "bucket geometry");
+    __shared__ uint32_t s_P[NB + 1];
+    __shared__ uint2 s_el[BUCKET_CHUNK];
+    __shared__ uint32_t s_f[NF + 1];
+    __shared__ uint32_t s_tot[4];
+    __shared__ uint32_t s_red[4][4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t cnt[BPT], pre[BPT];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(ctl->bucket_count) + (size_t)tid * (BPT / 4u);
+#pragma unroll
+        for (uint32_t q = 0; q < BPT / 4u; ++q) {
+            const uint4 v = src[q];
+            cnt[4 * q] = v.x; cnt[4 * q + 1] = v.y; cnt[4 * q + 2] = v.z; cnt[4 * q + 3] = v.w;
+        }
+    }
+    uint32_t local = 0u, mx = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < BPT; ++j) {
+        mx = max(mx, cnt[j]);
+        cnt[j] = min(cnt[j], BUCKET_CAP);  // slots past the capacity were never written
+        pre[j] = local;
+        local += cnt[j];
+    }
+    uint32_t total;
+    const uint32_t excl0 = block_exclusive_scan_256(local, s_tot, total);
+#pragma unroll
+    for (uint32_t j = 0; j < BPT; ++j) {
+        pre[j] += excl0;
+        s_P[(uint32_t)tid * BPT + j] = pre[j];
+    }
+    if (tid == 0) s_P[NB] = total;
+    if (blockIdx.x == 0u) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+        if (lane == 0) {
+            atomicMax(&ctl->bucket_max, mx);
+            if (mx > BUCKET_CAP) atomicOr(&ctl->sort_overflow, 1u);
+        }
+    }
+    __syncthreads();
+    if (total == 0u) return;
+    const uint32_t num_chunks = (total - 1u) / BUCKET_HALF + 1u;
+
+    for (uint32_t c = blockIdx.x; c < num_chunks; c += gridDim.x) {
+        // ---- 1. the chunk's bucket range [b0, b1) ----
+        uint32_t b0 = NB, b1 = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < BPT; ++j)
+            if (cnt[j] != 0u && pre[j] / BUCKET_HALF == c) {
+                b0 = min(b0, (uint32_t)tid * BPT + j);
+                b1 = max(b1, (uint32_t)tid * BPT + j + 1u);
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            b0 = min(b0, (uint32_t)__shfl_xor((int)b0, off, 64));
+            b1 = max(b1, (uint32_t)__shfl_xor((int)b1, off, 64));
+        }
+        if (lane == 0) { s_red[wave][0] = b0; s_red[wave][1] = b1; }
+        __syncthreads();
+        b0 = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
+        b1 = max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1]));
+        __syncthreads();
+        if (b1 == 0u) continue;  // (every chunk id below num_chunks owns a bucket; defensive)
+        const uint32_t base = s_P[b0], m = s_P[b1] - base;
+
+        // ---- 2. gather ----
+        uint2 kv[EPT];
+        uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < EPT; ++k) {
+            const uint32_t e = k * 256u + (uint32_t)tid;
+            kv[k] = make_uint2(0u, 0u);
+            if (e < m) {
+                const uint32_t x = base + e;
+                uint32_t lo = b0, hi = b1 - 1u;  // largest b with P[b] <= x (empty buckets share their successor's P)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    if (s_P[mid] <= x) lo = mid; else hi = mid - 1u;
+                }
+                kv[k] = slots[(size_t)lo * BUCKET_CAP + (x - s_P[lo])];
+                kmn = min(kmn, kv[k].x);
+                kmx = max(kmx, kv[k].x);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, off, 64));
+            kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, off, 64));
+        }
+        if (lane == 0) { s_red[wave][2] = kmn; s_red[wave][3] = kmx; }
+#pragma unroll
+        for (uint32_t j = 0; j < FPT; ++j) s_f[j * 256u + (uint32_t)tid] = 0u;
+        __syncthreads();
+        kmn = min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2]));
+        kmx = max(max(s_red[0][3], s_red[1][3]), max(s_red[2][3], s_red[3][3]));
+        const uint32_t span = kmx - kmn;
+        const uint32_t bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
+        const uint32_t fshift = bits > 11u ? bits - 11u : 0u;  // (span >> fshift) < NF = 2^11
+        static_assert(NF == 2048u, "fshift assumes 2^11 fine buckets");
+
+        // ---- 3. counting sort on the fine buckets ----
+        uint32_t slot[EPT];
+#pragma unroll
+        for (uint32_t k = 0; k < EPT; ++k) {
+            const uint32_t e = k * 256u + (uint32_t)tid;
+            if (e < m) slot[k] = atomicAdd(&s_f[(kv[k].x - kmn) >> fshift], 1u);
+        }
+        __syncthreads();
+        uint32_t f[FPT], fsum = 0u, fmax = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < FPT; ++j) {
+            f[j] = s_f[(uint32_t)tid * FPT + j];
+            fmax = max(fmax, f[j]);
+            fsum += f[j];
+        }
+        uint32_t ftotal;
+        uint32_t fexcl = block_exclusive_scan_256(fsum, s_tot, ftotal);
+#pragma unroll
+        for (uint32_t j = 0; j < FPT; ++j) {
+            s_f[(uint32_t)tid * FPT + j] = fexcl;
+            fexcl += f[j];
+        }
+        if (tid == 0) s_f[NF] = m;
+        if (__syncthreads_or(fmax > BUCKET_FINE_MAX ? 1 : 0)) {  // step 4 is quadratic in equal keys: give up
+            if (tid == 0) atomicOr(&ctl->sort_overflow, 2u);
+            continue;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < EPT; ++k) {
+            const uint32_t e = k * 256u + (uint32_t)tid;
+            if (e < m) s_el[s_f[(kv[k].x - kmn) >> fshift] + slot[k]] = kv[k];
+        }
+        __syncthreads();
+
+        // ---- 4. rank among the fine bucket's pairs by (key, index), write out ----
+#pragma unroll 4
+        for (uint32_t k = 0; k < EPT; ++k) {
+            const uint32_t p = k * 256u + (uint32_t)tid;
+            if (p < m) {
+                const uint2 el = s_el[p];
+                const uint32_t fb = (el.x - kmn) >> fshift;
+                const uint32_t fs = s_f[fb], fe = s_f[fb + 1u];
+                uint32_t r = 0u;
+                for (uint32_t j = fs; j < fe; ++j) {
+                    const uint2 o = s_el[j];
+                    r += (o.x < el.x || (o.x == el.x && o.y < el.y)) ? 1u : 0u;
+                }
+                out[base + fs + r] = make_uint2(el.x ^ key_xor, el.y);
+            }
+        }
+        __syncthreads();  // s_el / s_f are rewritten by the next chunk
+    }
+}
+
+void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor,
+                        int blocks) {
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, bucket_slots, out, ctl,
+                       key_xor);
 }
 
 // ---------------------------------------------------------------------------------------

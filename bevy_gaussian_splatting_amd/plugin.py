@@ -244,7 +244,7 @@ class GaussianSplattingPlugin:
         self._check(self._lib.bgs_set_pipeline_streams(self._ctx, int(streams)))
 
     def set_graphs(self, enabled: bool) -> None:
-        """Replay steady-state async frames from a captured hipGraph (default on; bgs_set_graphs)."""
+        """Replay steady-state async frames from a captured hipGraph (default off; opt-in for CPU-bound hosts; bgs_set_graphs)."""
         self._check(self._lib.bgs_set_graphs(self._ctx, 1 if enabled else 0))
 
     def graph_counters(self) -> tuple:
@@ -308,6 +308,11 @@ class GaussianSplattingPlugin:
         """Kernel-ablation switches for experiments only (non-zero => wrong images)."""
         self._check(self._lib.bgs_set_debug_flags(self._ctx, int(flags)))
 
+    def reset_adaptive_state(self) -> None:
+        """Forget the hints completed frames left in the context (draw count, key range, list capacity,
+        supertile rule): the next frames behave like the first frames of a fresh context."""
+        self._check(self._lib.bgs_reset_adaptive_state(self._ctx))
+
     def framebuffer_device_ptr(self):
         p = ctypes.c_void_p()
         nbytes = ctypes.c_uint64()
@@ -334,6 +339,8 @@ class GaussianSplattingPlugin:
             "tile_passes": int(st.tile_passes),
             "algorithmic_bytes": int(st.algorithmic_bytes),
             "regrow_count": int(st.regrow_count),
+            "sort_path": "bucket" if st.sort_path else "onesweep",
+            "list_capacity": int(st.list_capacity),
             "binning": "sort" if st.binning_mode else "scan",
             "frames_averaged": int(st.frames_averaged),
             "stage_ms": {n: float(st.stage_ms[i]) for i, n in enumerate(_native.STAGE_NAMES)},

@@ -144,18 +144,20 @@ typedef struct bgs_stats {
     uint32_t visible_count;      /* V: splats that pass the frustum test               */
     uint32_t draw_count;         /* D: entries that go through the radix passes / reach the
                                     vertex stage (key != culled sentinel)               */
-    uint32_t pad;
+    uint32_t sort_path;          /* depth sort of the call: 0 = onesweep digit passes, 1 = bucket sort
+                                    (one launch; chosen per frame)        */
     uint64_t instance_count;     /* I: (tile, splat) instances emitted                 */
     uint64_t instance_capacity;
     uint32_t tiles_x, tiles_y;
     uint32_t depth_passes;       /* radix digit places used for the depth keys         */
     uint32_t tile_passes;        /* radix passes used for the tile ids                 */
     uint64_t algorithmic_bytes;  /* SURVEY 8(d) bytes_frame (or bytes_sort) of the call */
-    uint32_t regrow_count;       /* times the instance buffers were grown + re-run     */
+    uint32_t regrow_count;       /* times a frame was re-run because a data-dependent capacity was
+                                    too small (tile instances, supertile lists, bucket sort) */
     uint32_t binning_mode;       /* BGS_BINNING_* used by the call                     */
     uint32_t frames_averaged;    /* stage_ms/total_ms = mean over this many frames (async: all
                                     frames since the last read-back, at most 64)        */
-    uint32_t reserved;
+    uint32_t list_capacity;      /* BGS_BINNING_SCAN: entries each supertile list could hold  */
 } bgs_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -245,7 +247,8 @@ int bgs_sorted_entries_device_ptr(bgs_ctx* ctx, void** dptr, uint32_t* n);
 int bgs_synchronize(bgs_ctx* ctx);
 /* Async frames (default off). When on, bgs_render(..., rgba_host_out = NULL) under
  * BGS_BINNING_SCAN only ENQUEUES the frame and returns: that pipeline needs no host round trip
- * (every data-dependent size stays on the device and its lists cannot overflow), so successive
+ * (every data-dependent size stays on the device; a frame whose supertile lists or bucket sort outgrow
+ * their capacity is re-run on its lane when it is completed, before anyone sees it), so successive
  * frames run back-to-back on the GPU. Any call that needs results (a host copy, bgs_get_stats,
  * bgs_framebuffer_device_ptr, bgs_synchronize, bgs_sort) completes the pending frame first. */
 int bgs_set_async(bgs_ctx* ctx, int enabled);
@@ -268,9 +271,17 @@ int bgs_set_binning(bgs_ctx* ctx, uint32_t mode);
  * rasteriser's in-kernel clean-up), 0x2000 (no draw-count hint for the sort grids), 0x4000 (no
  * hipGraph replay even when bgs_set_graphs is on), 0x8000 / 0x10000 (force the coarse / the fine
  * supertile edge instead of choosing by the last frame's list statistics), 0x40000 (sRGB8 image from the
- * separate encode pass instead of the rasteriser's fused output) keep images correct and
- * exist for A/B timing. Production code leaves this at 0. */
+ * separate encode pass instead of the rasteriser's fused output), 0x80000 (depth sort always by the
+ * onesweep digit passes, never the bucket sort), 0x200000 (bucket sort even before a completed frame has
+ * told the key range: full 32-bit range guessed), 0x100000 (supertile lists start at 64 entries, to
+ * exercise the overflow -> re-run path) keep images correct and exist for A/B timing and tests.
+ * Production code leaves this at 0. */
 int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags);
+/* Forget what completed frames taught the context: draw-count hint (grid sizes), drawable key range and
+ * the bucket-sort back-off, supertile rule, list-capacity hint. Buffers stay allocated. The next frames
+ * behave like the first frames of a fresh context (onesweep passes, default capacities, re-run on
+ * overflow). Completes the frames in flight. */
+int bgs_reset_adaptive_state(bgs_ctx* ctx);
 
 /* HIP-event timing level: 0 = none, 1 = frame start/end only (total_ms), 2 = every stage
  * (default). Each recorded event costs a few microseconds of GPU timeline. */

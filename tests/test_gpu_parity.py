@@ -443,6 +443,203 @@ def test_full_size_2dgs_1m_crop(plugin, oracle, cloud_1m):
         h.free()
 
 
+def _crop_parity(plugin, oracle, dec, h, v, s, what, crops=((936, 516), (40, 30), (1800, 1000))):
+    """Oracle-checked 48x48 crops of one full frame; prints how many values needed the ambiguity slack."""
+    got = plugin.render(h, v, s)
+    assert got.shape == (v.height, v.width, 4) and np.isfinite(got).all()
+    e = oracle.sort(dec, v, s)
+    used = total = 0
+    for (x0, y0) in crops:
+        win = (x0, y0, x0 + 48, y0 + 48)
+        ref, amb = oracle.render(dec, e, v, s, window=win, with_ambiguity=True)
+        crop = got[y0:y0 + 48, x0:x0 + 48]
+        _assert_image(ref, crop, amb, frac_slack=0.01, what=f"{what} crop {win}")
+        strict, err = H.tolerance_mask(ref, crop, None)
+        used += int((~strict).sum())
+        total += strict.size
+        print(f"[{what}] crop {win}: max |err| {err.max():.2e}, values on ambiguity slack {int((~strict).sum())}/{strict.size}")
+    print(f"[{what}] ambiguity slack used by {used} of {total} values")
+    return got
+
+
+def test_full_size_f16_5m_default_scale_crops(plugin, oracle):
+    """configs[2] AT THE BENCHMARKED SETTING (global_scale = 1.0, the dense frame: ~600 k visible splats,
+    ~9 M coarse list entries): three oracle-checked crops of the same frame."""
+    c = random_gaussians_3d_seeded(5_000_000, 3).to_f16()
+    v = View.headless(1920, 1080)
+    s = CloudSettings()
+    h = plugin.upload(c)
+    dec = oracle.decode_f16(c)
+    got = _crop_parity(plugin, oracle, dec, h, v, s, "5M f16 gs=1.0")
+    assert np.allclose(got[..., 3], 1.0, atol=1e-5)
+    es = plugin.sort(h, v, s)
+    e = oracle.sort(dec, v, s)
+    assert np.array_equal(es["key"], e["key"]) and np.array_equal(es["index"], e["index"])
+    h.free()
+
+
+@pytest.mark.parametrize("aabb", [True, False])
+def test_full_size_2dgs_1m_default_scale_crops(plugin, oracle, cloud_1m, aabb):
+    """configs[3] AT THE BENCHMARKED SETTING (global_scale = 1.0): the true surfel path (aabb) and the
+    default OBB quad, three oracle-checked crops each."""
+    v = View.headless(1920, 1080)
+    s = CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, aabb=aabb)
+    h = plugin.upload(cloud_1m)
+    _crop_parity(plugin, oracle, cloud_1m, h, v, s, f"1M 2dgs aabb={aabb} gs=1.0")
+    h.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# depth sort paths: bucket sort (one launch) vs onesweep digit passes; re-run on overflow
+# ---------------------------------------------------------------------------------------------
+def _sort_equal(got, ref):
+    return np.array_equal(got["key"], ref["key"]) and np.array_equal(got["index"], ref["index"])
+
+
+@pytest.mark.parametrize("mode", [SortMode.Radix, SortMode.Rayon, SortMode.Std])
+@pytest.mark.parametrize("n", [1, 65, 2049, 50_000, 300_000, 1_000_000])
+def test_bucket_sort_is_bit_exact(plugin, oracle, mode, n):
+    """The first frame of a context has no key range and runs the onesweep passes; the frames behind it
+    use the bucket sort (stats say which). Both must give the reference's stable order, bit for bit —
+    also with a guessed range (debug flag 0x200000: the full 32-bit range, i.e. badly balanced buckets)."""
+    c = random_gaussians_3d_seeded(n, 900 + n % 97)
+    v = View.headless(960, 540, yaw=0.1)
+    s = CloudSettings(sort_mode=mode)
+    ref = oracle.sort(c, v, s)
+    h = plugin.upload(c)
+    plugin.reset_adaptive_state()
+    first = plugin.sort(h, v, s)
+    assert plugin.stats()["sort_path"] == "onesweep" and _sort_equal(first, ref)
+    second = plugin.sort(h, v, s)
+    st = plugin.stats()
+    assert _sort_equal(second, ref)
+    if st["draw_count"] <= 4096 * 128:
+        assert st["sort_path"] == "bucket" and st["regrow_count"] == 0
+    # a stale range from another camera: order may not depend on it
+    v2 = View.headless(960, 540, yaw=2.0)
+    third = plugin.sort(h, v2, s)
+    assert _sort_equal(third, oracle.sort(c, v2, s))
+    plugin.reset_adaptive_state()
+    plugin.set_debug_flags(0x200000)
+    try:
+        guessed = plugin.sort(h, v, s)
+        assert _sort_equal(guessed, ref)
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.reset_adaptive_state()
+    h.free()
+
+
+def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
+    """Keys the buckets cannot split: (a) 6000 splats at exactly one distance (one key value far beyond the
+    tie limit), (b) 40 000 splats inside a key range of a few ulps (one bucket over capacity, whatever the
+    range hint). The frame is re-run with the digit passes before anyone sees it; order stays bit-exact and
+    the following frames stay on the passes for a while."""
+    base = random_gaussians_3d_seeded(20_000, 41)
+    v = View.headless(640, 360)
+    s = CloudSettings()
+    for case in ("ties", "cluster"):
+        c = random_gaussians_3d_seeded(60_000, 42)
+        if case == "ties":
+            c.position_visibility[:6000, :3] = np.float32([0.25, 1.0, -3.0])
+        else:
+            rng = np.random.default_rng(5)
+            c.position_visibility[:40_000, :3] = (np.float32([0.0, 1.5, -4.0]) +
+                                                   rng.uniform(-2e-6, 2e-6, (40_000, 3)).astype(np.float32))
+        ref = oracle.sort(c, v, s)
+        h = plugin.upload(c)
+        plugin.reset_adaptive_state()
+        hb = plugin.upload(base)
+        plugin.sort(hb, v, s)  # teaches the context a key range: the next frame takes the bucket path
+        got = plugin.sort(h, v, s)
+        st = plugin.stats()
+        assert _sort_equal(got, ref), case
+        assert st["regrow_count"] >= 1 and st["sort_path"] == "onesweep", (case, st)
+        again = plugin.sort(h, v, s)
+        assert _sort_equal(again, ref) and plugin.stats()["sort_path"] == "onesweep"
+        img = plugin.render(h, v, s)
+        e = oracle.sort(c, v, s)
+        refimg, amb = oracle.render(c, e, v, s, with_ambiguity=True)
+        _assert_image(refimg, img, amb, frac_slack=0.01, what=f"render after bucket overflow ({case})")
+        h.free()
+        hb.free()
+    plugin.reset_adaptive_state()
+
+
+def test_bucket_and_onesweep_frames_are_bit_identical(plugin):
+    """Pipelined frames (6 lanes on 3 streams, with and without frame graphs) on either sort path give the
+    same bits as a blocking frame."""
+    from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
+    c = random_gaussians_3d_seeded(400_000, 77)
+    v = View.headless(1280, 720)
+    s = CloudSettings(global_scale=0.5)
+    h = plugin.upload(c)
+    plugin.reset_adaptive_state()
+    plugin.set_debug_flags(0x80000)
+    ref = plugin.render(h, v, s)
+    assert plugin.stats()["sort_path"] == "onesweep"
+    plugin.set_debug_flags(0)
+    plugin.render(h, v, s)
+    got = plugin.render(h, v, s)
+    assert plugin.stats()["sort_path"] == "bucket"
+    assert np.array_equal(got, ref)
+    plugin.set_async(True)
+    plugin.set_pipeline_depth(6)
+    for graphs in (False, True):
+        plugin.set_graphs(graphs)
+        plugin.set_profiling(0 if graphs else 2)
+        for _ in range(24):
+            plugin.render(h, v, s, download=False)
+        plugin.synchronize()
+        assert np.array_equal(framebuffer_as_tensor(plugin, 720, 1280).cpu().numpy(), ref)
+        assert plugin.stats()["sort_path"] == "bucket"
+    plugin.set_graphs(False)
+    plugin.set_profiling(2)
+    plugin.set_async(False)
+    plugin.set_pipeline_depth(1)
+    h.free()
+
+
+def test_supertile_list_overflow_reruns_the_frame(plugin, oracle):
+    """The supertile lists are sized from the longest list seen, not for the worst case (n entries in each
+    of up to 256 lists). Started at 64 entries (debug flag 0x100000) every list of this frame overflows:
+    the frame is re-run with larger lists, blocking and pipelined, and the image is the one a context with
+    ample lists produces. Also: a 5 M-splat cloud on 8 lanes allocates < 8 GB of lists."""
+    from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
+    c = random_gaussians_3d_seeded(200_000, 9)
+    v = View.headless(1280, 720)
+    s = CloudSettings()
+    h = plugin.upload(c)
+    plugin.reset_adaptive_state()
+    ref = plugin.render(h, v, s)
+    ample = plugin.stats()
+    plugin.reset_adaptive_state()
+    plugin.set_debug_flags(0x100000)
+    try:
+        got = plugin.render(h, v, s)
+        st = plugin.stats()
+        assert st["regrow_count"] >= 1 and np.array_equal(got, ref)
+        assert st["list_capacity"] < 200_000 and st["instance_count"] == ample["instance_count"]
+        # pipelined: the overflow is discovered when a lane is completed; every popped frame is correct
+        plugin.reset_adaptive_state()
+        plugin.set_async(True)
+        plugin.set_pipeline_depth(4)
+        for _ in range(10):
+            plugin.render(h, v, s, download=False)
+        plugin.synchronize()
+        assert np.array_equal(framebuffer_as_tensor(plugin, 720, 1280).cpu().numpy(), ref)
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.reset_adaptive_state()
+    e = oracle.sort(c, v, s)
+    win = (616, 336, 664, 384)
+    refo, amb = oracle.render(c, e, v, s, window=win, with_ambiguity=True)
+    _assert_image(refo, got[336:384, 616:664], amb, frac_slack=0.01, what="crop after list regrow")
+    h.free()
+
+
 def test_async_frames_match_synchronous_frames(plugin, oracle):
     """bgs_set_async: frames are only enqueued; results and the watchdog check arrive at the next
     blocking call. Images must be bit-identical to the synchronous path."""
