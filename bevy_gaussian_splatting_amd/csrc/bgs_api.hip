@@ -179,11 +179,12 @@ struct bgs_ctx {
     uint32_t draw_hint = 0;
     bool draw_hint_valid = false;
     bool sup_fine = false;   // supertile edge rule of the next frames (see enqueue_frame)
-    // Bucket sort (one launch instead of four digit passes) is used while the last completed frame's
-    // drawable key range is known, the draw count fits the bucket geometry, and it has not just failed.
-    bool key_range_valid = false;
-    uint32_t key_lo = 0, key_hi = 0;  // drawable key range of the most recently completed frame
+    // Bucket sort (one launch instead of four digit passes) is used while a completed frame's quantile keys
+    // are known, the draw count fits the bucket geometry, and it has not just failed.
+    bool splitters_valid = false;
+    SplitterTable splitters{};        // quantile keys of the most recently completed frame's sorted list
     uint32_t bucket_block = 0;        // frames to stay on the onesweep passes after a bucket-sort overflow
+    uint32_t bucket_fail_streak = 0;  // consecutive bucket-sort frames that overflowed
     uint64_t bucket_frames = 0, onesweep_frames = 0;
     // entries per supertile list the next frames allocate (grown from the longest list seen; a frame whose
     // lists overflow is re-run): the worst case is n entries in each of up to 256 lists (1.9 GB per lane at
@@ -457,7 +458,7 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             // nothing a tripped frame left behind is trusted: not its counters, not the scratch region
             L.scratch_clean = false;
             ctx->draw_hint_valid = false;
-            ctx->key_range_valid = false;
+            ctx->splitters_valid = false;
             return fail(ctx, BGS_EINTERNAL,
                         "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
         }
@@ -465,17 +466,19 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             ctx->draw_hint = (uint32_t)std::min<uint64_t>((uint64_t)h.draw_count + h.draw_count / 8 + 1024, 0xFFFFFFFFull);
             ctx->draw_hint_valid = true;
         }
-        if (places == 4 && h.draw_count > 0 && h.key_max >= ~h.key_min_inv) {
-            ctx->key_lo = ~h.key_min_inv;
-            ctx->key_hi = h.key_max;
-            ctx->key_range_valid = true;
-        }
 
         // ---- capacities that depend on the data ----
         bool rerun = false;
         if (L.pending_bucket && h.sort_overflow) {
-            ctx->bucket_block = 256;  // stay on the digit passes for a while: the keys do not suit the buckets
+            // a bucket over capacity (1): the view changed faster than the splitters follow, the re-run below
+            // delivers fresh ones; one key value far too often (2): stay on the digit passes for a while
+            // (doubling while it keeps happening: equal keys by the thousand overflow a bucket whatever the table)
+            ctx->bucket_fail_streak = std::min(ctx->bucket_fail_streak + 1u, 8u);
+            ctx->bucket_block = (h.sort_overflow & 2u) ? 256u : (1u << ctx->bucket_fail_streak) - 1u;
+            ctx->splitters_valid = false;
             rerun = true;
+        } else if (L.pending_bucket) {
+            ctx->bucket_fail_streak = 0;
         }
         uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
         if (render && scan) {
@@ -512,6 +515,16 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             continue;
         }
 
+        if (places == 4 && h.draw_count >= BUCKET_COUNT) {
+            // the frame's sorted list is good: its quantile keys balance the buckets of the next frames.
+            // bucket() is only monotone for an ascending table, so that is checked, not assumed
+            bool ascending = true;
+            for (uint32_t i = 1; i + 1 < BUCKET_COUNT; ++i) ascending = ascending && h.splitters[i - 1] <= h.splitters[i];
+            if (ascending) {
+                std::memcpy(ctx->splitters.key, h.splitters, sizeof ctx->splitters.key);
+                ctx->splitters_valid = true;
+            }
+        }
         // after a render only the drawable prefix of the list is materialised (the culled tail stays
         // in its side buffer); bgs_sort appends it so that callers get the reference's full list
         L.last_sorted_n = render ? h.draw_count : n;
@@ -654,20 +667,13 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     // range of a recent frame; it is checked on the device and the frame re-run with the digit passes when
     // it does not work out (then bucket_block keeps the following frames on the passes for a while).
     // Debug flags: 0x80000 never, 0x200000 also with a guessed range (no completed frame yet).
+    const bool guess = (ctx->debug_flags & 0x200000u) != 0u;
     bool bucket = places == 4 && n > 0 && !(ctx->debug_flags & 0x80000u) && ctx->bucket_block == 0 &&
-                  ((ctx->key_range_valid && ctx->draw_hint_valid) || (ctx->debug_flags & 0x200000u)) &&
-                  (!ctx->draw_hint_valid || ctx->draw_hint <= BUCKET_COUNT * 128u);
+                  ((ctx->splitters_valid && ctx->draw_hint_valid) || guess) &&
+                  (!ctx->draw_hint_valid || ctx->draw_hint <= BUCKET_COUNT * (BUCKET_CAP / 8u) * 5u);
     if (ctx->bucket_block > 0 && places == 4) ctx->bucket_block -= 1;
     if (bucket) {
-        // 1/16 of the span as a margin on both sides; keys outside fall into the first / last bucket
-        const uint64_t lo0 = ctx->key_range_valid ? ctx->key_lo : 0u, hi0 = ctx->key_range_valid ? ctx->key_hi : 0xFFFFFFFFull;
-        const uint64_t margin = (hi0 - lo0) / 16 + 1;
-        const uint64_t lo = lo0 > margin ? lo0 - margin : 0, hi = std::min<uint64_t>(hi0 + margin, 0xFFFFFFFFull);
-        uint32_t shift = 0;
-        while (((hi - lo) >> shift) >= BUCKET_COUNT) ++shift;
         fp.sort_path = 1u;
-        fp.bucket_lo = (uint32_t)lo;
-        fp.bucket_shift = shift;
         if ((rc = ensure_bucket_slots(ctx, L)) != BGS_OK) return rc;
         ctx->bucket_frames += 1;
     } else if (places > 0) {
@@ -744,6 +750,12 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     kg.ticket_slot = 7;
     kg.fp_out = L.d_fp;
     kg.bucket_slots = L.bucket_slots;
+    kg.bucket_status = depth_status;  // the depth passes' look-back words are free in a bucket-sort frame
+    if (bucket) {
+        if (ctx->splitters_valid) kg.split = ctx->splitters;
+        else  // debug flag 0x200000: a guessed table (equal steps over the 32-bit range: badly balanced)
+            for (uint32_t i = 0; i < BUCKET_COUNT; ++i) kg.split.key[i] = (i + 1u) << 24;
+    }
     const bool have_keygen = kg.prepare(ctx->num_cus * 4);
     const bool large = n > (4u << 20);
     const size_t depth_tiles = ((size_t)L.scratch_n + sort_tile_size(false) - 1) / sort_tile_size(false) + 1;
@@ -761,11 +773,10 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     int bin_blocks = ctx->num_cus * 3;
     if (hinted)
         bin_blocks = (int)std::min<uint64_t>((uint64_t)bin_blocks, std::max<uint64_t>((uint64_t)ctx->draw_hint / 256 + 8, 32));
-    // bucket sort grid: one workgroup per chunk of ~BUCKET_HALF..BUCKET_CHUNK pairs (grid-stride beyond)
-    const int bucket_blocks = (int)std::min<uint64_t>((uint64_t)ctx->num_cus * 2,
-                                                      (ctx->draw_hint_valid ? ctx->draw_hint : n) / BUCKET_HALF + 8);
     const bool want_srgb8 = render && (ctx->output_srgb8 || ctx->next_srgb8_target);
     uint2* const draw_list = L.entries[places & 1u];  // the passes ping-pong from entries[0]
+    // SortMode::Rayon / Std sort ascending on the inverted key; the last step of either path un-inverts it
+    const uint32_t final_xor = (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD) ? 0xFFFFFFFFu : 0u;
     FrameCleanup cl{};
     if (render && scan) {
         cl.part_status = part_status;
@@ -774,8 +785,11 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         cl.other_ctl = (Control*)(L.scratch + (L.ctl_parity ? 0 : L.off_ctl1));
         cl.host_ctl = L.h_ctl_dev;
         cl.pass_stride = (uint32_t)(depth_tiles * RADIX_BASE);
-        cl.places = bucket ? 0u : places;  // the bucket sort has no look-back words (its counters live in Control)
+        cl.places = bucket ? 0u : places;
         cl.depth_tile = sort_tile_size(large);
+        cl.bucket_chain_words = bucket ? (uint32_t)((n + (n >= (1u << 19) ? 4096u : 2048u) - 1u) / (n >= (1u << 19) ? 4096u : 2048u)) * BUCKET_COUNT : 0u;
+        cl.sorted = draw_list;
+        cl.key_xor = final_xor;
         if (ctx->debug_flags & 0x1000u) cl = FrameCleanup{};  // experiment: classic memset + copy path
     }
     const bool raster_cleans = render && scan && fp.tiles_x > 0 && fp.tiles_y > 0 && cl.other_ctl != nullptr;
@@ -790,9 +804,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         mark(1);
         int cur = 0;
         if (bucket)
-            launch_bucket_sort(st, L.bucket_slots, draw_list, ctl,
-                               (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD) ? 0xFFFFFFFFu : 0u,
-                               bucket_blocks);
+            launch_bucket_sort(st, L.bucket_slots, draw_list, ctl, final_xor);
         for (uint32_t p = 0; p < (bucket ? 0u : places); ++p) {
             const uint32_t key_xor =
                 (p + 1 == places && (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD)) ? 0xFFFFFFFFu : 0u;
@@ -910,7 +922,10 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     // A BINNING_SCAN frame's rasteriser has already written the counters to L.h_ctl and left the
     // scratch region zeroed for the next frame.
     if (raster_cleans) { L.scratch_clean = true; L.ctl_parity ^= 1u; }
-    else HIP_TRY(ctx, hipMemcpyAsync(L.h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+    else {
+        if (places == 4 && n > 0) launch_splitters(st, draw_list, ctl, final_xor);
+        HIP_TRY(ctx, hipMemcpyAsync(L.h_ctl, ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+    }
 
     HIP_TRY(ctx, hipEventRecord(L.done, st));
     L.pending = true;
@@ -1352,8 +1367,9 @@ int bgs_reset_adaptive_state(bgs_ctx* ctx) {
     int rc = finish_all(ctx);
     if (rc != BGS_OK) return rc;
     ctx->draw_hint_valid = false;
-    ctx->key_range_valid = false;
+    ctx->splitters_valid = false;
     ctx->bucket_block = 0;
+    ctx->bucket_fail_streak = 0;
     ctx->sup_fine = false;
     ctx->coarse_cap_hint = 0;
     return BGS_OK;

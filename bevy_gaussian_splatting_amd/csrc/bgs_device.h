@@ -44,12 +44,9 @@ struct FrameParams {
     float delta_time;                // globals.delta_time
     float clear[4];                  // the camera's clear colour (premultiplied RGBA)
     uint64_t srgb8_target;           // device address the frame's Rgba8UnormSrgb image goes to; 0 = the lane's own
-    // Depth-sort path of the frame (sort_kernels.hip): 0 = onesweep digit passes, 1 = bucket sort —
-    // keygen scatters the drawable pairs into BUCKET_COUNT key-range buckets,
-    // bucket = clamp((key - bucket_lo) >> bucket_shift, 0, BUCKET_COUNT - 1) (monotone in the key for
-    // ANY lo / shift, so a stale range costs balance, never order), one kernel sorts them in LDS.
+    // Depth-sort path of the frame (sort_kernels.hip): 0 = onesweep digit passes, 1 = bucket sort (keygen
+    // places the drawable pairs into key-range buckets, one kernel sorts each bucket in LDS)
     uint32_t sort_path;
-    uint32_t bucket_lo, bucket_shift;
     uint32_t pad_sort;
 };
 static_assert(sizeof(FrameParams) % 8 == 0 && sizeof(FrameParams) / 4 <= 256, "keygen copies it with one block");
@@ -93,16 +90,16 @@ struct RecordSurfel {
 };
 static_assert(sizeof(RecordSurfel) == 96, "RecordSurfel must be 96 bytes");
 
-// Bucket sort geometry (sort_kernels.hip: bucket_sort_kernel). Buckets own fixed slot regions of
-// BUCKET_CAP pairs; consecutive buckets are grouped into chunks of <= BUCKET_CHUNK pairs (bucket b belongs
-// to chunk floor(prefix[b] / BUCKET_HALF)), each sorted in the LDS of one workgroup.
-constexpr uint32_t BUCKET_COUNT = 4096;
-constexpr uint32_t BUCKET_CAP = 2048;
-constexpr uint32_t BUCKET_HALF = 2048;
-constexpr uint32_t BUCKET_CHUNK = BUCKET_HALF + BUCKET_CAP;  // 4096 pairs = 32 KB of LDS
-constexpr uint32_t BUCKET_FINE = 2048;       // fine buckets inside a chunk (counting sort + rank among equals)
-constexpr uint32_t BUCKET_FINE_MAX = 1024;   // more pairs than this in one fine bucket: give up (ties), onesweep re-run
-static_assert(BUCKET_CAP <= BUCKET_HALF, "a bucket may advance the chunk id by at most one");
+// Bucket sort geometry (sort_kernels.hip). keygen places every drawable pair into one of BUCKET_COUNT
+// key-range buckets (fixed slot regions of BUCKET_CAP pairs); bucket_sort_kernel sorts each bucket in the
+// LDS of one workgroup. bucket(key) = number of splitters <= key, the splitters being the 255 keys at
+// the 1/256-quantiles of a recently completed frame's sorted list: balanced by construction while the
+// view changes slowly, and monotone in the key whatever the table holds (order never depends on it).
+constexpr uint32_t BUCKET_COUNT = 256;       // = the 256 chains of the look-back (thread = bucket)
+constexpr uint32_t BUCKET_CAP = 4096;        // pairs per bucket: 32 KB of LDS
+constexpr uint32_t BUCKET_FINE = 2048;       // fine key ranges inside a bucket (counting sort + rank among equals)
+constexpr uint32_t BUCKET_FINE_MAX = 1024;   // more pairs than this in one fine range: give up (ties), onesweep re-run
+struct SplitterTable { uint32_t key[BUCKET_COUNT]; };  // key[0..254] ascending; key[255] unused
 
 // Device-resident control block, zeroed at the start of every frame by one memset.
 struct Control {
@@ -113,11 +110,9 @@ struct Control {
     uint32_t error;           // device watchdog (bounded spins)
     uint32_t visible_count;   // splats that pass the vertex-stage cull (stats)
     uint32_t splat_count;     // N, parked on the device so the sort kernels read every size the same way
-    uint32_t key_min_inv;     // ~(smallest drawable key) (stored inverted so that zero-initialisation works)
-    uint32_t key_max;         // largest drawable key: the next frames' bucket range comes from these two
     uint32_t sort_overflow;   // bucket sort gave up (1 bucket over capacity, 2 too many equal keys): re-run with onesweep
     uint32_t bucket_max;      // fullest bucket (stats)
-    uint32_t pad0[20];        // the read-mostly header owns its 128-byte line (see ticket)
+    uint32_t pad0[22];        // the read-mostly header owns its 128-byte line (see ticket)
     // dynamic tile ids, one word per kernel launch of the frame, each in its OWN 128-byte line: every
     // block of a launch does a returning atomic on its ticket and the L2 retires same-line atomics one
     // at a time (~8 ns), so a load of draw_count queued behind them on a shared line waited for all.
@@ -125,9 +120,11 @@ struct Control {
     uint32_t hist_depth[4][RADIX_BASE];  // global digit histograms of the depth keys
     uint32_t hist_tile[2][RADIX_BASE];   // digit 0 = tile x, digit 1 = tile y
     uint32_t coarse_total[RADIX_BASE];   // scan binning: entries in each supertile's ordered list
-    uint32_t bucket_count[BUCKET_COUNT];        // bucket sort: pairs scattered into each key-range bucket (BUCKET_COUNT)
+    uint32_t bucket_count[BUCKET_COUNT]; // bucket sort: pairs in each key-range bucket (written by keygen's last tile)
+    uint32_t splitters[BUCKET_COUNT];    // quantile keys of THIS frame's sorted list (keygen key space): the
+                                         // host hands them to later frames' keygen (SplitterTable)
 };
-constexpr uint32_t CONTROL_HEADER_WORDS = 12;  // draw_count .. bucket_max: what a frame reports to the host
+constexpr uint32_t CONTROL_HEADER_WORDS = 10;  // draw_count .. bucket_max: what a frame reports to the host
 
 
 // packed tile rectangle x0 | x1 << 8 | y0 << 16 | y1 << 24 (inclusive); x0 > x1 = touches no tile

@@ -49,8 +49,6 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     memcpy(fp.clear, view->clear_color, sizeof fp.clear);
     fp.srgb8_target = 0;
     fp.sort_path = 0;  // chosen per frame by the host (bgs_api.hip)
-    fp.bucket_lo = 0;
-    fp.bucket_shift = 0;
     fp.pad_sort = 0;
     for (int i = 0; i < 3; ++i) {
         fp.pos_min[i] = s->position_min[i];

@@ -37,6 +37,10 @@ struct FrameCleanup {
     uint32_t pass_stride;     // words between the status arrays of consecutive depth passes
     uint32_t places;
     uint32_t depth_tile;      // keys per onesweep tile of the depth passes
+    uint32_t bucket_chain_words;  // bucket sort frames: look-back words keygen used at depth_status (else 0)
+    // quantile keys of this frame's sorted list -> host_ctl->splitters (keygen key space = key ^ key_xor)
+    const uint2* sorted;
+    uint32_t key_xor;
 };
 
 // Onesweep geometry: 256 threads x KPT keys per tile.
@@ -62,10 +66,12 @@ struct KeygenLaunch {
     uint32_t ticket_slot;
     FrameParams* fp_out;
     uint2* bucket_slots;  // fp.sort_path == 1: [BUCKET_COUNT][BUCKET_CAP] slot regions
+    uint32_t* bucket_status;  // fp.sort_path == 1: zeroed look-back words [keygen tiles][BUCKET_COUNT]
+    SplitterTable split;      // fp.sort_path == 1: bucket = number of entries <= key
     // filled by prepare(): the launch geometry and the argument vector (points into this object)
     const void* func;
     uint32_t blocks;
-    void* argv[10];
+    void* argv[12];
     bool prepare(int max_blocks);  // false: nothing to launch (n == 0)
     hipError_t launch(hipStream_t stream);
     hipError_t update_node(hipGraphExec_t exec, hipGraphNode_t node);  // same launch, as a graph node update
@@ -87,14 +93,14 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
                           uint32_t* error_flag, uint32_t shift, uint32_t key_xor, bool large_tiles,
                           int max_blocks);
 
-// Bucket sort of the drawable pairs keygen scattered (fp.sort_path == 1): one launch instead of the digit
-// passes. Chunks of consecutive buckets (<= BUCKET_CHUNK pairs) are sorted by (key, index) in the LDS of one
-// workgroup and written to out[] at the chunk's global offset; out[0 .. draw_count) is then bit-identical
-// to what the stable LSD passes produce. Sets ctl->sort_overflow instead when a bucket holds more than
-// BUCKET_CAP pairs or one key value repeats more than BUCKET_FINE_MAX times (the host re-runs the frame
-// with the onesweep passes).
-void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor,
-                        int blocks);
+// Bucket sort of the drawable pairs keygen placed (fp.sort_path == 1): one launch instead of the digit
+// passes, workgroup = bucket: each bucket (<= BUCKET_CAP pairs) is sorted by (key, index) in LDS and written
+// to out[] at its offset; out[0 .. draw_count) is then bit-identical to what the stable LSD passes
+// produce. Sets ctl->sort_overflow instead when a bucket holds more than BUCKET_CAP pairs or one key value
+// repeats more than BUCKET_FINE_MAX times (the host re-runs the frame with the onesweep passes).
+void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor);
+// ctl->splitters = the 255 quantile keys of the sorted draw list (for frames without a cleaning rasteriser).
+void launch_splitters(hipStream_t stream, const uint2* sorted, Control* ctl, uint32_t key_xor);
 
 // Vertex stage in front-to-back order + ordered tile-instance emission
 // (vs_points once per splat, src/render/gaussian.wgsl:184-436).

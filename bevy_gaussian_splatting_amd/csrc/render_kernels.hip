@@ -755,8 +755,14 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
             uint32_t* host = reinterpret_cast<uint32_t*>(cl.host_ctl);
             constexpr uint32_t HEADER_WORDS = CONTROL_HEADER_WORDS;  // draw_count .. bucket_max
             constexpr uint32_t COARSE_OFF = (uint32_t)(offsetof(Control, coarse_total) / 4u);
+            constexpr uint32_t SPLIT_OFF = (uint32_t)(offsetof(Control, splitters) / 4u);
             if ((uint32_t)tid < HEADER_WORDS) host[tid] = src[tid];
             host[COARSE_OFF + (uint32_t)tid] = src[COARSE_OFF + (uint32_t)tid];
+            // the 1/256-quantile keys of this frame's sorted list: later frames' bucket splitters
+            host[SPLIT_OFF + (uint32_t)tid] =
+                (draw_count != 0u && (uint32_t)tid < BUCKET_COUNT - 1u)
+                    ? (cl.sorted[(uint32_t)(((unsigned long long)((uint32_t)tid + 1u) * draw_count) >> 8)].x ^ cl.key_xor)
+                    : 0xFFFFFFFFu;
         }
         const uint32_t part_words = (fp.n + KEYGEN_TILE - 1u) / KEYGEN_TILE;
         for (uint32_t i = g; i < part_words; i += gn) cl.part_status[i] = 0u;
@@ -764,6 +770,10 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
         for (uint32_t p = 0u; p < cl.places; ++p) {
             uint4* dst = reinterpret_cast<uint4*>(cl.depth_status + (size_t)p * cl.pass_stride);
             for (uint32_t i = g; i < depth_v4; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        {   // bucket-sort frames: keygen's per-bucket chains live at the start of the depth status words
+            uint4* dst = reinterpret_cast<uint4*>(cl.depth_status);
+            for (uint32_t i = g; i < cl.bucket_chain_words / 4u; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         const uint32_t bin_v4 = ((draw_count + 255u) / 256u) * (MAX_SUPERTILES / 4u);
         uint4* bdst = reinterpret_cast<uint4*>(cl.bin_status);

@@ -58,12 +58,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 }
 
 
-// key-range bucket of a depth key: monotone (non-decreasing) in the key for every lo / shift
-__device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t lo, uint32_t shift) {
-    const uint32_t d = key > lo ? key - lo : 0u;
-    return min(d >> shift, BUCKET_COUNT - 1u);
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -77,21 +71,28 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t lo, uint32_
 // reference's full stable sort. The ordered split is a chained scan over 2048-splat tiles.
 // ---------------------------------------------------------------------------------------
 // BUCKET (fp.sort_path == 1): instead of the index-ordered list + digit histograms that the onesweep
-// passes need, the drawable pairs are scattered into BUCKET_COUNT key-range buckets (fixed slot regions of
-// BUCKET_CAP pairs, a returning atomic per pair on the bucket's counter; order inside a bucket is
-// arbitrary — bucket_sort_kernel orders by (key, index), which is what "stable" means for these pairs).
+// passes need, the drawable pairs go straight into BUCKET_COUNT key-range buckets (fixed slot regions of
+// BUCKET_CAP pairs): bucket = number of splitters <= key (binary search of a 255-entry table in LDS),
+// slot = [pairs of the bucket in earlier tiles: chained-scan look-back, one chain per bucket, exactly the
+// radix pass's machinery] + [arrival order within the tile: a returning LDS atomic]. The sum of the 256
+// exclusive prefixes is the tile's drawable-entry offset, so the partition needs no chain of its own.
+// Order inside a bucket is arbitrary; bucket_sort_kernel orders by (key, index).
 template <int KG_ITEMS, bool BUCKET>  // splats per thread
 __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
                                                      uint2* __restrict__ entries,
                                                      uint2* __restrict__ culled, Control* ctl,
                                                      uint32_t* part_status, uint32_t places,
                                                      uint32_t ticket_slot, FrameParams* fp_out,
-                                                     uint2* __restrict__ bucket_slots) {
+                                                     uint2* __restrict__ bucket_slots, uint32_t* bucket_status,
+                                                     SplitterTable split) {
     __shared__ uint32_t s_hist[BUCKET ? 1 : 4][RADIX_BASE];
     __shared__ uint32_t s_cnt[KG_ITEMS][4];  // drawable per (row, wave)
-    __shared__ uint32_t s_keys[256 * KG_ITEMS];  // the tile's drawable keys, compacted (for the histograms / the scatter)
+    __shared__ uint32_t s_keys[256 * KG_ITEMS];  // the tile's drawable keys, compacted (for the histograms / the buckets)
     __shared__ uint32_t s_idx[BUCKET ? 256 * KG_ITEMS : 1];  // their splat indices (BUCKET)
-    __shared__ uint32_t s_minmax[2][4];
+    __shared__ uint32_t s_split[BUCKET ? BUCKET_COUNT : 1];
+    __shared__ uint32_t s_bcnt[BUCKET ? BUCKET_COUNT : 1];   // pairs of this tile per bucket
+    __shared__ uint32_t s_bexcl[BUCKET ? BUCKET_COUNT : 1];  // pairs of earlier tiles per bucket
+    __shared__ uint32_t s_tot[4];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,11 +101,12 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
     // a new view by updating this one node's arguments.
     if (fp_out && blockIdx.x == 0 && (uint32_t)tid < (uint32_t)(sizeof(FrameParams) / 4u))
         reinterpret_cast<uint32_t*>(fp_out)[tid] = reinterpret_cast<const uint32_t*>(&fp)[tid];
-    if constexpr (!BUCKET) {
+    if constexpr (BUCKET) {
+        s_split[tid] = tid < (int)BUCKET_COUNT - 1 ? split.key[tid] : 0xFFFFFFFFu;
+    } else {
 #pragma unroll
         for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
     }
-    uint32_t kmin_inv = 0u, kmax = 0u;  // over this block's drawable keys (~min so that 0 = nothing seen)
     const uint32_t sentinel = KEY_CULLED >> fp.key_shift;
     const uint32_t per_tile = 256u * KG_ITEMS;
     const uint32_t num_tiles = (fp.n + per_tile - 1u) / per_tile;
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
 
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
+        if constexpr (BUCKET) s_bcnt[tid] = 0u;
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
@@ -167,50 +170,78 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
             if (draw[k]) {
                 s_keys[off[k] + below[k]] = key[k];
                 if constexpr (BUCKET) s_idx[off[k] + below[k]] = base + (uint32_t)k * 256u + (uint32_t)tid;
-                kmin_inv = max(kmin_inv, ~key[k]);
-                kmax = max(kmax, key[k]);
             }
-        if (wave == 0) {  // one chain per block: the whole wave walks it, 64 predecessors per hop
-            uint32_t* const my_status = part_status + tile;
-            uint32_t excl = 0u;
-            if (tile > 0u) {
-                if (lane == 0) st_agent(my_status, STATUS_AGGREGATE | total);
-                excl = lookback_wave(part_status, tile, lane, &ctl->error, 8u);
-            }
-            if (lane == 0) {
-                st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
-                s_base = excl;
-                if (tile == num_tiles - 1u) {
-                    ctl->draw_count = excl + total;
-                    ctl->splat_count = fp.n;
+        if constexpr (!BUCKET) {
+            if (wave == 0) {  // one chain per block: the whole wave walks it, 64 predecessors per hop
+                uint32_t* const my_status = part_status + tile;
+                uint32_t excl = 0u;
+                if (tile > 0u) {
+                    if (lane == 0) st_agent(my_status, STATUS_AGGREGATE | total);
+                    excl = lookback_wave(part_status, tile, lane, &ctl->error, 8u);
+                }
+                if (lane == 0) {
+                    st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
+                    s_base = excl;
+                    if (tile == num_tiles - 1u) {
+                        ctl->draw_count = excl + total;
+                        ctl->splat_count = fp.n;
+                    }
                 }
             }
-        }
-        __syncthreads();
-        if constexpr (BUCKET) {
-            // the tile's ~12 % drawable pairs, compacted: full waves of returning atomics, all of a thread's
-            // atomics in flight before the first slot is written
-            constexpr int ROUNDS = KG_ITEMS;
-            uint32_t bk[ROUNDS], at[ROUNDS];
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                const uint32_t j = (uint32_t)r * 256u + (uint32_t)tid;
-                if (j < total) {
-                    bk[r] = bucket_of(s_keys[j], fp.bucket_lo, fp.bucket_shift);
-                    at[r] = atomicAdd(&ctl->bucket_count[bk[r]], 1u);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                const uint32_t j = (uint32_t)r * 256u + (uint32_t)tid;
-                if (j < total && at[r] < BUCKET_CAP)  // a full bucket is seen by bucket_sort_kernel (count > cap)
-                    bucket_slots[(size_t)bk[r] * BUCKET_CAP + at[r]] = make_uint2(s_keys[j], s_idx[j]);
-            }
-        } else {
+            __syncthreads();
             for (uint32_t j = (uint32_t)tid; j < total; j += 256u) {
                 const uint32_t kk = s_keys[j];
                 for (uint32_t pl = 0; pl < places; ++pl)
                     atomicAdd(&s_hist[pl][(kk >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
+            }
+        }
+        uint32_t bk[KG_ITEMS], at[KG_ITEMS];  // BUCKET: bucket and arrival slot of compacted pair r * 256 + tid
+        if constexpr (BUCKET) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < KG_ITEMS; ++r) {
+                const uint32_t j = (uint32_t)r * 256u + (uint32_t)tid;
+                if (j < total) {
+                    const uint32_t kk = s_keys[j];
+                    uint32_t lo = 0u;  // number of splitters <= kk (s_split[255] = ~0: never counted unless kk = ~0)
+#pragma unroll
+                    for (uint32_t step = BUCKET_COUNT / 2u; step > 0u; step >>= 1)
+                        if (s_split[lo + step - 1u] <= kk) lo += step;
+                    bk[r] = min(lo, BUCKET_COUNT - 1u);
+                    at[r] = atomicAdd(&s_bcnt[bk[r]], 1u);
+                }
+            }
+            __syncthreads();
+            // thread = bucket: chained scan over the tiles, one chain per bucket
+            const uint32_t mine = s_bcnt[tid];
+            uint32_t* const my_status = bucket_status + (size_t)tile * BUCKET_COUNT + tid;
+            uint32_t excl = 0u;
+            if (tile > 0u) {
+                st_agent(my_status, STATUS_AGGREGATE | mine);
+                excl = num_tiles > 1024u ? lookback_u32<16>(bucket_status + tid, tile, BUCKET_COUNT, &ctl->error, 8u)
+                                         : lookback_u32<4>(bucket_status + tid, tile, BUCKET_COUNT, &ctl->error, 8u);
+            }
+            st_agent(my_status, STATUS_PREFIX | ((excl + mine) & STATUS_VALUE_MASK));
+            s_bexcl[tid] = excl;
+            uint32_t before_tile;
+            (void)block_exclusive_scan_256(excl, s_tot, before_tile);  // two barriers inside
+            if (tile == num_tiles - 1u) {
+                ctl->bucket_count[tid] = excl + mine;
+                if (tid == 0) {
+                    ctl->draw_count = before_tile + total;
+                    ctl->splat_count = fp.n;
+                }
+            }
+            if (tid == 0) s_base = before_tile;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < KG_ITEMS; ++r) {
+                const uint32_t j = (uint32_t)r * 256u + (uint32_t)tid;
+                if (j < total) {
+                    const uint32_t slot = s_bexcl[bk[r]] + at[r];
+                    if (slot < BUCKET_CAP)  // a bucket over capacity is seen by bucket_sort_kernel (count > cap)
+                        bucket_slots[(size_t)bk[r] * BUCKET_CAP + slot] = make_uint2(s_keys[j], s_idx[j]);
+                }
             }
         }
         const uint32_t vis_base = s_base;
@@ -232,20 +263,6 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
             if (v) atomicAdd(&ctl->hist_depth[pl][tid], v);
         }
     }
-    // range of the drawable keys: the bucket range of the NEXT frames (two atomics per block)
-#pragma unroll
-    for (int off2 = 32; off2 > 0; off2 >>= 1) {
-        kmin_inv = max(kmin_inv, (uint32_t)__shfl_xor((int)kmin_inv, off2, 64));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off2, 64));
-    }
-    if (lane == 0) { s_minmax[0][wave] = kmin_inv; s_minmax[1][wave] = kmax; }
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t a = max(max(s_minmax[0][0], s_minmax[0][1]), max(s_minmax[0][2], s_minmax[0][3]));
-        const uint32_t b = max(max(s_minmax[1][0], s_minmax[1][1]), max(s_minmax[1][2], s_minmax[1][3]));
-        if (a) atomicMax(&ctl->key_min_inv, a);
-        if (b) atomicMax(&ctl->key_max, b);
-    }
 }
 
 bool KeygenLaunch::prepare(int max_blocks) {
@@ -262,6 +279,7 @@ bool KeygenLaunch::prepare(int max_blocks) {
         func = wide ? reinterpret_cast<const void*>(&keygen_kernel<16, false>) : reinterpret_cast<const void*>(&keygen_kernel<8, false>);
     argv[0] = &fp; argv[1] = &pos; argv[2] = &entries; argv[3] = &culled; argv[4] = &ctl;
     argv[5] = &part_status; argv[6] = &places; argv[7] = &ticket_slot; argv[8] = &fp_out; argv[9] = &bucket_slots;
+    argv[10] = &bucket_status; argv[11] = &split;
     return true;
 }
 
@@ -465,187 +483,147 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
 // Bucket sort: ONE launch instead of the digit passes, for draw lists that fit the bucket geometry
 // (bgs_device.h). A digit pass over ~10^5 pairs is a chain of dependent L2 round trips (ticket -> load ->
 // look-back -> scatter, ~11 us whatever its bandwidth) and 32-bit keys need four of them; here keygen has
-// already scattered the pairs into BUCKET_COUNT key-range buckets, so the rest of the sort is local:
-//   0. every workgroup scans the 4096 bucket counts (16 KB out of L2): exclusive prefix P[b]
-//   1. chunk c = the non-empty buckets with floor(P[b] / BUCKET_HALF) == c: consecutive buckets holding at
-//      most BUCKET_HALF + BUCKET_CAP pairs; its output offset is P[first bucket]. No workgroup waits for
-//      another one.
-//   2. gather the chunk's pairs (bucket regions are contiguous: coalesced per bucket)
-//   3. counting sort in LDS on BUCKET_FINE fine key ranges of the chunk's own [min, max] (returning LDS
-//      atomics: order inside a fine bucket is arbitrary)
-//   4. rank every pair among the handful that share its fine bucket by (key, index) and write it to
-//      out[P[first] + rank] — ascending key, ties by ascending index: the order of the stable LSD passes.
-// Order never depends on the bucket range, balance does: a bucket over capacity, or a key value repeated
-// more than BUCKET_FINE_MAX times (step 4 is quadratic in the ties), sets ctl->sort_overflow and the host
-// re-runs the frame with the onesweep passes.
+// already placed the pairs into 256 key-range buckets, so the rest of the sort is local. Workgroup = bucket:
+//   1. output offset = sum of the counts of the buckets before it (256 words out of L2)
+//   2. load the bucket's pairs (one contiguous region: coalesced)
+//   3. counting sort in LDS on BUCKET_FINE fine key ranges of the bucket's own [min, max] (returning LDS
+//      atomics: order inside a fine range is arbitrary)
+//   4. rank every pair among the handful that share its fine range by (key, index) and write it to
+//      out[offset + rank] — ascending key, ties by ascending index: the order of the stable LSD passes.
+// No workgroup waits for another one. Order never depends on the splitters, balance does: a bucket over
+// capacity, or a key value repeated more than BUCKET_FINE_MAX times (step 4 is quadratic in the ties), sets
+// ctl->sort_overflow and the host re-runs the frame with the onesweep passes.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restrict__ slots,
                                                           uint2* __restrict__ out, Control* ctl,
                                                           uint32_t key_xor) {
-    constexpr uint32_t NB = BUCKET_COUNT, BPT = NB / 256u;   // buckets per thread (contiguous)
-    constexpr uint32_t EPT = BUCKET_CHUNK / 256u;            // pairs per thread (strided)
-    constexpr uint32_t NF = BUCKET_FINE, FPT = NF / 256u;    // fine buckets per thread (contiguous)
-    static_assert(BPT == 16 && (NF & (NF - 1u)) == 0u, "bucket geometry");
-    __shared__ uint32_t s_P[NB + 1];
-    __shared__ uint2 s_el[BUCKET_CHUNK];
+    constexpr uint32_t EPT = BUCKET_CAP / 256u;              // pairs per thread (strided)
+    constexpr uint32_t NF = BUCKET_FINE, FPT = NF / 256u;    // fine ranges per thread (contiguous)
+    static_assert(NF == 2048u && BUCKET_COUNT == 256u, "bucket geometry");
+    __shared__ uint2 s_el[BUCKET_CAP];
     __shared__ uint32_t s_f[NF + 1];
     __shared__ uint32_t s_tot[4];
-    __shared__ uint32_t s_red[4][4];
+    __shared__ uint32_t s_red[4][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t cnt[BPT], pre[BPT];
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(ctl->bucket_count) + (size_t)tid * (BPT / 4u);
+    const uint32_t b = blockIdx.x;
+    const uint32_t cnt = ctl->bucket_count[tid];
+    // offset of this bucket in the sorted list, its own count, the fullest bucket
+    uint32_t before = tid < (int)b ? cnt : 0u, mine = tid == (int)b ? cnt : 0u, mx = cnt;
 #pragma unroll
-        for (uint32_t q = 0; q < BPT / 4u; ++q) {
-            const uint4 v = src[q];
-            cnt[4 * q] = v.x; cnt[4 * q + 1] = v.y; cnt[4 * q + 2] = v.z; cnt[4 * q + 3] = v.w;
+    for (int off = 32; off > 0; off >>= 1) {
+        before += (uint32_t)__shfl_xor((int)before, off, 64);
+        mine += (uint32_t)__shfl_xor((int)mine, off, 64);
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    }
+    if (lane == 0) { s_red[wave][0] = before; s_red[wave][1] = mine; s_tot[wave] = mx; }
+#pragma unroll
+    for (uint32_t j = 0; j < FPT; ++j) s_f[j * 256u + (uint32_t)tid] = 0u;
+    __syncthreads();
+    const uint32_t base = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+    const uint32_t m = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
+    mx = max(max(s_tot[0], s_tot[1]), max(s_tot[2], s_tot[3]));
+    if (b == 0u && tid == 0) {
+        ctl->bucket_max = mx;
+        if (mx > BUCKET_CAP) ctl->sort_overflow = 1u;  // some bucket lost pairs: the whole list is void
+    }
+    if (m == 0u || mx > BUCKET_CAP) return;
+    __syncthreads();  // s_red / s_tot are reused below
+
+    // ---- 2. load ----
+    const uint2* __restrict__ src = slots + (size_t)b * BUCKET_CAP;
+    uint2 kv[EPT];
+    uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < EPT; ++k) {
+        const uint32_t e = k * 256u + (uint32_t)tid;
+        kv[k] = make_uint2(0u, 0u);
+        if (e < m) {
+            kv[k] = src[e];
+            kmn = min(kmn, kv[k].x);
+            kmx = max(kmx, kv[k].x);
         }
     }
-    uint32_t local = 0u, mx = 0u;
 #pragma unroll
-    for (uint32_t j = 0; j < BPT; ++j) {
-        mx = max(mx, cnt[j]);
-        cnt[j] = min(cnt[j], BUCKET_CAP);  // slots past the capacity were never written
-        pre[j] = local;
-        local += cnt[j];
+    for (int off = 32; off > 0; off >>= 1) {
+        kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, off, 64));
+        kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, off, 64));
     }
-    uint32_t total;
-    const uint32_t excl0 = block_exclusive_scan_256(local, s_tot, total);
+    if (lane == 0) { s_red[wave][0] = kmn; s_red[wave][1] = kmx; }
+    __syncthreads();
+    kmn = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
+    kmx = max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1]));
+    const uint32_t span = kmx - kmn;
+    const uint32_t bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
+    const uint32_t fshift = bits > 11u ? bits - 11u : 0u;  // (span >> fshift) < NF = 2^11
+
+    // ---- 3. counting sort on the fine ranges ----
+    uint32_t slot[EPT];
 #pragma unroll
-    for (uint32_t j = 0; j < BPT; ++j) {
-        pre[j] += excl0;
-        s_P[(uint32_t)tid * BPT + j] = pre[j];
-    }
-    if (tid == 0) s_P[NB] = total;
-    if (blockIdx.x == 0u) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-        if (lane == 0) {
-            atomicMax(&ctl->bucket_max, mx);
-            if (mx > BUCKET_CAP) atomicOr(&ctl->sort_overflow, 1u);
-        }
+    for (uint32_t k = 0; k < EPT; ++k) {
+        const uint32_t e = k * 256u + (uint32_t)tid;
+        if (e < m) slot[k] = atomicAdd(&s_f[(kv[k].x - kmn) >> fshift], 1u);
     }
     __syncthreads();
-    if (total == 0u) return;
-    const uint32_t num_chunks = (total - 1u) / BUCKET_HALF + 1u;
+    uint32_t f[FPT], fsum = 0u, fmax = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < FPT; ++j) {
+        f[j] = s_f[(uint32_t)tid * FPT + j];
+        fmax = max(fmax, f[j]);
+        fsum += f[j];
+    }
+    uint32_t ftotal;
+    uint32_t fexcl = block_exclusive_scan_256(fsum, s_tot, ftotal);
+#pragma unroll
+    for (uint32_t j = 0; j < FPT; ++j) {
+        s_f[(uint32_t)tid * FPT + j] = fexcl;
+        fexcl += f[j];
+    }
+    if (tid == 0) s_f[NF] = m;
+    if (__syncthreads_or(fmax > BUCKET_FINE_MAX ? 1 : 0)) {  // step 4 is quadratic in equal keys: give up
+        if (tid == 0) atomicOr(&ctl->sort_overflow, 2u);
+        return;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < EPT; ++k) {
+        const uint32_t e = k * 256u + (uint32_t)tid;
+        if (e < m) s_el[s_f[(kv[k].x - kmn) >> fshift] + slot[k]] = kv[k];
+    }
+    __syncthreads();
 
-    for (uint32_t c = blockIdx.x; c < num_chunks; c += gridDim.x) {
-        // ---- 1. the chunk's bucket range [b0, b1) ----
-        uint32_t b0 = NB, b1 = 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < BPT; ++j)
-            if (cnt[j] != 0u && pre[j] / BUCKET_HALF == c) {
-                b0 = min(b0, (uint32_t)tid * BPT + j);
-                b1 = max(b1, (uint32_t)tid * BPT + j + 1u);
-            }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            b0 = min(b0, (uint32_t)__shfl_xor((int)b0, off, 64));
-            b1 = max(b1, (uint32_t)__shfl_xor((int)b1, off, 64));
-        }
-        if (lane == 0) { s_red[wave][0] = b0; s_red[wave][1] = b1; }
-        __syncthreads();
-        b0 = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
-        b1 = max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1]));
-        __syncthreads();
-        if (b1 == 0u) continue;  // (every chunk id below num_chunks owns a bucket; defensive)
-        const uint32_t base = s_P[b0], m = s_P[b1] - base;
-
-        // ---- 2. gather ----
-        uint2 kv[EPT];
-        uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < EPT; ++k) {
-            const uint32_t e = k * 256u + (uint32_t)tid;
-            kv[k] = make_uint2(0u, 0u);
-            if (e < m) {
-                const uint32_t x = base + e;
-                uint32_t lo = b0, hi = b1 - 1u;  // largest b with P[b] <= x (empty buckets share their successor's P)
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi + 1u) >> 1;
-                    if (s_P[mid] <= x) lo = mid; else hi = mid - 1u;
-                }
-                kv[k] = slots[(size_t)lo * BUCKET_CAP + (x - s_P[lo])];
-                kmn = min(kmn, kv[k].x);
-                kmx = max(kmx, kv[k].x);
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, off, 64));
-            kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, off, 64));
-        }
-        if (lane == 0) { s_red[wave][2] = kmn; s_red[wave][3] = kmx; }
-#pragma unroll
-        for (uint32_t j = 0; j < FPT; ++j) s_f[j * 256u + (uint32_t)tid] = 0u;
-        __syncthreads();
-        kmn = min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2]));
-        kmx = max(max(s_red[0][3], s_red[1][3]), max(s_red[2][3], s_red[3][3]));
-        const uint32_t span = kmx - kmn;
-        const uint32_t bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
-        const uint32_t fshift = bits > 11u ? bits - 11u : 0u;  // (span >> fshift) < NF = 2^11
-        static_assert(NF == 2048u, "fshift assumes 2^11 fine buckets");
-
-        // ---- 3. counting sort on the fine buckets ----
-        uint32_t slot[EPT];
-#pragma unroll
-        for (uint32_t k = 0; k < EPT; ++k) {
-            const uint32_t e = k * 256u + (uint32_t)tid;
-            if (e < m) slot[k] = atomicAdd(&s_f[(kv[k].x - kmn) >> fshift], 1u);
-        }
-        __syncthreads();
-        uint32_t f[FPT], fsum = 0u, fmax = 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < FPT; ++j) {
-            f[j] = s_f[(uint32_t)tid * FPT + j];
-            fmax = max(fmax, f[j]);
-            fsum += f[j];
-        }
-        uint32_t ftotal;
-        uint32_t fexcl = block_exclusive_scan_256(fsum, s_tot, ftotal);
-#pragma unroll
-        for (uint32_t j = 0; j < FPT; ++j) {
-            s_f[(uint32_t)tid * FPT + j] = fexcl;
-            fexcl += f[j];
-        }
-        if (tid == 0) s_f[NF] = m;
-        if (__syncthreads_or(fmax > BUCKET_FINE_MAX ? 1 : 0)) {  // step 4 is quadratic in equal keys: give up
-            if (tid == 0) atomicOr(&ctl->sort_overflow, 2u);
-            continue;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < EPT; ++k) {
-            const uint32_t e = k * 256u + (uint32_t)tid;
-            if (e < m) s_el[s_f[(kv[k].x - kmn) >> fshift] + slot[k]] = kv[k];
-        }
-        __syncthreads();
-
-        // ---- 4. rank among the fine bucket's pairs by (key, index), write out ----
+    // ---- 4. rank among the fine range's pairs by (key, index), write out ----
 #pragma unroll 4
-        for (uint32_t k = 0; k < EPT; ++k) {
-            const uint32_t p = k * 256u + (uint32_t)tid;
-            if (p < m) {
-                const uint2 el = s_el[p];
-                const uint32_t fb = (el.x - kmn) >> fshift;
-                const uint32_t fs = s_f[fb], fe = s_f[fb + 1u];
-                uint32_t r = 0u;
-                for (uint32_t j = fs; j < fe; ++j) {
-                    const uint2 o = s_el[j];
-                    r += (o.x < el.x || (o.x == el.x && o.y < el.y)) ? 1u : 0u;
-                }
-                out[base + fs + r] = make_uint2(el.x ^ key_xor, el.y);
+    for (uint32_t k = 0; k < EPT; ++k) {
+        const uint32_t p = k * 256u + (uint32_t)tid;
+        if (p < m) {
+            const uint2 el = s_el[p];
+            const uint32_t fb = (el.x - kmn) >> fshift;
+            const uint32_t fs = s_f[fb], fe = s_f[fb + 1u];
+            uint32_t r = 0u;
+            for (uint32_t j = fs; j < fe; ++j) {
+                const uint2 o = s_el[j];
+                r += (o.x < el.x || (o.x == el.x && o.y < el.y)) ? 1u : 0u;
             }
+            out[base + fs + r] = make_uint2(el.x ^ key_xor, el.y);
         }
-        __syncthreads();  // s_el / s_f are rewritten by the next chunk
     }
 }
 
-void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor,
-                        int blocks) {
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, bucket_slots, out, ctl,
-                       key_xor);
+void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor) {
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(BUCKET_COUNT), dim3(256), 0, stream, bucket_slots, out, ctl, key_xor);
+}
+
+// The 255 keys at the 1/256-quantiles of a sorted draw list, in keygen's key space (key ^ key_xor): the
+// SplitterTable of later frames. Frames whose rasteriser does the clean-up (BINNING_SCAN) get them from
+// there; this one-block kernel serves the others (bgs_sort, BINNING_SORT).
+__global__ __launch_bounds__(256) void splitter_kernel(const uint2* __restrict__ sorted, Control* ctl, uint32_t key_xor) {
+    const uint32_t d = ctl->draw_count, t = threadIdx.x;
+    ctl->splitters[t] = (d != 0u && t < BUCKET_COUNT - 1u)
+                            ? (sorted[(uint32_t)(((unsigned long long)(t + 1u) * d) >> 8)].x ^ key_xor) : 0xFFFFFFFFu;
+}
+
+void launch_splitters(hipStream_t stream, const uint2* sorted, Control* ctl, uint32_t key_xor) {
+    hipLaunchKernelGGL(splitter_kernel, dim3(1), dim3(256), 0, stream, sorted, ctl, key_xor);
 }
 
 // ---------------------------------------------------------------------------------------

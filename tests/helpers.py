@@ -46,8 +46,7 @@ class FrameParamsC(ctypes.Structure):
         ("draw_mode", ctypes.c_uint32),
         ("prev_clip_from_world", ctypes.c_float * 16), ("delta_time", ctypes.c_float),
         ("clear", ctypes.c_float * 4), ("srgb8_target", ctypes.c_uint64),
-        ("sort_path", ctypes.c_uint32), ("bucket_lo", ctypes.c_uint32), ("bucket_shift", ctypes.c_uint32),
-        ("pad_sort", ctypes.c_uint32),
+        ("sort_path", ctypes.c_uint32), ("pad_sort", ctypes.c_uint32),
     ]
 
 

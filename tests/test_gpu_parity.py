@@ -499,9 +499,10 @@ def _sort_equal(got, ref):
 @pytest.mark.parametrize("mode", [SortMode.Radix, SortMode.Rayon, SortMode.Std])
 @pytest.mark.parametrize("n", [1, 65, 2049, 50_000, 300_000, 1_000_000])
 def test_bucket_sort_is_bit_exact(plugin, oracle, mode, n):
-    """The first frame of a context has no key range and runs the onesweep passes; the frames behind it
-    use the bucket sort (stats say which). Both must give the reference's stable order, bit for bit —
-    also with a guessed range (debug flag 0x200000: the full 32-bit range, i.e. badly balanced buckets)."""
+    """The first frame of a context has no splitter table and runs the onesweep passes; the frames behind
+    it use the bucket sort (stats say which). Both must give the reference's stable order, bit for bit —
+    also with a guessed table (debug flag 0x200000: equal steps over the 32-bit range, i.e. badly balanced
+    buckets; when a bucket overflows the frame is re-run with the passes)."""
     c = random_gaussians_3d_seeded(n, 900 + n % 97)
     v = View.headless(960, 540, yaw=0.1)
     s = CloudSettings(sort_mode=mode)
@@ -513,8 +514,8 @@ def test_bucket_sort_is_bit_exact(plugin, oracle, mode, n):
     second = plugin.sort(h, v, s)
     st = plugin.stats()
     assert _sort_equal(second, ref)
-    if st["draw_count"] <= 4096 * 128:
-        assert st["sort_path"] == "bucket" and st["regrow_count"] == 0
+    if 256 <= st["draw_count"] <= 500_000:
+        assert st["sort_path"] == "bucket" and st["regrow_count"] == 0, st
     # a stale range from another camera: order may not depend on it
     v2 = View.headless(960, 540, yaw=2.0)
     third = plugin.sort(h, v2, s)
@@ -531,9 +532,9 @@ def test_bucket_sort_is_bit_exact(plugin, oracle, mode, n):
 
 
 def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
-    """Keys the buckets cannot split: (a) 6000 splats at exactly one distance (one key value far beyond the
-    tie limit), (b) 40 000 splats inside a key range of a few ulps (one bucket over capacity, whatever the
-    range hint). The frame is re-run with the digit passes before anyone sees it; order stays bit-exact and
+    """Keys the buckets cannot split: (a) 2000 splats at exactly one distance (one key value beyond the
+    tie limit of the in-bucket ranking), (b) 40 000 splats inside a key range of a few ulps (one bucket over
+    capacity, whatever the splitters). The frame is re-run with the digit passes before anyone sees it; order stays bit-exact and
     the following frames stay on the passes for a while."""
     base = random_gaussians_3d_seeded(20_000, 41)
     v = View.headless(640, 360)
@@ -541,7 +542,7 @@ def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
     for case in ("ties", "cluster"):
         c = random_gaussians_3d_seeded(60_000, 42)
         if case == "ties":
-            c.position_visibility[:6000, :3] = np.float32([0.25, 1.0, -3.0])
+            c.position_visibility[:2000, :3] = np.float32([0.25, 1.0, -3.0])
         else:
             rng = np.random.default_rng(5)
             c.position_visibility[:40_000, :3] = (np.float32([0.0, 1.5, -4.0]) +
@@ -550,7 +551,7 @@ def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
         h = plugin.upload(c)
         plugin.reset_adaptive_state()
         hb = plugin.upload(base)
-        plugin.sort(hb, v, s)  # teaches the context a key range: the next frame takes the bucket path
+        plugin.sort(hb, v, s)  # teaches the context a splitter table: the next frame takes the bucket path
         got = plugin.sort(h, v, s)
         st = plugin.stats()
         assert _sort_equal(got, ref), case
