@@ -381,8 +381,9 @@ int ensure_coarse(bgs_ctx* ctx, Lane& L, uint32_t n, uint32_t num_st, uint32_t* 
                                              " MiB per lane (8 B x supertiles x longest list); fewer lanes (bgs_set_pipeline_depth) need less");
         L.coarse_entries = need;
     }
-    // everything that is allocated is used (a lane that grew for an earlier frame keeps its longer lists)
-    *cap_out = (uint32_t)std::min<size_t>(L.coarse_entries / num_st, n1);
+    // everything that is allocated is used (a lane that grew for an earlier frame keeps its longer lists;
+    // not under debug flag 0x100000, which exists to exercise the overflow path)
+    *cap_out = (ctx->debug_flags & 0x100000u) ? want : (uint32_t)std::min<size_t>(L.coarse_entries / num_st, n1);
     return BGS_OK;
 }
 
