@@ -463,11 +463,6 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             return fail(ctx, BGS_EINTERNAL,
                         "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
         }
-        if (!ctx->draw_hint_valid || h.draw_count > ctx->draw_hint || (uint64_t)h.draw_count * 2 < ctx->draw_hint) {
-            ctx->draw_hint = (uint32_t)std::min<uint64_t>((uint64_t)h.draw_count + h.draw_count / 8 + 1024, 0xFFFFFFFFull);
-            ctx->draw_hint_valid = true;
-        }
-
         // ---- capacities that depend on the data ----
         bool rerun = false;
         if (L.pending_bucket && h.sort_overflow) {
@@ -516,6 +511,10 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             continue;
         }
 
+        if (!ctx->draw_hint_valid || h.draw_count > ctx->draw_hint || (uint64_t)h.draw_count * 2 < ctx->draw_hint) {
+            ctx->draw_hint = (uint32_t)std::min<uint64_t>((uint64_t)h.draw_count + h.draw_count / 8 + 1024, 0xFFFFFFFFull);
+            ctx->draw_hint_valid = true;
+        }
         if (places == 4 && h.draw_count >= BUCKET_COUNT) {
             // the frame's sorted list is good: its quantile keys balance the buckets of the next frames.
             // bucket() is only monotone for an ascending table, so that is checked, not assumed

@@ -525,7 +525,12 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
     mx = max(max(s_tot[0], s_tot[1]), max(s_tot[2], s_tot[3]));
     if (b == 0u && tid == 0) {
         ctl->bucket_max = mx;
-        if (mx > BUCKET_CAP) ctl->sort_overflow = 1u;  // some bucket lost pairs: the whole list is void
+        if (mx > BUCKET_CAP) {
+            // some bucket lost pairs: the list is void. draw_count = 0 keeps the kernels behind this one
+            // (project, raster) away from the unwritten entries; the host re-runs the frame.
+            ctl->sort_overflow = 1u;
+            ctl->draw_count = 0u;
+        }
     }
     if (m == 0u || mx > BUCKET_CAP) return;
     __syncthreads();  // s_red / s_tot are reused below
@@ -581,7 +586,10 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
     }
     if (tid == 0) s_f[NF] = m;
     if (__syncthreads_or(fmax > BUCKET_FINE_MAX ? 1 : 0)) {  // step 4 is quadratic in equal keys: give up
-        if (tid == 0) atomicOr(&ctl->sort_overflow, 2u);
+        if (tid == 0) {
+            atomicOr(&ctl->sort_overflow, 2u);
+            ctl->draw_count = 0u;  // this bucket's stretch of the list stays unwritten: see above
+        }
         return;
     }
 #pragma unroll

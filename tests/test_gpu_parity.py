@@ -558,10 +558,14 @@ def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
         assert st["regrow_count"] >= 1 and st["sort_path"] == "onesweep", (case, st)
         again = plugin.sort(h, v, s)
         assert _sort_equal(again, ref) and plugin.stats()["sort_path"] == "onesweep"
+        # the same in a RENDER frame: the kernels behind the sort must not touch the void list
+        plugin.reset_adaptive_state()
+        plugin.render(hb, v, s)
         img = plugin.render(h, v, s)
-        e = oracle.sort(c, v, s)
-        refimg, amb = oracle.render(c, e, v, s, with_ambiguity=True)
-        _assert_image(refimg, img, amb, frac_slack=0.01, what=f"render after bucket overflow ({case})")
+        st = plugin.stats()
+        assert st["regrow_count"] >= 1 and st["sort_path"] == "onesweep", (case, st)
+        refimg, amb = oracle.render(c, ref, v, s, with_ambiguity=True)
+        _assert_image(refimg, img, amb, frac_slack=0.01, what=f"render with bucket overflow ({case})")
         h.free()
         hb.free()
     plugin.reset_adaptive_state()

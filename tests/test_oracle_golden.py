@@ -246,3 +246,371 @@ def test_render_window_equals_crop_of_full_frame(oracle):
     full = oracle.render(c, e, v, s)
     win = oracle.render(c, e, v, s, window=(17, 9, 70, 41))
     assert np.array_equal(win, full[9:41, 17:70])
+
+
+# ---------------------------------------------------------------------------------------------------
+# Independent float64 pins of the render half of the oracle (projection, quad, falloff, SH, surfel, blend).
+# Nothing below re-types the WGSL: every expectation is derived from the geometry (camera model, world
+# covariance, ray-plane intersection, the textbook real spherical harmonics via scipy) in float64.
+# Where the reference deliberately or accidentally departs from the geometric truth, the departure is
+# spelled out in the test that meets it (and in DESIGN.md section 2).
+# ---------------------------------------------------------------------------------------------------
+import math
+
+from scipy.spatial.transform import Rotation
+import scipy.special
+
+
+def _cam(view):
+    wfv = np.asarray(view.world_from_view, np.float64)
+    cfv = np.asarray(view.clip_from_view, np.float64)
+    return wfv[:3, :3], wfv[:3, 3], cfv[0, 0], cfv[1, 1]
+
+
+def _pixel_of(view, pw):
+    """World point -> framebuffer coordinates (x right, y down, origin at the top-left CORNER, pixel
+    centres at +0.5): pinhole camera looking down -Z of the view frame, then the viewport transform."""
+    Rc, tc, fx, fy = _cam(view)
+    t = Rc.T @ (np.asarray(pw, np.float64) - tc)
+    ndc = np.array([fx * t[0] / -t[2], fy * t[1] / -t[2]])
+    return np.array([(ndc[0] + 1) / 2 * view.width, (1 - ndc[1]) / 2 * view.height])
+
+
+def _screen_gaussian(view, pos, sigma_world):
+    """Centre and 2x2 covariance (px^2) of the projected Gaussian: numerical Jacobian of _pixel_of."""
+    pos = np.asarray(pos, np.float64)
+    J = np.zeros((2, 3))
+    for k in range(3):
+        d = np.zeros(3)
+        d[k] = 1e-6
+        J[:, k] = (_pixel_of(view, pos + d) - _pixel_of(view, pos - d)) / 2e-6
+    return _pixel_of(view, pos), J @ sigma_world @ J.T
+
+
+def _sigma_world(scale, rot_wxyz, unit=True, gs=1.0, A=np.eye(3)):
+    w, x, y, z = (float(v) for v in rot_wxyz)
+    if unit:
+        R = Rotation.from_quat([x, y, z, w]).as_matrix()
+    else:
+        # Rodrigues' form R = I + 2w[v]x + 2[v]x^2 evaluated WITHOUT normalising q: what the reference's
+        # polynomial does for the slightly non-unit quaternions of its own tools (helpers.wgsl:137-157)
+        vx = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
+        R = np.eye(3) + 2 * w * vx + 2 * vx @ vx
+    S2 = np.diag(np.square(np.asarray(scale, np.float64) * gs))
+    return A @ R @ S2 @ R.T @ A.T
+
+
+LOWPASS_PX2 = 0.3 / 4.0  # the reference adds 0.3 to the diagonal in HALF-pixel units (helpers.wgsl:44-46)
+
+
+def _oracle_corners(vs, view):
+    pr = np.array(vs.projected, np.float64)
+    out = []
+    for k in range(4):
+        nx, ny = (pr[0] + vs.bb[k][0]) / pr[3], (pr[1] + vs.bb[k][1]) / pr[3]
+        out.append([(nx + 1) / 2 * view.width, (1 - ny) / 2 * view.height])
+    return np.array(out)
+
+
+def _same_point_set(a, b, atol):
+    a, b = np.asarray(a), np.asarray(b)
+    used = set()
+    for p in a:
+        d = np.abs(b - p).max(1)
+        j = int(np.argmin(d))
+        if d[j] > atol or j in used:
+            return False
+        used.add(j)
+    return True
+
+
+ANISO_CASES = [
+    # name, position, scale, rotation [w,x,y,z], unit quaternion?
+    ("tools/compare_aabb_obb.rs:19-58", (0.0, 0.0, 0.0), (10.0, 1.0, 1.0), (0.89, 0.0, -0.432, 0.144), False),
+    ("rotated off-axis", (0.5, -0.3, -2.0), (0.8, 0.15, 0.3),
+     tuple(np.array([0.89, 0.0, -0.432, 0.144]) / np.linalg.norm([0.89, 0.0, -0.432, 0.144])), True),
+    ("near the screen edge", (-2.2, 1.1, -1.0), (0.3, 0.05, 0.6), (0.5, 0.5, -0.5, 0.5), True),
+]
+
+
+@pytest.mark.parametrize("case", ANISO_CASES, ids=[c[0] for c in ANISO_CASES])
+@pytest.mark.parametrize("aabb", [False, True])
+def test_anisotropic_splat_covariance_and_quad_from_geometry(oracle, case, aabb):
+    """Sigma' = J W (R S S^T R^T) W^T J^T from the camera model (numerical Jacobian), eigen-decomposed with
+    numpy.linalg.eigh: the oracle's cov2d is 4 Sigma' + 0.3 I (half-pixel units, screen axes x right / y
+    down), its quad the rectangle centre +- cutoff sqrt(l1) e1 +- cutoff sqrt(l2) e2 (OBB) or the square of
+    half-size cutoff sqrt(l1) (AABB)."""
+    _, pos, scale, rot, unit = case
+    W_, H_ = 640, 360
+    view = View.perspective(transform_from((0.3, 0.2, 4.0), (0.0, math.sin(0.1), 0.0, math.cos(0.1))), W_, H_)
+    cloud = _single(pos, scale, 0.5, rot=rot)
+    st = CloudSettings(aabb=aabb, opacity_adaptive_radius=False, sh_degree=0)
+    e = oracle.sort(cloud, view, st)
+    vs = oracle.vs(cloud, e[0], view, st)
+    assert vs.discard == 0
+    c, S = _screen_gaussian(view, pos, _sigma_world(scale, rot, unit))
+    Sp = S + LOWPASS_PX2 * np.eye(2)
+    assert np.allclose([vs.cov2d[0], vs.cov2d[1], vs.cov2d[2]], [4 * Sp[0, 0], 4 * Sp[0, 1], 4 * Sp[1, 1]], rtol=2e-4)
+    lam, ev = np.linalg.eigh(Sp)  # ascending
+    corners = _oracle_corners(vs, view)
+    assert np.allclose(corners.mean(0), c, atol=2e-3 * max(1.0, math.sqrt(lam[1])))
+    k = 3.0
+    if aabb:
+        r = k * math.sqrt(lam[1])
+        expected = [c + [sx * r, sy * r] for sx in (-1, 1) for sy in (-1, 1)]
+    else:
+        expected = [c + sx * k * math.sqrt(lam[1]) * ev[:, 1] + sy * k * math.sqrt(lam[0]) * ev[:, 0]
+                    for sx in (-1, 1) for sy in (-1, 1)]
+    assert _same_point_set(corners, expected, atol=1e-3 * k * math.sqrt(lam[1]) + 0.02), (corners, expected)
+
+
+@pytest.mark.parametrize("aabb", [False, True])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_anisotropic_splat_image_is_the_projected_gaussian(oracle, aabb, adaptive):
+    """Every covered pixel of a single rotated anisotropic splat against the analytic projected Gaussian
+    alpha = opacity exp(-1/2 d^T Sigma'^-1 d), colour premultiplied, over an opaque black target; the
+    covered set against the analytic footprint. OBB with opacity_adaptive_radius: the reference ties the
+    falloff to the QUAD (exp(-4.5 |uv|^2), gaussian.wgsl:474-480), not to Sigma', so a shrunk quad
+    (cutoff < 3) also narrows the Gaussian by (3 / cutoff)^2 — reproduced, and stated here."""
+    W_, H_ = 200, 140
+    view = View.perspective(transform_from((0.1, 0.0, 3.0)), W_, H_)
+    pos, scale, rot, opacity = (0.15, -0.1, 0.0), (0.5, 0.12, 0.25), (0.8, 0.3, -0.4, 0.33166247903554), 0.6
+    rot = tuple(np.array(rot) / np.linalg.norm(rot))
+    cloud = _single(pos, scale, opacity, rot=rot)
+    st = CloudSettings(aabb=aabb, opacity_adaptive_radius=adaptive, sh_degree=0,
+                       color_space=GaussianColorSpace.LinRec709Display)
+    e = oracle.sort(cloud, view, st)
+    img = oracle.render(cloud, e, view, st).astype(np.float64)
+    c, S = _screen_gaussian(view, pos, _sigma_world(scale, rot))
+    Sp = S + LOWPASS_PX2 * np.eye(2)
+    lam, ev = np.linalg.eigh(Sp)
+    k = math.sqrt(9 + 2 * math.log(opacity)) if adaptive else 3.0
+    ys, xs = np.mgrid[0:H_, 0:W_]
+    d = np.stack([xs + 0.5 - c[0], ys + 0.5 - c[1]], -1)
+    a1, a2 = d @ ev[:, 1], d @ ev[:, 0]
+    if aabb:
+        r = k * math.sqrt(lam[1])
+        inside = (np.abs(d[..., 0]) <= r) & (np.abs(d[..., 1]) <= r)
+        edge = np.minimum(np.abs(np.abs(d[..., 0]) - r), np.abs(np.abs(d[..., 1]) - r))
+        power = -0.5 * np.einsum("...i,ij,...j->...", d, np.linalg.inv(Sp), d)
+    else:
+        u, v = a1 / (k * math.sqrt(lam[1])), a2 / (k * math.sqrt(lam[0]))
+        inside = (np.abs(u) <= 1) & (np.abs(v) <= 1)
+        edge = np.minimum(np.abs(np.abs(a1) - k * math.sqrt(lam[1])), np.abs(np.abs(a2) - k * math.sqrt(lam[0])))
+        power = -0.5 * (a1 * a1 / lam[1] + a2 * a2 / lam[0]) * (3.0 / k) ** 2
+    alpha = np.minimum(opacity * np.exp(power), 0.999)
+    rgb = 0.5 + 0.28209479177387814 * np.array([1.0, 0.5, 0.25])
+    covered = np.abs(img[..., :3]).sum(-1) > 0
+    sure = edge > 0.02  # pixel centres within 0.02 px of the quad's edge may fall either side
+    assert np.array_equal(covered[sure], inside[sure])
+    assert inside.sum() > 500
+    m = inside & sure
+    assert np.allclose(img[m][:, :3], alpha[m][:, None] * rgb, rtol=5e-4, atol=1e-6)
+    assert np.allclose(img[..., 3], 1.0)
+
+
+def _complex_sph_harm(l, m, polar, azimuth):
+    if hasattr(scipy.special, "sph_harm_y"):  # SciPy >= 1.15
+        return scipy.special.sph_harm_y(l, m, polar, azimuth)
+    return scipy.special.sph_harm(m, l, azimuth, polar)
+
+
+def _real_sh_basis(d):
+    """The 16 real spherical harmonics up to l = 3 at unit direction d, Condon-Shortley phase kept, in
+    the order k = l^2 + l + m of the INRIA coefficient layout — from scipy's complex Y_l^m."""
+    x, y, z = d
+    theta, phi = math.acos(max(-1.0, min(1.0, z))), math.atan2(y, x)
+    out = []
+    for l in range(4):
+        for m in range(-l, l + 1):
+            Y = _complex_sph_harm(l, abs(m), theta, phi)
+            out.append(Y.real if m == 0 else math.sqrt(2) * (Y.real if m > 0 else Y.imag))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+def test_sh_colour_against_scipy_real_spherical_harmonics(oracle, degree):
+    """colour = 0.5 + sum_k Y_k(dir) sh[k] (material/spherical_harmonics.wgsl:34-68) with dir the unit
+    vector from the camera to the splat, at 1000 random directions, against an independent basis."""
+    n = 1000
+    rng = np.random.default_rng(40 + degree)
+    c = random_gaussians_3d_seeded(n, 11)
+    view = View.headless(640, 360)
+    c.position_visibility[:, :3] = (rng.uniform(-1, 1, (n, 3)) * [3.5, 2.0, 6.0] + [0, 1.5, -4.0]).astype(np.float32)
+    st = CloudSettings(sh_degree=degree, color_space=GaussianColorSpace.LinRec709Display)
+    cam = view.world_position.astype(np.float64)
+    checked = 0
+    for ent in oracle.sort(c, view, st):
+        if ent["key"] == 0xFFFFFFFF:
+            continue
+        i = int(ent["index"])
+        vs = oracle.vs(c, ent, view, st)
+        if vs.discard:
+            continue
+        d = c.position_visibility[i, :3].astype(np.float64) - cam
+        B = _real_sh_basis(d / np.linalg.norm(d))[: (degree + 1) ** 2]
+        sh = c.spherical_harmonic[i].astype(np.float64).reshape(16, 3)[: (degree + 1) ** 2]
+        assert np.allclose(list(vs.color)[:3], 0.5 + B @ sh, atol=3e-6)
+        checked += 1
+    assert checked > 300
+
+
+def test_sh_direction_follows_the_model_transform(oracle):
+    """The view direction is taken to the cloud's local frame (gaussian.wgsl:166-183,408-412): rotating
+    cloud AND camera together must not change the colour; rotating the cloud alone must."""
+    c = _single((0.4, 0.2, -3.0), (0.1, 0.1, 0.1), 0.5)
+    rng = np.random.default_rng(3)
+    c.spherical_harmonic[:] = rng.uniform(-1, 1, c.spherical_harmonic.shape).astype(np.float32)
+    q = Rotation.from_euler("xyz", [0.3, -0.8, 0.5])
+    Rm = q.as_matrix()
+    cam0 = transform_from((0.0, 0.0, 1.0))
+    v0 = View.perspective(cam0, 64, 64)
+    lin = dict(color_space=GaussianColorSpace.LinRec709Display)
+    col0 = list(oracle.vs(c, oracle.sort(c, v0, CloudSettings(**lin))[0], v0, CloudSettings(**lin)).color)[:3]
+    tr = np.eye(4, dtype=np.float32)
+    tr[:3, :3] = Rm
+    cam1 = np.eye(4, dtype=np.float32)
+    cam1[:3, :3] = Rm
+    cam1[:3, 3] = Rm @ np.array([0.0, 0.0, 1.0])
+    v1 = View.perspective(cam1, 64, 64)
+    s1 = CloudSettings(transform=tr, **lin)
+    col1 = list(oracle.vs(c, oracle.sort(c, v1, s1)[0], v1, s1).color)[:3]
+    assert np.allclose(col0, col1, atol=2e-5)
+    col2 = list(oracle.vs(c, oracle.sort(c, v0, s1)[0], v0, s1).color)[:3]
+    assert not np.allclose(col0, col2, atol=1e-3)
+
+
+def _surfel_case():
+    W_, H_ = 320, 200
+    view = View.perspective(transform_from((0.2, 0.1, 3.0), (0.0, math.sin(0.075), 0.0, math.cos(0.075))), W_, H_)
+    q = Rotation.from_euler("xyz", [0.4, 0.7, -0.3])
+    x, y, z, w = q.as_quat()
+    pos, scale = (0.3, -0.2, -1.0), (0.5, 0.2, 0.01)
+    return view, q.as_matrix(), (w, x, y, z), pos, scale
+
+
+def _internal_frame(view, pw):
+    """The 2DGS branch's own 'pixel' frame (helpers.wgsl:122-135 intrinsic_matrix applied to CLIP space):
+    x = ndc.x * (P00 W / 2) + (W - 1) / 2, y likewise, y UP. Not framebuffer pixels: the projection's
+    focal factor P00 = f / aspect is applied a second time. That is the reference's behaviour; the frame
+    is only ever used consistently inside the surfel code, so it is modelled, not corrected."""
+    Rc, tc, fx, fy = _cam(view)
+    t = Rc.T @ (np.asarray(pw, np.float64) - tc)
+    ndc = np.array([fx * t[0] / -t[2], fy * t[1] / -t[2]])
+    return np.array([ndc[0] * fx * view.width / 2 + (view.width - 1) / 2,
+                     ndc[1] * fy * view.height / 2 + (view.height - 1) / 2])
+
+
+def test_surfel_ray_plane_intersection_and_bounds_from_geometry(oracle):
+    """2DGS: (a) local_to_pixel must intersect a pixel's camera ray with the surfel plane — solved here as
+    a 3x3 linear system in float64 (camera centre + t dir = p + u t_u + v t_v); (b) mean_2d / extent must be
+    the centre / squared half-size of the bounding box of the projected cutoff ellipse — found here by
+    sampling the ellipse (gaussian_2d.wgsl:80-156)."""
+    view, R, rot, pos, scale = _surfel_case()
+    W_, H_ = view.width, view.height
+    cloud = _single(pos, scale, 0.7, rot=rot)
+    st = CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, aabb=True, sh_degree=0, opacity_adaptive_radius=False)
+    vs = oracle.vs(cloud, oracle.sort(cloud, view, st)[0], view, st)
+    assert vs.discard == 0
+    T = np.array(vs.local_to_pixel, np.float64).reshape(3, 3)
+    tu, tv = R[:, 0] * scale[0], R[:, 1] * scale[1]
+    Rc, tc, fx, fy = _cam(view)
+    rng = np.random.default_rng(1)
+    for pc in rng.uniform([60, 20], [300, 160], (200, 2)):
+        ndc = np.array([(pc[0] - (W_ - 1) / 2) / (fx * W_ / 2), (pc[1] - (H_ - 1) / 2) / (fy * H_ / 2)])
+        dw = Rc @ np.array([ndc[0] / fx, ndc[1] / fy, -1.0])
+        u, v, _ = np.linalg.solve(np.stack([tu, tv, -dw], 1), tc - np.asarray(pos, np.float64))
+        hu, hv = pc[0] * T[2] - T[0], pc[1] * T[2] - T[1]
+        p = np.cross(hu, hv)
+        assert np.allclose([p[0] / p[2], p[1] / p[2]], [u, v], rtol=2e-5, atol=2e-5)
+    ang = np.linspace(0, 2 * np.pi, 20001)
+    pts = np.array([_internal_frame(view, np.asarray(pos) + 3 * math.cos(a) * tu + 3 * math.sin(a) * tv) for a in ang])
+    mn, mx = pts.min(0), pts.max(0)
+    assert np.allclose(list(vs.mean_2d), (mn + mx) / 2, atol=2e-3)
+    assert np.allclose(np.sqrt(list(vs.extent)), (mx - mn) / 2, rtol=2e-5)
+    assert np.isclose(vs.radius[0], max((mx - mn) / 2)) or vs.radius[0] >= 3 * 0.707106
+
+
+def test_surfel_image_follows_the_intersection(oracle):
+    """Every pixel the surfel quad covers: alpha = opacity exp(-1/2 min(u^2 + v^2, 2 |mean_2d - pc|^2)) with
+    (u, v) from the float64 ray-plane intersection at the coordinate pc the fragment stage derives for that
+    pixel (gaussian.wgsl:440-455: pc = uv_quad * radius * (1, W/H) + mean_2d, the quad being the square of
+    half-size radius / 2 framebuffer pixels about the projected centre). The quad is in framebuffer pixels,
+    pc in the surfel code's own frame: the two scales do not agree in the reference, and are not made to."""
+    view, R, rot, pos, scale = _surfel_case()
+    W_, H_ = view.width, view.height
+    opacity = 0.7
+    cloud = _single(pos, scale, opacity, rot=rot)
+    st = CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, aabb=True, sh_degree=0, opacity_adaptive_radius=False,
+                       color_space=GaussianColorSpace.LinRec709Display)
+    e = oracle.sort(cloud, view, st)
+    vs = oracle.vs(cloud, e[0], view, st)
+    img = oracle.render(cloud, e, view, st).astype(np.float64)
+    tu, tv = R[:, 0] * scale[0], R[:, 1] * scale[1]
+    Rc, tc, fx, fy = _cam(view)
+    c = _pixel_of(view, pos)
+    mean = np.array(list(vs.mean_2d), np.float64)
+    radius = float(vs.radius[0])
+    rgb = 0.5 + 0.28209479177387814 * np.array([1.0, 0.5, 0.25])
+    checked = 0
+    for j in range(H_):
+        for i in range(W_):
+            ux, uy = (i + 0.5 - c[0]) / (radius / 2), -(j + 0.5 - c[1]) / (radius / 2)
+            if max(abs(ux), abs(uy)) > 1 - 1e-3:
+                if max(abs(ux), abs(uy)) > 1 + 1e-3:
+                    assert np.all(img[j, i, :3] == 0)
+                continue
+            pc = np.array([ux * radius, uy * radius * W_ / H_]) + mean
+            ndc = np.array([(pc[0] - (W_ - 1) / 2) / (fx * W_ / 2), (pc[1] - (H_ - 1) / 2) / (fy * H_ / 2)])
+            dw = Rc @ np.array([ndc[0] / fx, ndc[1] / fy, -1.0])
+            u, v, _ = np.linalg.solve(np.stack([tu, tv, -dw], 1), tc - np.asarray(pos, np.float64))
+            power = -0.5 * min(u * u + v * v, 2 * float(((mean - pc) ** 2).sum()))
+            alpha = min(opacity * math.exp(power), 0.999)
+            assert np.allclose(img[j, i, :3], alpha * rgb, rtol=2e-3, atol=2e-6), (i, j)
+            checked += 1
+    assert checked > 2000
+
+
+def test_three_splat_stack_blends_back_to_front(oracle):
+    """Three overlapping splats at different depths (AABB, analytic alphas as above): the target must hold
+    sum_i c_i a_i prod_{j nearer} (1 - a_j) over an opaque clear colour — premultiplied 'over' in
+    back-to-front draw order (render/mod.rs:944-948) — and the farthest splat must be drawn first."""
+    W_, H_ = 96, 80
+    view = View.perspective(transform_from((0.0, 0.0, 3.0)), W_, H_, clear_color=(0.2, 0.1, 0.05, 1.0))
+    specs = [((0.05, 0.0, 0.0), (0.30, 0.20, 0.2), 0.7, (1.0, 0.0, 0.0)),
+             ((-0.05, 0.05, -1.0), (0.45, 0.30, 0.2), 0.5, (0.0, 1.0, 0.0)),
+             ((0.0, -0.05, -2.5), (0.90, 0.60, 0.2), 0.9, (0.0, 0.0, 1.0))]
+    rot = tuple(np.array([0.9, 0.1, 0.2, -0.3]) / np.linalg.norm([0.9, 0.1, 0.2, -0.3]))
+    gs = []
+    for pos, scale, op, colour in specs:
+        sh = SphericalHarmonicCoefficients()
+        for ch, val in enumerate(colour):
+            sh.set(ch, (val - 0.5) / 0.28209479177387814)
+        gs.append(Gaussian3d(np.array([*pos, 1.0], np.float32), sh.coefficients, np.array(rot, np.float32),
+                             np.array([*scale, op], np.float32)))
+    cloud = PlanarGaussian3d.from_interleaved(gs)
+    st = CloudSettings(aabb=True, opacity_adaptive_radius=False, sh_degree=0,
+                       color_space=GaussianColorSpace.LinRec709Display)
+    e = oracle.sort(cloud, view, st)
+    assert [int(i) for i in e["index"]] == [2, 1, 0]  # farthest first
+    img = oracle.render(cloud, e, view, st).astype(np.float64)
+    ys, xs = np.mgrid[0:H_, 0:W_]
+    C = np.tile(np.array([0.2, 0.1, 0.05]), (H_, W_, 1))
+    A = np.ones((H_, W_))
+    unsure = np.zeros((H_, W_), bool)
+    for pos, scale, op, colour in reversed(specs):  # back to front
+        c, S = _screen_gaussian(view, pos, _sigma_world(scale, rot))
+        Sp = S + LOWPASS_PX2 * np.eye(2)
+        lam = np.linalg.eigvalsh(Sp)
+        r = 3.0 * math.sqrt(lam[1])
+        d = np.stack([xs + 0.5 - c[0], ys + 0.5 - c[1]], -1)
+        inside = (np.abs(d[..., 0]) <= r) & (np.abs(d[..., 1]) <= r)
+        unsure |= np.minimum(np.abs(np.abs(d[..., 0]) - r), np.abs(np.abs(d[..., 1]) - r)) < 0.02
+        a = np.where(inside, np.minimum(op * np.exp(-0.5 * np.einsum("...i,ij,...j->...", d, np.linalg.inv(Sp), d)), 0.999), 0.0)
+        C = a[..., None] * np.array(colour) + C * (1 - a[..., None])
+        A = a + A * (1 - a)
+    ok = ~unsure
+    assert np.allclose(img[ok][:, :3], C[ok], rtol=5e-4, atol=2e-6)
+    assert np.allclose(img[..., 3], 1.0, atol=1e-6)
+    # the order matters: the same entries drawn front to back give a different image
+    assert np.abs(oracle.render(cloud, e[::-1].copy(), view, st) - img).max() > 0.05
