@@ -233,8 +233,43 @@ static int cmp_desc_f32(const void* pa, const void* pb) {
     return (a->index > b->index) - (a->index < b->index);
 }
 
+/* src/sort/rayon.rs:100-104 is rayon's par_sort_unstable_by: a PARALLEL comparison sort. The oracle's
+ * comparator is a total order (ties by index), so any correct sort gives the same list; here: one sorted
+ * run per thread (qsort), then rounds of pairwise merges, all in parallel over the runs. */
+static void merge_runs(const bgs_sort_entry* a, size_t na, const bgs_sort_entry* b, size_t nb, bgs_sort_entry* out) {
+    size_t i = 0, j = 0, k = 0;
+    while (i < na && j < nb) out[k++] = cmp_desc_f32(&b[j], &a[i]) < 0 ? b[j++] : a[i++];
+    while (i < na) out[k++] = a[i++];
+    while (j < nb) out[k++] = b[j++];
+}
+
 void oracle_sort_descending_f32(bgs_sort_entry* entries, uint32_t n) {
-    qsort(entries, n, sizeof(bgs_sort_entry), cmp_desc_f32);
+    int runs = 1;
+    while (runs * 2 <= omp_get_max_threads() && (size_t)n / (size_t)(runs * 2) >= 4096) runs *= 2;
+    bgs_sort_entry* tmp = runs > 1 ? (bgs_sort_entry*)malloc((size_t)n * sizeof(bgs_sort_entry)) : NULL;
+    if (!tmp) {
+        qsort(entries, n, sizeof(bgs_sort_entry), cmp_desc_f32);
+        return;
+    }
+    const size_t len = ((size_t)n + (size_t)runs - 1) / (size_t)runs;
+#pragma omp parallel for schedule(static, 1)
+    for (int r = 0; r < runs; ++r) {
+        const size_t lo = (size_t)r * len, hi = lo + len < n ? lo + len : n;
+        if (lo < hi) qsort(entries + lo, hi - lo, sizeof(bgs_sort_entry), cmp_desc_f32);
+    }
+    bgs_sort_entry *src = entries, *dst = tmp;
+    for (size_t width = len; width < n; width *= 2) {
+        const long pairs = (long)(((size_t)n + 2 * width - 1) / (2 * width));
+#pragma omp parallel for schedule(static, 1)
+        for (long p = 0; p < pairs; ++p) {
+            const size_t lo = (size_t)p * 2 * width;
+            const size_t mid = lo + width < n ? lo + width : n, hi = lo + 2 * width < n ? lo + 2 * width : n;
+            merge_runs(src + lo, mid - lo, src + mid, hi - mid, dst + lo);
+        }
+        bgs_sort_entry* t = src; src = dst; dst = t;
+    }
+    if (src != entries) memcpy(entries, src, (size_t)n * sizeof(bgs_sort_entry));
+    free(tmp);
 }
 
 int oracle_sort(const float* pv, uint32_t n, const bgs_view* view, const bgs_settings* s,

@@ -17,7 +17,8 @@ from bevy_gaussian_splatting_amd.gaussian import PlanarGaussian3d, PlanarGaussia
 from bevy_gaussian_splatting_amd.settings import BgsSettings, CloudSettings
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbgs_oracle.so")
+# BGS_ORACLE_LIB: load another build of the same source instead (the sanitizer build of tests/test_oracle_sanitize.py)
+LIB_PATH = os.environ.get("BGS_ORACLE_LIB") or os.path.join(_HERE, "libbgs_oracle.so")
 SORT_ENTRY_DTYPE = np.dtype([("key", np.uint32), ("index", np.uint32)])
 
 
@@ -53,6 +54,8 @@ class VsOut(ctypes.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (no-op if up to date)."""
+    if os.environ.get("BGS_ORACLE_LIB"):
+        return LIB_PATH
     if force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(LIB_PATH)
         for f in ("bgs_oracle.c", "bgs_oracle.h")
