@@ -29,8 +29,11 @@ Prints ONE JSON line on rank 0. `value` = whole-job frames/s. Extra objects:
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -46,6 +49,54 @@ WIDTH, HEIGHT = 1920, 1080
 GATHER_BATCH = 8  # frames per framebuffer gather (N > 1)
 
 
+def kernel_source_sha256() -> str:
+    """Identity of the kernels a counter file was measured on: SHA-256 over the HIP sources and headers of
+    libbgs (not the commit id, which also changes with every documentation commit)."""
+    d = os.path.join(ROOT, "bevy_gaussian_splatting_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def load_pmc():
+    """profiles/pmc_traffic.json (rocprofv3 --pmc passes, scripts/gpu_pmc.sh + scripts/make_pmc_traffic.py) if
+    it was measured on THESE kernel sources, else (None, why): a counter value from another revision of the
+    kernels must not be printed into this run's line."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            d = json.load(f)
+    except Exception as e:  # noqa: BLE001
+        return None, f"profiles/pmc_traffic.json unreadable: {e}"
+    have, want = d.get("kernel_source_sha256"), kernel_source_sha256()
+    if have != want:
+        return None, f"profiles/pmc_traffic.json was measured on kernel sources {str(have)[:12]}, this run is {want[:12]}"
+    return d, f"rocprofv3 PMC passes on kernel sources {want[:12]} ({d.get('measured', 'profiles/')})"
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks ourselves, one per GPU, exactly as the
+    driver would (torch.distributed.run, rendezvous on 127.0.0.1). Fails loudly when the box has fewer
+    than N devices."""
+    import socket
+
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} HIP devices, {have} visible on this box "
+              "(there is no CPU fallback and no oversubscription of one GPU by several ranks)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) -> dict:
     """Algorithmic bytes per stage (SURVEY 8(d) terms) and the launches each stage comprises."""
     N, V, I = stats["splat_count"], stats["visible_count"], stats["instance_count"]
@@ -53,18 +104,22 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
     k, kt = stats["depth_passes"], stats["tile_passes"]
     P = WIDTH * HEIGHT
     B = cloud_bytes_per_splat
+    bucket = stats.get("sort_path") == "bucket"
+    # bucket sort: keygen also writes the D drawable pairs into their buckets (8 B each, instead of the
+    # index-ordered list), ONE launch reads them and writes the sorted list (16 B per pair)
+    sort_stage = {"bytes": D * 16, "launches": 1} if bucket else {"bytes": k * D * 16, "launches": max(k, 1)}
     if stats.get("binning") == "scan":
         # I = coarse (supertile) list entries (rank + tile rect, 8 B): written once by project_bin, read
         # once by the rasteriser, which also reads each visible record at least once
         return {
             "keygen": {"bytes": N * 16 + N * 8, "launches": 1},
-            "depth_sort": {"bytes": k * D * 16, "launches": max(k, 1)},
+            "depth_sort": sort_stage,
             "project": {"bytes": V * 8 + V * (B - 16) + V * rec_bytes + I * 8, "launches": 1},
             "raster": {"bytes": I * 8 + V * rec_bytes + P * 16, "launches": 1},
         }
     return {
         "keygen": {"bytes": N * 16 + N * 8, "launches": 1},
-        "depth_sort": {"bytes": k * D * 16, "launches": max(k, 1)},
+        "depth_sort": sort_stage,
         "project": {"bytes": V * (B - 16) + V * rec_bytes + I * 8, "launches": 1},
         "tile_sort": {"bytes": kt * I * 16, "launches": max(kt, 1)},
         "ranges": {"bytes": I * 8, "launches": 1},  # not in SURVEY's bytes_frame (pure overhead pass)
@@ -72,13 +127,18 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
     }
 
 
-def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=None, depth=1):
+def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=None, depth=1, trials=1,
+            busy_warm_s=0.0):
     """W untimed + K timed steps. A step ENQUEUES one frame: the scan pipeline needs no host round
     trip, and the context keeps `depth` frames in flight (lanes, multiplexed onto a few HIP streams). With a
     `gather` callback (N > 1 ranks) the oldest frame is popped and handed to it as soon as `depth`
     frames are in flight, so gathers overlap the following frames. The closing synchronize waits for
-    everything, so dt covers exactly K complete frames (and their gathers). Returns (seconds,
-    per-stage ms averaged by the library over the timed frames' HIP events, stats)."""
+    everything, so dt covers exactly K complete frames (and their gathers). With `trials` > 1 the timed
+    region (barrier, K steps, barrier) is repeated and the list of durations returned as well: K = 20 frames
+    are 1.5 ms of GPU time, which one clock ramp or one late lane moves by 10 %, so the headline reports the
+    median trial. `busy_warm_s`: keep rendering for at least that long before the first trial (clocks).
+    Returns (seconds of the median trial, per-stage ms averaged by the library over the timed frames' HIP
+    events, stats[, every trial's seconds])."""
     prepared = plugin.prepare(view, settings)  # marshal the C structs once, like a caller's per-view cache
 
     def run(k):
@@ -99,15 +159,22 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
     # --warmup (fewer steps than lanes) does not leave allocations inside the timed region
     run(depth)
     run(warmup)
-    if barrier:
-        barrier()
-    t0 = time.perf_counter()
-    run(steps)
-    if barrier:
-        barrier()
-    dt = time.perf_counter() - t0
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < busy_warm_s:
+        run(max(steps, 4 * depth))
+    dts = []
+    for _ in range(max(1, trials)):
+        if barrier:
+            barrier()
+        t0 = time.perf_counter()
+        run(steps)
+        if barrier:
+            barrier()
+        dts.append(time.perf_counter() - t0)
     st = plugin.stats()
-    return dt, dict(st["stage_ms"]), st
+    if trials > 1:
+        return statistics.median(dts), dict(st["stage_ms"]), st, dts
+    return dts[0], dict(st["stage_ms"]), st
 
 
 def cpu_baseline(cloud, view, settings):
@@ -116,6 +183,14 @@ def cpu_baseline(cloud, view, settings):
     rayon/std descending-f32 semantics) + the vertex stage for every splat + the raster of the
     WHOLE 1920x1080 frame (no scaling); and the same pinned to ONE core with the centred 480x270
     window (1/16 of the frame, time scaled x16). About 15-20 s of CPU work in total."""
+    # The checker library travels to this box prebuilt and portable (-O2, no -march); the BASELINE is the same
+    # source built here, for this host: -O3 -march=native (BASELINE.md section 3). Arithmetic is unchanged
+    # (-ffp-contract=off, no fast-math).
+    flags = "-O2 (portable checker build; the native build failed)"
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libbgs_oracle_native.so"], capture_output=True, text=True)
+    if r.returncode == 0 and "oracle.oracle" not in sys.modules:
+        os.environ["BGS_ORACLE_LIB"] = os.path.join(ROOT, "oracle", "libbgs_oracle_native.so")
+        flags = "-O3 -march=native -fopenmp -ffp-contract=off, built on this host"
     from oracle import oracle
     from bevy_gaussian_splatting_amd import CloudSettings, SortMode
 
@@ -153,12 +228,14 @@ def cpu_baseline(cloud, view, settings):
         "unit": "frames/s",
         "cores": all_cores,
         "kind": "port",
-        "sample": ("oracle/bgs_oracle.c (gcc -O2 -fopenmp): full 1M-splat keygen+LSD radix sort "
+        "sample": (f"oracle/bgs_oracle.c (gcc {flags}): full 1M-splat keygen+LSD radix sort "
                    f"({t_sort:.3f}s) + vertex stage of all splats ({t_vs:.3f}s) + raster of the "
-                   f"whole {WIDTH}x{HEIGHT} frame ({t_win:.2f}s)"),
+                   f"whole {WIDTH}x{HEIGHT} frame ({t_win:.2f}s): the reference's algorithm as it stands, every quad "
+                   "rasterised in full, back to front, no early termination"),
         "sort_msplats_per_s": len(cloud) / t_sort / 1e6,
         "sort_std_msplats_per_s": len(cloud) / t_sort_std / 1e6,
-        "sort_std_note": "rayon/std semantics (src/sort/rayon.rs:86-104): keygen + descending-f32 comparison sort (qsort, 1 thread)",
+        "sort_std_note": ("rayon semantics (src/sort/rayon.rs:86-104): parallel keygen + parallel descending-f32 "
+                          "comparison sort (one qsort run per thread, parallel pairwise merges)"),
         "one_core": {"value": 1.0 / t_frame1, "unit": "frames/s", "cores": 1,
                      "sort_msplats_per_s": len(cloud) / s1 / 1e6,
                      "sample": (f"same, OMP threads = 1: sort {s1:.3f}s + vertex stage {v1:.2f}s + centred 480x270 window "
@@ -176,17 +253,24 @@ def main():
     ap.add_argument("--depth", type=int, default=6, help="frames in flight (pipeline lanes, 1..8)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the lanes are multiplexed onto (0 = one per lane): frames competing for the chip")
+    ap.add_argument("--trials", type=int, default=0,
+                    help="timed regions of --steps frames; the median is reported (default: 5, 3 from 2000 steps up)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("BGS_BENCH_FORCE_DIST") != "1":
+        raise SystemExit(launch_ranks(args.gpus))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus and (world > 1 or os.environ.get("BGS_BENCH_FORCE_DIST") != "1"):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} HIP devices visible")
     torch.cuda.set_device(local_rank)
     dist = None
     # BGS_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, sRGB8 output, popped frames,
@@ -256,12 +340,15 @@ def main():
     # the headline region runs without stage events (each record is a packet on the stream; timing every
     # 16th frame cost ~5 % of the rate being measured); the per-stage numbers come from separate passes
     plugin.set_profiling(0)
-    dt, _, _ = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, lanes)
+    trials = args.trials if args.trials > 0 else (5 if args.steps < 2000 else 3)
+    _, _, _, dts = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, lanes,
+                           trials=max(trials, 2), busy_warm_s=0.25)
     plugin.set_profiling(2)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:  # a trial lasts as long as its slowest rank
+        t = torch.tensor(dts, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dts = [float(x) for x in t.tolist()]
+    dt = statistics.median(dts)
     fps = world * args.steps / dt
 
     # ---- side measurements on rank 0 (outside the timed region) -----------------------------
@@ -282,18 +369,17 @@ def main():
         per_launch_s = stage_ms[dom] * 1e-3 / launches if stage_ms.get(dom, 0) > 0 else float("inf")
         achieved = per_launch_bytes / per_launch_s / 1e9
         scan_mode = st.get("binning") == "scan"
-        kernel_names = {"keygen": "keygen_kernel", "depth_sort": "onesweep_kernel",
+        kernel_names = {"keygen": "keygen_kernel",
+                        "depth_sort": "bucket_sort_kernel" if st.get("sort_path") == "bucket" else "onesweep_kernel",
                         "project": "project_bin_kernel" if scan_mode else "project_emit_kernel",
                         "tile_sort": "onesweep_kernel", "ranges": "tile_ranges_kernel",
                         "raster": "raster_scan_kernel" if scan_mode else "raster_kernel"}
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
-        # doubled per the gfx950 correction + WRITE_SIZE), for the same dense workload; null if absent
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"][kernel_names[dom]]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        # doubled per the gfx950 correction + WRITE_SIZE), for the same dense workload; null unless that
+        # file was measured on exactly these kernel sources
+        pmc, pmc_note = load_pmc()
+        pmc_kernels = pmc["kernels"] if pmc else {}
+        traffic = pmc_kernels.get(kernel_names[dom], {}).get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "kernel": kernel_names[dom], "stage": dom,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -327,38 +413,29 @@ def main():
         # kernel durations under profiles/). Inside the pipelined timed region an event interval also
         # contains the time a kernel waits for the other lanes' kernels, which is reported as `in_flight`.
         roofline_main = dict(single["roofline"])
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                roofline_main["traffic"] = json.load(f)["kernels"][roofline_main["kernel"]]["hbm_bytes_per_launch"]
-        except Exception:
-            roofline_main["traffic"] = None
+        roofline_main["traffic"] = pmc_kernels.get(roofline_main["kernel"], {}).get("hbm_bytes_per_launch")
+        roofline_main["traffic_source"] = pmc_note
         roofline_main["measured_peak"] = roofline["measured_peak"]
         roofline_main["frac_of_measured"] = round(roofline_main["achieved"] / measured, 4) if measured else None
         roofline_main["measured_on"] = "single-stream frames (HIP events, every kernel of every Nth frame)"
         # the kernel is VALU-issue bound, not HBM bound: its vector instruction count (SQ_INSTS_VALU from the
         # committed PMC pass) against what 1024 SIMDs issue at 4 clocks per wave64 fp32 instruction, 2.4 GHz max clock
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                wi = json.load(f)["kernels"][roofline_main["kernel"]].get("valu_wave_instructions")
-            if wi:
-                min_ms = wi * 4.0 / (4 * 256) / 2.4e9 * 1e3
-                roofline_main["valu"] = {"wave_instructions_per_launch": int(wi), "issue_bound_ms": round(min_ms, 4),
-                                         "frac_of_issue_peak": round(min_ms / roofline_main["launch_ms"], 3)}
+        wi = pmc_kernels.get(roofline_main["kernel"], {}).get("valu_wave_instructions")
+        if wi:
+            min_ms = wi * 4.0 / (4 * 256) / 2.4e9 * 1e3
+            roofline_main["valu"] = {"wave_instructions_per_launch": int(wi), "issue_bound_ms": round(min_ms, 4),
+                                     "frac_of_issue_peak": round(min_ms / roofline_main["launch_ms"], 3)}
             # the whole frame against the same bound: every kernel's vector instructions x its launches per
             # frame, at the frame rate of the timed region — the chip-wide VALU-issue utilisation
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                kk = json.load(f)["kernels"]
-            per_frame = {"keygen_kernel": 1, "onesweep_kernel": st["depth_passes"], "project_bin_kernel": 1,
-                         "raster_scan_kernel": 1}
-            if scan_mode and all(kk.get(k, {}).get("valu_wave_instructions") for k in per_frame):
-                fw = sum(kk[k]["valu_wave_instructions"] * m for k, m in per_frame.items())
+            per_frame = {"keygen_kernel": 1, kernel_names["depth_sort"]: table["depth_sort"]["launches"],
+                         "project_bin_kernel": 1, "raster_scan_kernel": 1}
+            if scan_mode and all(pmc_kernels.get(k, {}).get("valu_wave_instructions") for k in per_frame):
+                fw = sum(pmc_kernels[k]["valu_wave_instructions"] * m for k, m in per_frame.items())
                 frame_issue_ms = fw * 4.0 / (4 * 256) / 2.4e9 * 1e3
                 roofline_main["valu"]["frame"] = {
                     "wave_instructions_per_frame": int(fw), "issue_bound_ms": round(frame_issue_ms, 4),
                     "ms_per_frame": round(1e3 * dt / args.steps, 4),
                     "frac_of_issue_peak": round(frame_issue_ms / (1e3 * dt / args.steps), 3)}
-        except Exception:
-            pass
         roofline_main["in_flight"] = roofline
 
         # "Msplats/s sorted": keygen + depth sort only (blocking calls, every one timed)
@@ -398,6 +475,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
+            "timing": {"trials_ms": [round(1e3 * x, 4) for x in dts], "reported": "median trial",
+                       "note": "every trial is a barrier + sync, --steps frames, barrier + sync; 0.25 s of "
+                               "rendering precedes the first one"},
             "config": {"workload": f"{args.splats}-splat 3DGS f32 planar cloud (seed {SEED}, reference random_gaussians_3d "
                                    "distributions), 1920x1080, SH degree 3, CloudSettings::default(), "
                                    "examples/headless.rs camera; one camera per GPU",
@@ -424,7 +504,7 @@ def main():
                            "device_ms": round(ms2, 4), "visible_splats": st2["visible_count"],
                            "tile_instances": st2["instance_count"],
                            "GBps": round(st2["algorithmic_bytes"] / (ms2 * 1e-3) / 1e9, 1) if ms2 > 0 else None},
-            "binning": st["binning"],
+            "binning": st["binning"], "sort_path": st.get("sort_path"),
             "instance_sort_pipeline": {
                 "note": "bgs_set_binning(SORT): (tile,splat) instances + stable radix sort on tile ids + ranges",
                 "value": round(max(args.steps // 3, 3) / dt3, 2), "unit": "frames/s",

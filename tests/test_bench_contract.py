@@ -21,6 +21,38 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert not any(line.startswith("{") for line in r.stdout.splitlines())   # no metric line is fabricated
 
 
+def test_bench_gpus_flag_without_enough_devices_fails_loudly():
+    """`python bench.py --gpus 2` outside a launcher starts the ranks itself — and must refuse, non-zero and
+    with a message, when the box has fewer than 2 devices (never a 1-GPU number labelled by the flag)."""
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two HIP devices are present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "--gpus 2 needs 2 HIP devices" in r.stderr
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
+def test_pmc_counters_are_only_quoted_for_the_kernels_they_were_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic / roofline.valu come from a committed counter file: bench.load_pmc hands it out only
+    when the file's kernel-source hash is the hash of the sources in the tree."""
+    sys.path.insert(0, ROOT)
+    import bench
+    d, note = bench.load_pmc()
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        on_disk = json.load(f)
+    if on_disk.get("kernel_source_sha256") == bench.kernel_source_sha256():
+        assert d is not None and "kernels" in d
+    else:
+        assert d is None and "measured on kernel sources" in note
+    monkeypatch.setattr(bench, "kernel_source_sha256", lambda: "0" * 64)
+    d2, note2 = bench.load_pmc()
+    assert d2 is None and "this run is 000000000000" in note2
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "4"],
@@ -47,3 +79,4 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert d["value"] > 1000.0     # BASELINE.json's target on this config, with a wide margin to the measured 12 k
+    assert len(d["timing"]["trials_ms"]) >= 5 and "traffic_source" in rf
