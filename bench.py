@@ -179,7 +179,7 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
 
 def cpu_baseline(cloud, view, settings):
     """The oracle (C restatement, OpenMP) on a bounded sample of the SAME workload:
-    all host cores: the full 1M-splat sort (both reference sorts: the radix semantics and the
+    all host cores this process is granted (affinity capped by the cgroup quota): the full 1M-splat sort (both reference sorts: the radix semantics and the
     rayon/std descending-f32 semantics) + the vertex stage for every splat + the raster of the
     WHOLE 1920x1080 frame (no scaling); and the same pinned to ONE core with the centred 480x270
     window (1/16 of the frame, time scaled x16). About 15-20 s of CPU work in total."""
@@ -195,7 +195,7 @@ def cpu_baseline(cloud, view, settings):
     from bevy_gaussian_splatting_amd import CloudSettings, SortMode
 
     oracle.build()
-    all_cores = oracle.max_threads()
+    all_cores = oracle.max_threads()  # already capped to the CPUs the cgroup grants this process (oracle.effective_cpus)
 
     def frame(window_w, window_h):
         t0 = time.perf_counter()

@@ -128,7 +128,7 @@ struct Lane {
 
     bool pending = false;  // a frame is enqueued whose Control block has not been checked yet
     bool pending_render = false, pending_scan = false, pending_bucket = false;
-    uint32_t pending_coarse_cap = 0;
+    uint32_t pending_coarse_cap = 0, pending_level = 1;
     // what the pending frame was enqueued with: a frame whose data-dependent capacities turn out too
     // small (coarse lists, bucket sort, tile instances) is re-run on its lane when it is completed
     const bgs_cloud* in_cloud = nullptr;
@@ -178,7 +178,7 @@ struct bgs_ctx {
     // kernels read the real count on the device and loop over tickets if the grid is short.
     uint32_t draw_hint = 0;
     bool draw_hint_valid = false;
-    bool sup_fine = false;   // supertile edge rule of the next frames (see enqueue_frame)
+    uint32_t sup_level = 1;  // supertile edge level of the next frames (see enqueue_frame)
     // Bucket sort (one launch instead of four digit passes) is used while a completed frame's quantile keys
     // are known, the draw count fits the bucket geometry, and it has not just failed.
     bool splitters_valid = false;
@@ -537,9 +537,17 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
         if (render && scan && h.visible_count > 0) {
             // list entries per visible splat: ~1.2 when splats are smaller than a supertile, 15-20 when they
             // span many; thresholds far apart so that the rule does not flip on a moving camera
+            // (> 4 -> one level coarser, < 1.6 -> one level finer: a level step changes the ratio by less
+            // than the gap between the two thresholds; stepping from the level THIS frame ran at, so that
+            // several frames in flight do not step twice)
             const uint64_t v = h.visible_count;
-            if (!ctx->sup_fine && total < 3 * v) ctx->sup_fine = true;
-            else if (ctx->sup_fine && total > 8 * v) ctx->sup_fine = false;
+            const uint32_t lv = L.pending_level;
+            if (10 * total > 40 * v && lv < 3) {
+                if (ctx->sup_level != lv + 1) ctx->coarse_cap_hint = std::min<uint64_t>((uint64_t)ctx->coarse_cap_hint * 2, 1u << 30);
+                ctx->sup_level = lv + 1;
+            } else if (10 * total < 16 * v && lv > 0) {
+                ctx->sup_level = lv - 1;
+            }
         }
 
         bgs_stats& stt = L.result;
@@ -679,14 +687,16 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     } else if (places > 0) {
         ctx->onesweep_frames += 1;
     }
-    // Supertile edge (in tiles). Two candidates: the smallest power of two >= 8 that keeps the coarse bins
-    // <= 256 and <= 32 per axis (8 at 1080p: 135 bins) and the smallest edge >= 3/4 of it that does
-    // (6 at 1080p: 240 bins).
-    // Small splats want the fine one — every tile scans its supertile's whole list, and the lists are
-    // 1.8x shorter (scene-like frame: 91.7 -> 87.9 us) — splats that span many supertiles the coarse one
-    // (1.5x fewer list entries to append; dense frame: 79.2 vs 86.4 us). Images do not depend on it; the
-    // choice follows the entries-per-splat ratio of the last completed frame (ctx->sup_fine).
-    // Debug flags: 0x8000 forces the coarse edge, 0x10000 the fine one.
+    // Supertile edge (in tiles): four levels. Level 1 is the smallest power of two >= 8 that keeps the coarse
+    // bins <= 256 and <= 32 per axis (8 at 1080p: 135 bins); level 0 the smallest edge >= 3/4 of it that does
+    // (6 at 1080p: 240 bins); levels 2 and 3 are 2x and 4x level 1 (16 and 32 at 1080p: 40 and 12 bins).
+    // Every tile scans its supertile's whole list, so small splats want short lists (level 0: scene-like frame
+    // 91.7 -> 87.9 us against level 1); a splat that spans many supertiles costs one list entry, one append and
+    // a share of the ballots in each, while a tile that saturates after ~60 hits does not mind scanning three
+    // times as many candidates (dense frame, 6 lanes on 3 streams: 13.3 k frames/s at level 1, 14.6 k at level
+    // 2, 15.3 k at level 3). Images do not depend on the level; it follows the entries-per-visible-splat ratio
+    // of the completed frames (finish_lane). Debug flags force a level: 0x10000 -> 0, 0x8000 -> 1,
+    // 0x400000 -> 2, 0x800000 -> 3.
     auto bins = [&](uint32_t e, uint32_t& bx, uint32_t& by) {
         bx = ((uint32_t)fp.tiles_x + e - 1) / e;
         by = ((uint32_t)fp.tiles_y + e - 1) / e;
@@ -694,13 +704,18 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     };
     uint32_t edge_c = 8, cbx = 0, cby = 0, edge_f = 1, fbx = 0, fby = 0;
     while (!bins(edge_c, cbx, cby)) edge_c *= 2;
-    // the fine edge stays within 3/4 of the coarse one: the entries-per-splat statistic then differs by
-    // < 1.8x between the two rules, less than the gap between the switching thresholds (no flip-flop)
+    // the fine edge stays within 3/4 of the coarse one (no flip-flop between the two rules)
     edge_f = (3 * edge_c + 3) / 4;
     while (!bins(edge_f, fbx, fby)) ++edge_f;
     if (edge_f >= edge_c) { edge_f = edge_c; fbx = cbx; fby = cby; }
-    const bool fine = (ctx->debug_flags & 0x10000u) || (ctx->sup_fine && !(ctx->debug_flags & 0x8000u));
-    const uint32_t sup_edge = fine ? edge_f : edge_c, sup_bx = fine ? fbx : cbx, sup_by = fine ? fby : cby;
+    uint32_t level = ctx->sup_level;
+    if (ctx->debug_flags & 0x10000u) level = 0;
+    else if (ctx->debug_flags & 0x8000u) level = 1;
+    else if (ctx->debug_flags & 0x400000u) level = 2;
+    else if (ctx->debug_flags & 0x800000u) level = 3;
+    // tile / edge by reciprocal multiply is exact for edges <= 32 (supertile_div)
+    uint32_t sup_edge = level == 0 ? edge_f : std::min<uint32_t>(edge_c << (level - 1u), 32u), sup_bx = 0, sup_by = 0;
+    if (!bins(sup_edge, sup_bx, sup_by)) { sup_edge = edge_c; sup_bx = cbx; sup_by = cby; }
     const uint32_t num_st = sup_bx * sup_by;
     uint32_t coarse_cap = 1;  // entries per supertile list
     if (render) {
@@ -933,6 +948,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     L.pending_scan = scan;
     L.pending_bucket = bucket;
     L.pending_coarse_cap = coarse_cap;
+    L.pending_level = level;
     L.pending_n = n;
     L.pending_places = places;
     L.pending_num_st = num_st;
@@ -1370,7 +1386,7 @@ int bgs_reset_adaptive_state(bgs_ctx* ctx) {
     ctx->splitters_valid = false;
     ctx->bucket_block = 0;
     ctx->bucket_fail_streak = 0;
-    ctx->sup_fine = false;
+    ctx->sup_level = 1;
     ctx->coarse_cap_hint = 0;
     return BGS_OK;
 }

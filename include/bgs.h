@@ -269,8 +269,8 @@ int bgs_set_binning(bgs_ctx* ctx, uint32_t mode);
 /* Kernel-ablation switches for performance experiments (scripts/ablate.py). Bits 1..64 switch parts
  * of kernels off and produce WRONG images; 0x1000 (per-frame memset + Control copy instead of the
  * rasteriser's in-kernel clean-up), 0x2000 (no draw-count hint for the sort grids), 0x4000 (no
- * hipGraph replay even when bgs_set_graphs is on), 0x8000 / 0x10000 (force the coarse / the fine
- * supertile edge instead of choosing by the last frame's list statistics), 0x40000 (sRGB8 image from the
+ * hipGraph replay even when bgs_set_graphs is on), 0x10000 / 0x8000 / 0x400000 / 0x800000 (force supertile
+ * level 0 / 1 / 2 / 3 instead of choosing by the completed frames' list statistics), 0x40000 (sRGB8 image from the
  * separate encode pass instead of the rasteriser's fused output), 0x80000 (depth sort always by the
  * onesweep digit passes, never the bucket sort), 0x200000 (bucket sort even before a completed frame has
  * told the key range: full 32-bit range guessed), 0x100000 (supertile lists start at 64 entries, to

@@ -64,6 +64,20 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def effective_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes show
+    256 logical CPUs under a 16-CPU quota: 128 OpenMP threads there are throttled to a crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 _lib = None
 
 
@@ -113,6 +127,8 @@ def lib() -> ctypes.CDLL:
         l.oracle_set_threads.restype = None
         l.oracle_max_threads.argtypes = []
         l.oracle_max_threads.restype = ctypes.c_int
+        if "OMP_NUM_THREADS" not in os.environ:
+            l.oracle_set_threads(min(l.oracle_max_threads(), effective_cpus()))
         _lib = l
     return _lib
 

@@ -677,9 +677,9 @@ def test_async_frames_match_synchronous_frames(plugin, oracle):
 
 @pytest.mark.parametrize("size", [(1920, 1080), (1000, 600), (250, 130), (4096, 2304)])
 def test_supertile_edge_does_not_change_the_image(plugin, size):
-    """The coarse-bin (supertile) edge is a performance choice made from the previous frame's list
-    statistics — 6 or 8 tiles at 1080p, 13 or 16 at 4096x2304 (division by reciprocal multiply):
-    the forced-fine, forced-coarse and automatic frames must be bit-identical, for splats smaller and
+    """The coarse-bin (supertile) edge is a performance choice made from the completed frames' list
+    statistics — 6, 8, 16 or 32 tiles at 1080p, 13, 16 or 32 at 4096x2304 (division by reciprocal multiply):
+    the frames forced to every level and the automatic ones must be bit-identical, for splats smaller and
     larger than a supertile."""
     c = random_gaussians_3d_seeded(60_000, 71)
     h = plugin.upload(c)
@@ -688,10 +688,11 @@ def test_supertile_edge_does_not_change_the_image(plugin, size):
         for gs in (0.05, 1.0):
             s = CloudSettings(global_scale=gs)
             imgs = []
-            for flags in (0x8000, 0x10000, 0, 0):   # coarse, fine, automatic (twice: the rule may have flipped)
+            # levels 1, 0, 2, 3, then automatic (four times: the rule steps one level per completed frame)
+            for flags in (0x8000, 0x10000, 0x400000, 0x800000, 0, 0, 0, 0):
                 plugin.set_debug_flags(flags)
                 imgs.append(plugin.render(h, v, s))
-            for k in (1, 2, 3):
+            for k in range(1, len(imgs)):
                 assert np.array_equal(imgs[0], imgs[k]), (size, gs, k)
     finally:
         plugin.set_debug_flags(0)
