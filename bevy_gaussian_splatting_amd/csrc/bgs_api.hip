@@ -128,7 +128,7 @@ struct Lane {
 
     bool pending = false;  // a frame is enqueued whose Control block has not been checked yet
     bool pending_render = false, pending_scan = false, pending_bucket = false;
-    uint32_t pending_coarse_cap = 0, pending_level = 1;
+    uint32_t pending_coarse_cap = 0, pending_level = 1, pending_edges[4] = {6, 8, 16, 32};
     // what the pending frame was enqueued with: a frame whose data-dependent capacities turn out too
     // small (coarse lists, bucket sort, tile instances) is re-run on its lane when it is completed
     const bgs_cloud* in_cloud = nullptr;
@@ -537,16 +537,31 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
         if (render && scan && h.visible_count > 0) {
             // list entries per visible splat: ~1.2 when splats are smaller than a supertile, 15-20 when they
             // span many; thresholds far apart so that the rule does not flip on a moving camera
-            // (> 4 -> one level coarser, < 1.6 -> one level finer: a level step changes the ratio by less
-            // than the gap between the two thresholds; stepping from the level THIS frame ran at, so that
-            // several frames in flight do not step twice)
+            // Outside [1.6, 4] the level moves — straight to the level the frame's own geometry asks for, so
+            // that a change of scene is followed within one completed frame even with six frames in flight: a
+            // splat of s supertile edges overlaps (s + 1)^2 supertiles on average, so sqrt(ratio) - 1 is the
+            // typical splat extent in edges of THIS frame's level, and the finest level whose edge is at least
+            // that extent keeps the ratio under 4. (Stepping is relative to the level this frame ran at, not
+            // to ctx->sup_level, which frames completed in the meantime may already have moved.)
             const uint64_t v = h.visible_count;
             const uint32_t lv = L.pending_level;
-            if (10 * total > 40 * v && lv < 3) {
-                if (ctx->sup_level != lv + 1) ctx->coarse_cap_hint = std::min<uint64_t>((uint64_t)ctx->coarse_cap_hint * 2, 1u << 30);
-                ctx->sup_level = lv + 1;
-            } else if (10 * total < 16 * v && lv > 0) {
-                ctx->sup_level = lv - 1;
+            const double ratio = (double)total / (double)v;
+            if ((ratio > 4.0 && lv < 3) || (ratio < 1.6 && lv > 0)) {
+                const double extent_tiles = (std::sqrt(ratio) - 1.0) * (double)L.pending_edges[lv];
+                uint32_t target = 3;
+                for (uint32_t k = 0; k < 4; ++k)
+                    if ((double)L.pending_edges[k] >= extent_tiles) { target = k; break; }
+                if (ratio > 4.0) target = std::max(target, lv + 1);
+                else target = std::min(target, lv - 1);
+                if (target > lv && ctx->sup_level != target) {
+                    // coarser supertiles hold longer lists: entries scale with the ratio, lists with the area
+                    const double e0 = (double)L.pending_edges[lv], e1 = (double)L.pending_edges[target];
+                    const double r1 = (extent_tiles / e1 + 1.0) * (extent_tiles / e1 + 1.0);
+                    const double longer = (r1 / ratio) * (e1 / e0) * (e1 / e0);
+                    const uint64_t want2 = pow2_ceil((uint64_t)((double)ctx->coarse_cap_hint * std::max(longer, 1.0)));
+                    ctx->coarse_cap_hint = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want2, ctx->coarse_cap_hint), 1u << 30);
+                }
+                ctx->sup_level = target;
             }
         }
 
@@ -678,7 +693,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     const bool guess = (ctx->debug_flags & 0x200000u) != 0u;
     bool bucket = places == 4 && n > 0 && !(ctx->debug_flags & 0x80000u) && ctx->bucket_block == 0 &&
                   ((ctx->splitters_valid && ctx->draw_hint_valid) || guess) &&
-                  (!ctx->draw_hint_valid || ctx->draw_hint <= BUCKET_COUNT * (BUCKET_CAP / 8u) * 5u);
+                  (!ctx->draw_hint_valid || ctx->draw_hint <= BUCKET_COUNT * (BUCKET_CAP / 4u) * 3u);
     if (ctx->bucket_block > 0 && places == 4) ctx->bucket_block -= 1;
     if (bucket) {
         fp.sort_path = 1u;
@@ -949,6 +964,8 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     L.pending_bucket = bucket;
     L.pending_coarse_cap = coarse_cap;
     L.pending_level = level;
+    L.pending_edges[0] = edge_f;
+    for (uint32_t k = 1; k < 4; ++k) L.pending_edges[k] = std::min<uint32_t>(edge_c << (k - 1u), 32u);
     L.pending_n = n;
     L.pending_places = places;
     L.pending_num_st = num_st;

@@ -83,7 +83,7 @@ struct RecordSurfel {
     float m00, m11;     // uv = (m00*dx, m11*dy) (axis-aligned square quad)
     float radius;       // input.radius (both components equal), half-pixel units
     float mean_x, mean_y;
-    float T[9];         // local_to_pixel columns u, v, w
+    float T[9];         // A = T1 x T2, B = T2 x T0, C = T0 x T1 of local_to_pixel's columns (render_kernels.hip: stage_surfel)
     float r, g, b, a;
     uint32_t rect;
     uint32_t pad[3];

@@ -151,9 +151,18 @@ __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const Cl
     if constexpr (SURFEL) {
         float4* dst = records + (size_t)j * 6u;
         dst[0] = make_float4(pr.quad.cx, pr.quad.cy, pr.p[0], pr.p[1]);
-        dst[1] = make_float4(pr.radius, pr.surfel.mean_x, pr.surfel.mean_y, pr.surfel.T[0]);
-        dst[2] = make_float4(pr.surfel.T[1], pr.surfel.T[2], pr.surfel.T[3], pr.surfel.T[4]);
-        dst[3] = make_float4(pr.surfel.T[5], pr.surfel.T[6], pr.surfel.T[7], pr.surfel.T[8]);
+        // the fragment stage's ray-surfel intersection p = (pcx T2 - T0) x (pcy T2 - T1) is affine in the
+        // pixel: p = pcx (T1 x T2) + pcy (T2 x T0) + T0 x T1 (stage_surfel). The three cross products are
+        // formed here, once per splat and in double (they cancel for surfels seen edge-on), and travel in
+        // the record in place of local_to_pixel.
+        const double T0x = pr.surfel.T[0], T0y = pr.surfel.T[1], T0z = pr.surfel.T[2];
+        const double T1x = pr.surfel.T[3], T1y = pr.surfel.T[4], T1z = pr.surfel.T[5];
+        const double T2x = pr.surfel.T[6], T2y = pr.surfel.T[7], T2z = pr.surfel.T[8];
+        dst[1] = make_float4(pr.radius, pr.surfel.mean_x, pr.surfel.mean_y, (float)(T1y * T2z - T1z * T2y));
+        dst[2] = make_float4((float)(T1z * T2x - T1x * T2z), (float)(T1x * T2y - T1y * T2x),
+                             (float)(T2y * T0z - T2z * T0y), (float)(T2z * T0x - T2x * T0z));
+        dst[3] = make_float4((float)(T2x * T0y - T2y * T0x), (float)(T0y * T1z - T0z * T1y),
+                             (float)(T0z * T1x - T0x * T1z), (float)(T0x * T1y - T0y * T1x));
         dst[4] = make_float4(pr.color[0], pr.color[1], pr.color[2], pr.color[3]);
         dst[5] = make_float4(__uint_as_float(rect), 0.0f, 0.0f, 0.0f);
     } else {
@@ -538,7 +547,7 @@ constexpr float T_EPS = 1.0f / 65536.0f;  // stop compositing a pixel below this
 // One staged record, decoded once per splat and shared by every pixel a lane owns.
 template <int VARIANT>
 struct StagedRecord {
-    float4 a0, a1, a2, a3, a4;
+    float4 a0, a1, a2, a3, a4, a5;
     __device__ __forceinline__ void load(const float4* __restrict__ rec) {
         a0 = rec[0];
         a1 = rec[1];
@@ -546,6 +555,7 @@ struct StagedRecord {
         if constexpr (VARIANT == 2) {
             a3 = rec[3];
             a4 = rec[4];
+            a5 = rec[5];
         }
     }
 };
@@ -564,6 +574,40 @@ __device__ __forceinline__ void stage_obb(float4& r0, float4& r1, const float ox
     r0 = make_float4(fmaf(m01, dy, m00 * dx), fmaf(m11, dy, m10 * dx), m00, m01);
     r1.x = m10;
     r1.y = m11;
+}
+
+// 2DGS surfel records (AABB quad, gaussian.wgsl:440-455 + gaussian_2d.wgsl:134-156) are re-expressed at
+// staging time too. The fragment stage intersects the pixel's ray with the surfel as
+//     p = (pcx T2 - T0) x (pcy T2 - T1) = pcx (T1 x T2) + pcy (T2 x T0) + T0 x T1,   (us, vs) = p.xy / p.z
+// and pcx = u radius + mean.x, pcy = v radius aspect + mean.y are affine in the pixel, so p is an affine
+// vec3 function of the pixel's position (xl, yl) inside the tile: p = P0 + Px xl + Py yl. The cross products
+// come with the record (formed once per splat, in double, by project_rank); P0, Px, Py are formed here ONCE per
+// record and tile, and a pixel then costs three FMAs and one reciprocal instead of six FMAs and a cross
+// product (where a ray grazes the surfel plane p.z cancels in either form; the oracle's ambiguity bound covers it). Constants are folded as for OBB:
+//     exp(-0.5 min(s3, s2)) = exp2(-min(c^2 s3, c^2 s2)), c^2 = 0.5 log2(e): p.xy carry c, the deltas sqrt(2) c.
+// Staged layout (6 x float4):
+//   a0 = U0 du V0 dv          u = fma(du, xl, U0), v = fma(dv, yl, V0): the quad's own uv (coverage)
+//   a1 = P0x P0y P0z Pxx | a2 = Pxy Pxz Pyx Pyy | a3 = Pyz Dx0 dDx Dy0 | a4 = dDy r g b | a5 = opacity keep - -
+// Both rasterisers stage through this function, so their images stay bit-identical.
+__device__ __forceinline__ void stage_surfel(const float4* __restrict__ src, const float ox, const float oy,
+                                             const float aspect, float4 out[6]) {
+    // record: cx cy m00 m11 | radius mean.x mean.y A.x | A.y A.z B.x B.y | B.z C.x C.y C.z | rgba
+    // with A = T1 x T2, B = T2 x T0, C = T0 x T1 (project_rank)
+    const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3], r4 = src[4];
+    const float Ax = r1.w, Ay = r2.x, Az = r2.y, Bx = r2.z, By = r2.w, Bz = r3.x, Cx = r3.y, Cy = r3.z, Cz = r3.w;
+    const float U0 = r0.z * (ox - r0.x), V0 = r0.w * (oy - r0.y);  // uv = (m00 dx, m11 dy) at the tile's first pixel
+    const float radius = r1.x;
+    const float ax = r0.z * radius, bx = fmaf(U0, radius, r1.y);                         // pcx = ax xl + bx
+    const float ay = r0.w * radius * aspect, by = fmaf(V0 * radius, aspect, r1.z);       // pcy = ay yl + by
+    constexpr float C1 = 0.84932180028801907f;   // sqrt(0.5 * log2(e))
+    constexpr float C2 = 1.2011224087864498f;    // sqrt(2) * C1
+    out[0] = make_float4(U0, r0.z, V0, r0.w);
+    out[1] = make_float4(C1 * fmaf(Ax, bx, fmaf(Bx, by, Cx)), C1 * fmaf(Ay, bx, fmaf(By, by, Cy)),
+                         fmaf(Az, bx, fmaf(Bz, by, Cz)), C1 * Ax * ax);
+    out[2] = make_float4(C1 * Ay * ax, Az * ax, C1 * Bx * ay, C1 * By * ay);
+    out[3] = make_float4(Bz * ay, C2 * (r1.y - bx), -C2 * ax, C2 * (r1.z - by));
+    out[4] = make_float4(-C2 * ay, r4.x, r4.y, r4.z);
+    out[5] = make_float4(r4.w, 0.0f, 0.0f, 0.0f);
 }
 
 // fs_main + blend for ONE record and ONE pixel (src/render/gaussian.wgsl:438-505,
@@ -598,33 +642,25 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
         alpha = fminf(__expf(power) * s.a2.z, 0.999f);
         r = s.a1.w; g = s.a2.x; b = s.a2.y;
     } else {
-        // a0 = cx cy m00 m11 | a1 = radius mean.xy T0 | a2 = T1..T4 | a3 = T5..T8 | a4 = rgba
-        const float dx = qx - s.a0.x, dy = qy - s.a0.y;
-        const float u = s.a0.z * dx, v = s.a0.w * dy;
+        // staged by stage_surfel; (qx, qy) is the pixel's position INSIDE the tile (0..15)
+        const float u = fmaf(s.a0.y, qx, s.a0.x), v = fmaf(s.a0.w, qy, s.a0.z);
         hit = fmaxf(fabsf(u), fabsf(v)) <= 1.0f;
-        // fs_main GAUSSIAN_2D + USE_AABB (gaussian.wgsl:440-455), aspect = (1, W/H)
-        const float pcx = fmaf(u, s.a1.x, s.a1.y);
-        const float pcy = fmaf(v * s.a1.x, aspect, s.a1.z);
-        // surfel_fragment_power (gaussian_2d.wgsl:134-156)
-        const float T0x = s.a1.w, T0y = s.a2.x, T0z = s.a2.y;
-        const float T1x = s.a2.z, T1y = s.a2.w, T1z = s.a3.x;
-        const float T2x = s.a3.y, T2y = s.a3.z, T2z = s.a3.w;
-        const float hux = fmaf(pcx, T2x, -T0x), huy = fmaf(pcx, T2y, -T0y), huz = fmaf(pcx, T2z, -T0z);
-        const float hvx = fmaf(pcy, T2x, -T1x), hvy = fmaf(pcy, T2y, -T1y), hvz = fmaf(pcy, T2z, -T1z);
-        const float cpx = fmaf(huy, hvz, -(hvy * huz));
-        const float cpy = fmaf(huz, hvx, -(hvz * hux));
-        const float cpz = fmaf(hux, hvy, -(hvx * huy));
-        // one reciprocal instead of two IEEE divisions (~20 fewer instructions per pixel; v_rcp_f32 is
-        // good to 1 ulp, far inside the 1e-3 tolerance of the image)
-        const float icz = __builtin_amdgcn_rcpf(cpz);
-        const float us = cpx * icz, vs = cpy * icz;
-        const float ddx = s.a1.y - pcx, ddy = s.a1.z - pcy;
+        // surfel_fragment_power (gaussian_2d.wgsl:134-156): p = P0 + Px xl + Py yl, the x part is shared
+        // by the pixels of a lane
+        const float px = fmaf(s.a2.z, qy, fmaf(s.a1.w, qx, s.a1.x));
+        const float py = fmaf(s.a2.w, qy, fmaf(s.a2.x, qx, s.a1.y));
+        const float pz = fmaf(s.a3.x, qy, fmaf(s.a2.y, qx, s.a1.z));
+        // one reciprocal instead of two IEEE divisions (v_rcp_f32 is good to 1 ulp, far inside the 1e-3
+        // tolerance of the image)
+        const float icz = __builtin_amdgcn_rcpf(pz);
+        const float us = px * icz, vs = py * icz;
+        const float ddx = fmaf(s.a3.z, qx, s.a3.y), ddy = fmaf(s.a4.x, qy, s.a3.w);
         const float s3 = fmaf(us, us, vs * vs);
-        const float s2 = 2.0f * fmaf(ddx, ddx, ddy * ddy);
-        const float power = -0.5f * fminf(s3, s2);
-        hit = hit && !(power > 0.0f);
-        alpha = fminf(__expf(power) * s.a4.w, 0.999f);
-        r = s.a4.x; g = s.a4.y; b = s.a4.z;
+        const float s2 = fmaf(ddx, ddx, ddy * ddy);
+        // power = -0.5 min(sigmas_3d, sigmas_2d) <= 0 always (fs_main's `power > 0` discard never fires; a NaN
+        // goes through min / exp as in the reference's expression)
+        alpha = fminf(__builtin_amdgcn_exp2f(-fminf(s3, s2)) * s.a5.x, 0.999f);
+        r = s.a4.y; g = s.a4.z; b = s.a4.w;
     }
     // a real branch on purpose: it becomes an exec-mask region that a wave skips entirely when none
     // of its 64 pixels (a 16x4 strip in the wave-per-tile rasteriser) is covered
@@ -674,9 +710,9 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     const int tid = threadIdx.x;
     const int px = (int)tx * TILE_PX + (tid & 15), py = (int)ty * TILE_PX + (tid >> 4);
     const bool in_image = px < fp.width && py < fp.height;
-    // OBB records are staged tile-local (stage_obb): the pixel is addressed inside its tile
-    const float qx = VARIANT == RV_OBB ? (float)(tid & 15) : (float)px + 0.5f;
-    const float qy = VARIANT == RV_OBB ? (float)(tid >> 4) : (float)py + 0.5f;
+    // OBB and surfel records are staged tile-local (stage_obb / stage_surfel): the pixel is addressed inside its tile
+    const float qx = VARIANT != RV_AABB3D ? (float)(tid & 15) : (float)px + 0.5f;
+    const float qy = VARIANT != RV_AABB3D ? (float)(tid >> 4) : (float)py + 0.5f;
     const float tile_ox = (float)((int)tx * TILE_PX) + 0.5f, tile_oy = (float)((int)ty * TILE_PX) + 0.5f;
     const float aspect = fp.viewport_w / fp.viewport_h;
 
@@ -694,6 +730,11 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
                 s_rec[tid * REC_V4 + 0] = r0;
                 s_rec[tid * REC_V4 + 1] = r1;
                 s_rec[tid * REC_V4 + 2] = src[2];
+            } else if constexpr (VARIANT == RV_SURFEL) {
+                float4 st[6];
+                stage_surfel(src, tile_ox, tile_oy, aspect, st);
+#pragma unroll
+                for (int v = 0; v < 6; ++v) s_rec[tid * REC_V4 + v] = st[v];
             } else {
 #pragma unroll
                 for (int v = 0; v < REC_V4; ++v) s_rec[tid * REC_V4 + v] = src[v];
@@ -727,7 +768,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 // __launch_bounds__(256, 8): 8 waves/SIMD (<= 64 VGPRs). A 1080p frame is 8160 one-wave tiles for
 // 1024 SIMDs x 8 slots, so at 7 waves/SIMD a second, nearly empty round of waves appears.
 template <int VARIANT>
-__global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
+__global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_mul,
                                                           uint32_t sup_x, Control* ctl,
@@ -736,7 +777,10 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
                                                           FrameCleanup cl) {
     const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
-    __shared__ float4 s_rec_all[4][64 * REC_V4];
+    // records staged per round: 64 (the whole queue) for the 48-byte records; 32 for the 96-byte surfel
+    // records, so that eight workgroups' LDS (4 x 3 KB each) still fit a CU and the kernel keeps 8 waves/SIMD
+    constexpr uint32_t STAGE = VARIANT == RV_SURFEL ? 32u : 64u;
+    __shared__ float4 s_rec_all[4][STAGE * REC_V4];
     __shared__ uint32_t s_queue_all[4][64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -785,8 +829,8 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
 
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
     const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + (lane >> 4);
-    // OBB records are staged tile-local (stage_obb): pixels are then addressed inside the tile
-    const float qx = VARIANT == RV_OBB ? (float)(lane & 15) : (float)px + 0.5f;
+    // OBB and surfel records are staged tile-local (stage_obb / stage_surfel): pixels are then addressed inside the tile
+    const float qx = VARIANT != RV_AABB3D ? (float)(lane & 15) : (float)px + 0.5f;
     const float aspect = fp.viewport_w / fp.viewport_h;
     const float tile_cx = (float)((int)tx * TILE_PX + 8), tile_cy = (float)((int)ty * TILE_PX + 8);
     const float tile_ox = (float)((int)tx * TILE_PX) + 0.5f, tile_oy = (float)((int)ty * TILE_PX) + 0.5f;
@@ -795,7 +839,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int py = py0 + 4 * r;
-        qy[r] = VARIANT == RV_OBB ? (float)((lane >> 4) + 4 * r) : (float)py + 0.5f;
+        qy[r] = VARIANT != RV_AABB3D ? (float)((lane >> 4) + 4 * r) : (float)py + 0.5f;
         T[r] = (px < fp.width && py < fp.height) ? 1.0f : 0.0f;
         cr[r] = cg[r] = cb[r] = 0.0f;
     }
@@ -840,9 +884,12 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
         if (qn && (qn >= FLUSH_AT || !fits || end) && !(fp.debug & 32u)) {  // ablation bit 32: scan only
             const uint32_t cnt = qn;
             qn = 0u;
+            bool saturated = false;
+            for (uint32_t c0 = 0u; c0 < cnt && !saturated; c0 += STAGE) {
+            const uint32_t ccnt = min(STAGE, cnt - c0);
             __builtin_amdgcn_wave_barrier();
-            if ((uint32_t)lane < cnt) {
-                const float4* src = records + (size_t)s_queue[lane] * REC_V4;
+            if ((uint32_t)lane < ccnt) {
+                const float4* src = records + (size_t)s_queue[c0 + (uint32_t)lane] * REC_V4;
                 float4 r0 = src[0], r1 = src[1];
                 // exact test the tile rect cannot do: the quad is the parallelogram |u|,|v| <= 1, so
                 // it misses the tile iff the tile's pixel-centre box lies wholly beyond one of its
@@ -864,42 +911,45 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 4 : 8) void raster_scan_kernel(
                     keep = !(fabsf(uc) - eu > 1.0001f) && !(fabsf(vc) - ev > 1.0001f);
                 }
                 keep = keep || (fp.debug & 64u);
-                s_rec[lane * REC_V4 + 0] = r0;
                 if constexpr (VARIANT == RV_OBB) {
+                    s_rec[lane * REC_V4 + 0] = r0;
                     r1.z = __uint_as_float(keep ? 1u : 0u);  // p[4] is unused by the OBB record
                     s_rec[lane * REC_V4 + 1] = r1;
                     s_rec[lane * REC_V4 + 2] = src[2];
-                } else {
+                } else if constexpr (VARIANT == RV_AABB3D) {
+                    s_rec[lane * REC_V4 + 0] = r0;
                     s_rec[lane * REC_V4 + 1] = r1;
                     float4 r2 = src[2];
-                    if constexpr (VARIANT == RV_AABB3D) r2.w = __uint_as_float(keep ? 1u : 0u);  // rect dword
+                    r2.w = __uint_as_float(keep ? 1u : 0u);  // rect dword
                     s_rec[lane * REC_V4 + 2] = r2;
+                } else {
+                    float4 st[6];
+                    stage_surfel(src, tile_ox, tile_oy, aspect, st);
+                    st[5].y = __uint_as_float(keep ? 1u : 0u);
 #pragma unroll
-                    for (int v = 3; v < REC_V4; ++v) {
-                        float4 rr = src[v];
-                        if (v == 5) rr.y = __uint_as_float(keep ? 1u : 0u);  // surfel: pad dword
-                        s_rec[lane * REC_V4 + v] = rr;
-                    }
+                    for (int v = 0; v < 6; ++v) s_rec[lane * REC_V4 + v] = st[v];
                 }
             }
             // make the staged records visible to every lane of this wave before the broadcast reads
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t kend = (fp.debug & 16u) ? min(cnt, 1u) : cnt;  // ablation bit 16: stage, blend 1
+            const uint32_t kend = (fp.debug & 16u) ? min(ccnt, 1u) : ccnt;  // ablation bit 16: stage, blend 1
             for (uint32_t k = 0; k < kend; ++k) {
                 StagedRecord<VARIANT> sr;
                 sr.load(s_rec + k * REC_V4);
                 uint32_t keep_flag;
                 if constexpr (VARIANT == RV_OBB) keep_flag = __float_as_uint(sr.a1.z);
                 else if constexpr (VARIANT == RV_AABB3D) keep_flag = __float_as_uint(sr.a2.w);
-                else keep_flag = __float_as_uint(s_rec[k * REC_V4 + 5].y);
+                else keep_flag = __float_as_uint(sr.a5.y);
                 if (__builtin_amdgcn_readfirstlane(keep_flag) == 0u) continue;  // scalar branch
 #pragma unroll
                 for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, T[r], cr[r], cg[r], cb[r]);
             }
             const bool sat = T[0] < T_EPS && T[1] < T_EPS && T[2] < T_EPS && T[3] < T_EPS;
-            if (__all(sat)) break;
+            saturated = __all(sat);
+            }
+            if (saturated) break;
             __builtin_amdgcn_wave_barrier();  // blend reads of s_rec / s_queue done before they are rewritten
         }
         if (fp.debug & 32u) qn = 0u;

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevy_gaussian_splatting_amd import (CloudSettings, GaussianMode, GaussianSplattingPlugin, View,
                                          random_gaussians_3d_seeded)
 
-def run(p, h, v, s, steps=60, warm=8, depth=6):
+def run(p, h, v, s, steps=60, warm=30, depth=6):
     # throughput with `depth` lanes (on the default 3 streams), no stage events in the timed loop
     p.set_async(True); p.set_pipeline_depth(depth); p.set_profiling(0)
     for _ in range(warm): p.render(h, v, s, download=False)
@@ -29,7 +29,8 @@ def run(p, h, v, s, steps=60, warm=8, depth=6):
     p.set_async(False)
     return {"frames_per_s": round(steps / dt, 1), "single_stream_frames_per_s": round(steps / dt1, 1),
             "single_stream_stage_ms": {k: round(x, 4) for k, x in st1["stage_ms"].items() if x},
-            "visible_splats": st["visible_count"], "coarse_entries": st["instance_count"]}
+            "visible_splats": st["visible_count"], "coarse_entries": st["instance_count"], "sort_path": st["sort_path"],
+            "list_capacity": st["list_capacity"], "reruns": st["regrow_count"]}
 
 out = {}
 p = GaussianSplattingPlugin(0)
@@ -37,12 +38,12 @@ c = random_gaussians_3d_seeded(10_000, 1); h = p.upload(c)
 out["cfg0_10k_256x256"] = run(p, h, View.headless(256, 256), CloudSettings()); h.free()
 c = random_gaussians_3d_seeded(5_000_000, 3).to_f16(); h = p.upload(c)
 for gs in (1.0, 0.05):
-    out[f"cfg2_5M_f16_1080p_gs{gs}"] = run(p, h, View.headless(1920, 1080), CloudSettings(global_scale=gs), steps=20)
+    out[f"cfg2_5M_f16_1080p_gs{gs}"] = run(p, h, View.headless(1920, 1080), CloudSettings(global_scale=gs), steps=40)
 h.free()
 c = random_gaussians_3d_seeded(1_000_000, 4); h = p.upload(c)
 for name, kw in (("surfel_aabb", {"aabb": True}), ("obb", {})):
     for gs in (1.0, 0.05):
         s = CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, global_scale=gs, **kw)
-        out[f"cfg3_1M_2dgs_{name}_gs{gs}"] = run(p, h, View.headless(1920, 1080), s, steps=20)
+        out[f"cfg3_1M_2dgs_{name}_gs{gs}"] = run(p, h, View.headless(1920, 1080), s, steps=40)
 h.free()
 print(json.dumps(out, indent=1))
