@@ -62,6 +62,7 @@ EXPORTED_SYMBOLS = (
     "bgs_set_graphs",
     "bgs_graph_counters",
     "bgs_reset_adaptive_state",
+    "bgs_cloud_upload_cov3d_f32",
 )
 
 
@@ -188,6 +189,9 @@ def load() -> ctypes.CDLL:
     lib.bgs_set_graphs.restype = ctypes.c_int
     lib.bgs_graph_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.bgs_graph_counters.restype = ctypes.c_int
+    lib.bgs_cloud_upload_cov3d_f32.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(vp)]
+    lib.bgs_cloud_upload_cov3d_f32.restype = ctypes.c_int
     lib.bgs_reset_adaptive_state.argtypes = [vp]
     lib.bgs_reset_adaptive_state.restype = ctypes.c_int
     _lib = lib

@@ -430,6 +430,9 @@ int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
     if (s->draw_mode > BGS_DRAW_HIGHLIGHT_SELECTED) return fail(ctx, BGS_EINVAL, "unknown draw_mode");
     if (s->rasterize_mode == BGS_RASTERIZE_CLASSIFICATION && s->num_classes == 0)
         return fail(ctx, BGS_EINVAL, "num_classes must be >= 1");
+    if (render && cloud->ptrs.is_f16 == CLOUD_COV3D &&
+        (s->gaussian_mode != BGS_GAUSSIAN_3D || s->rasterize_mode == BGS_RASTERIZE_NORMAL))
+        return fail(ctx, BGS_EINVAL, "a precomputed-covariance cloud has no rotation / scale: 3D gaussian mode only, no Normal raster mode");
     if (render) {
         const float w = view->viewport[2], h = view->viewport[3];
         if (!(w >= 1.0f) || !(h >= 1.0f) || w > 4096.0f || h > 4096.0f || w != std::floor(w) || h != std::floor(h))
@@ -587,7 +590,7 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             const uint64_t N = n, k = places, D = h.draw_count;
             uint64_t bytes = N * 16 + N * 8 + (L.pending_bucket ? D * 24 : k * D * 16);
             if (render) {
-                const uint64_t B = L.pending_is_f16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
+                const uint64_t B = L.pending_is_f16 == CLOUD_F16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
                 const uint64_t P = (uint64_t)L.pending_w * L.pending_h;
                 if (scan)  // coarse entries (rank + tile rect, 8 B): written once, read by the tiles of their supertile
                     bytes += V * (B - 16) + V * R + V * 8 + I * 8 + I * 8 + P * 16;
@@ -1188,6 +1191,32 @@ int bgs_cloud_upload_f16(bgs_ctx* ctx, uint32_t n, const float* pv, const uint32
     c->ptrs.rot_scale_opacity_f16 = (const uint4*)c->allocs[2];
     c->ptrs.n = n;
     c->ptrs.is_f16 = 1;
+    *out = c;
+    return BGS_OK;
+}
+
+int bgs_cloud_upload_cov3d_f32(bgs_ctx* ctx, uint32_t n, const float* pv, const float* sh, const float* cov3d_opacity,
+                               bgs_cloud** out) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    if (!out) return fail(ctx, BGS_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n > MAX_SPLATS) return fail(ctx, BGS_EINVAL, "too many splats");
+    if (n && (!pv || !sh || !cov3d_opacity)) return fail(ctx, BGS_EINVAL, "NULL plane pointer");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
+    bgs_cloud* c = new (std::nothrow) bgs_cloud();
+    if (!c) return fail(ctx, BGS_ENOMEM, "out of host memory");
+    const void* src[3] = {pv, sh, cov3d_opacity};
+    const size_t bytes[3] = {(size_t)n * 16, (size_t)n * 192, (size_t)n * 32};
+    for (int i = 0; i < 3; ++i) {
+        int rc = upload_plane(ctx, src[i], bytes[i], &c->allocs[i]);
+        if (rc != BGS_OK) { bgs_cloud_free(ctx, c); return rc; }
+        c->bytes += bytes[i];
+    }
+    c->ptrs.position_visibility = (const float4*)c->allocs[0];
+    c->ptrs.sh_f32 = (const float*)c->allocs[1];
+    c->ptrs.cov3d_opacity = (const float4*)c->allocs[2];
+    c->ptrs.n = n;
+    c->ptrs.is_f16 = CLOUD_COV3D;
     *out = c;
     return BGS_OK;
 }

@@ -16,9 +16,11 @@ struct CloudPtrs {
     const float4* scale_opacity;        // n         (f32 format)
     const uint32_t* sh_f16;             // n*24      (f16 format)
     const uint4* rot_scale_opacity_f16; // n         (f16 format)
+    const float4* cov3d_opacity;        // n*2       (cov3d format: Covariance3dOpacity = cov3d[6], opacity, pad)
     uint32_t n;
-    uint32_t is_f16;
+    uint32_t is_f16;                    // cloud format: 0 = f32 planes, 1 = f16 planes, 2 = f32 with precomputed covariance
 };
+constexpr uint32_t CLOUD_F32 = 0, CLOUD_F16 = 1, CLOUD_COV3D = 2;
 
 // What the rasteriser of a BINNING_SCAN frame tidies up so that the NEXT frame of the same lane needs
 // neither a memset of the scratch region nor a device-to-host copy of the Control block (each a

@@ -117,15 +117,21 @@ __device__ __forceinline__ ColorInputs frame_color_inputs(const FrameParams& fp,
     return ci;
 }
 
-template <bool F16, bool SURFEL, bool ANY_MODE>
+template <int FMT, bool SURFEL, bool ANY_MODE>
 __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const CloudPtrs& cloud,
                                                  const uint2 entry, const uint32_t j,
                                                  float4* __restrict__ records, ColorInputs ci,
                                                  bool& visible) {
     const uint32_t si = entry.y;
     const float4 pv = cloud.position_visibility[si];
-    float rot[4], so[4];
-    if constexpr (F16) {
+    float rot[4], so[4], cov[6];
+    if constexpr (FMT == (int)CLOUD_COV3D) {
+        // Covariance3dOpacity (src/gaussian/f32.rs:218-251): cov3d[6], opacity, pad
+        const float4 c0 = cloud.cov3d_opacity[2u * si], c1 = cloud.cov3d_opacity[2u * si + 1u];
+        cov[0] = c0.x; cov[1] = c0.y; cov[2] = c0.z; cov[3] = c0.w; cov[4] = c1.x; cov[5] = c1.y;
+        rot[0] = 1.0f; rot[1] = rot[2] = rot[3] = 0.0f;
+        so[0] = so[1] = so[2] = 0.0f; so[3] = c1.z;
+    } else if constexpr (FMT == (int)CLOUD_F16) {
         // src/render/planar.wgsl:154-176: first value of each pair in the HIGH half
         const uint4 raw = cloud.rot_scale_opacity_f16[si];
         rot[0] = half_hi(raw.x); rot[1] = half_lo(raw.x);
@@ -140,8 +146,10 @@ __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const Cl
     }
     Projected pr;
     ci.visibility = pv.w;
-    if constexpr (F16)
+    if constexpr (FMT == (int)CLOUD_F16)
         project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF16{cloud.sh_f16 + (size_t)si * 24u}, ci, pr);
+    else if constexpr (FMT == (int)CLOUD_COV3D)
+        project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{cloud.sh_f32 + (size_t)si * 48u}, ci, pr, cov);
     else
         project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{cloud.sh_f32 + (size_t)si * 48u}, ci, pr);
     visible = pr.visible;
@@ -177,7 +185,7 @@ __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const Cl
 // ---------------------------------------------------------------------------------------
 // BINNING_SORT: project + ordered instance emission
 // ---------------------------------------------------------------------------------------
-template <bool F16, bool SURFEL, bool ANY_MODE>
+template <int FMT, bool SURFEL, bool ANY_MODE>
 __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, CloudPtrs cloud,
                                                            const uint2* __restrict__ draw_list,
                                                            const uint2* __restrict__ culled,
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
         if (j < count) {
             // the LAST entry of the draw list is drawn on top => it is the front-most
             bool vis;
-            const uint32_t r = project_rank<F16, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis);
+            const uint32_t r = project_rank<FMT, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis);
             visible_acc += vis ? 1u : 0u;
             if (r != RECT_EMPTY) {
                 rect = r;
@@ -322,10 +330,12 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
                        ticket_slot)
 #define BGS_LAUNCH_PE2(F16, SURFEL) \
     do { if (any_mode) BGS_LAUNCH_PE(F16, SURFEL, true); else BGS_LAUNCH_PE(F16, SURFEL, false); } while (0)
-    if (cloud.is_f16) {
-        if (surfel) BGS_LAUNCH_PE2(true, true); else BGS_LAUNCH_PE2(true, false);
+    if (cloud.is_f16 == CLOUD_F16) {
+        if (surfel) BGS_LAUNCH_PE2(1, true); else BGS_LAUNCH_PE2(1, false);
+    } else if (cloud.is_f16 == CLOUD_COV3D) {
+        BGS_LAUNCH_PE2(2, false);  // 2DGS needs rotation and scale: refused for these clouds (validate)
     } else {
-        if (surfel) BGS_LAUNCH_PE2(false, true); else BGS_LAUNCH_PE2(false, false);
+        if (surfel) BGS_LAUNCH_PE2(0, true); else BGS_LAUNCH_PE2(0, false);
     }
 #undef BGS_LAUNCH_PE2
 #undef BGS_LAUNCH_PE
@@ -334,7 +344,7 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
 // ---------------------------------------------------------------------------------------
 // BINNING_SCAN: project + ordered coarse binning (supertile lists), one pass
 // ---------------------------------------------------------------------------------------
-template <bool F16, bool SURFEL, bool ANY_MODE>
+template <int FMT, bool SURFEL, bool ANY_MODE>
 __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __restrict__ fpp, CloudPtrs cloud,
                                                           const uint2* __restrict__ draw_list,
                                                           const uint2* __restrict__ culled,
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
             if (fp.debug & 1u) {  // ablation: no projection, a fixed 2x1-tile rectangle
                 rect = 0x01000000u | (j & 63u) | (((j & 63u) + 1u) << 8);
             } else {
-                rect = project_rank<F16, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis);
+                rect = project_rank<FMT, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis);
             }
             visible_acc += vis ? 1u : 0u;
         }
@@ -512,10 +522,12 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
                        coarse_cap, sup_mul, sup_x, sup_y, ticket_slot)
 #define BGS_LAUNCH_PB2(F16, SURFEL) \
     do { if (any_mode) BGS_LAUNCH_PB(F16, SURFEL, true); else BGS_LAUNCH_PB(F16, SURFEL, false); } while (0)
-    if (cloud.is_f16) {
-        if (surfel) BGS_LAUNCH_PB2(true, true); else BGS_LAUNCH_PB2(true, false);
+    if (cloud.is_f16 == CLOUD_F16) {
+        if (surfel) BGS_LAUNCH_PB2(1, true); else BGS_LAUNCH_PB2(1, false);
+    } else if (cloud.is_f16 == CLOUD_COV3D) {
+        BGS_LAUNCH_PB2(2, false);  // 2DGS needs rotation and scale: refused for these clouds (validate)
     } else {
-        if (surfel) BGS_LAUNCH_PB2(false, true); else BGS_LAUNCH_PB2(false, false);
+        if (surfel) BGS_LAUNCH_PB2(0, true); else BGS_LAUNCH_PB2(0, false);
     }
 #undef BGS_LAUNCH_PB2
 #undef BGS_LAUNCH_PB

@@ -141,16 +141,25 @@ BGS_HD M3 scale_matrix(const float* scale, float gs) {
                    V3{0.0f, 0.0f, scale[2] * gs});
 }
 
-// src/render/gaussian_3d.wgsl:49-72 followed by src/render/helpers.wgsl:8-47
+// src/render/gaussian_3d.wgsl:49-72 followed by src/render/helpers.wgsl:8-47.
+// cov3d_pre != nullptr: the PRECOMPUTE_COVARIANCE_3D variant (gaussian_3d.wgsl:77-88, planar.wgsl:132-152):
+// the six covariance entries come from the cloud (Covariance3dOpacity, src/gaussian/f32.rs:218-251) and
+// compute_cov3d is skipped — with it the model transform's linear part and global_scale, which the
+// reference applies inside compute_cov3d only.
 BGS_HD void cov2d_3dgs(const FrameParams& fp, V3 position, const float* scale, const float* rot,
-                       float out[3]) {
-    M3 S = scale_matrix(scale, fp.global_scale);
-    M3 T = m3_from_m4(fp.transform);
-    M3 R = rotation_matrix(rot);
-    M3 M = m3_mul(S, R);
-    M3 Sigma = m3_mul(m3_transpose(M), M);
-    M3 TS = m3_mul(m3_mul(T, Sigma), m3_transpose(T));
-    const float c0 = TS.m[0], c1 = TS.m[1], c2 = TS.m[2], c3 = TS.m[4], c4 = TS.m[5], c5 = TS.m[8];
+                       const float* cov3d_pre, float out[3]) {
+    float c0, c1, c2, c3, c4, c5;
+    if (cov3d_pre) {
+        c0 = cov3d_pre[0]; c1 = cov3d_pre[1]; c2 = cov3d_pre[2]; c3 = cov3d_pre[3]; c4 = cov3d_pre[4]; c5 = cov3d_pre[5];
+    } else {
+        M3 S = scale_matrix(scale, fp.global_scale);
+        M3 T = m3_from_m4(fp.transform);
+        M3 R = rotation_matrix(rot);
+        M3 M = m3_mul(S, R);
+        M3 Sigma = m3_mul(m3_transpose(M), M);
+        M3 TS = m3_mul(m3_mul(T, Sigma), m3_transpose(T));
+        c0 = TS.m[0]; c1 = TS.m[1]; c2 = TS.m[2]; c3 = TS.m[4]; c4 = TS.m[5]; c5 = TS.m[8];
+    }
     M3 Vrk = m3_cols(V3{c0, c1, c2}, V3{c1, c3, c4}, V3{c2, c4, c5});
 
     V4 t = m4_mul_point(fp.view_from_world, position);
@@ -492,9 +501,11 @@ struct Projected {
 
 // ANY_MODE = false compiles the benchmarked RASTERIZE_COLOR path only (the mode tests fold away and
 // the kernel keeps its register budget); true honours fp.rasterize_mode.
+// cov3d_pre: the splat's precomputed covariance (six floats) or nullptr; with it rot / so[0..2] are unused.
 template <bool ANY_MODE, class ShFn>
 BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const float rot[4],
-                          const float so[4], ShFn sh, const ColorInputs& ci, Projected& o) {
+                          const float so[4], ShFn sh, const ColorInputs& ci, Projected& o,
+                          const float* cov3d_pre = nullptr) {
     const uint32_t mode = ANY_MODE ? fp.rasterize_mode : RASTERIZE_COLOR;
     o.visible = false;
     o.draw = false;
@@ -524,7 +535,7 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
         o.radius = bb[0][2];
     } else {                                                       // GAUSSIAN_3D :257-306
         float c2d[3];
-        cov2d_3dgs(fp, tp, so, rot, c2d);
+        cov2d_3dgs(fp, tp, so, rot, cov3d_pre, c2d);
 #pragma unroll
         for (int k = 0; k < 4; ++k) bounding_box_clip(fp, c2d, corners[k], cutoff, bb[k]);
         if (fp.aabb) {

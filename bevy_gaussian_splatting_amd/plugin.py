@@ -138,9 +138,23 @@ class GaussianSplattingPlugin:
         _native.check(self._lib, self._ctx, status)
 
     # -- cloud upload ----------------------------------------------------------------
-    def upload(self, cloud: Union[PlanarGaussian3d, PlanarGaussian3dF16]) -> PlanarGaussian3dHandle:
+    def upload(self, cloud: Union[PlanarGaussian3d, PlanarGaussian3dF16],
+               precompute_covariance_3d: bool = False) -> PlanarGaussian3dHandle:
+        """Make the cloud resident in HBM (the reference's asset upload). `precompute_covariance_3d`: store
+        the `Covariance3dOpacity` plane (src/gaussian/f32.rs:218-251) instead of rotation and scale, as the
+        reference's feature of that name does; the vertex stage then skips compute_cov3d."""
         out = ctypes.c_void_p()
         n = len(cloud)
+        if precompute_covariance_3d:
+            if not isinstance(cloud, PlanarGaussian3d):
+                raise TypeError("precompute_covariance_3d needs an f32 PlanarGaussian3d")
+            from .gaussian import covariance_3d_opacity
+            cov = np.ascontiguousarray(covariance_3d_opacity(cloud), np.float32)
+            self._check(
+                self._lib.bgs_cloud_upload_cov3d_f32(
+                    self._ctx, n, _fptr(cloud.position_visibility), _fptr(cloud.spherical_harmonic),
+                    _fptr(cov), ctypes.byref(out)))
+            return PlanarGaussian3dHandle(self, out, n, "cov3d", n * (16 + 192 + 32))
         if isinstance(cloud, PlanarGaussian3dF16):
             self._check(
                 self._lib.bgs_cloud_upload_f16(

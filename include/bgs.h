@@ -190,6 +190,15 @@ int bgs_cloud_upload_f32(bgs_ctx* ctx, uint32_t n, const float* position_visibil
 int bgs_cloud_upload_f16(bgs_ctx* ctx, uint32_t n, const float* position_visibility,
                          const uint32_t* spherical_harmonic_h2,
                          const uint32_t* rotation_scale_opacity, bgs_cloud** out);
+/* The `precompute_covariance_3d` storage variant (src/gaussian/f32.rs:218-251 Covariance3dOpacity,
+ * src/render/planar.wgsl:132-152, src/render/gaussian_3d.wgsl:77-88): instead of rotation and scale the
+ * cloud carries covariance_3d_opacity[n][8] = cov3d[6] (xx, xy, xz, yy, yz, zz of M^T M, M = S R:
+ * src/gaussian/covariance.rs:4-41), opacity, pad. The vertex stage then skips compute_cov3d — and with
+ * it the model transform's linear part and global_scale, which the reference applies only there.
+ * 3D gaussian mode only (BGS_EINVAL for 2DGS and for RasterizeMode::Normal: both need rotation / scale). */
+int bgs_cloud_upload_cov3d_f32(bgs_ctx* ctx, uint32_t n, const float* position_visibility,
+                               const float* spherical_harmonic, const float* covariance_3d_opacity,
+                               bgs_cloud** out);
 void bgs_cloud_free(bgs_ctx* ctx, bgs_cloud* cloud);
 uint32_t bgs_cloud_len(const bgs_cloud* cloud);
 

@@ -645,6 +645,34 @@ def test_supertile_list_overflow_reruns_the_frame(plugin, oracle):
     h.free()
 
 
+def test_precomputed_covariance_cloud(plugin, oracle):
+    """The `precompute_covariance_3d` storage variant (Covariance3dOpacity plane instead of rotation + scale,
+    src/gaussian/f32.rs:218-251, gaussian_3d.wgsl:77-88): with an identity model transform and global_scale 1
+    (the two things compute_cov3d folds in and the precomputed path therefore cannot see) it must draw what
+    the rotation / scale path draws — sort bit-exact, images equal to 1e-6 relative (the covariance entries
+    are formed on the host by the CPU twin of the shader's arithmetic), and agree with the oracle."""
+    c = random_gaussians_3d_seeded(30_000, 91)
+    v = View.headless(640, 360, yaw=0.2)
+    for kw in ({}, {"aabb": True}, {"sh_degree": 1, "opacity_adaptive_radius": False}):
+        s = CloudSettings(**kw)
+        h0, h1 = plugin.upload(c), plugin.upload(c, precompute_covariance_3d=True)
+        a, b = plugin.render(h0, v, s), plugin.render(h1, v, s)
+        e0, e1 = plugin.sort(h0, v, s), plugin.sort(h1, v, s)
+        assert np.array_equal(e0["key"], e1["key"]) and np.array_equal(e0["index"], e1["index"])
+        assert np.allclose(a, b, rtol=1e-6, atol=2e-6), np.abs(a - b).max()
+        ref, amb = oracle.render(c, oracle.sort(c, v, s), v, s, with_ambiguity=True)
+        _assert_image(ref, b, amb, frac_slack=0.01, what=f"cov3d cloud {kw}")
+        h0.free()
+    # what the variant cannot do is refused, not guessed
+    for bad in (CloudSettings(gaussian_mode=GaussianMode.Gaussian2d), CloudSettings(rasterize_mode=RasterizeMode.Normal)):
+        with pytest.raises(RuntimeError):
+            plugin.render(h1, v, bad)
+    # and it ignores global_scale / the transform's linear part, as the reference's shader variant does
+    s2 = CloudSettings(global_scale=0.5)
+    assert np.array_equal(plugin.render(h1, v, s2), plugin.render(h1, v, CloudSettings()))
+    h1.free()
+
+
 def test_async_frames_match_synchronous_frames(plugin, oracle):
     """bgs_set_async: frames are only enqueued; results and the watchdog check arrive at the next
     blocking call. Images must be bit-identical to the synchronous path."""
