@@ -8,7 +8,7 @@
 // Flags follow the reference's GaussianSplattingViewer args (src/utils.rs): --gaussian-count, --seed,
 // --width, --height; plus --frames, --output-dir, --depth (lanes in flight), and two hooks for the parity
 // test: --cloud <file> (u32 n, then the four f32 planes) and --dump-f32 <file> (the last frame, RGBA f32).
-// --input-cloud <file.ply> loads an INRIA .ply (the reference viewer's --input-cloud), --f16 uploads the cloud
+// --input-cloud <file.ply | file.gcloud> loads an INRIA .ply or a .gcloud container (the reference viewer's --input-cloud), --f16 uploads the cloud
 // in the f16 planar format.
 #include <chrono>
 #include <cstdio>
@@ -125,9 +125,7 @@ int main(int argc, char** argv) {
         bgs::GaussianSplattingPlugin plugin(0);
         bgs::PlanarGaussian3d cloud;
         if (!ply_path.empty()) {
-            std::ifstream in(ply_path, std::ios::binary);
-            if (!in) throw std::runtime_error("cannot open " + ply_path);
-            cloud = bgs::parse_ply_3d(in);
+            cloud = bgs::load_cloud(ply_path);  // .ply or .gcloud, like the reference's Gaussian3dLoader
         } else {
             cloud = cloud_path.empty() ? bgs::PlanarGaussian3d::random(count, seed) : read_planes(cloud_path);
         }

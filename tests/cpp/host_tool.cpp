@@ -1,6 +1,8 @@
 // Test driver for include/bgs_host.hpp (no GPU needed for these subcommands): tests/test_cpp_host.py
 // compares every output with the Python mirror.
 //   host_tool ply <in.ply> <out.bin>        parse_ply_3d -> u32 n + the four f32 planes
+//   host_tool cloud <in.ply|in.gcloud> <out.bin>   load_cloud (Gaussian3dLoader's dispatch) -> the same
+//   host_tool cov3d <planes.bin> <out.bin>  compute_covariance_3d -> Covariance3dOpacity rows (8 f32)
 //   host_tool f16 <planes.bin> <out.bin>    PlanarGaussian3dF16::from_f32 -> pv f32, sh u32[n][24], rso u32[n][4]
 //   host_tool half <in.f32> <out.u16>       f32_to_f16 of every value
 //   host_tool trigger <period_ms>           stdin: "t x y z order" per line -> "camera_index needs_sort" per line
@@ -39,7 +41,17 @@ static bgs::PlanarGaussian3d read_planes(const std::string& path) {
 int main(int argc, char** argv) {
     const std::string cmd = argc > 1 ? argv[1] : "";
     try {
-        if (cmd == "ply" && argc == 4) {
+        if (cmd == "cloud" && argc == 4) {  // load_cloud: the loader's dispatch on the extension (.ply / .gcloud)
+            write_planes(argv[3], bgs::load_cloud(argv[2]));
+        } else if (cmd == "cov3d" && argc == 4) {  // Covariance3dOpacity plane of a cloud
+            const auto c = read_planes(argv[2]);
+            std::ofstream f(argv[3], std::ios::binary);
+            for (size_t i = 0; i < c.size(); ++i) {
+                const auto s6 = bgs::compute_covariance_3d(c.rotation[i], {c.scale_opacity[i][0], c.scale_opacity[i][1], c.scale_opacity[i][2]});
+                const float row[8] = {s6[0], s6[1], s6[2], s6[3], s6[4], s6[5], c.scale_opacity[i][3], 0.0f};
+                f.write((const char*)row, 32);
+            }
+        } else if (cmd == "ply" && argc == 4) {
             std::ifstream in(argv[2], std::ios::binary);
             write_planes(argv[3], bgs::parse_ply_3d(in));
         } else if (cmd == "f16" && argc == 4) {

@@ -932,6 +932,37 @@ def test_ply_loaded_cloud_renders_like_the_oracle(plugin, oracle, binning, tmp_p
         h.free()
 
 
+def test_gcloud_loaded_cloud_renders_like_the_oracle(plugin, oracle, tmp_path):
+    """The `.gcloud` container on the hot path (src/io/gcloud/flexbuffers.rs:9-22, loader dispatch
+    src/io/loader.rs:22-61): encode -> file -> decode (the vectorised path, and the general reader on the same
+    bytes) -> upload -> sort + render, held to the oracle run on the ORIGINAL cloud — the codec is bit-exact
+    for f32 planes, so the round trip may not move a pixel. Parity of the byte format itself stays unpinned
+    (no reference-written file exists here)."""
+    from bevy_gaussian_splatting_amd.io_gcloud import decode_gcloud, read_gcloud, write_gcloud
+    c = random_gaussians_3d_seeded(6000, 21)
+    c.position_visibility[:, 3] = np.arange(len(c)) % 4
+    path = os.path.join(tmp_path, "cloud.gcloud")
+    write_gcloud(c, path)
+    loaded = read_gcloud(path)
+    with open(path, "rb") as f:
+        general = decode_gcloud(f.read(), fast=False)
+    for a, b, d in zip((c.position_visibility, c.spherical_harmonic, c.rotation, c.scale_opacity),
+                       (loaded.position_visibility, loaded.spherical_harmonic, loaded.rotation, loaded.scale_opacity),
+                       (general.position_visibility, general.spherical_harmonic, general.rotation, general.scale_opacity)):
+        assert np.array_equal(a, b) and np.array_equal(a, d)
+    v = View.headless(320, 180)
+    for kw in ({}, {"aabb": True, "rasterize_mode": RasterizeMode.Classification, "num_classes": 4}):
+        s = CloudSettings(**kw)
+        h = plugin.upload(loaded)
+        got = plugin.render(h, v, s)
+        e = oracle.sort(c, v, s)
+        gs = plugin.sort(h, v, s)
+        assert np.array_equal(gs["key"], e["key"]) and np.array_equal(gs["index"], e["index"])
+        ref, amb = oracle.render(c, e, v, s, with_ambiguity=True)
+        _assert_image(ref, got, amb, what=f"gcloud {kw}")
+        h.free()
+
+
 # ---------------------------------------------------------------------------------------------
 # SURVEY 8(f): RasterizeMode colour variants (src/render/gaussian.wgsl:312-405)
 # ---------------------------------------------------------------------------------------------
