@@ -63,6 +63,9 @@ EXPORTED_SYMBOLS = (
     "bgs_graph_counters",
     "bgs_reset_adaptive_state",
     "bgs_cloud_upload_cov3d_f32",
+    "bgs_set_output_rgba16f",
+    "bgs_framebuffer_rgba16f_device_ptr",
+    "bgs_set_packed_only",
 )
 
 
@@ -192,6 +195,12 @@ def load() -> ctypes.CDLL:
     lib.bgs_cloud_upload_cov3d_f32.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                                ctypes.POINTER(ctypes.c_float), ctypes.POINTER(vp)]
     lib.bgs_cloud_upload_cov3d_f32.restype = ctypes.c_int
+    lib.bgs_set_output_rgba16f.argtypes = [vp, ctypes.c_int]
+    lib.bgs_set_output_rgba16f.restype = ctypes.c_int
+    lib.bgs_set_packed_only.argtypes = [vp, ctypes.c_int]
+    lib.bgs_set_packed_only.restype = ctypes.c_int
+    lib.bgs_framebuffer_rgba16f_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
+    lib.bgs_framebuffer_rgba16f_device_ptr.restype = ctypes.c_int
     lib.bgs_reset_adaptive_state.argtypes = [vp]
     lib.bgs_reset_adaptive_state.restype = ctypes.c_int
     _lib = lib

@@ -117,7 +117,8 @@ struct Lane {
     uint32_t* fb8_out = nullptr; // where the last frame's sRGB8 image went (fb8 or a caller's target)
     size_t fb8_pixels = 0;
     uint32_t fb_w = 0, fb_h = 0;
-    bool fb8_valid = false;
+    bool fb8_valid = false, fb8_is_f16 = false;
+    bool fb_valid = true;  // false after a packed-only frame (the f32 target was not written)
 
     Control* h_ctl = nullptr;  // pinned; filled by a copy enqueued with the frame, or by the rasteriser
     Control* h_ctl_dev = nullptr;  // the same memory as the device sees it
@@ -170,6 +171,8 @@ struct bgs_ctx {
     uint32_t frame_counter = 0;
     bool async_frames = false;
     bool output_srgb8 = false;
+    bool output_rgba16f = false;   // the packed image is Rgba16Float (8 B per pixel) instead of Rgba8UnormSrgb
+    bool packed_only = false;      // frames with a packed image do not write the f32 target
     uint32_t* next_srgb8_target = nullptr;  // bgs_set_srgb8_target: one-shot destination of the next frame
 
     // Sizes the grids of the next frames' sort and projection launches: the draw_count of a completed
@@ -404,7 +407,7 @@ int ensure_framebuffer(bgs_ctx* ctx, Lane& L, uint32_t w, uint32_t h, bool want8
     }
     if (want8 && (px > L.fb8_pixels || !L.fb8)) {
         if (L.fb8) (void)hipFree(L.fb8);
-        L.fb8 = dev_alloc<uint32_t>(px);
+        L.fb8 = dev_alloc<uint32_t>(2 * px);  // room for either packed format (4 or 8 bytes per pixel)
         if (!L.fb8) return fail(ctx, BGS_ENOMEM, "hipMalloc(srgb8 framebuffer) failed");
         L.fb8_pixels = px;
     }
@@ -743,7 +746,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
             if ((rc = ensure_instances(ctx, L, std::max<uint64_t>(L.inst_cap, MIN_INSTANCE_CAPACITY))) != BGS_OK) return rc;
         }
         if ((rc = ensure_records(ctx, L, (size_t)n * rec_bytes)) != BGS_OK) return rc;
-        if ((rc = ensure_framebuffer(ctx, L, (uint32_t)fp.width, (uint32_t)fp.height, ctx->output_srgb8)) != BGS_OK) return rc;
+        if ((rc = ensure_framebuffer(ctx, L, (uint32_t)fp.width, (uint32_t)fp.height, ctx->output_srgb8 || ctx->output_rgba16f)) != BGS_OK) return rc;
     }
     if ((rc = ensure_scratch(ctx, L, n, L.inst_cap)) != BGS_OK) return rc;
 
@@ -806,7 +809,9 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     int bin_blocks = ctx->num_cus * 3;
     if (hinted)
         bin_blocks = (int)std::min<uint64_t>((uint64_t)bin_blocks, std::max<uint64_t>((uint64_t)ctx->draw_hint / 256 + 8, 32));
-    const bool want_srgb8 = render && (ctx->output_srgb8 || ctx->next_srgb8_target);
+    const bool want_srgb8 = render && (ctx->output_srgb8 || ctx->output_rgba16f || ctx->next_srgb8_target);
+    const uint32_t out_format = !want_srgb8 ? 0u : ((ctx->output_rgba16f ? OUT_RGBA16F : OUT_SRGB8) |
+                                                    ((ctx->packed_only && scan) ? OUT_SKIP_F32 : 0u));
     uint2* const draw_list = L.entries[places & 1u];  // the passes ping-pong from entries[0]
     // SortMode::Rayon / Std sort ascending on the inverted key; the last step of either path un-inverts it
     const uint32_t final_xor = (s->sort_mode == BGS_SORT_RAYON || s->sort_mode == BGS_SORT_STD) ? 0xFFFFFFFFu : 0u;
@@ -853,7 +858,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
                                coarse_cap, sup_edge, /*ticket_slot=*/4, bin_blocks);
             mark(3);
             launch_raster_scan(st, fp, L.d_fp, L.records, L.coarse, coarse_cap, sup_edge, ctl, L.fb, L.fb8,
-                               want_srgb8 && !(ctx->debug_flags & 0x40000u), cl);
+                               (ctx->debug_flags & 0x40000u) ? 0u : out_format, cl);
             mark(6);
         } else if (render) {
             const uint32_t capacity = (uint32_t)std::min<uint64_t>(L.inst_cap, MAX_INSTANCE_CAPACITY);
@@ -874,7 +879,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         // BINNING_SCAN frames get their sRGB8 image from the rasteriser itself (debug flag 0x40000: from the
         // separate encode pass, for A/B runs)
         if (want_srgb8 && !(render && scan && !(ctx->debug_flags & 0x40000u)))
-            launch_encode_srgb8(st, L.fb, L.fb8, (uint32_t)fp.width * (uint32_t)fp.height, L.d_fp);
+            launch_encode_srgb8(st, L.fb, L.fb8, (uint32_t)fp.width * (uint32_t)fp.height, L.d_fp, out_format);
         return hipGetLastError();
     };
 
@@ -902,7 +907,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         key.gaussian_mode = fp.gaussian_mode;
         key.aabb = fp.aabb;
         key.any_mode = (fp.rasterize_mode != RASTERIZE_COLOR || fp.draw_mode != 0u) ? 1u : 0u;
-        key.srgb8 = want_srgb8 ? 1u : 0u;
+        key.srgb8 = out_format;
         key.debug_flags = ctx->debug_flags;
         key.width = fp.width;
         key.height = fp.height;
@@ -946,6 +951,8 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     L.last_sorted = draw_list;
     L.last_sorted_n = n;
     L.fb8_valid = false;
+    L.fb_valid = !(out_format & OUT_SKIP_F32) || (ctx->debug_flags & 0x40000u);
+    L.fb8_is_f16 = (out_format & OUT_RGBA16F) != 0u;
     if (want_srgb8) {
         L.fb8_out = ctx->next_srgb8_target ? ctx->next_srgb8_target : L.fb8;
         L.fb8_valid = true;
@@ -1254,6 +1261,7 @@ int bgs_render(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const
     if (rgba_host_out) {
         Lane& L = ctx->lanes[ctx->recent];
         if (L.pending && (rc = finish_lane(ctx, L)) != BGS_OK) return rc;
+        if (!L.fb_valid) return fail(ctx, BGS_EINVAL, "the frame wrote its packed image only (bgs_set_packed_only): no f32 target to copy");
         HIP_TRY(ctx, hipMemcpy(rgba_host_out, L.fb, (size_t)L.fb_w * L.fb_h * sizeof(float4), hipMemcpyDeviceToHost));
     }
     return BGS_OK;
@@ -1267,6 +1275,7 @@ int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes) {
         if (rc != BGS_OK) return rc;
     }
     if (!L.fb) return fail(ctx, BGS_EINVAL, "no frame has been rendered yet");
+    if (!L.fb_valid) return fail(ctx, BGS_EINVAL, "the last frame wrote its packed image only (bgs_set_packed_only)");
     *dptr = L.fb;
     if (bytes) *bytes = (uint64_t)L.fb_w * L.fb_h * sizeof(float4);
     return BGS_OK;
@@ -1279,7 +1288,7 @@ int bgs_framebuffer_srgb8_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes)
         int rc = finish_lane(ctx, L);
         if (rc != BGS_OK) return rc;
     }
-    if (!L.fb8_out || !L.fb8_valid)
+    if (!L.fb8_out || !L.fb8_valid || L.fb8_is_f16)
         return fail(ctx, BGS_EINVAL, "no Rgba8UnormSrgb frame: call bgs_set_output_srgb8(ctx, 1) before rendering");
     *dptr = L.fb8_out;
     if (bytes) *bytes = (uint64_t)L.fb_w * L.fb_h * 4u;
@@ -1296,7 +1305,7 @@ int bgs_pipeline_pop(bgs_ctx* ctx, void** rgba_f32, void** rgba8) {
     Lane& L = ctx->lanes[best];
     int rc = finish_lane(ctx, L);
     if (rc != BGS_OK) return rc;
-    if (rgba_f32) *rgba_f32 = L.fb;
+    if (rgba_f32) *rgba_f32 = L.fb_valid ? L.fb : nullptr;
     if (rgba8) *rgba8 = L.fb8_valid ? L.fb8_out : nullptr;
     return BGS_OK;
 }
@@ -1384,6 +1393,34 @@ int bgs_download(bgs_ctx* ctx, const void* device_ptr, void* host_out, uint64_t 
 int bgs_set_output_srgb8(bgs_ctx* ctx, int enabled) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     ctx->output_srgb8 = enabled != 0;
+    if (enabled) ctx->output_rgba16f = false;
+    return BGS_OK;
+}
+
+int bgs_set_output_rgba16f(bgs_ctx* ctx, int enabled) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    ctx->output_rgba16f = enabled != 0;
+    if (enabled) ctx->output_srgb8 = false;
+    return BGS_OK;
+}
+
+int bgs_set_packed_only(bgs_ctx* ctx, int enabled) {
+    if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
+    ctx->packed_only = enabled != 0;
+    return BGS_OK;
+}
+
+int bgs_framebuffer_rgba16f_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes) {
+    if (!ctx || !dptr) return fail(ctx, BGS_EINVAL, "NULL argument");
+    Lane& L = ctx->lanes[ctx->recent];
+    if (L.pending) {
+        int rc = finish_lane(ctx, L);
+        if (rc != BGS_OK) return rc;
+    }
+    if (!L.fb8_out || !L.fb8_valid || !L.fb8_is_f16)
+        return fail(ctx, BGS_EINVAL, "no Rgba16Float frame: call bgs_set_output_rgba16f(ctx, 1) before rendering");
+    *dptr = L.fb8_out;
+    if (bytes) *bytes = (uint64_t)L.fb_w * L.fb_h * 8u;
     return BGS_OK;
 }
 

@@ -128,7 +128,11 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
-                        bool want_srgb8, const FrameCleanup& cleanup);
+                        uint32_t out_format, const FrameCleanup& cleanup);
+// out_format bits: which packed image the rasteriser writes next to (or instead of) the f32 target
+constexpr uint32_t OUT_SRGB8 = 1u;     // Rgba8UnormSrgb, 4 B per pixel
+constexpr uint32_t OUT_RGBA16F = 2u;   // Rgba16Float, 8 B per pixel (the reference's hdr target)
+constexpr uint32_t OUT_SKIP_F32 = 4u;  // do not write the f32 target (bgs_set_packed_only)
 
 // Per-tile [start, end) over the tile-sorted instances; ranges indexed by (ty << 8 | tx).
 void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Control* ctl, uint2* ranges);
@@ -142,7 +146,7 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
 // Rgba8UnormSrgb image of the f32 framebuffer (the reference's render-target format).
 // The destination is d_fp->srgb8_target when that is non-zero, else default_out.
 void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* default_out, uint32_t pixels,
-                         const FrameParams* d_fp);
+                         const FrameParams* d_fp, uint32_t out_format = 1u);
 
 // STREAM-triad on float4: a = b + s * c (HBM ceiling probe, bgs_hbm_probe).
 void launch_triad(hipStream_t stream, float4* a, const float4* b, const float4* c, float s, size_t n4,

@@ -695,6 +695,13 @@ __device__ __forceinline__ float srgb_oetf(float x) {
     x = fminf(fmaxf(x, 0.0f), 1.0f);
     return x <= 0.0031308f ? 12.92f * x : fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)), -0.055f);
 }
+// Rgba16Float texel: IEEE binary16, round to nearest even, overflow to inf (what a float16 target stores)
+__device__ __forceinline__ uint2 pack_rgba16f(const float4 c) {
+    const _Float16 h[4] = {(_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};
+    uint2 out;
+    __builtin_memcpy(&out, h, 8);
+    return out;
+}
 __device__ __forceinline__ uint32_t pack_srgb8(const float4 c) {
     return unorm8(srgb_oetf(c.x)) | (unorm8(srgb_oetf(c.y)) << 8) | (unorm8(srgb_oetf(c.z)) << 16) | (unorm8(c.w) << 24);
 }
@@ -980,11 +987,14 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
                 const float4 c = make_float4(fmaf(T[r], fp.clear[0], cr[r]), fmaf(T[r], fp.clear[1], cg[r]),
                                              fmaf(T[r], fp.clear[2], cb[r]), fmaf(T[r], fp.clear[3], 1.0f - T[r]));
                 const size_t at = (size_t)py * (size_t)fp.width + (size_t)pxw;
-                fb[at] = c;
-                // the frame in the reference's target format too, here instead of in a separate pass over
-                // the 33 MB f32 image (the frame's own destination travels in FrameParams)
-                if (want_srgb8)
+                if (!(want_srgb8 & OUT_SKIP_F32)) fb[at] = c;
+                // the frame in the reference's target format too (Rgba8UnormSrgb, or Rgba16Float for an hdr
+                // camera), here instead of in a separate pass over the 33 MB f32 image (the frame's own
+                // destination travels in FrameParams)
+                if (want_srgb8 & OUT_SRGB8)
                     (fp.srgb8_target ? reinterpret_cast<uint32_t*>(fp.srgb8_target) : fb8_default)[at] = pack_srgb8(c);
+                else if (want_srgb8 & OUT_RGBA16F)
+                    (fp.srgb8_target ? reinterpret_cast<uint2*>(fp.srgb8_target) : reinterpret_cast<uint2*>(fb8_default))[at] = pack_rgba16f(c);
             }
         }
     }
@@ -995,7 +1005,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
-                        bool want_srgb8, const FrameCleanup& cleanup) {
+                        uint32_t out_format, const FrameCleanup& cleanup) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4* rec = (const float4*)records;
@@ -1003,7 +1013,7 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
 #define BGS_LAUNCH_RS(V)                                                                          \
     hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,      \
-                       coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, want_srgb8 ? 1u : 0u, cleanup)
+                       coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup)
     if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
     else BGS_LAUNCH_RS(RV_SURFEL);
@@ -1036,21 +1046,22 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void encode_srgb8_kernel(const float4* __restrict__ fb,
                                                            uint32_t* __restrict__ default_out, uint32_t n,
-                                                           const FrameParams* __restrict__ fpp) {
+                                                           const FrameParams* __restrict__ fpp, uint32_t out_format) {
     // the frame's own destination (bgs_set_srgb8_target) travels in FrameParams
     uint32_t* __restrict__ out = fpp->srgb8_target ? reinterpret_cast<uint32_t*>(fpp->srgb8_target) : default_out;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const float4 c = fb[i];
-        out[i] = pack_srgb8(c);
+        if (out_format & OUT_RGBA16F) reinterpret_cast<uint2*>(out)[i] = pack_rgba16f(c);
+        else out[i] = pack_srgb8(c);
     }
 }
 
 void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* default_out, uint32_t pixels,
-                         const FrameParams* d_fp) {
+                         const FrameParams* d_fp, uint32_t out_format) {
     if (pixels == 0) return;
     uint32_t blocks = (pixels + 255u) / 256u;
     if (blocks > 2048u) blocks = 2048u;
-    hipLaunchKernelGGL(encode_srgb8_kernel, dim3(blocks), dim3(256), 0, stream, framebuffer, default_out, pixels, d_fp);
+    hipLaunchKernelGGL(encode_srgb8_kernel, dim3(blocks), dim3(256), 0, stream, framebuffer, default_out, pixels, d_fp, out_format);
 }
 
 }  // namespace bgs

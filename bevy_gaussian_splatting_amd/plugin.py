@@ -292,6 +292,20 @@ class GaussianSplattingPlugin:
         """The next `render` writes its Rgba8UnormSrgb image to this device address (one-shot)."""
         self._check(self._lib.bgs_set_srgb8_target(self._ctx, ctypes.c_void_p(device_ptr or 0)))
 
+    def set_output_rgba16f(self, enabled: bool) -> None:
+        """Also produce every frame as Rgba16Float (the reference's hdr colour attachment); exclusive with sRGB8."""
+        self._check(self._lib.bgs_set_output_rgba16f(self._ctx, 1 if enabled else 0))
+
+    def set_packed_only(self, enabled: bool) -> None:
+        """Frames that write a packed image (sRGB8 / Rgba16Float) skip the f32 target."""
+        self._check(self._lib.bgs_set_packed_only(self._ctx, 1 if enabled else 0))
+
+    def framebuffer_rgba16f_device_ptr(self):
+        p = ctypes.c_void_p()
+        nbytes = ctypes.c_uint64()
+        self._check(self._lib.bgs_framebuffer_rgba16f_device_ptr(self._ctx, ctypes.byref(p), ctypes.byref(nbytes)))
+        return p.value, nbytes.value
+
     def framebuffer_srgb8_device_ptr(self):
         p = ctypes.c_void_p()
         nbytes = ctypes.c_uint64()

@@ -224,6 +224,17 @@ int bgs_framebuffer_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes);
  * RGB -> sRGB transfer -> unorm8, alpha linear, 4 bytes per pixel R,G,B,A. Default off. */
 int bgs_set_output_srgb8(bgs_ctx* ctx, int enabled);
 int bgs_framebuffer_srgb8_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes);
+/* The same for an hdr camera: the reference's colour attachment is then TextureFormat::Rgba16Float
+ * (src/render/mod.rs:917-921). Every bgs_render also produces the frame as IEEE binary16 RGBA (8 bytes per
+ * pixel, round to nearest even, overflow to inf), linear and unclamped. Exclusive with the sRGB8 output
+ * (enabling one disables the other); bgs_set_srgb8_target / bgs_pipeline_pop's second pointer then carry
+ * this image. Like the 8-bit image it is ONE conversion of the f32 result, not a per-blend quantisation. */
+int bgs_set_output_rgba16f(bgs_ctx* ctx, int enabled);
+int bgs_framebuffer_rgba16f_device_ptr(bgs_ctx* ctx, void** dptr, uint64_t* bytes);
+/* Frames that write a packed image (sRGB8 or Rgba16Float) skip the f32 target (33 MB of writes per 1080p
+ * frame) — for consumers that only ship the packed frame (the multi-GPU gather). BGS_BINNING_SCAN only.
+ * bgs_framebuffer_device_ptr / a host copy of such a frame is BGS_EINVAL; bgs_pipeline_pop gives NULL. */
+int bgs_set_packed_only(bgs_ctx* ctx, int enabled);
 /* The NEXT bgs_render writes its Rgba8UnormSrgb image (width * height * 4 bytes) to this caller-owned
  * device memory instead of the lane's own buffer (one-shot; NULL cancels). Lets a consumer that ships
  * frames in batches (the multi-GPU gather) have each frame land in its slot of the batch with no copy

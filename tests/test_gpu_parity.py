@@ -907,6 +907,59 @@ def test_pipelined_frames_and_srgb8_output(plugin, oracle):
     h.free()
 
 
+def test_rgba16f_target_and_packed_only_frames(plugin):
+    """The reference's hdr colour attachment (TextureFormat::Rgba16Float, src/render/mod.rs:917-921): the
+    binary16 image must be the f32 target rounded to nearest even (numpy float16), in both binning modes
+    (fused into the rasteriser / separate encode pass); packed-only frames skip the f32 target, give the
+    same packed bytes, and refuse an f32 read-back instead of handing out a stale buffer."""
+    from bevy_gaussian_splatting_amd.multiview import device_ptr_as_tensor
+    c = random_gaussians_3d_seeded(40_000, 33)
+    c.spherical_harmonic *= 4.0   # some channels beyond [0, 1] and a few past the f16 range after the pow
+    v = View.headless(640, 360)
+    v.clear_color = (0.25, 0.5, 0.125, 0.75)
+    s = CloudSettings()
+    h = plugin.upload(c)
+
+    def packed(ptr, typestr):
+        return device_ptr_as_tensor(ptr, (360, 640, 4), typestr, "cuda:0").cpu().numpy()
+    try:
+        for binning in ("scan", "sort"):
+            plugin.set_binning(binning)
+            plugin.set_output_rgba16f(True)
+            img = plugin.render(h, v, s)
+            ptr, nbytes = plugin.framebuffer_rgba16f_device_ptr()
+            assert nbytes == 640 * 360 * 8
+            half = packed(ptr, "<f2")
+            with np.errstate(over="ignore"):
+                assert np.array_equal(half.view(np.uint16), img.astype(np.float16).view(np.uint16)), binning
+            with pytest.raises(RuntimeError):
+                plugin.framebuffer_srgb8_device_ptr()
+        plugin.set_binning("scan")
+        plugin.set_packed_only(True)
+        plugin.render(h, v, s, download=False)
+        ptr, _ = plugin.framebuffer_rgba16f_device_ptr()
+        assert np.array_equal(packed(ptr, "<f2").view(np.uint16), half.view(np.uint16))
+        with pytest.raises(RuntimeError):
+            plugin.framebuffer_device_ptr()
+        with pytest.raises(RuntimeError):
+            plugin.render(h, v, s)   # asks for a host copy of the f32 target
+        plugin.set_output_srgb8(True)   # switches the packed format back
+        plugin.render(h, v, s, download=False)
+        p8, n8 = plugin.framebuffer_srgb8_device_ptr()
+        assert n8 == 640 * 360 * 4
+        only = packed(p8, "|u1")
+        plugin.set_packed_only(False)
+        ref = plugin.render(h, v, s)
+        p8b, _ = plugin.framebuffer_srgb8_device_ptr()
+        assert np.array_equal(only, packed(p8b, "|u1")) and np.isfinite(ref).all()
+    finally:
+        plugin.set_packed_only(False)
+        plugin.set_output_srgb8(False)
+        plugin.set_output_rgba16f(False)
+        plugin.set_binning("scan")
+    h.free()
+
+
 # ---------------------------------------------------------------------------------------------
 # SURVEY 8(f): a cloud that arrives through the INRIA .ply loader, padding splats included
 # ---------------------------------------------------------------------------------------------
