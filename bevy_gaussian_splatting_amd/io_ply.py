@@ -54,8 +54,10 @@ def _read_header(f: BinaryIO):
         elif tok[0] == "element":
             elements.append((tok[1], int(tok[2]), []))
         elif tok[0] == "property":
-            if tok[1] == "list":
-                elements[-1][2].append((tok[4], None))
+            if tok[1] == "list":  # property list <count type> <item type> <name>
+                if tok[2] not in _PLY_TYPES or tok[3] not in _PLY_TYPES:
+                    raise ValueError(f"unknown PLY list types {tok[2]} {tok[3]}")
+                elements[-1][2].append((tok[4], None, _PLY_TYPES[tok[2]], _PLY_TYPES[tok[3]]))
             else:
                 if tok[1] not in _PLY_TYPES:
                     raise ValueError(f"unknown PLY property type {tok[1]}")
@@ -68,22 +70,42 @@ def _read_header(f: BinaryIO):
 
 
 def _read_element(f: BinaryIO, fmt: str, count: int, props):
-    names = [p[0] for p in props]
+    scalars = [(p[0], p[1]) for p in props if p[1] is not None]
     if fmt == "ascii":
-        cols = {n: np.zeros(count, np.float64) for n, t in props if t is not None}
+        cols = {n: np.zeros(count, np.float64) for n, t in scalars}
         for r in range(count):
             tok = f.readline().split()
             k = 0
-            for n, t in props:
-                if t is None:  # list: count followed by that many items
+            for p in props:
+                if p[1] is None:  # list: count followed by that many items
                     k += 1 + int(tok[k])
                 else:
-                    cols[n][r] = float(tok[k])
+                    cols[p[0]][r] = float(tok[k])
                     k += 1
-        return {n: (cols[n].astype(t), t) for n, t in props if t is not None}
-    if any(t is None for _, t in props):
-        raise ValueError("list properties in a binary vertex element are not supported")
+        return {n: (cols[n].astype(t), t) for n, t in scalars}
     order = "<" if fmt == "binary_little_endian" else ">"
+    if any(p[1] is None for p in props):
+        # an element with list properties (a trailing `face` element of a mesh export, which ply-rs parses
+        # and the reference then ignores) has rows of varying length: walk it row by row
+        cols = {n: np.zeros(count, np.dtype(order + t)) for n, t in scalars}
+        for r in range(count):
+            for p in props:
+                if p[1] is None:
+                    cdt, idt = np.dtype(order + p[2]), np.dtype(order + p[3])
+                    raw = f.read(cdt.itemsize)
+                    if len(raw) != cdt.itemsize:
+                        raise ValueError("truncated PLY payload")
+                    k = int(np.frombuffer(raw, cdt)[0])
+                    if k < 0 or len(f.read(k * idt.itemsize)) != k * idt.itemsize:
+                        raise ValueError("truncated PLY payload")
+                else:
+                    dt1 = np.dtype(order + p[1])
+                    raw = f.read(dt1.itemsize)
+                    if len(raw) != dt1.itemsize:
+                        raise ValueError("truncated PLY payload")
+                    cols[p[0]][r] = np.frombuffer(raw, dt1)[0]
+        return {n: (cols[n], t) for n, t in scalars}
+    props = scalars
     dt = np.dtype([(n, order + t) for n, t in props])
     raw = f.read(dt.itemsize * count)
     if len(raw) != dt.itemsize * count:

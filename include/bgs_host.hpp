@@ -2,13 +2,19 @@
 // include/bgs.hpp: the f16 planar cloud (src/gaussian/f16.rs), the sort trigger / throttle policy
 // (src/sort/mod.rs:76-86,143-194, src/sort/rayon.rs:124-129), the multi-camera SortedEntries asset
 // (src/sort/mod.rs:331-393), compute_aabb (src/gaussian/interface.rs:22-63) and the INRIA `.ply` loader
-// (src/io/ply.rs:23-132, with the reference's quirks). Header-only; tests/test_cpp_host.py checks each
+// (src/io/ply.rs:23-132, with the reference's quirks), the `.gcloud` container reader and the loader's dispatch on
+// the file extension (src/io/gcloud/flexbuffers.rs:9-22, src/io/loader.rs:22-61), the precomputed-covariance
+// plane (src/gaussian/covariance.rs:4-41, src/gaussian/f32.rs:218-251). Header-only; tests/test_cpp_host.py checks each
 // against the Python mirror, which is pinned by known answers.
 #ifndef BGS_HOST_HPP
 #define BGS_HOST_HPP
 
 #include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
 #include <istream>
+#include <iterator>
 #include <map>
 #include <optional>
 #include <sstream>
@@ -177,7 +183,7 @@ inline bool compute_aabb(const PlanarGaussian3d& c, std::array<float, 3>& mn_out
 constexpr float MAX_SIZE_VARIANCE = 4.0f;  // src/io/ply.rs:21
 
 namespace ply_detail {
-struct Prop { std::string name; char kind; int bytes; bool list; };  // kind: 'i' 'u' 'f'
+struct Prop { std::string name; char kind; int bytes; bool list; int count_bytes = 0; char count_kind = 'u'; };  // kind: 'i' 'u' 'f'; lists: bytes = item size
 inline bool scalar_type(const std::string& t, char& kind, int& bytes) {
     static const std::map<std::string, std::pair<char, int>> types = {
         {"char", {'i', 1}}, {"int8", {'i', 1}}, {"uchar", {'u', 1}}, {"uint8", {'u', 1}}, {"short", {'i', 2}},
@@ -213,7 +219,12 @@ inline PlanarGaussian3d parse_ply_3d(std::istream& in) {
         if (tok[0] == "format" && tok.size() > 1) format = tok[1];
         else if (tok[0] == "element" && tok.size() > 2) elements.push_back({tok[1], (size_t)std::stoull(tok[2]), {}});
         else if (tok[0] == "property" && tok.size() > 2 && !elements.empty()) {
-            if (tok[1] == "list" && tok.size() > 4) elements.back().props.push_back({tok[4], 'l', 0, true});
+            if (tok[1] == "list" && tok.size() > 4) {  // property list <count type> <item type> <name>
+                Prop p{tok[4], 'f', 4, true};
+                if (!scalar_type(tok[2], p.count_kind, p.count_bytes) || !scalar_type(tok[3], p.kind, p.bytes))
+                    throw Error(BGS_EINVAL, "unknown PLY list types " + tok[2] + " " + tok[3]);
+                elements.back().props.push_back(p);
+            }
             else {
                 Prop p{tok[2], 'f', 4, false};
                 if (!scalar_type(tok[1], p.kind, p.bytes)) throw Error(BGS_EINVAL, "unknown PLY property type " + tok[1]);
@@ -255,11 +266,42 @@ inline PlanarGaussian3d parse_ply_3d(std::istream& in) {
                 }
             }
         } else {
-            size_t stride = 0;
-            for (const Prop& p : e.props) {
-                if (p.list) throw Error(BGS_EINVAL, "list properties in a binary vertex element are not supported");
-                stride += (size_t)p.bytes;
+            if (std::any_of(e.props.begin(), e.props.end(), [](const Prop& p) { return p.list; })) {
+                // an element with list properties (a trailing `face` element of a mesh export, which ply-rs
+                // parses and the reference then ignores) has rows of varying length: walk it row by row
+                auto read_uint = [&](int bytes, char kind) -> long long {
+                    unsigned char b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    in.read((char*)b, bytes);
+                    if (in.gcount() != bytes) throw Error(BGS_EINVAL, "truncated PLY payload");
+                    if (be) std::reverse(b, b + bytes);
+                    if (kind == 'f') { if (bytes == 4) { float x; std::memcpy(&x, b, 4); return (long long)x; } double x; std::memcpy(&x, b, 8); return (long long)x; }
+                    unsigned long long v = 0;
+                    for (int k = 0; k < bytes; ++k) v |= (unsigned long long)b[k] << (8 * k);
+                    if (kind == 'i' && bytes < 8 && (v >> (8 * bytes - 1))) v |= ~0ull << (8 * bytes);
+                    return (long long)v;
+                };
+                for (size_t r = 0; r < e.count; ++r)
+                    for (const Prop& p : e.props) {
+                        if (p.list) {
+                            const long long k = read_uint(p.count_bytes, p.count_kind);
+                            if (k < 0) throw Error(BGS_EINVAL, "truncated PLY payload");
+                            in.ignore((std::streamsize)k * p.bytes);
+                            if (in.gcount() != (std::streamsize)k * p.bytes) throw Error(BGS_EINVAL, "truncated PLY payload");
+                        } else if (vertex && p.kind == 'f' && p.bytes == 4) {
+                            unsigned char b[4];
+                            in.read((char*)b, 4);
+                            if (in.gcount() != 4) throw Error(BGS_EINVAL, "truncated PLY payload");
+                            if (be) std::swap(b[0], b[3]), std::swap(b[1], b[2]);
+                            std::memcpy(&cols[p.name][r], b, 4);
+                        } else {
+                            in.ignore(p.bytes);
+                            if (in.gcount() != p.bytes) throw Error(BGS_EINVAL, "truncated PLY payload");
+                        }
+                    }
+                continue;
             }
+            size_t stride = 0;
+            for (const Prop& p : e.props) stride += (size_t)p.bytes;
             std::vector<char> raw(stride * e.count);
             in.read(raw.data(), (std::streamsize)raw.size());
             if ((size_t)in.gcount() != raw.size()) throw Error(BGS_EINVAL, "truncated PLY payload");

@@ -341,3 +341,64 @@ def test_cpp_example_loads_a_gcloud_file(tmp_path):
     assert np.array_equal(got, p.render(h, View.headless(480, 270), CloudSettings()))
     h.free()
     p.close()
+
+
+@pytest.mark.parametrize("fmt", ["binary_little_endian", "binary_big_endian", "ascii"])
+def test_ply_with_a_trailing_face_element_loads_in_both_hosts(host_tool, tmp_path, fmt):
+    """A mesh-style export: the vertex element followed by `element face` with a list property. ply-rs parses
+    it and the reference ignores it (src/io/ply.rs:76-91 reads only "vertex"); so do the Python and the C++
+    loader, binary list rows included."""
+    from bevy_gaussian_splatting_amd.io_ply import parse_ply_3d
+    rng = np.random.default_rng(4)
+    n, faces = 70, 13
+    names = ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2", "opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    cols = {k: rng.normal(0, 1, n).astype(np.float32) for k in names}
+    header = f"ply\nformat {fmt} 1.0\nelement vertex {n}\n" + "".join(f"property float {k}\n" for k in names)
+    header += f"element face {faces}\nproperty list uchar int vertex_indices\nproperty uchar flags\nend_header\n"
+    path = tmp_path / "mesh.ply"
+    order = ">" if fmt == "binary_big_endian" else "<"
+    with open(path, "wb") as f:
+        f.write(header.encode())
+        if fmt == "ascii":
+            for r in range(n):
+                f.write((" ".join(repr(float(cols[k][r])) for k in names) + "\n").encode())
+            for r in range(faces):
+                k = 3 + r % 3
+                f.write((f"{k} " + " ".join(str(int(v)) for v in rng.integers(0, n, k)) + " 7\n").encode())
+        else:
+            rec = np.zeros(n, np.dtype([(k, order + "f4") for k in names]))
+            for k in names:
+                rec[k] = cols[k]
+            f.write(rec.tobytes())
+            for r in range(faces):
+                k = 3 + r % 3
+                f.write(bytes([k]) + rng.integers(0, n, k).astype(order + "i4").tobytes() + bytes([7]))
+    ref = parse_ply_3d(str(path))
+    assert len(ref) == 96 and np.array_equal(ref.position_visibility[:n, 0], cols["x"])
+    subprocess.run([host_tool, "ply", str(path), str(tmp_path / "o.bin")], check=True)
+    pv, sh, rot, so = _read_planes(tmp_path / "o.bin")
+    assert np.array_equal(pv, ref.position_visibility) and np.array_equal(sh, ref.spherical_harmonic)
+    assert np.allclose(rot, ref.rotation, rtol=3e-7, atol=0, equal_nan=True) and np.allclose(so, ref.scale_opacity, rtol=1e-6, atol=0)
+    if fmt != "ascii":   # truncated inside the face element: an error, not a crash
+        data = path.read_bytes()
+        (tmp_path / "cut.ply").write_bytes(data[:-5])
+        with pytest.raises(ValueError):
+            parse_ply_3d(str(tmp_path / "cut.ply"))
+        r = subprocess.run([host_tool, "ply", str(tmp_path / "cut.ply"), str(tmp_path / "o2.bin")], capture_output=True, text=True)
+        assert r.returncode == 1 and "truncated" in r.stderr
+
+
+def test_gcloud_general_reader_reports_malformed_input_as_value_error():
+    from bevy_gaussian_splatting_amd import random_gaussians_3d_seeded
+    from bevy_gaussian_splatting_amd.io_gcloud import decode_gcloud, encode_gcloud, flexbuffers_loads
+    data = encode_gcloud(random_gaussians_3d_seeded(40, 3))
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        bad = bytearray(data[: int(rng.integers(3, len(data)))]) if trial % 2 else bytearray(data)
+        for _ in range(4):
+            bad[int(rng.integers(0, len(bad)))] = int(rng.integers(0, 256))
+        for fn in (flexbuffers_loads, lambda b: decode_gcloud(b, fast=False), decode_gcloud):
+            try:
+                fn(bytes(bad))
+            except ValueError:
+                pass   # the only exception type callers have to expect
