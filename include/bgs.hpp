@@ -275,6 +275,12 @@ class GaussianSplattingPlugin {
     void set_pipeline_streams(uint32_t streams) { check(bgs_set_pipeline_streams(ctx_, streams), "bgs_set_pipeline_streams"); }
     void set_graphs(bool on) { check(bgs_set_graphs(ctx_, on ? 1 : 0), "bgs_set_graphs"); }
     void set_output_srgb8(bool on) { check(bgs_set_output_srgb8(ctx_, on ? 1 : 0), "bgs_set_output_srgb8"); }
+    // hdr cameras: the colour attachment is Rgba16Float (src/render/mod.rs:917-921); exclusive with sRGB8
+    void set_output_rgba16f(bool on) { check(bgs_set_output_rgba16f(ctx_, on ? 1 : 0), "bgs_set_output_rgba16f"); }
+    // frames that write a packed image skip the f32 target
+    void set_packed_only(bool on) { check(bgs_set_packed_only(ctx_, on ? 1 : 0), "bgs_set_packed_only"); }
+    // forget what completed frames taught the context (grid sizes, splitters, list capacity, supertile level)
+    void reset_adaptive_state() { check(bgs_reset_adaptive_state(ctx_), "bgs_reset_adaptive_state"); }
     void set_profiling(int level) { check(bgs_set_profiling(ctx_, level), "bgs_set_profiling"); }
     void synchronize() { check(bgs_synchronize(ctx_), "bgs_synchronize"); }
     uint32_t frames_in_flight() {
@@ -297,6 +303,17 @@ class GaussianSplattingPlugin {
         std::vector<uint8_t> out(static_cast<size_t>(v.width) * v.height * 4);
         if (bytes < out.size()) throw Error(BGS_EINVAL, "sRGB8 image smaller than the view");
         check(bgs_download(ctx_, dptr, out.data(), out.size()), "bgs_download");
+        return out;
+    }
+    // The most recent frame's Rgba16Float image on the host (IEEE binary16 bit patterns, 4 per pixel).
+    std::vector<uint16_t> download_rgba16f(const View& v) {
+        void* dptr = nullptr;
+        uint64_t bytes = 0;
+        check(bgs_synchronize(ctx_), "bgs_synchronize");
+        check(bgs_framebuffer_rgba16f_device_ptr(ctx_, &dptr, &bytes), "bgs_framebuffer_rgba16f_device_ptr");
+        std::vector<uint16_t> out(static_cast<size_t>(v.width) * v.height * 4);
+        if (bytes < out.size() * 2) throw Error(BGS_EINVAL, "Rgba16Float image smaller than the view");
+        check(bgs_download(ctx_, dptr, out.data(), out.size() * 2), "bgs_download");
         return out;
     }
     void download(const void* device_ptr, void* host_out, uint64_t bytes) {
