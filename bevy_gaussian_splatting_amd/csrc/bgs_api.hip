@@ -28,6 +28,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/bgs.h"
 #include "bgs_device.h"
@@ -894,8 +895,8 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     if (use_graph) {
         GraphKey key;
         std::memset(&key, 0, sizeof key);
-        const void* planes[6] = {cloud->ptrs.position_visibility, cloud->ptrs.sh_f32, cloud->ptrs.rotation,
-                                 cloud->ptrs.scale_opacity, cloud->ptrs.sh_f16, cloud->ptrs.rot_scale_opacity_f16};
+        const void* planes[6] = {cloud->ptrs.position_visibility, cloud->ptrs.sh_f32, cloud->ptrs.rot_scale,
+                                 cloud->ptrs.cov3d_opacity, cloud->ptrs.sh_f16, cloud->ptrs.rot_scale_opacity_f16};
         std::memcpy(key.cloud, planes, sizeof planes);
         const void* bufs[11] = {L.entries[0], L.entries[1], L.culled, L.records, L.coarse, L.fb, L.fb8, L.scratch, L.d_fp,
                                 L.h_ctl_dev, L.bucket_slots};
@@ -1159,17 +1160,29 @@ int bgs_cloud_upload_f32(bgs_ctx* ctx, uint32_t n, const float* pv, const float*
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
     bgs_cloud* c = new (std::nothrow) bgs_cloud();
     if (!c) return fail(ctx, BGS_ENOMEM, "out of host memory");
-    const void* src[4] = {pv, sh, rot, so};
-    const size_t bytes[4] = {(size_t)n * 16, (size_t)n * 192, (size_t)n * 16, (size_t)n * 16};
-    for (int i = 0; i < 4; ++i) {
+    // rotation and scale_opacity are read together, by visible splats only, at sorted (random) indices:
+    // interleaved into one 32-byte record per splat they cost one cache line instead of two
+    std::vector<float> rs;
+    try {
+        rs.resize((size_t)n * 8);
+    } catch (const std::bad_alloc&) {
+        delete c;
+        return fail(ctx, BGS_ENOMEM, "out of host memory");
+    }
+    for (size_t i = 0; i < n; ++i) {
+        std::memcpy(&rs[8 * i], rot + 4 * i, 16);
+        std::memcpy(&rs[8 * i + 4], so + 4 * i, 16);
+    }
+    const void* src[3] = {pv, sh, rs.data()};
+    const size_t bytes[3] = {(size_t)n * 16, (size_t)n * 192, (size_t)n * 32};
+    for (int i = 0; i < 3; ++i) {
         int rc = upload_plane(ctx, src[i], bytes[i], &c->allocs[i]);
         if (rc != BGS_OK) { bgs_cloud_free(ctx, c); return rc; }
         c->bytes += bytes[i];
     }
     c->ptrs.position_visibility = (const float4*)c->allocs[0];
     c->ptrs.sh_f32 = (const float*)c->allocs[1];
-    c->ptrs.rotation = (const float4*)c->allocs[2];
-    c->ptrs.scale_opacity = (const float4*)c->allocs[3];
+    c->ptrs.rot_scale = (const float4*)c->allocs[2];
     c->ptrs.n = n;
     c->ptrs.is_f16 = 0;
     *out = c;

@@ -139,8 +139,8 @@ __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const Cl
         so[0] = half_hi(raw.z); so[1] = half_lo(raw.z);
         so[2] = half_hi(raw.w); so[3] = half_lo(raw.w);
     } else {
-        const float4 r4 = cloud.rotation[si];
-        const float4 s4 = cloud.scale_opacity[si];
+        const float4 r4 = cloud.rot_scale[2u * si];
+        const float4 s4 = cloud.rot_scale[2u * si + 1u];
         rot[0] = r4.x; rot[1] = r4.y; rot[2] = r4.z; rot[3] = r4.w;
         so[0] = s4.x; so[1] = s4.y; so[2] = s4.z; so[3] = s4.w;
     }

@@ -21,11 +21,16 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
+SLACK_USED = {"values": 0, "checked": 0}  # how often the oracle's ambiguity slack was needed (printed at the end)
+
+
 def _assert_image(ref, got, amb, frac_slack=0.002, what=""):
     assert got.shape == ref.shape and np.isfinite(got).all()
     ok, err = H.tolerance_mask(ref, got, amb)
     assert ok.all(), f"{what}: {(~ok).sum()} values out of tolerance, max err {err.max():.3e}"
     strict, _ = H.tolerance_mask(ref, got, None)
+    SLACK_USED["values"] += int((~strict).sum())
+    SLACK_USED["checked"] += int(strict.size)
     assert (~strict).sum() <= frac_slack * strict.size, f"{what}: ambiguity slack used by too many pixels"
 
 
@@ -235,6 +240,8 @@ def test_render_against_committed_goldens(plugin, name, kw, cloud, view):
     assert np.array_equal(es["key"], g["keys"]) and np.array_equal(es["index"], g["index"])
     ok, err = H.tolerance_mask(g["rgba"], got, None, atol=1e-3, rtol=1e-4)
     # goldens carry no ambiguity map: allow the edge-flip pixels (<= 0.5 %) a 2e-2 bound
+    print(f"[golden {name}] values beyond 1e-3 (edge flips, no ambiguity map in the golden): {int((~ok).sum())}/{ok.size}, "
+          f"max |err| {err.max():.2e}")
     assert (~ok).sum() <= 0.005 * ok.size and err.max() < 2e-2, f"max err {err.max():.3e}"
     h.free()
 
@@ -1181,3 +1188,12 @@ def test_draw_modes(plugin, oracle, binning):
                 vis, _ = oracle.instance_stats(cd, e, v, s)
                 assert plugin.stats()["visible_count"] == vis
                 h.free()
+
+
+def test_zz_report_ambiguity_slack_use():
+    """Last test of the file (run with -s to see it): over every oracle comparison of this run, how many
+    values were accepted only thanks to the oracle's per-pixel ambiguity bound (quad-edge coverage flips,
+    ill-conditioned surfel intersections) rather than the plain 1e-3 + 1e-4 |ref| tolerance."""
+    v, n = SLACK_USED["values"], SLACK_USED["checked"]
+    print(f"[ambiguity slack] used by {v} of {n} compared values ({100.0 * v / max(n, 1):.5f} %)")
+    assert v <= 2e-3 * max(n, 1)
