@@ -358,11 +358,7 @@ int ensure_records(bgs_ctx* ctx, Lane& L, size_t bytes) {
     return BGS_OK;
 }
 
-uint32_t pow2_ceil(uint64_t v) {
-    uint64_t p = 1;
-    while (p < v) p <<= 1;
-    return (uint32_t)std::min<uint64_t>(p, 1ull << 31);
-}
+uint32_t pow2_ceil(uint64_t v) { return pow2_ceil_u32(v); }
 
 // Supertile lists: `num_st` lists of `cap` (rank, tile rect) entries each. `cap` follows the longest list
 // seen so far (ctx->coarse_cap_hint, never more than n: a list holds each rank at most once); a frame
@@ -525,9 +521,7 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
         if (places == 4 && h.draw_count >= BUCKET_COUNT) {
             // the frame's sorted list is good: its quantile keys balance the buckets of the next frames.
             // bucket() is only monotone for an ascending table, so that is checked, not assumed
-            bool ascending = true;
-            for (uint32_t i = 1; i + 1 < BUCKET_COUNT; ++i) ascending = ascending && h.splitters[i - 1] <= h.splitters[i];
-            if (ascending) {
+            if (splitters_ascending(h.splitters, BUCKET_COUNT - 1u)) {
                 std::memcpy(ctx->splitters.key, h.splitters, sizeof ctx->splitters.key);
                 ctx->splitters_valid = true;
             }
@@ -543,33 +537,17 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
         }
         if (render && scan && h.visible_count > 0) {
             // list entries per visible splat: ~1.2 when splats are smaller than a supertile, 15-20 when they
-            // span many; thresholds far apart so that the rule does not flip on a moving camera
-            // Outside [1.6, 4] the level moves — straight to the level the frame's own geometry asks for, so
-            // that a change of scene is followed within one completed frame even with six frames in flight: a
-            // splat of s supertile edges overlaps (s + 1)^2 supertiles on average, so sqrt(ratio) - 1 is the
-            // typical splat extent in edges of THIS frame's level, and the finest level whose edge is at least
-            // that extent keeps the ratio under 4. (Stepping is relative to the level this frame ran at, not
-            // to ctx->sup_level, which frames completed in the meantime may already have moved.)
-            const uint64_t v = h.visible_count;
+            // span many -> the supertile level of the next frames (next_supertile_level, frame_params.h; relative
+            // to the level THIS frame ran at, not to ctx->sup_level, which frames completed in the meantime may
+            // already have moved)
             const uint32_t lv = L.pending_level;
-            const double ratio = (double)total / (double)v;
-            if ((ratio > 4.0 && lv < 3) || (ratio < 1.6 && lv > 0)) {
-                const double extent_tiles = (std::sqrt(ratio) - 1.0) * (double)L.pending_edges[lv];
-                uint32_t target = 3;
-                for (uint32_t k = 0; k < 4; ++k)
-                    if ((double)L.pending_edges[k] >= extent_tiles) { target = k; break; }
-                if (ratio > 4.0) target = std::max(target, lv + 1);
-                else target = std::min(target, lv - 1);
-                if (target > lv && ctx->sup_level != target) {
-                    // coarser supertiles hold longer lists: entries scale with the ratio, lists with the area
-                    const double e0 = (double)L.pending_edges[lv], e1 = (double)L.pending_edges[target];
-                    const double r1 = (extent_tiles / e1 + 1.0) * (extent_tiles / e1 + 1.0);
-                    const double longer = (r1 / ratio) * (e1 / e0) * (e1 / e0);
-                    const uint64_t want2 = pow2_ceil((uint64_t)((double)ctx->coarse_cap_hint * std::max(longer, 1.0)));
-                    ctx->coarse_cap_hint = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want2, ctx->coarse_cap_hint), 1u << 30);
-                }
-                ctx->sup_level = target;
+            double longer = 1.0;
+            const uint32_t target = next_supertile_level((double)total / (double)h.visible_count, lv, L.pending_edges, &longer);
+            if (target > lv && ctx->sup_level != target) {  // coarser supertiles hold longer lists
+                const uint64_t want2 = pow2_ceil((uint64_t)((double)ctx->coarse_cap_hint * longer));
+                ctx->coarse_cap_hint = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want2, ctx->coarse_cap_hint), 1u << 30);
             }
+            if (target != lv) ctx->sup_level = target;
         }
 
         bgs_stats& stt = L.result;

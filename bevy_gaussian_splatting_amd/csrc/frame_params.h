@@ -56,4 +56,47 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     }
 }
 
+// ---- adaptive policies of the host side (plain functions so that the CPU suite can test them) -----------
+
+inline uint32_t pow2_ceil_u32(uint64_t v) {
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return (uint32_t)(p < (1ull << 31) ? p : (1ull << 31));
+}
+
+// Supertile level of the next frames from a completed frame's statistics (bgs_api.hip, finish_lane).
+// `ratio` = list entries per visible splat of a frame that ran at level `lv`; `edges` = supertile edge in
+// tiles of levels 0..3. Inside [1.6, 4] the level stays. Outside it moves straight to the level the frame's
+// own geometry asks for: a splat of s supertile edges overlaps (s + 1)^2 supertiles on average, so
+// sqrt(ratio) - 1 is the typical splat extent in edges of THIS frame's level, and the finest level whose
+// edge is at least that extent keeps the ratio under 4 — but always at least one level in the direction the
+// band was left. *longer_out (if the level gets coarser): by how much the longest list is expected to grow
+// (entries scale with the ratio, lists with the supertile area).
+inline uint32_t next_supertile_level(double ratio, uint32_t lv, const uint32_t edges[4], double* longer_out) {
+    if (longer_out) *longer_out = 1.0;
+    if (!(ratio > 4.0 && lv < 3) && !(ratio < 1.6 && lv > 0)) return lv;
+    const double root = ratio > 0.0 ? __builtin_sqrt(ratio) : 0.0;
+    const double extent_tiles = (root > 1.0 ? root - 1.0 : 0.0) * (double)edges[lv];
+    uint32_t target = 3;
+    for (uint32_t k = 0; k < 4; ++k)
+        if ((double)edges[k] >= extent_tiles) { target = k; break; }
+    if (ratio > 4.0) target = target > lv + 1 ? target : lv + 1;
+    else target = target < lv - 1 ? target : lv - 1;
+    if (target > lv && longer_out) {
+        const double e0 = (double)edges[lv], e1 = (double)edges[target];
+        const double r1 = (extent_tiles / e1 + 1.0) * (extent_tiles / e1 + 1.0);
+        const double longer = (r1 / ratio) * (e1 / e0) * (e1 / e0);
+        *longer_out = longer > 1.0 ? longer : 1.0;
+    }
+    return target;
+}
+
+// A splitter table is usable only if it is ascending: bucket(key) = number of splitters <= key is monotone in
+// the key exactly then, and the bucket sort's ORDER (not just its balance) rests on that.
+inline bool splitters_ascending(const uint32_t* key, uint32_t count) {
+    for (uint32_t i = 1; i < count; ++i)
+        if (key[i - 1] > key[i]) return false;
+    return true;
+}
+
 }  // namespace bgs

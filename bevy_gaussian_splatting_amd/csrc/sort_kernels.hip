@@ -9,6 +9,13 @@
 // Output contract is the reference's: ascending key, ties by ascending input position
 // (stable LSD, 8-bit digits), so the final order is bit-identical to radix.wgsl's.
 //
+// Two paths produce that order (the host picks one per frame, bgs_api.hip):
+//   onesweep   keygen (partition + digit histograms) + one onesweep_kernel per digit place — any key width,
+//              any key distribution, any size; ~11 us per place at 10^5 pairs (a chain of L2 round trips)
+//   bucket     keygen places the drawable pairs into 256 key-range buckets (splitters = quantile keys of a
+//              completed frame's sorted list) + ONE bucket_sort_kernel that sorts every bucket in LDS by
+//              (key, index): 6.5 us at 10^5 pairs. Falls back (re-run) when a bucket overflows.
+//
 // Onesweep pass, per 256-thread block and per tile of 256*KPT pairs (tiles are handed out by
 // an atomic ticket, so a tile's predecessors have always started — no dispatch-order assumption):
 //   1. coalesced load, wave-striped (wave w owns KPT consecutive 64-pair rows)

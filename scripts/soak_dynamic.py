@@ -1,5 +1,6 @@
 """Soak with everything that adapts in motion: an orbiting camera (draw count drifts -> sticky grid hint),
-splat size switching between scene-like and dense (supertile rule flips), 6 lanes on 3 streams, frame
+splat size switching between scene-like and dense (supertile level jumps, list capacities regrow, bucket
+splitters go stale and the frame is re-run), 6 lanes on 3 streams, frame
 graphs on for every other phase. Every phase ends with a check against a blocking, directly launched frame.
 python scripts/soak_dynamic.py [frames]"""
 import sys, os, time
@@ -35,4 +36,7 @@ while done < total:
     phase += 1
 dt = time.perf_counter() - t0
 c, r = p.graph_counters()
-print(f"{done} frames in {phase} phases, {dt:.1f} s ({done / dt:.0f} fps incl. checks); graph captures {c}, replays {r}; all phase checks passed")
+st = p.stats()
+print(f"{done} frames in {phase} phases, {dt:.1f} s ({done / dt:.0f} fps incl. checks); graph captures {c}, replays {r}; "
+      f"frames re-run for capacity {st['regrow_count']}, last sort path {st['sort_path']}, list capacity {st['list_capacity']}; "
+      "all phase checks passed")

@@ -85,6 +85,13 @@ def shim() -> ctypes.CDLL:
     l.shim_fill_params.restype = None
     l.shim_supertile_div.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     l.shim_supertile_div.restype = ctypes.c_uint32
+    l.shim_next_supertile_level.argtypes = [ctypes.c_double, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
+                                            ctypes.POINTER(ctypes.c_double)]
+    l.shim_next_supertile_level.restype = ctypes.c_uint32
+    l.shim_pow2_ceil.argtypes = [ctypes.c_uint64]
+    l.shim_pow2_ceil.restype = ctypes.c_uint32
+    l.shim_splitters_ascending.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32]
+    l.shim_splitters_ascending.restype = ctypes.c_int
     l.shim_frame_params_size.argtypes = []
     l.shim_frame_params_size.restype = ctypes.c_uint32
     l.shim_sort_keys.argtypes = [ctypes.POINTER(FrameParamsC), fp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]

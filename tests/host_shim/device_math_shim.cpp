@@ -38,6 +38,13 @@ uint32_t shim_frame_params_size(void) { return (uint32_t)sizeof(FrameParams); }
 // supertile index of a tile for a supertile edge (bgs_device.h: reciprocal multiply)
 uint32_t shim_supertile_div(uint32_t tile, uint32_t edge) { return supertile_div(tile, supertile_mul(edge)); }
 
+// host-side adaptive policies (frame_params.h)
+uint32_t shim_next_supertile_level(double ratio, uint32_t lv, const uint32_t* edges, double* longer_out) {
+    return next_supertile_level(ratio, lv, edges, longer_out);
+}
+uint32_t shim_pow2_ceil(uint64_t v) { return pow2_ceil_u32(v); }
+int shim_splitters_ascending(const uint32_t* key, uint32_t count) { return splitters_ascending(key, count) ? 1 : 0; }
+
 // keys exactly as keygen_kernel stores them (before any final-pass un-inversion)
 void shim_sort_keys(const FrameParams* fp, const float* pos_vis, uint32_t n, uint32_t* keys_out) {
     for (uint32_t i = 0; i < n; ++i)

@@ -124,3 +124,57 @@ def test_compute_covariance_3d_cpu_twin():
         assert np.allclose(planes[i], [S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]], rtol=1e-5, atol=1e-6)
     co = covariance_3d_opacity(c)
     assert co.shape == (500, 8) and np.array_equal(co[:, 6], c.scale_opacity[:, 3]) and np.all(co[:, 7] == 0)
+
+
+def test_supertile_level_rule_is_stable_and_direct():
+    """frame_params.h next_supertile_level (what finish_lane applies to every completed frame): inside
+    [1.6, 4] entries per visible splat the level stays; outside it jumps straight to the level the frame's
+    geometry asks for; a step never lands on a level that would step back (no flip-flop)."""
+    import ctypes
+    import helpers as H
+    sh = H.shim()
+    edges = (ctypes.c_uint32 * 4)(6, 8, 16, 32)
+
+    def nxt(ratio, lv):
+        longer = ctypes.c_double(0.0)
+        return sh.shim_next_supertile_level(ratio, lv, edges, ctypes.byref(longer)), longer.value
+
+    def ratio_at(extent_tiles, lv):   # a splat of that extent overlaps (extent / edge + 1)^2 supertiles on average
+        return (extent_tiles / edges[lv] + 1.0) ** 2
+
+    for lv in range(4):
+        for r in (1.6, 2.0, 3.99, 4.0):
+            assert nxt(r, lv)[0] == lv
+    assert nxt(14.8, 1) == (3, pytest.approx(((22.77 / 32 + 1) ** 2 / 14.8) * 16, rel=1e-2))   # the dense headline frame
+    assert nxt(1.3, 1)[0] == 0 and nxt(1.3, 3)[0] == 0 and nxt(1.2, 0)[0] == 0                  # scene-like
+    assert nxt(5.0, 3)[0] == 3 and nxt(100.0, 0)[0] == 3
+    # from any level and any splat extent the rule settles within two completed frames and then stays
+    for extent in np.geomspace(0.05, 400.0, 60):
+        for start in range(4):
+            lv = start
+            seen = [lv]
+            for _ in range(4):
+                lv = nxt(ratio_at(extent, lv), lv)[0]
+                seen.append(lv)
+            assert seen[2] == seen[3] == seen[4], (extent, seen)
+    assert sh.shim_pow2_ceil(0) == 1 and sh.shim_pow2_ceil(1) == 1 and sh.shim_pow2_ceil(5) == 8
+    assert sh.shim_pow2_ceil(1 << 20) == 1 << 20 and sh.shim_pow2_ceil((1 << 40) + 1) == 1 << 31
+
+
+def test_splitter_tables_are_only_accepted_when_ascending():
+    """bucket(key) = number of splitters <= key orders the buckets only for an ascending table."""
+    import ctypes
+    import helpers as H
+    sh = H.shim()
+    rng = np.random.default_rng(2)
+    good = np.sort(rng.integers(0, 1 << 32, 255, dtype=np.uint64).astype(np.uint32))
+    ptr = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    assert sh.shim_splitters_ascending(ptr(good), 255) == 1
+    assert sh.shim_splitters_ascending(ptr(np.full(255, 7, np.uint32)), 255) == 1   # all equal keys: still monotone
+    bad = good.copy()
+    bad[100], bad[101] = bad[101], bad[100]
+    assert good[100] == good[101] or sh.shim_splitters_ascending(ptr(bad), 255) == 0
+    # the search keygen runs (branchless count of entries <= key over 255 sorted values) is monotone in the key
+    keys = np.sort(rng.integers(0, 1 << 32, 5000, dtype=np.uint64).astype(np.uint32))
+    buckets = np.searchsorted(good, keys, side="right")
+    assert np.all(np.diff(buckets) >= 0) and buckets.min() >= 0 and buckets.max() <= 255
