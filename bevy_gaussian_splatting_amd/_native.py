@@ -63,6 +63,7 @@ EXPORTED_SYMBOLS = (
     "bgs_graph_counters",
     "bgs_reset_adaptive_state",
     "bgs_cloud_upload_cov3d_f32",
+    "bgs_adaptive_counters",
     "bgs_set_output_rgba16f",
     "bgs_framebuffer_rgba16f_device_ptr",
     "bgs_set_packed_only",
@@ -201,6 +202,8 @@ def load() -> ctypes.CDLL:
     lib.bgs_set_packed_only.restype = ctypes.c_int
     lib.bgs_framebuffer_rgba16f_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
     lib.bgs_framebuffer_rgba16f_device_ptr.restype = ctypes.c_int
+    lib.bgs_adaptive_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.bgs_adaptive_counters.restype = ctypes.c_int
     lib.bgs_reset_adaptive_state.argtypes = [vp]
     lib.bgs_reset_adaptive_state.restype = ctypes.c_int
     _lib = lib

@@ -131,6 +131,9 @@ struct Lane {
     bool pending = false;  // a frame is enqueued whose Control block has not been checked yet
     bool pending_render = false, pending_scan = false, pending_bucket = false;
     uint32_t pending_coarse_cap = 0, pending_level = 1, pending_edges[4] = {6, 8, 16, 32};
+    bool force_onesweep = false;       // the pending frame is a re-run of one whose bucket sort gave up
+    int pending_split_slot = -1;       // splitter slot the pending bucket-sort frame used (-1: a guessed table)
+    uint64_t pending_split_epoch = 0;
     // what the pending frame was enqueued with: a frame whose data-dependent capacities turn out too
     // small (coarse lists, bucket sort, tile instances) is re-run on its lane when it is completed
     const bgs_cloud* in_cloud = nullptr;
@@ -185,11 +188,30 @@ struct bgs_ctx {
     uint32_t sup_level = 1;  // supertile edge level of the next frames (see enqueue_frame)
     // Bucket sort (one launch instead of four digit passes) is used while a completed frame's quantile keys
     // are known, the draw count fits the bucket geometry, and it has not just failed.
-    bool splitters_valid = false;
-    SplitterTable splitters{};        // quantile keys of the most recently completed frame's sorted list
+    // Splitter tables: the quantile keys of completed frames' sorted lists, kept per "view slot" — a context that
+    // alternates between cameras (the reference's multi_camera example), clouds or model transforms would
+    // otherwise hand every frame the table of the wrong view. A table is used for a frame of the same cloud and
+    // transform whose camera is near the pose it was measured at; it is dropped when a frame it served overflows.
+    struct SplitterSlot {
+        SplitterTable table{};
+        const bgs_cloud* cloud = nullptr;
+        uint32_t n = 0;
+        float transform[16] = {};
+        float pos[3] = {}, fwd[3] = {};
+        float reach = 0.0f;       // median view distance of the list the table came from (scale of "near")
+        uint64_t epoch = 0;       // 0 = empty
+        uint64_t last_used = 0;
+    };
+    static constexpr int SPLITTER_SLOTS = 8;
+    SplitterSlot split_slots[SPLITTER_SLOTS];
+    uint64_t split_epoch = 0;         // epochs handed out so far
+    uint64_t split_failed_epoch = 0;  // newest epoch whose table overflowed (escalation looks at newer ones only)
     uint32_t bucket_block = 0;        // frames to stay on the onesweep passes after a bucket-sort overflow
-    uint32_t bucket_fail_streak = 0;  // consecutive bucket-sort frames that overflowed
-    uint64_t bucket_frames = 0, onesweep_frames = 0;
+    uint32_t bucket_fail_streak = 0;  // tables in a row that overflowed on their first use
+    uint32_t list_shrink_votes = 0;   // completed frames in a row whose lists would fit a much smaller capacity
+    bool rerun_onesweep = false;      // set while finish_lane re-enqueues a frame whose bucket sort gave up
+    uint64_t bucket_frames = 0, onesweep_frames = 0;  // frames enqueued on either sort path (incl. re-runs)
+    uint64_t reruns_sort = 0, reruns_lists = 0, reruns_instances = 0, level_changes = 0;
     // entries per supertile list the next frames allocate (grown from the longest list seen; a frame whose
     // lists overflow is re-run): the worst case is n entries in each of up to 256 lists (1.9 GB per lane at
     // 1 M splats), the real lists of a frame hold ~1 % of that
@@ -369,6 +391,8 @@ int ensure_coarse(bgs_ctx* ctx, Lane& L, uint32_t n, uint32_t num_st, uint32_t* 
         ctx->coarse_cap_hint = (ctx->debug_flags & 0x100000u) ? 64u : std::max<uint32_t>(pow2_ceil(n1 / 16u), 4096u);
     const uint32_t want = std::min<uint32_t>(n1, ctx->coarse_cap_hint);
     const size_t need = (size_t)num_st * want;
+    // (grown when too small; a lane keeps what it has when the hint falls — a context that alternates between
+    // views of different density would otherwise free and allocate every frame)
     if (need > L.coarse_entries || !L.coarse) {
         if (need * 8u > (64ull << 30))
             return fail(ctx, BGS_ECAPACITY, "coarse bin lists would exceed 64 GiB; use bgs_set_binning(ctx, 1)");
@@ -444,6 +468,34 @@ int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
 int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s,
                   bool render, bool allow_graph);
 
+// camera pose of a view: world position and viewing direction (-Z of the view frame)
+void view_pose(const bgs_view* v, float pos[3], float fwd[3]) {
+    for (int k = 0; k < 3; ++k) { pos[k] = v->world_from_view[12 + k]; fwd[k] = -v->world_from_view[8 + k]; }
+    const float len = std::sqrt(fwd[0] * fwd[0] + fwd[1] * fwd[1] + fwd[2] * fwd[2]);
+    if (len > 0.0f) for (int k = 0; k < 3; ++k) fwd[k] /= len;
+}
+
+// The splitter slot that fits a frame (same cloud, same transform, camera within 5 % of the slot's reach and
+// 10 degrees of its direction), or -1.
+int find_splitter_slot(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s) {
+    float pos[3], fwd[3];
+    view_pose(view, pos, fwd);
+    int best = -1;
+    float best_d = 0.0f;
+    for (int i = 0; i < bgs_ctx::SPLITTER_SLOTS; ++i) {
+        const auto& sl = ctx->split_slots[i];
+        if (!sl.epoch || sl.cloud != cloud || sl.n != cloud->ptrs.n) continue;
+        if (std::memcmp(sl.transform, s->transform, sizeof sl.transform) != 0) continue;
+        const float dx = pos[0] - sl.pos[0], dy = pos[1] - sl.pos[1], dz = pos[2] - sl.pos[2];
+        const float d = std::sqrt(dx * dx + dy * dy + dz * dz);
+        const float c = fwd[0] * sl.fwd[0] + fwd[1] * sl.fwd[1] + fwd[2] * sl.fwd[2];
+        if (!(d <= 0.05f * sl.reach) || !(c >= 0.9848f)) continue;
+        const float score = d / std::max(sl.reach, 1e-30f) + (1.0f - c);
+        if (best < 0 || score < best_d) { best = i; best_d = score; }
+    }
+    return best;
+}
+
 // Complete the frame pending on a lane: wait for it, check the watchdog word of the Control copy that
 // travelled with the frame, and RE-RUN the frame on its lane if a data-dependent capacity turned out too
 // small (a supertile list, the bucket sort's geometry, the tile-instance buffer): nobody has seen the
@@ -462,24 +514,35 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             // nothing a tripped frame left behind is trusted: not its counters, not the scratch region
             L.scratch_clean = false;
             ctx->draw_hint_valid = false;
-            ctx->splitters_valid = false;
+            for (auto& sl : ctx->split_slots) sl.epoch = 0;
             return fail(ctx, BGS_EINTERNAL,
                         "device watchdog tripped (look-back spin bound), code " + std::to_string(h.error));
         }
         // ---- capacities that depend on the data ----
-        bool rerun = false;
+        bool rerun = false, sort_gave_up = false;
         if (L.pending_bucket && h.sort_overflow) {
+            sort_gave_up = true;
             // a bucket over capacity (1): the view changed faster than the splitters follow, the re-run below
             // delivers fresh ones; one key value far too often (2): stay on the digit passes for a while
             // (doubling while it keeps happening: equal keys by the thousand overflow a bucket whatever the table)
-            ctx->bucket_fail_streak = std::min(ctx->bucket_fail_streak + 1u, 8u);
-            ctx->bucket_block = (h.sort_overflow & 2u) ? 256u : (1u << ctx->bucket_fail_streak) - 1u;
-            ctx->splitters_valid = false;
+            // Frames already in flight with the same stale table fail for the same reason: only a table that
+            // is NEWER than the last failed one counts towards the back-off.
+            if (L.pending_split_slot >= 0 && ctx->split_slots[L.pending_split_slot].epoch == L.pending_split_epoch)
+                ctx->split_slots[L.pending_split_slot].epoch = 0;  // drop the table
+            if (h.sort_overflow & 2u) {
+                ctx->bucket_block = 256u;
+            } else if (L.pending_split_epoch > ctx->split_failed_epoch) {
+                ctx->bucket_fail_streak = std::min(ctx->bucket_fail_streak + 1u, 8u);
+                if (ctx->bucket_fail_streak >= 3u) ctx->bucket_block = (1u << ctx->bucket_fail_streak) - 1u;
+            }
+            ctx->split_failed_epoch = std::max(ctx->split_failed_epoch, L.pending_split_epoch);
+            ctx->reruns_sort += 1;
             rerun = true;
         } else if (L.pending_bucket) {
             ctx->bucket_fail_streak = 0;
         }
         uint64_t total = (uint64_t)h.instance_total_lo | ((uint64_t)h.instance_total_hi << 32);
+        uint32_t pending_longest = 0;
         if (render && scan) {
             total = 0;
             uint32_t longest = 0;
@@ -487,9 +550,25 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
                 total += h.coarse_total[i];
                 longest = std::max(longest, h.coarse_total[i]);
             }
-            const uint32_t want = pow2_ceil((uint64_t)longest + longest / 4);
-            if (want > ctx->coarse_cap_hint) ctx->coarse_cap_hint = want;  // the next allocations
-            if (longest > L.pending_coarse_cap) rerun = true;              // this frame dropped entries
+            // the capacity the next allocations aim at follows the longest list SEEN (25 % head-room, power of
+            // two): up at once, down only after 64 completed frames in a row that would fit an eighth of it
+            const uint32_t want = std::max<uint32_t>(pow2_ceil((uint64_t)longest + longest / 4), 4096u);
+            if (L.pending_level == ctx->sup_level) {
+                if (want > ctx->coarse_cap_hint) {
+                    ctx->coarse_cap_hint = want;
+                    ctx->list_shrink_votes = 0;
+                } else if ((uint64_t)want * 8u <= ctx->coarse_cap_hint) {
+                    if (++ctx->list_shrink_votes >= 64u) { ctx->coarse_cap_hint = want * 2u; ctx->list_shrink_votes = 0; }
+                } else {
+                    ctx->list_shrink_votes = 0;
+                }
+            }
+            if (longest > L.pending_coarse_cap) {  // this frame dropped entries
+                if (want > ctx->coarse_cap_hint) ctx->coarse_cap_hint = want;
+                rerun = true;
+                ctx->reruns_lists += 1;
+            }
+            pending_longest = longest;
         }
         if (render && !scan && h.overflow) {
             // BINNING_SORT overflow: grow to the next power of two with 25 % headroom
@@ -501,6 +580,7 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             cap = std::min(cap, MAX_INSTANCE_CAPACITY);
             int rc = ensure_instances(ctx, L, cap);
             if (rc != BGS_OK) return rc;
+            ctx->reruns_instances += 1;
             rerun = true;
         }
         if (rerun) {
@@ -508,12 +588,16 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             ctx->regrow_count += 1;
             uint32_t* const next_target = ctx->next_srgb8_target;  // belongs to a frame not enqueued yet
             ctx->next_srgb8_target = L.in_srgb8_target;
+            if (sort_gave_up) L.force_onesweep = true;  // stays for every further attempt of this frame
+            ctx->rerun_onesweep = L.force_onesweep;
             int rc = enqueue_frame(ctx, L, L.in_cloud, &L.in_view, &L.in_settings, render, L.in_allow_graph);
+            ctx->rerun_onesweep = false;
             ctx->next_srgb8_target = next_target;
             if (rc != BGS_OK) return rc;
             continue;
         }
 
+        L.force_onesweep = false;
         if (!ctx->draw_hint_valid || h.draw_count > ctx->draw_hint || (uint64_t)h.draw_count * 2 < ctx->draw_hint) {
             ctx->draw_hint = (uint32_t)std::min<uint64_t>((uint64_t)h.draw_count + h.draw_count / 8 + 1024, 0xFFFFFFFFull);
             ctx->draw_hint_valid = true;
@@ -521,9 +605,28 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
         if (places == 4 && h.draw_count >= BUCKET_COUNT) {
             // the frame's sorted list is good: its quantile keys balance the buckets of the next frames.
             // bucket() is only monotone for an ascending table, so that is checked, not assumed
-            if (splitters_ascending(h.splitters, BUCKET_COUNT - 1u)) {
-                std::memcpy(ctx->splitters.key, h.splitters, sizeof ctx->splitters.key);
-                ctx->splitters_valid = true;
+            if (splitters_ascending(h.splitters, BUCKET_COUNT - 1u) && L.in_cloud) {
+                int slot = find_splitter_slot(ctx, L.in_cloud, &L.in_view, &L.in_settings);
+                if (slot < 0) {  // a view not seen lately: take an empty slot, else the least recently used one
+                    slot = 0;
+                    for (int i = 0; i < bgs_ctx::SPLITTER_SLOTS; ++i) {
+                        if (!ctx->split_slots[i].epoch) { slot = i; break; }
+                        if (ctx->split_slots[i].last_used < ctx->split_slots[slot].last_used) slot = i;
+                    }
+                }
+                auto& sl = ctx->split_slots[slot];
+                std::memcpy(sl.table.key, h.splitters, sizeof sl.table.key);
+                sl.cloud = L.in_cloud;
+                sl.n = n;
+                std::memcpy(sl.transform, L.in_settings.transform, sizeof sl.transform);
+                view_pose(&L.in_view, sl.pos, sl.fwd);
+                // the median key is ~bits(dist^2) of the median drawable splat (keys are 0xFFFFFFFF - bits)
+                const uint32_t mid_bits = 0xFFFFFFFFu - h.splitters[BUCKET_COUNT / 2 - 1];
+                float d2;
+                std::memcpy(&d2, &mid_bits, 4);
+                sl.reach = (d2 > 0.0f && d2 < 3.0e38f) ? std::sqrt(d2) : 1.0f;
+                sl.epoch = ++ctx->split_epoch;
+                sl.last_used = ctx->seq;
             }
         }
         // after a render only the drawable prefix of the list is materialised (the culled tail stays
@@ -543,11 +646,14 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             const uint32_t lv = L.pending_level;
             double longer = 1.0;
             const uint32_t target = next_supertile_level((double)total / (double)h.visible_count, lv, L.pending_edges, &longer);
-            if (target > lv && ctx->sup_level != target) {  // coarser supertiles hold longer lists
-                const uint64_t want2 = pow2_ceil((uint64_t)((double)ctx->coarse_cap_hint * longer));
-                ctx->coarse_cap_hint = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want2, ctx->coarse_cap_hint), 1u << 30);
+            if (target != lv && ctx->sup_level != target) {
+                // lists of another level: predicted from THIS frame's longest list (coarser supertiles hold
+                // longer lists: entries scale with the ratio, lists with the area), never from the old hint
+                const double predicted = (double)pending_longest * (target > lv ? longer : 1.0) * 1.25;
+                ctx->coarse_cap_hint = std::max<uint32_t>(pow2_ceil((uint64_t)std::min(predicted, 1.0e9)), 4096u);
+                ctx->list_shrink_votes = 0;
             }
-            if (target != lv) ctx->sup_level = target;
+            if (target != lv) { if (ctx->sup_level != target) ctx->level_changes += 1; ctx->sup_level = target; }
         }
 
         bgs_stats& stt = L.result;
@@ -676,8 +782,9 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     // it does not work out (then bucket_block keeps the following frames on the passes for a while).
     // Debug flags: 0x80000 never, 0x200000 also with a guessed range (no completed frame yet).
     const bool guess = (ctx->debug_flags & 0x200000u) != 0u;
-    bool bucket = places == 4 && n > 0 && !(ctx->debug_flags & 0x80000u) && ctx->bucket_block == 0 &&
-                  ((ctx->splitters_valid && ctx->draw_hint_valid) || guess) &&
+    const int split_slot = (places == 4 && n > 0) ? find_splitter_slot(ctx, cloud, view, s) : -1;
+    bool bucket = places == 4 && n > 0 && !(ctx->debug_flags & 0x80000u) && ctx->bucket_block == 0 && !ctx->rerun_onesweep &&
+                  ((split_slot >= 0 && ctx->draw_hint_valid) || guess) &&
                   (!ctx->draw_hint_valid || ctx->draw_hint <= BUCKET_COUNT * (BUCKET_CAP / 4u) * 3u);
     if (ctx->bucket_block > 0 && places == 4) ctx->bucket_block -= 1;
     if (bucket) {
@@ -766,10 +873,17 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     kg.fp_out = L.d_fp;
     kg.bucket_slots = L.bucket_slots;
     kg.bucket_status = depth_status;  // the depth passes' look-back words are free in a bucket-sort frame
+    L.pending_split_slot = -1;
+    L.pending_split_epoch = 0;
     if (bucket) {
-        if (ctx->splitters_valid) kg.split = ctx->splitters;
-        else  // debug flag 0x200000: a guessed table (equal steps over the 32-bit range: badly balanced)
+        if (split_slot >= 0) {
+            kg.split = ctx->split_slots[split_slot].table;
+            ctx->split_slots[split_slot].last_used = ctx->seq + 1;
+            L.pending_split_slot = split_slot;
+            L.pending_split_epoch = ctx->split_slots[split_slot].epoch;
+        } else {  // debug flag 0x200000: a guessed table (equal steps over the 32-bit range: badly balanced)
             for (uint32_t i = 0; i < BUCKET_COUNT; ++i) kg.split.key[i] = (i + 1u) << 24;
+        }
     }
     const bool have_keygen = kg.prepare(ctx->num_cus * 4);
     const bool large = n > (4u << 20);
@@ -1228,6 +1342,8 @@ void bgs_cloud_free(bgs_ctx* ctx, bgs_cloud* cloud) {
             if (L.stream) (void)hipStreamSynchronize(L.stream);
             if (L.in_cloud == cloud) L.in_cloud = nullptr;
         }
+        for (auto& sl : ctx->split_slots)
+            if (sl.cloud == cloud) sl.epoch = 0;  // a later cloud may get the same address
     }
     for (auto p : cloud->allocs) if (p) (void)hipFree(p);
     delete cloud;
@@ -1451,15 +1567,30 @@ int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags) {
     return BGS_OK;
 }
 
+int bgs_adaptive_counters(bgs_ctx* ctx, uint64_t out[8]) {
+    if (!ctx || !out) return fail(ctx, BGS_EINVAL, "NULL argument");
+    out[0] = ctx->bucket_frames;
+    out[1] = ctx->onesweep_frames;
+    out[2] = ctx->reruns_sort;
+    out[3] = ctx->reruns_lists;
+    out[4] = ctx->reruns_instances;
+    out[5] = ctx->level_changes;
+    out[6] = ctx->sup_level;
+    out[7] = ctx->coarse_cap_hint;
+    return BGS_OK;
+}
+
 int bgs_reset_adaptive_state(bgs_ctx* ctx) {
     if (!ctx) return fail(nullptr, BGS_EINVAL, "ctx is NULL");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, BGS_EHIP, "hipSetDevice failed");
     int rc = finish_all(ctx);
     if (rc != BGS_OK) return rc;
     ctx->draw_hint_valid = false;
-    ctx->splitters_valid = false;
+    for (auto& sl : ctx->split_slots) sl.epoch = 0;
+    ctx->split_failed_epoch = ctx->split_epoch;
     ctx->bucket_block = 0;
     ctx->bucket_fail_streak = 0;
+    ctx->list_shrink_votes = 0;
     ctx->sup_level = 1;
     ctx->coarse_cap_hint = 0;
     return BGS_OK;

@@ -336,6 +336,14 @@ class GaussianSplattingPlugin:
         """Kernel-ablation switches for experiments only (non-zero => wrong images)."""
         self._check(self._lib.bgs_set_debug_flags(self._ctx, int(flags)))
 
+    def adaptive_counters(self) -> dict:
+        """Cumulative counters of the adaptive machinery (bgs_adaptive_counters)."""
+        out = (ctypes.c_uint64 * 8)()
+        self._check(self._lib.bgs_adaptive_counters(self._ctx, out))
+        names = ("bucket_frames", "onesweep_frames", "reruns_sort", "reruns_lists", "reruns_instances",
+                 "level_changes", "supertile_level", "list_capacity_hint")
+        return {k: int(v) for k, v in zip(names, out)}
+
     def reset_adaptive_state(self) -> None:
         """Forget the hints completed frames left in the context (draw count, key range, list capacity,
         supertile rule): the next frames behave like the first frames of a fresh context."""

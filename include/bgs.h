@@ -302,6 +302,11 @@ int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags);
  * behave like the first frames of a fresh context (onesweep passes, default capacities, re-run on
  * overflow). Completes the frames in flight. */
 int bgs_reset_adaptive_state(bgs_ctx* ctx);
+/* What the adaptive machinery has done since bgs_create: out[0] frames enqueued on the bucket sort path,
+ * [1] on the onesweep passes (both counts include re-runs), [2] frames re-run because the bucket sort gave
+ * up, [3] because a supertile list overflowed, [4] because the tile-instance buffer was too small,
+ * [5] supertile level changes, [6] the current level, [7] the current list-capacity hint (entries). */
+int bgs_adaptive_counters(bgs_ctx* ctx, uint64_t out[8]);
 
 /* HIP-event timing level: 0 = none, 1 = frame start/end only (total_ms), 2 = every stage
  * (default). Each recorded event costs a few microseconds of GPU timeline. */

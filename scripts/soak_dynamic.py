@@ -34,9 +34,11 @@ while done < total:
     assert np.array_equal(got, ref), f"phase {phase} (global_scale {gs}): pipelined frame differs from the blocking one"
     done += phase_len
     phase += 1
+    if os.environ.get("SOAK_VERBOSE"):
+        print(f"phase {phase} gs {gs} graphs {phase % 2 == 0}: {time.perf_counter() - t0:.2f} s so far; {p.adaptive_counters()} graphs {p.graph_counters()}", flush=True)
 dt = time.perf_counter() - t0
 c, r = p.graph_counters()
 st = p.stats()
 print(f"{done} frames in {phase} phases, {dt:.1f} s ({done / dt:.0f} fps incl. checks); graph captures {c}, replays {r}; "
       f"frames re-run for capacity {st['regrow_count']}, last sort path {st['sort_path']}, list capacity {st['list_capacity']}; "
-      "all phase checks passed")
+      f"{p.adaptive_counters()}; all phase checks passed")

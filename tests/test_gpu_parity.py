@@ -541,9 +541,9 @@ def test_bucket_sort_is_bit_exact(plugin, oracle, mode, n):
 def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
     """Keys the buckets cannot split: (a) 2000 splats at exactly one distance (one key value beyond the
     tie limit of the in-bucket ranking), (b) 40 000 splats inside a key range of a few ulps (one bucket over
-    capacity, whatever the splitters). The frame is re-run with the digit passes before anyone sees it; order stays bit-exact and
-    the following frames stay on the passes for a while."""
-    base = random_gaussians_3d_seeded(20_000, 41)
+    capacity, whatever the splitters). Forced onto the bucket path with a guessed table (debug flag 0x200000)
+    and then with the table their own sorted list yields, the frame is re-run with the digit passes before
+    anyone sees it: order stays bit-exact, the image is right, and the context backs off."""
     v = View.headless(640, 360)
     s = CloudSettings()
     for case in ("ties", "cluster"):
@@ -557,24 +557,62 @@ def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
         ref = oracle.sort(c, v, s)
         h = plugin.upload(c)
         plugin.reset_adaptive_state()
-        hb = plugin.upload(base)
-        plugin.sort(hb, v, s)  # teaches the context a splitter table: the next frame takes the bucket path
-        got = plugin.sort(h, v, s)
-        st = plugin.stats()
-        assert _sort_equal(got, ref), case
-        assert st["regrow_count"] >= 1 and st["sort_path"] == "onesweep", (case, st)
-        again = plugin.sort(h, v, s)
-        assert _sort_equal(again, ref) and plugin.stats()["sort_path"] == "onesweep"
-        # the same in a RENDER frame: the kernels behind the sort must not touch the void list
+        plugin.set_debug_flags(0x200000)
+        try:
+            got = plugin.sort(h, v, s)
+            st = plugin.stats()
+            assert _sort_equal(got, ref), case
+            assert st["regrow_count"] >= 1 and st["sort_path"] == "onesweep", (case, st)
+            # the same in a RENDER frame: the kernels behind the sort must not touch the void list
+            plugin.reset_adaptive_state()
+            img = plugin.render(h, v, s)
+            st = plugin.stats()
+            assert st["regrow_count"] >= 1 and st["sort_path"] == "onesweep", (case, st)
+            refimg, amb = oracle.render(c, ref, v, s, with_ambiguity=True)
+            _assert_image(refimg, img, amb, frac_slack=0.01, what=f"render with bucket overflow ({case})")
+        finally:
+            plugin.set_debug_flags(0)
+        # without the flag: the table this view's own sorted list yields cannot split these keys either
         plugin.reset_adaptive_state()
-        plugin.render(hb, v, s)
-        img = plugin.render(h, v, s)
-        st = plugin.stats()
-        assert st["regrow_count"] >= 1 and st["sort_path"] == "onesweep", (case, st)
-        refimg, amb = oracle.render(c, ref, v, s, with_ambiguity=True)
-        _assert_image(refimg, img, amb, frac_slack=0.01, what=f"render with bucket overflow ({case})")
+        before = plugin.adaptive_counters()["reruns_sort"]
+        for _ in range(6):
+            assert _sort_equal(plugin.sort(h, v, s), ref), case
+        after = plugin.adaptive_counters()
+        assert after["reruns_sort"] > before               # it was tried, it failed, the frame was re-run ...
+        assert plugin.stats()["sort_path"] == "onesweep"   # ... and the context has backed off by now
         h.free()
-        hb.free()
+    plugin.reset_adaptive_state()
+
+
+def test_splitter_tables_are_kept_per_view(plugin, oracle):
+    """A context that alternates between cameras (the reference's multi_camera example) or clouds must not
+    hand a frame the splitter table of another view: tables live in slots keyed by cloud, model transform and
+    camera pose. After one frame per view every later frame runs the bucket sort without a single re-run."""
+    ca, cb = random_gaussians_3d_seeded(300_000, 51), random_gaussians_3d_seeded(200_000, 52)
+    ha, hb = plugin.upload(ca), plugin.upload(cb)
+    views = [View.headless(640, 360, yaw=y) for y in (0.0, 1.6, 3.1, 4.7)]
+    s = CloudSettings()
+    plugin.reset_adaptive_state()
+    jobs = [(ha, ca, v) for v in views] + [(hb, cb, views[0]), (hb, cb, views[2])]
+    refs = [oracle.sort(c, v, s) for _, c, v in jobs]
+    for (h, _, v), ref in zip(jobs, refs):   # one frame per (cloud, view): onesweep, leaves a table
+        assert _sort_equal(plugin.sort(h, v, s), ref)
+    before = plugin.adaptive_counters()
+    for rnd in range(3):
+        for (h, _, v), ref in zip(jobs, refs):
+            assert _sort_equal(plugin.sort(h, v, s), ref)
+            assert plugin.stats()["sort_path"] == "bucket", (rnd, plugin.stats())
+    after = plugin.adaptive_counters()
+    assert after["reruns_sort"] == before["reruns_sort"]
+    assert after["bucket_frames"] - before["bucket_frames"] == 3 * len(jobs)
+    # a small camera move reuses the table (that is what it is for); a model transform change does not
+    near = View.perspective(transform_from((0.05, 1.5, 5.02)), 640, 360)
+    assert _sort_equal(plugin.sort(ha, near, s), oracle.sort(ca, near, s)) and plugin.stats()["sort_path"] == "bucket"
+    moved = CloudSettings(transform=transform_from((3.0, 0.0, 0.0)))
+    assert _sort_equal(plugin.sort(ha, views[0], moved), oracle.sort(ca, views[0], moved))
+    assert plugin.stats()["sort_path"] == "onesweep"
+    ha.free()
+    hb.free()
     plugin.reset_adaptive_state()
 
 
