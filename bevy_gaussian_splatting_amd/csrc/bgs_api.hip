@@ -66,7 +66,7 @@ T* dev_alloc(size_t count) {
 struct GraphKey {
     const void* cloud[6];
     const void* bufs[11];
-    uint32_t n, is_f16, places, sort_mode, gaussian_mode, aabb, any_mode, srgb8, debug_flags;
+    uint32_t n, format, places, sort_mode, gaussian_mode, aabb, any_mode, srgb8, debug_flags;
     int32_t width, height;
     int32_t sort_blocks, bin_blocks, keygen_blocks;
     uint32_t sup_edge;
@@ -141,7 +141,7 @@ struct Lane {
     bgs_settings in_settings{};
     uint32_t* in_srgb8_target = nullptr;
     bool in_allow_graph = false;
-    uint32_t pending_n = 0, pending_places = 0, pending_num_st = 0, pending_rec_bytes = 0, pending_is_f16 = 0;
+    uint32_t pending_n = 0, pending_places = 0, pending_num_st = 0, pending_rec_bytes = 0, pending_cloud_format = 0;
     uint32_t pending_w = 0, pending_h = 0, pending_tx = 0, pending_ty = 0;
     uint64_t seq = 0;  // enqueue sequence number (to find the oldest pending lane)
 
@@ -454,7 +454,7 @@ int validate(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const b
     if (s->draw_mode > BGS_DRAW_HIGHLIGHT_SELECTED) return fail(ctx, BGS_EINVAL, "unknown draw_mode");
     if (s->rasterize_mode == BGS_RASTERIZE_CLASSIFICATION && s->num_classes == 0)
         return fail(ctx, BGS_EINVAL, "num_classes must be >= 1");
-    if (render && cloud->ptrs.is_f16 == CLOUD_COV3D &&
+    if (render && cloud->ptrs.format == CLOUD_COV3D &&
         (s->gaussian_mode != BGS_GAUSSIAN_3D || s->rasterize_mode == BGS_RASTERIZE_NORMAL))
         return fail(ctx, BGS_EINVAL, "a precomputed-covariance cloud has no rotation / scale: 3D gaussian mode only, no Normal raster mode");
     if (render) {
@@ -678,7 +678,7 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
             const uint64_t N = n, k = places, D = h.draw_count;
             uint64_t bytes = N * 16 + N * 8 + (L.pending_bucket ? D * 24 : k * D * 16);
             if (render) {
-                const uint64_t B = L.pending_is_f16 == CLOUD_F16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
+                const uint64_t B = L.pending_cloud_format == CLOUD_F16 ? 128 : 240, R = rec_bytes, V = h.visible_count, I = total;
                 const uint64_t P = (uint64_t)L.pending_w * L.pending_h;
                 if (scan)  // coarse entries (rank + tile rect, 8 B): written once, read by the tiles of their supertile
                     bytes += V * (B - 16) + V * R + V * 8 + I * 8 + I * 8 + P * 16;
@@ -994,7 +994,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
                                 L.h_ctl_dev, L.bucket_slots};
         std::memcpy(key.bufs, bufs, sizeof bufs);
         key.n = n;
-        key.is_f16 = cloud->ptrs.is_f16;
+        key.format = cloud->ptrs.format;
         key.places = places;
         key.sort_mode = s->sort_mode;
         key.gaussian_mode = fp.gaussian_mode;
@@ -1073,7 +1073,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
     L.pending_places = places;
     L.pending_num_st = num_st;
     L.pending_rec_bytes = (uint32_t)rec_bytes;
-    L.pending_is_f16 = cloud->ptrs.is_f16;
+    L.pending_cloud_format = cloud->ptrs.format;
     L.pending_w = (uint32_t)fp.width;
     L.pending_h = (uint32_t)fp.height;
     L.pending_tx = (uint32_t)fp.tiles_x;
@@ -1276,7 +1276,7 @@ int bgs_cloud_upload_f32(bgs_ctx* ctx, uint32_t n, const float* pv, const float*
     c->ptrs.sh_f32 = (const float*)c->allocs[1];
     c->ptrs.rot_scale = (const float4*)c->allocs[2];
     c->ptrs.n = n;
-    c->ptrs.is_f16 = 0;
+    c->ptrs.format = CLOUD_F32;
     *out = c;
     return BGS_OK;
 }
@@ -1302,7 +1302,7 @@ int bgs_cloud_upload_f16(bgs_ctx* ctx, uint32_t n, const float* pv, const uint32
     c->ptrs.sh_f16 = (const uint32_t*)c->allocs[1];
     c->ptrs.rot_scale_opacity_f16 = (const uint4*)c->allocs[2];
     c->ptrs.n = n;
-    c->ptrs.is_f16 = 1;
+    c->ptrs.format = CLOUD_F16;
     *out = c;
     return BGS_OK;
 }
@@ -1328,7 +1328,7 @@ int bgs_cloud_upload_cov3d_f32(bgs_ctx* ctx, uint32_t n, const float* pv, const 
     c->ptrs.sh_f32 = (const float*)c->allocs[1];
     c->ptrs.cov3d_opacity = (const float4*)c->allocs[2];
     c->ptrs.n = n;
-    c->ptrs.is_f16 = CLOUD_COV3D;
+    c->ptrs.format = CLOUD_COV3D;
     *out = c;
     return BGS_OK;
 }

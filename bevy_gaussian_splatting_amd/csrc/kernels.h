@@ -19,7 +19,7 @@ struct CloudPtrs {
     const uint4* rot_scale_opacity_f16; // n         (f16 format)
     const float4* cov3d_opacity;        // n*2       (cov3d format: Covariance3dOpacity = cov3d[6], opacity, pad)
     uint32_t n;
-    uint32_t is_f16;                    // cloud format: 0 = f32 planes, 1 = f16 planes, 2 = f32 with precomputed covariance
+    uint32_t format;                    // cloud format: 0 = f32 planes, 1 = f16 planes, 2 = f32 with precomputed covariance
 };
 constexpr uint32_t CLOUD_F32 = 0, CLOUD_F16 = 1, CLOUD_COV3D = 2;
 

@@ -330,9 +330,9 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
                        ticket_slot)
 #define BGS_LAUNCH_PE2(F16, SURFEL) \
     do { if (any_mode) BGS_LAUNCH_PE(F16, SURFEL, true); else BGS_LAUNCH_PE(F16, SURFEL, false); } while (0)
-    if (cloud.is_f16 == CLOUD_F16) {
+    if (cloud.format == CLOUD_F16) {
         if (surfel) BGS_LAUNCH_PE2(1, true); else BGS_LAUNCH_PE2(1, false);
-    } else if (cloud.is_f16 == CLOUD_COV3D) {
+    } else if (cloud.format == CLOUD_COV3D) {
         BGS_LAUNCH_PE2(2, false);  // 2DGS needs rotation and scale: refused for these clouds (validate)
     } else {
         if (surfel) BGS_LAUNCH_PE2(0, true); else BGS_LAUNCH_PE2(0, false);
@@ -522,9 +522,9 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
                        coarse_cap, sup_mul, sup_x, sup_y, ticket_slot)
 #define BGS_LAUNCH_PB2(F16, SURFEL) \
     do { if (any_mode) BGS_LAUNCH_PB(F16, SURFEL, true); else BGS_LAUNCH_PB(F16, SURFEL, false); } while (0)
-    if (cloud.is_f16 == CLOUD_F16) {
+    if (cloud.format == CLOUD_F16) {
         if (surfel) BGS_LAUNCH_PB2(1, true); else BGS_LAUNCH_PB2(1, false);
-    } else if (cloud.is_f16 == CLOUD_COV3D) {
+    } else if (cloud.format == CLOUD_COV3D) {
         BGS_LAUNCH_PB2(2, false);  // 2DGS needs rotation and scale: refused for these clouds (validate)
     } else {
         if (surfel) BGS_LAUNCH_PB2(0, true); else BGS_LAUNCH_PB2(0, false);
