@@ -1,24 +1,31 @@
 // bgs_api.hip — libbgs host side: context, frame lanes, device buffers, orchestration, C ABI.
 //
-// One frame (bgs_render, default BGS_BINNING_SCAN) is 9 enqueues on ONE lane's stream with no host
-// round trip in between; every size that depends on the data (drawable count V', list lengths)
-// stays on the device in the lane's Control block and is consumed by persistent, ticket-driven
-// kernels:
+// One frame (bgs_render, default BGS_BINNING_SCAN) is 4 kernel launches in the steady state (7 on a frame
+// without a splitter table) on ONE lane's stream with no host round trip in between; every size that
+// depends on the data (drawable count V', list lengths) stays on the device in the lane's Control block
+// and is consumed by persistent, ticket-driven kernels:
 //
-//   memset(zeroed scratch: Control | look-back words)
-//   keygen                        N x (16 B read, 8 B write) + digit histograms + stable partition
-//   onesweep x places             the V' drawable depth keys, 16 B/pair/pass
+//   [memset]                      only when the scratch region is not known to be clean
+//   keygen                        N x 16 B read; stable partition; drawable pairs -> key-range buckets
+//                                 (bucket path) or -> an index-ordered list + digit histograms (onesweep path)
+//   bucket_sort | onesweep x places   the V' drawable depth keys: one launch, or one per digit place
 //   project_bin                   V' splats -> records (front-to-back) + ordered coarse lists of (rank, tile rect)
-//   raster_scan                   one wave per 16x16 tile, lazy binning, saturation exit
-//   [encode_srgb8]                optional Rgba8UnormSrgb image (the reference's target format)
-//   copy Control -> pinned host   read when the frame is completed
+//   raster_scan                   one wave per 16x16 tile, lazy binning, saturation exit; writes the f32 target
+//                                 and / or the packed image, zeroes the scratch the frame used, reports the
+//                                 frame's counters and quantile keys to pinned host memory
+//
+// ADAPTIVE STATE. What a completed frame teaches the context sizes the next ones: the draw count (grid
+// sizes), the sorted list's quantile keys (bucket splitters, kept per view slot), the longest supertile
+// list (list capacity) and the entries-per-splat ratio (supertile level). Each is only a hint: kernels
+// guard every write and count true totals, finish_lane compares them with what the frame ran with and
+// RE-RUNS the frame on its lane when a capacity was too small — before anyone has seen its output.
 //
 // FRAME LANES (bgs_set_pipeline_depth): a single stream of these latency-bound kernels leaves most
-// of the chip idle (1.9k waves of projection work, 59-tile sort passes), so the context owns K
-// lanes, each with its own stream and per-frame buffers; async frames go round-robin over the
-// lanes and the GPU overlaps one frame's sort with another frame's rasteriser (measured 1.8x at
-// K = 3). A lane is completed (stream wait + watchdog check) when it is reused, popped, or on any
-// blocking call.
+// of the chip idle (1.9k waves of projection work, a 256-workgroup sort), so the context owns K
+// lanes, each with its own per-frame buffers, multiplexed onto a few streams; async frames go round-robin
+// over the lanes and the GPU overlaps one frame's sort with another frame's rasteriser (measured 2.0x with
+// 6 lanes on 3 streams). A lane is completed (event wait + watchdog check + capacity check) when it is
+// reused, popped, or on any blocking call.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
