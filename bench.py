@@ -128,7 +128,7 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
 
 
 def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=None, depth=1, trials=1,
-            busy_warm_s=0.0):
+            busy_warm_frames=0):
     """W untimed + K timed steps. A step ENQUEUES one frame: the scan pipeline needs no host round
     trip, and the context keeps `depth` frames in flight (lanes, multiplexed onto a few HIP streams). With a
     `gather` callback (N > 1 ranks) the oldest frame is popped and handed to it as soon as `depth`
@@ -136,7 +136,8 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
     everything, so dt covers exactly K complete frames (and their gathers). With `trials` > 1 the timed
     region (barrier, K steps, barrier) is repeated and the list of durations returned as well: K = 20 frames
     are 1.5 ms of GPU time, which one clock ramp or one late lane moves by 10 %, so the headline reports the
-    median trial. `busy_warm_s`: keep rendering for at least that long before the first trial (clocks).
+    median trial. `busy_warm_frames`: that many more untimed frames before the first trial (clocks, adaptive
+    state) — a frame COUNT, not a duration, so that every rank of a multi-GPU run issues the same collectives.
     Returns (seconds of the median trial, per-stage ms averaged by the library over the timed frames' HIP
     events, stats[, every trial's seconds])."""
     prepared = plugin.prepare(view, settings)  # marshal the C structs once, like a caller's per-view cache
@@ -159,9 +160,9 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
     # --warmup (fewer steps than lanes) does not leave allocations inside the timed region
     run(depth)
     run(warmup)
-    t_warm = time.perf_counter()
-    while time.perf_counter() - t_warm < busy_warm_s:
-        run(max(steps, 4 * depth))
+    chunk = max(steps, 4 * depth)
+    for _ in range((busy_warm_frames + chunk - 1) // chunk):
+        run(chunk)
     dts = []
     for _ in range(max(1, trials)):
         if barrier:
@@ -346,7 +347,7 @@ def main():
     plugin.set_profiling(0)
     trials = args.trials if args.trials > 0 else (5 if args.steps < 2000 else 3)
     _, _, _, dts = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, lanes,
-                           trials=max(trials, 2), busy_warm_s=0.25)
+                           trials=max(trials, 2), busy_warm_frames=3000)
     plugin.set_profiling(2)
     plugin.set_packed_only(False)
     if dist is not None:  # a trial lasts as long as its slowest rank
@@ -481,8 +482,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "timing": {"trials_ms": [round(1e3 * x, 4) for x in dts], "reported": "median trial",
-                       "note": "every trial is a barrier + sync, --steps frames, barrier + sync; 0.25 s of "
-                               "rendering precedes the first one"},
+                       "note": "every trial is a barrier + sync, --steps frames, barrier + sync; 3000 untimed "
+                               "frames (~0.2 s) precede the first one"},
             "config": {"workload": f"{args.splats}-splat 3DGS f32 planar cloud (seed {SEED}, reference random_gaussians_3d "
                                    "distributions), 1920x1080, SH degree 3, CloudSettings::default(), "
                                    "examples/headless.rs camera; one camera per GPU",
