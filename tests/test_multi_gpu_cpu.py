@@ -136,3 +136,85 @@ def test_batched_asynchronous_frame_gather(frames, batch, zero_copy):
         seq = np.concatenate([b[r] for b in batches])
         assert seq.shape == (frames, 4, 6, 4)
         assert [int(f[0, 0, 0]) for f in seq] == [(17 * r + i) % 251 for i in range(frames)]
+
+
+class _FakePlugin:
+    """What bench.measure needs from the plugin, without a GPU: frames are 'rendered' into the staging slot the
+    gather handed out; `delay` makes one rank slower than the other."""
+
+    def __init__(self, delay):
+        self.delay, self.in_flight, self.target, self.rendered = delay, [], None, 0
+
+    def prepare(self, view, settings):
+        return (view, settings)
+
+    def set_target(self, t):
+        self.target = t
+
+    def render(self, handle, prepared, download=False):
+        import time
+        time.sleep(self.delay)
+        self.target.fill_(self.rendered % 251)
+        self.rendered += 1
+        self.in_flight.append(self.target)
+
+    def frames_in_flight(self):
+        return len(self.in_flight)
+
+    def pipeline_pop(self):
+        self.in_flight.pop(0)
+        return None, None
+
+    def synchronize(self):
+        pass
+
+    def stats(self):
+        return {"stage_ms": {}}
+
+
+def _measure_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from bevy_gaussian_splatting_amd.multiview import BatchedFrameGather
+
+    plugin = _FakePlugin(delay=0.0004 if rank == 0 else 0.0015)   # rank 1 is ~4x slower
+    batcher = BatchedFrameGather((2, 3, 4), torch.uint8, "cpu", batch=4)
+
+    def gather(f32_ptr, srgb8_ptr):
+        batcher.frame_completed()
+
+    gather.flush = batcher.flush
+    gather.before_render = lambda: plugin.set_target(batcher.next_target())
+    dt, _, _, dts = bench.measure(plugin, None, None, None, steps=5, warmup=3, gather=gather, barrier=dist.barrier,
+                                  depth=2, trials=3, busy_warm_frames=17)
+    t = torch.tensor(dts, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        q.put((plugin.rendered, batcher.frames_received, len(dts), t.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bench_measure_issues_the_same_collectives_on_every_rank():
+    """bench.measure with N > 1: warm-up, extra warm-up frames and the timed trials are all frame COUNTS, so a
+    slow and a fast rank run the same number of frames and gathers (a time-based warm-up would leave the
+    ranks with different numbers of collectives: a hang). Every frame of every rank arrives on rank 0."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_measure_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    rendered, received, ntrials, dts = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # depth + warmup + extra warm-up (17 frames in chunks of max(steps, 4 * depth) = 8 -> 3 chunks) + 3 trials
+    expected = 2 + 3 + 3 * 8 + 3 * 5
+    assert rendered == expected and received == expected * world and ntrials == 3
+    assert all(d > 5 * 0.0015 * 0.5 for d in dts)   # a trial lasts as long as its slowest rank
