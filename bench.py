@@ -499,7 +499,7 @@ def main():
                       "visible_splats": st["visible_count"], "tile_instances": st["instance_count"],
                       "gather_ms_per_step": round(gather_ms[0] / max(args.steps + args.warmup, 1), 4),
                       "gathered_format": "Rgba8UnormSrgb (packed-only frames: no f32 target)" if dist is not None else None,
-                      "gather_batch_frames": GATHER_BATCH if world > 1 else None,
+                      "gather_batch_frames": GATHER_BATCH if dist is not None else None,
                       "frames_gathered_on_rank0": batcher.frames_received if batcher is not None else None},
             "stages": stages,
             "sort_msplats_per_s": round(args.splats / (sort_dev_ms * 1e-3) / 1e6, 1) if sort_dev_ms > 0 else None,

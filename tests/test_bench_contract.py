@@ -80,3 +80,25 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert d["value"] > 1000.0     # BASELINE.json's target on this config, with a wide margin to the measured 12 k
     assert len(d["timing"]["trials_ms"]) >= 5 and "traffic_source" in rf
+
+
+@pytest.mark.gpu
+def test_bench_gather_path_runs_with_one_rank():
+    """The N > 1 code path of bench.py (process group on RCCL, packed-only sRGB8 frames rendered straight into
+    the staging batch, asynchronous batched gather, max over ranks) with a single rank
+    (BGS_BENCH_FORCE_DIST=1): every timed and untimed frame must arrive on rank 0."""
+    env = dict(os.environ, BGS_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "4",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 1000.0 and d["cpu_baseline"] is None
+    assert "Rgba8UnormSrgb" in d["frame"]["gathered_format"] and d["frame"]["gather_batch_frames"] in (8, None)
+    lanes = d["config"]["lanes"]
+    chunk = max(24, 4 * lanes)
+    expected = lanes + 4 + -(-3000 // chunk) * chunk + len(d["timing"]["trials_ms"]) * 24
+    assert d["frame"]["frames_gathered_on_rank0"] == expected
