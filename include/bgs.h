@@ -335,8 +335,9 @@ int bgs_hbm_probe(bgs_ctx* ctx, uint64_t bytes, uint32_t iters, float* copy_gbs,
  * Default 3. With fewer streams than lanes (depth 6 on 3 streams) a stream already holds the next
  * frame of a sibling lane while one executes, so it never idles between frames waiting for the
  * host, and no more than `streams` frames compete for the chip at a time (measured on the headline
- * workload: 11.8 k frames/s with 3 lanes on 3 streams, 12.7 k with 6 lanes on 3 streams; more than 3
- * concurrent frames is slower). Completes the frames in flight. */
+ * workload, round 2: 14.8 k frames/s with 3 lanes on 3 streams, 15.3 k with 6 on 3, 15.5 k with 6 on 6, 12.6 k
+ * with 8 on 4 — but 16.5 k with 8 on 4 for packed-only frames that are popped one by one: the best pair
+ * depends on how the host consumes the frames; measure). Completes the frames in flight. */
 int bgs_set_pipeline_streams(bgs_ctx* ctx, uint32_t streams);
 
 /* Frame graphs (opt-in, default off). An asynchronous BINNING_SCAN frame (bgs_set_async) in the
