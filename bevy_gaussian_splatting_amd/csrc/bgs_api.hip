@@ -203,6 +203,7 @@ struct bgs_ctx {
         SplitterTable table{};
         const bgs_cloud* cloud = nullptr;
         uint32_t n = 0;
+        uint32_t sort_mode = 0;   // Radix culls (a frustum's worth of keys), Rayon / Std keep every splat
         float transform[16] = {};
         float pos[3] = {}, fwd[3] = {};
         float reach = 0.0f;       // median view distance of the list the table came from (scale of "near")
@@ -482,8 +483,8 @@ void view_pose(const bgs_view* v, float pos[3], float fwd[3]) {
     if (len > 0.0f) for (int k = 0; k < 3; ++k) fwd[k] /= len;
 }
 
-// The splitter slot that fits a frame (same cloud, same transform, camera within 5 % of the slot's reach and
-// 10 degrees of its direction), or -1.
+// The splitter slot that fits a frame (same cloud, sort mode and model transform, camera within 5 % of the
+// slot's reach and 10 degrees of its direction), or -1.
 int find_splitter_slot(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* view, const bgs_settings* s) {
     float pos[3], fwd[3];
     view_pose(view, pos, fwd);
@@ -491,7 +492,7 @@ int find_splitter_slot(bgs_ctx* ctx, const bgs_cloud* cloud, const bgs_view* vie
     float best_d = 0.0f;
     for (int i = 0; i < bgs_ctx::SPLITTER_SLOTS; ++i) {
         const auto& sl = ctx->split_slots[i];
-        if (!sl.epoch || sl.cloud != cloud || sl.n != cloud->ptrs.n) continue;
+        if (!sl.epoch || sl.cloud != cloud || sl.n != cloud->ptrs.n || sl.sort_mode != s->sort_mode) continue;
         if (std::memcmp(sl.transform, s->transform, sizeof sl.transform) != 0) continue;
         const float dx = pos[0] - sl.pos[0], dy = pos[1] - sl.pos[1], dz = pos[2] - sl.pos[2];
         const float d = std::sqrt(dx * dx + dy * dy + dz * dz);
@@ -529,11 +530,11 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
         bool rerun = false, sort_gave_up = false;
         if (L.pending_bucket && h.sort_overflow) {
             sort_gave_up = true;
-            // a bucket over capacity (1): the view changed faster than the splitters follow, the re-run below
-            // delivers fresh ones; one key value far too often (2): stay on the digit passes for a while
-            // (doubling while it keeps happening: equal keys by the thousand overflow a bucket whatever the table)
-            // Frames already in flight with the same stale table fail for the same reason: only a table that
-            // is NEWER than the last failed one counts towards the back-off.
+            // A bucket over capacity (1): the view changed faster than the splitters follow; the table is dropped
+            // and the re-run below (always on the digit passes) delivers a fresh one. Frames already in flight
+            // with the same stale table fail for the same reason, so only a table NEWER than the last failed one
+            // counts towards the back-off (three such tables in a row: 7, 15, ... 255 frames on the passes).
+            // One key value far too often (2): no table can split that; 256 frames on the passes.
             if (L.pending_split_slot >= 0 && ctx->split_slots[L.pending_split_slot].epoch == L.pending_split_epoch)
                 ctx->split_slots[L.pending_split_slot].epoch = 0;  // drop the table
             if (h.sort_overflow & 2u) {
@@ -625,6 +626,7 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
                 std::memcpy(sl.table.key, h.splitters, sizeof sl.table.key);
                 sl.cloud = L.in_cloud;
                 sl.n = n;
+                sl.sort_mode = L.in_settings.sort_mode;
                 std::memcpy(sl.transform, L.in_settings.transform, sizeof sl.transform);
                 view_pose(&L.in_view, sl.pos, sl.fwd);
                 // the median key is ~bits(dist^2) of the median drawable splat (keys are 0xFFFFFFFF - bits)
