@@ -187,11 +187,12 @@ struct bgs_ctx {
     uint32_t* next_srgb8_target = nullptr;  // bgs_set_srgb8_target: one-shot destination of the next frame
 
     // Sizes the grids of the next frames' sort and projection launches: the draw_count of a completed
-    // frame plus head-room, kept while the counts that follow stay inside [hint / 2, hint] so that a
+    // frame plus head-room, raised at once and lowered only after 64 frames at under a quarter of it, so that a
     // captured frame graph (whose grids are frozen) survives a moving camera. A hint only — the
     // kernels read the real count on the device and loop over tickets if the grid is short.
     uint32_t draw_hint = 0;
     bool draw_hint_valid = false;
+    uint32_t draw_shrink_votes = 0;
     uint32_t sup_level = 1;  // supertile edge level of the next frames (see enqueue_frame)
     // Bucket sort (one launch instead of four digit passes) is used while a completed frame's quantile keys
     // are known, the draw count fits the bucket geometry, and it has not just failed.
@@ -606,9 +607,20 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
         }
 
         L.force_onesweep = false;
-        if (!ctx->draw_hint_valid || h.draw_count > ctx->draw_hint || (uint64_t)h.draw_count * 2 < ctx->draw_hint) {
+        // (up at once; down only after 64 completed frames in a row at under a quarter of it: a context that
+        // cycles through cameras seeing different shares of the cloud keeps one hint — and one captured graph
+        // per lane)
+        if (!ctx->draw_hint_valid || h.draw_count > ctx->draw_hint) {
             ctx->draw_hint = (uint32_t)std::min<uint64_t>((uint64_t)h.draw_count + h.draw_count / 8 + 1024, 0xFFFFFFFFull);
             ctx->draw_hint_valid = true;
+            ctx->draw_shrink_votes = 0;
+        } else if ((uint64_t)h.draw_count * 4 < ctx->draw_hint) {
+            if (++ctx->draw_shrink_votes >= 64u) {
+                ctx->draw_hint = (uint32_t)std::min<uint64_t>((uint64_t)h.draw_count * 2 + 1024, 0xFFFFFFFFull);
+                ctx->draw_shrink_votes = 0;
+            }
+        } else {
+            ctx->draw_shrink_votes = 0;
         }
         if (places == 4 && h.draw_count >= BUCKET_COUNT) {
             // the frame's sorted list is good: its quantile keys balance the buckets of the next frames.
@@ -1013,7 +1025,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         key.debug_flags = ctx->debug_flags;
         key.width = fp.width;
         key.height = fp.height;
-        key.sort_blocks = sort_blocks;
+        key.sort_blocks = bucket ? 0 : sort_blocks;  // the bucket sort's grid is fixed
         key.bin_blocks = bin_blocks;
         key.keygen_blocks = (int32_t)kg.blocks;
         key.sup_edge = sup_edge;
