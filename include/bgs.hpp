@@ -281,6 +281,13 @@ class GaussianSplattingPlugin {
     void set_packed_only(bool on) { check(bgs_set_packed_only(ctx_, on ? 1 : 0), "bgs_set_packed_only"); }
     // forget what completed frames taught the context (grid sizes, splitters, list capacity, supertile level)
     void reset_adaptive_state() { check(bgs_reset_adaptive_state(ctx_), "bgs_reset_adaptive_state"); }
+    // cumulative counters of the adaptive machinery (bgs_adaptive_counters: bucket / onesweep frames, re-runs by
+    // cause, supertile level changes, current level, list-capacity hint)
+    std::array<uint64_t, 8> adaptive_counters() {
+        std::array<uint64_t, 8> out{};
+        check(bgs_adaptive_counters(ctx_, out.data()), "bgs_adaptive_counters");
+        return out;
+    }
     void set_profiling(int level) { check(bgs_set_profiling(ctx_, level), "bgs_set_profiling"); }
     void synchronize() { check(bgs_synchronize(ctx_), "bgs_synchronize"); }
     uint32_t frames_in_flight() {
