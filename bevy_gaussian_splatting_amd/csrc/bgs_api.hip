@@ -686,7 +686,7 @@ int finish_lane(bgs_ctx* ctx, Lane& L) {
         stt.sort_path = L.pending_bucket ? 1u : 0u;
         stt.list_capacity = (render && scan) ? L.pending_coarse_cap : 0u;
         stt.instance_count = render ? total : 0;
-        stt.instance_capacity = L.inst_cap;
+        stt.instance_capacity = (render && scan) ? (uint64_t)L.coarse_entries : L.inst_cap;
         stt.tiles_x = render ? L.pending_tx : 0;
         stt.tiles_y = render ? L.pending_ty : 0;
         stt.depth_passes = places;

@@ -147,7 +147,8 @@ typedef struct bgs_stats {
     uint32_t sort_path;          /* depth sort of the call: 0 = onesweep digit passes, 1 = bucket sort
                                     (one launch; chosen per frame)        */
     uint64_t instance_count;     /* I: (tile, splat) instances emitted                 */
-    uint64_t instance_capacity;
+    uint64_t instance_capacity;  /* BINNING_SORT: tile instances the lane's buffers hold; BINNING_SCAN: 8-byte list
+                                    entries allocated for the lane (all supertile lists together)      */
     uint32_t tiles_x, tiles_y;
     uint32_t depth_passes;       /* radix digit places used for the depth keys         */
     uint32_t tile_passes;        /* radix passes used for the tile ids                 */
