@@ -397,7 +397,7 @@ uint32_t pow2_ceil(uint64_t v) { return pow2_ceil_u32(v); }
 int ensure_coarse(bgs_ctx* ctx, Lane& L, uint32_t n, uint32_t num_st, uint32_t* cap_out) {
     const uint32_t n1 = std::max<uint32_t>(n, 1);
     if (ctx->coarse_cap_hint == 0)
-        ctx->coarse_cap_hint = (ctx->debug_flags & 0x100000u) ? 64u : std::max<uint32_t>(pow2_ceil(n1 / 16u), 4096u);
+        ctx->coarse_cap_hint = (ctx->debug_flags & 0x100000u) ? 64u : std::max<uint32_t>(pow2_ceil(n1 / 64u), 4096u);  // a first guess: a frame that outgrows it is re-run
     const uint32_t want = std::min<uint32_t>(n1, ctx->coarse_cap_hint);
     const size_t need = (size_t)num_st * want;
     // (grown when too small; a lane keeps what it has when the hint falls — a context that alternates between
