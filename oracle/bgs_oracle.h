@@ -14,13 +14,21 @@
  * PINNING STATUS
  *   - sort keys / order / (places, shift, parity) table: PINNED by the reference's own
  *     known-answer tests tests/radix.rs:9-106 (fixtures in tests/golden/radix_keys.json).
- *   - per-splat projection, SH colour, per-pixel falloff and blending: PARITY UNPINNED
- *     against a running reference (none can run here). Pinned only by (a) float64
- *     closed-form single-splat cases and (b) the coarse thresholds of
- *     tests/visibility_render.rs:245-274 applied to the oracle's image.
- *   - RasterizeMode::{Depth, Normal, Position, Classification} colour variants
- *     (src/render/gaussian.wgsl:312-405): PARITY UNPINNED (closed-form cases only); Classification
- *     additionally restates bevy_render 0.19.0's hsv_to_rgb, which is not in the reference tree.
+ *   - per-splat projection, SH colour, per-pixel falloff and blending: no output of a RUNNING reference
+ *     exists to compare with (none can run here), so these are pinned by INDEPENDENT float64 derivations
+ *     instead (tests/test_oracle_golden.py; nothing there re-types the WGSL): cov2d and the four quad
+ *     corners from the camera model with a numerical Jacobian + numpy.linalg.eigh (OBB and AABB, incl. the
+ *     pair of tools/compare_aabb_obb.rs); every covered pixel of an anisotropic splat against the projected
+ *     Gaussian; SH degree 0-3 against scipy's spherical harmonics at 1000 directions; the 2DGS
+ *     local_to_pixel / mean_2d / extent against a ray-plane linear solve and the sampled cutoff ellipse, and
+ *     the surfel image against the same solve; a three-splat stack against the closed-form "over" sum; plus
+ *     the coarse thresholds of tests/visibility_render.rs:245-274 applied to the oracle's image. Where the
+ *     reference itself departs from the geometric truth (OBB falloff tied to the quad, the 2DGS frame's doubled
+ *     focal factor and half-size quad, the on-axis OBB NaN) the oracle follows the reference and the tests
+ *     say so.
+ *   - STILL PARITY UNPINNED: third-party arithmetic outside the reference tree — Bevy's projection matrix
+ *     helper, wgpu's rasterisation rules / blend unit, glam, bevy_render 0.19.0's hsv_to_rgb (Classification
+ *     and OpticalFlow colour variants) — restated and labelled where used.
  *
  * Arithmetic contract (so "bit-exact sort order" is well defined; WGSL leaves the
  * evaluation order of dot()/matrix products implementation-defined):
