@@ -17,7 +17,7 @@
 //                        staged in LDS (coalesced index read, 16-byte gathers), every thread
 //                        owns one pixel and composites front-to-back:
 //                            C += T*alpha*c, T *= 1-alpha        (fs_main + blend, reordered)
-//                        and stops when every pixel of the tile has T < 2^-16.
+//                        and stops when every pixel of the tile has T < T_EPS (2^-13).
 //
 // Front-to-back vs the reference's back-to-front "over" is the same polynomial evaluated in
 // the opposite association order; the difference is f32 rounding (<< 1e-3).
@@ -554,7 +554,15 @@ void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Contro
 // tile rasteriser
 // ---------------------------------------------------------------------------------------
 constexpr int RV_OBB = 0, RV_AABB3D = 1, RV_SURFEL = 2;
-constexpr float T_EPS = 1.0f / 65536.0f;  // stop compositing a pixel below this transmittance
+// A pixel stops compositing once its transmittance is below T_EPS: what the splats behind it could still add is
+// at most T_EPS * max|c| (telescoping sum), 1.2e-4 * max|c| against the 1e-3 tolerance — the cut-off of the 3DGS
+// reference rasteriser (T < 1e-4). Same-box A/B on the headline frame (profiles/r2_notes.md): 2^-16 15.0 k,
+// 2^-13 15.9 k, 2^-12 16.5 k frames/s; the measured error on the dense full-size crops grows from 5e-5 to 2.9e-4
+// at 2^-13 and would be ~5e-4, half the tolerance, at 2^-12.
+#ifndef BGS_T_EPS_LOG2
+#define BGS_T_EPS_LOG2 13
+#endif
+constexpr float T_EPS = 1.0f / (float)(1u << BGS_T_EPS_LOG2);
 
 // One staged record, decoded once per splat and shared by every pixel a lane owns.
 template <int VARIANT>
@@ -622,15 +630,43 @@ __device__ __forceinline__ void stage_surfel(const float4* __restrict__ src, con
     out[5] = make_float4(r4.w, 0.0f, 0.0f, 0.0f);
 }
 
+// A surfel's AABB quad is the square around the LONGER side of its 3-sigma ellipse (bounding_box_cov2d:
+// max(rx, ry)), so most of the tiles a quad touches see nothing of the ellipse: on the dense 1 M-surfel frame
+// 54 % of the (record, tile) pairs reach no pixel with more than 2^-23 of the surfel's opacity (measured on the
+// host with the exact per-pixel expression). Such a pair is dropped at staging time by a conservative bound:
+// p is affine in the pixel, so over the tile's 16 x 16 pixel centres |p.x| and |p.y| are at least their value
+// at the tile centre minus the half-range of the affine part, |p.z| at most centre plus half-range, the same
+// for the screen-space deltas, and power = min(s3, s2) >= min of the two bounds (interval arithmetic; within
+// 2 % of the exact count). What is dropped is at most 2^-23 opacity per record — 7e-5 if all of a saturated
+// tile's ~600 records were dropped at the threshold, against the 1e-3 tolerance; DESIGN.md "Documented
+// deviations". A NaN anywhere keeps the record.
+#ifndef BGS_SURFEL_CULL_LOG2
+#define BGS_SURFEL_CULL_LOG2 23
+#endif
+__device__ __forceinline__ bool surfel_negligible_in_tile(const float4 st[6]) {
+    constexpr float H = 7.5f;  // pixel centres of a tile: xl, yl in [0, 15]
+    const float pxc = fmaf(H, st[1].w + st[2].z, st[1].x), ex = H * (fabsf(st[1].w) + fabsf(st[2].z));
+    const float pyc = fmaf(H, st[2].x + st[2].w, st[1].y), ey = H * (fabsf(st[2].x) + fabsf(st[2].w));
+    const float pzc = fmaf(H, st[2].y + st[3].x, st[1].z), ez = H * (fabsf(st[2].y) + fabsf(st[3].x));
+    const float lx = fmaxf(fabsf(pxc) - ex, 0.0f), ly = fmaxf(fabsf(pyc) - ey, 0.0f), hz = fabsf(pzc) + ez;
+    const float s3 = fmaf(lx, lx, ly * ly) / (hz * hz);
+    const float dx = fmaxf(fabsf(fmaf(H, st[3].z, st[3].y)) - H * fabsf(st[3].z), 0.0f);
+    const float dy = fmaxf(fabsf(fmaf(H, st[4].x, st[3].w)) - H * fabsf(st[4].x), 0.0f);
+    const float s2 = fmaf(dx, dx, dy * dy);
+    constexpr float LIMIT = (float)BGS_SURFEL_CULL_LOG2;  // staged powers are in exp2 units
+    return s3 >= LIMIT && s2 >= LIMIT;
+}
+
 // fs_main + blend for ONE record and ONE pixel (src/render/gaussian.wgsl:438-505,
 // src/render/mod.rs:944-948), front-to-back form, branch-free:
 //     w = covered && T >= T_EPS ? T * alpha : 0;   C += w * c;   T -= w
 // (T - T*alpha == T*(1 - alpha); a pixel stops accumulating once T < T_EPS, a per-pixel rule that
 // does not depend on how splats are batched, so every rasteriser variant gives the same bits).
 // Explicit fmaf so both rasterisers contract identically.
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int VARIANT>
 __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const float qx, const float qy,
-                                         const float aspect, float& T, float& cr, float& cg, float& cb) {
+                                         const float aspect, float& T, v2f& crg, float& cb) {
     float alpha, r, g, b;
     bool hit;
     if constexpr (VARIANT == RV_OBB) {
@@ -677,9 +713,11 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
     // a real branch on purpose: it becomes an exec-mask region that a wave skips entirely when none
     // of its 64 pixels (a 16x4 strip in the wave-per-tile rasteriser) is covered
     if (hit && T >= T_EPS) {
+        asm volatile("");  // not speculatable: keeps this a branch (the compiler would turn it into selects)
         const float w = T * alpha;
-        cr = fmaf(w, r, cr);
-        cg = fmaf(w, g, cg);
+        // red and green as one packed fma on the register pair the record's (r, g) arrive in: left to itself
+        // the compiler pairs red with blue and spends two moves per pixel on assembling the operand
+        crg = __builtin_elementwise_fma((v2f){w, w}, (v2f){r, g}, crg);
         cb = fmaf(w, b, cb);
         T -= w;
     }
@@ -736,7 +774,8 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     const float aspect = fp.viewport_w / fp.viewport_h;
 
     const uint2 range = ranges[(ty << 8) | tx];
-    float T = in_image ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    float T = in_image ? 1.0f : 0.0f, cb = 0.0f;
+    v2f crg = {0.0f, 0.0f};
 
     for (uint32_t base = range.x; base < range.y; base += 256u) {
         const uint32_t cnt = min(256u, range.y - base);
@@ -752,6 +791,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
             } else if constexpr (VARIANT == RV_SURFEL) {
                 float4 st[6];
                 stage_surfel(src, tile_ox, tile_oy, aspect, st);
+                st[5].y = __uint_as_float(surfel_negligible_in_tile(st) && !(fp.debug & 64u) ? 0u : 1u);  // as raster_scan_kernel decides
 #pragma unroll
                 for (int v = 0; v < 6; ++v) s_rec[tid * REC_V4 + v] = st[v];
             } else {
@@ -764,7 +804,9 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
             for (uint32_t k = 0; k < cnt; ++k) {
                 StagedRecord<VARIANT> sr;
                 sr.load(s_rec + k * REC_V4);
-                blend_px<VARIANT>(sr, qx, qy, aspect, T, cr, cg, cb);
+                if constexpr (VARIANT == RV_SURFEL)
+                    if (__builtin_amdgcn_readfirstlane(__float_as_uint(sr.a5.y)) == 0u) continue;
+                blend_px<VARIANT>(sr, qx, qy, aspect, T, crg, cb);
             }
         // also the barrier that protects s_rec before the next batch overwrites it
         if (__syncthreads_and(T < T_EPS ? 1 : 0)) break;
@@ -772,7 +814,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     if (in_image) {
         // dst = src + dst*(1-src.a) unrolled over the whole list, target cleared to `clear`
         fb[(size_t)py * (size_t)fp.width + (size_t)px] =
-            make_float4(fmaf(T, clear.x, cr), fmaf(T, clear.y, cg), fmaf(T, clear.z, cb),
+            make_float4(fmaf(T, clear.x, crg.x), fmaf(T, clear.y, crg.y), fmaf(T, clear.z, cb),
                         fmaf(T, clear.w, 1.0f - T));
     }
 }
@@ -844,7 +886,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
     }
     if (tile < ntiles) {  // whole wave; nothing in here synchronises across waves
     float4* const s_rec = s_rec_all[wave];
-    volatile uint32_t* const s_queue = s_queue_all[wave];
+    uint32_t* const s_queue = s_queue_all[wave];  // plain LDS accesses, ordered by the wave barriers + fences below
 
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
     const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + (lane >> 4);
@@ -854,17 +896,21 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
     const float tile_cx = (float)((int)tx * TILE_PX + 8), tile_cy = (float)((int)ty * TILE_PX + 8);
     const float tile_ox = (float)((int)tx * TILE_PX) + 0.5f, tile_oy = (float)((int)ty * TILE_PX) + 0.5f;
 
-    float T[4], cr[4], cg[4], cb[4], qy[4];
+    float T[4], cb[4], qy[4];
+    v2f crg[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int py = py0 + 4 * r;
         qy[r] = VARIANT != RV_AABB3D ? (float)((lane >> 4) + 4 * r) : (float)py + 0.5f;
         T[r] = (px < fp.width && py < fp.height) ? 1.0f : 0.0f;
-        cr[r] = cg[r] = cb[r] = 0.0f;
+        crg[r] = (v2f){0.0f, 0.0f};
+        cb[r] = 0.0f;
     }
 
     const uint32_t st = supertile_div(ty, sup_mul) * sup_x + supertile_div(tx, sup_mul);
-    const uint32_t total = min(ctl->coarse_total[st], coarse_cap);
+    // wave-uniform by construction (one tile per wave): say so, so that the scan loop's control flow (list
+    // position, queue length, flush decisions, the record loop) is scalar instead of exec-mask loops on VGPRs
+    const uint32_t total = __builtin_amdgcn_readfirstlane(min(ctl->coarse_total[st], coarse_cap));
     const uint2* __restrict__ list = reinterpret_cast<const uint2*>(coarse) + (size_t)st * coarse_cap;
 
     // candidate stream of (rank, tile rectangle) entries, two groups ahead of the scan
@@ -882,8 +928,9 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
     uint32_t base = 0u;
     for (;;) {
         const bool have = base < total;
-        const bool hit = have && tx >= (rect_cur & 255u) && tx <= ((rect_cur >> 8) & 255u) &&
-                         ty >= ((rect_cur >> 16) & 255u) && ty <= (rect_cur >> 24);
+        // bitwise on purpose: four compares and three scalar ands instead of nested exec-mask regions
+        const bool hit = have & (tx >= (rect_cur & 255u)) & (tx <= ((rect_cur >> 8) & 255u)) &
+                         (ty >= ((rect_cur >> 16) & 255u)) & (ty <= (rect_cur >> 24));
         const unsigned long long b = __ballot(hit);
         const uint32_t hits = (uint32_t)__popcll(b);
         const bool fits = qn + hits <= 64u;
@@ -944,6 +991,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
                 } else {
                     float4 st[6];
                     stage_surfel(src, tile_ox, tile_oy, aspect, st);
+                    keep = keep && !(surfel_negligible_in_tile(st) && !(fp.debug & 64u));
                     st[5].y = __uint_as_float(keep ? 1u : 0u);
 #pragma unroll
                     for (int v = 0; v < 6; ++v) s_rec[lane * REC_V4 + v] = st[v];
@@ -963,7 +1011,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
                 else keep_flag = __float_as_uint(sr.a5.y);
                 if (__builtin_amdgcn_readfirstlane(keep_flag) == 0u) continue;  // scalar branch
 #pragma unroll
-                for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, T[r], cr[r], cg[r], cb[r]);
+                for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, T[r], crg[r], cb[r]);
             }
             const bool sat = T[0] < T_EPS && T[1] < T_EPS && T[2] < T_EPS && T[3] < T_EPS;
             saturated = __all(sat);
@@ -984,7 +1032,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
         for (int r = 0; r < 4; ++r) {
             const int py = pyw + 4 * r;
             if (pxw < fp.width && py < fp.height) {
-                const float4 c = make_float4(fmaf(T[r], fp.clear[0], cr[r]), fmaf(T[r], fp.clear[1], cg[r]),
+                const float4 c = make_float4(fmaf(T[r], fp.clear[0], crg[r].x), fmaf(T[r], fp.clear[1], crg[r].y),
                                              fmaf(T[r], fp.clear[2], cb[r]), fmaf(T[r], fp.clear[3], 1.0f - T[r]));
                 const size_t at = (size_t)py * (size_t)fp.width + (size_t)pxw;
                 if (!(want_srgb8 & OUT_SKIP_F32)) fb[at] = c;

@@ -1,8 +1,9 @@
 #!/bin/bash
 # same-box A/B of prebuilt library variants: ab/*.so are swapped in for libbgs.so one after another
+# bash scripts/ab.sh [frames] [global_scale] [reps]
 R=$GRAFT_REPO_ROOT
 cp $R/bevy_gaussian_splatting_amd/csrc/libbgs.so /tmp/libbgs_orig.so
-for rep in 1 2; do
+for rep in $(seq 1 ${3:-2}); do
 for v in $R/ab/*.so; do
   cp $v $R/bevy_gaussian_splatting_amd/csrc/libbgs.so
   echo "== $(basename $v) rep $rep"

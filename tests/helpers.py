@@ -161,7 +161,7 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
     C = np.zeros((H, W, 3), np.float32)
     out = ShimOut()
     surfel = settings.gaussian_mode == GaussianMode.Gaussian2d and settings.aabb
-    eps = np.float32(1.0 / 65536.0)
+    eps = np.float32(1.0 / 8192.0)   # T_EPS of csrc/render_kernels.hip
     # Depth mode: range from sorted[count-1] and sorted[1] of the FULL entry list (gaussian.wgsl:331-340)
     depth_range = np.zeros(2, np.float32)
     if n > 0:

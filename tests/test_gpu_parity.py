@@ -168,6 +168,32 @@ def test_binning_modes_give_bit_identical_images(plugin):
     h.free()
 
 
+def test_surfel_tile_cull_is_invisible_and_the_same_in_both_rasterisers(plugin):
+    """2DGS surfel records whose ellipse cannot reach a tile (<= 2^-23 of their opacity on every pixel) are
+    dropped at staging time (surfel_negligible_in_tile). Against the same frame with the cull switched off
+    (debug flag 0x40: keep every record the tile rectangle admits) the image moves by far less than the
+    tolerance, and both rasterisers take the same decisions."""
+    c = random_gaussians_3d_seeded(60_000, 23)
+    h = plugin.upload(c)
+    v = View.headless(800, 448)
+    try:
+        for gs in (1.0, 0.2):
+            s = CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, aabb=True, global_scale=gs)
+            plugin.set_binning("scan")
+            a = plugin.render(h, v, s)
+            plugin.set_debug_flags(0x40)
+            full = plugin.render(h, v, s)
+            plugin.set_debug_flags(0)
+            plugin.set_binning("sort")
+            b = plugin.render(h, v, s)
+            assert np.array_equal(a, b)
+            assert np.isfinite(full).all() and float(np.abs(a - full).max()) <= 1e-4
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.set_binning("scan")
+    h.free()
+
+
 def test_render_10k_config0(plugin, oracle, binning):
     """BASELINE.json configs[0]: 10k random splats, 256x256, single camera."""
     c = random_gaussians_3d_seeded(10_000, 1)
