@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
         if (tile >= num_tiles) break;
         const uint32_t base = tile * per_tile;
         uint32_t key[KG_ITEMS], below[KG_ITEMS];
-        bool draw[KG_ITEMS];
+        // which entries reach the vertex stage: everything unless the radix key is "culled" (out-of-range slots
+        // carry the sentinel too). Re-derived from the key where it is needed: sixteen lane masks kept alive
+        // across the tile cost 32 scalar registers, and this kernel spills them
+        const bool all_draw = fp.sort_mode != SORT_RADIX;
+#define BGS_KG_DRAWN(k) (all_draw ? (base + (uint32_t)(k) * 256u + (uint32_t)tid < fp.n) : (key[k] != sentinel))
         // all of the tile's position loads are issued before the first key is computed: with one
         // 4-wave block per CU nothing else hides their latency
         float4 pin[KG_ITEMS];
@@ -141,18 +145,21 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
             const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
             pin[k] = i < fp.n ? pos[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
+        // the sort mode is the launch's, not the splat's: one branch around the sixteen keys instead of
+        // sixteen copies of it (each re-reading its matrices from spilled scalar registers)
+#define BGS_KG_KEYS(KIND)                                                                      \
+    _Pragma("unroll") for (int k = 0; k < KG_ITEMS; ++k) {                                     \
+        const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;                          \
+        const float4 p = pin[k];                                                               \
+        key[k] = i < fp.n ? sort_key_kind<KIND>(fp, V3{p.x, p.y, p.z}) : sentinel;             \
+    }
+        if (fp.sort_mode == SORT_RADIX) { BGS_KG_KEYS(1) }
+        else if (fp.sort_mode == SORT_NONE) { BGS_KG_KEYS(0) }
+        else { BGS_KG_KEYS(2) }
+#undef BGS_KG_KEYS
 #pragma unroll
         for (int k = 0; k < KG_ITEMS; ++k) {
-            const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
-            key[k] = sentinel;
-            draw[k] = false;
-            if (i < fp.n) {
-                const float4 p = pin[k];
-                key[k] = sort_key(fp, V3{p.x, p.y, p.z});
-                // entries that reach the vertex stage: everything unless the radix key is "culled"
-                draw[k] = fp.sort_mode != SORT_RADIX || key[k] != sentinel;
-            }
-            const unsigned long long b = __ballot(draw[k]);
+            const unsigned long long b = __ballot(BGS_KG_DRAWN(k));
             below[k] = (uint32_t)__popcll(b & lanes_below);
             if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(b);
         }
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
         // compacted, a tile's ~600 keys are 3 rows.
 #pragma unroll
         for (int k = 0; k < KG_ITEMS; ++k)
-            if (draw[k]) {
+            if (BGS_KG_DRAWN(k)) {
                 s_keys[off[k] + below[k]] = key[k];
                 if constexpr (BUCKET) s_idx[off[k] + below[k]] = base + (uint32_t)k * 256u + (uint32_t)tid;
             }
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
             const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
             if (i < fp.n) {
                 const uint32_t before = vis_base + off[k] + below[k];  // drawable entries before i
-                if (draw[k]) { if constexpr (!BUCKET) entries[before] = make_uint2(key[k], i); }
+                if (BGS_KG_DRAWN(k)) { if constexpr (!BUCKET) entries[before] = make_uint2(key[k], i); }
                 else culled[i - before] = make_uint2(key[k], i);
             }
         }

@@ -105,26 +105,38 @@ BGS_HD bool in_frustum(V4 c) {
 //   SORT_RAYON/STD: src/sort/rayon.rs:91-97 stores bits(dist2) and sorts DESCENDING; the
 //     device sorts ascending on ~bits and un-inverts in the last pass, so this returns ~bits.
 //   SORT_NONE: src/sort/mod.rs:347-354 (key = 1, draw order = index order)
-BGS_HD uint32_t sort_key(const FrameParams& fp, V3 pos) {
-    if (fp.sort_mode == SORT_NONE) return 1u;
-    V4 t4 = m4_mul_point(fp.transform, pos);
-    V3 tp{t4.x, t4.y, t4.z};
-    V3 cam{fp.cam[0], fp.cam[1], fp.cam[2]};
-    if (fp.sort_mode != SORT_RADIX) {
-        V3 d = sub3(cam, tp);
-        float dist2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
-        // a NaN key's sign/payload is platform-dependent (x86 vs gfx950) and its order is
-        // unspecified in the reference (partial_cmp -> Equal): store the canonical quiet NaN
-        const uint32_t bits = dist2 != dist2 ? 0x7FC00000u : f2u(dist2);
-        return 0xFFFFFFFFu - bits;
+// KIND is the branch of the three a frame takes (0: SORT_NONE, 1: SORT_RADIX, 2: the CPU sorts' key), so that a
+// kernel can pick it once per launch instead of once per splat.
+template <int KIND>
+BGS_HD uint32_t sort_key_kind(const FrameParams& fp, V3 pos) {
+    if constexpr (KIND == 0) {
+        return 1u;
+    } else {
+        V4 t4 = m4_mul_point(fp.transform, pos);
+        V3 tp{t4.x, t4.y, t4.z};
+        V3 cam{fp.cam[0], fp.cam[1], fp.cam[2]};
+        if constexpr (KIND == 2) {
+            V3 d = sub3(cam, tp);
+            float dist2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
+            // a NaN key's sign/payload is platform-dependent (x86 vs gfx950) and its order is
+            // unspecified in the reference (partial_cmp -> Equal): store the canonical quiet NaN
+            const uint32_t bits = dist2 != dist2 ? 0x7FC00000u : f2u(dist2);
+            return 0xFFFFFFFFu - bits;
+        } else {
+            uint32_t key = KEY_CULLED;
+            V4 clip = world_to_clip(fp, tp);
+            V3 diff = sub3(tp, cam);
+            float dist2 = dot3(diff, diff);
+            uint32_t key_distance = 0xFFFFFFFFu - f2u(dist2);
+            if (in_frustum(clip)) key = key_distance;
+            return key >> fp.key_shift;
+        }
     }
-    uint32_t key = KEY_CULLED;
-    V4 clip = world_to_clip(fp, tp);
-    V3 diff = sub3(tp, cam);
-    float dist2 = dot3(diff, diff);
-    uint32_t key_distance = 0xFFFFFFFFu - f2u(dist2);
-    if (in_frustum(clip)) key = key_distance;
-    return key >> fp.key_shift;
+}
+BGS_HD uint32_t sort_key(const FrameParams& fp, V3 pos) {
+    if (fp.sort_mode == SORT_NONE) return sort_key_kind<0>(fp, pos);
+    if (fp.sort_mode != SORT_RADIX) return sort_key_kind<2>(fp, pos);
+    return sort_key_kind<1>(fp, pos);
 }
 
 // src/render/helpers.wgsl:137-157 (column-major constructor), rotation = [w, x, y, z]
