@@ -828,8 +828,11 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 // prefetched two groups (ranks) / one group (rectangles) ahead of the blend.
 // __launch_bounds__(256, 8): 8 waves/SIMD (<= 64 VGPRs). A 1080p frame is 8160 one-wave tiles for
 // 1024 SIMDs x 8 slots, so at 7 waves/SIMD a second, nearly empty round of waves appears.
+// The surfel variant carries a 24-dword staged record through a 30-slot blend: it spills at 64 registers
+// (14 VGPRs) and at 72 / 80; same-box A/B of the dense 1 M-surfel frame: 5 waves/SIMD (90 VGPRs, no spill)
+// 0.49 ms, 6: 0.54, 7: 0.55, 8: 0.51 (and 0.13 instead of 0.09 ms scene-like).
 template <int VARIANT>
-__global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
+__global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_mul,
                                                           uint32_t sup_x, Control* ctl,
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
     const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     // records staged per round: 64 (the whole queue) for the 48-byte records; 32 for the 96-byte surfel
-    // records, so that eight workgroups' LDS (4 x 3 KB each) still fit a CU and the kernel keeps 8 waves/SIMD
+    // records (4 x 3 KB per workgroup)
     constexpr uint32_t STAGE = VARIANT == RV_SURFEL ? 32u : 64u;
     __shared__ float4 s_rec_all[4][STAGE * REC_V4];
     __shared__ uint32_t s_queue_all[4][64];

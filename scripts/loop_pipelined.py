@@ -11,7 +11,9 @@ prof = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 flags = int(sys.argv[5], 0) if len(sys.argv) > 5 else 0
 streams = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 p = GaussianSplattingPlugin(0)
-h = p.upload(random_gaussians_3d_seeded(1_000_000, 2))
+n = int(os.environ.get("N", "1000000"))   # N=5000000 F16=1: the 5 M f16 cloud of BASELINE configs[2]
+c = random_gaussians_3d_seeded(n, 2 if n == 1_000_000 else 3)
+h = p.upload(c.to_f16() if os.environ.get("F16") else c)
 v = headless_view(0)
 s = CloudSettings(global_scale=gs)
 p.set_async(True)

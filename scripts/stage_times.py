@@ -7,7 +7,13 @@ from bevy_gaussian_splatting_amd import CloudSettings, GaussianSplattingPlugin, 
 from bevy_gaussian_splatting_amd.gaussian import PlanarGaussian3dF16
 p = GaussianSplattingPlugin(0)
 v = View.headless(1920, 1080)
+FLAGS = [int(a, 0) for a in os.environ.get("FLAGS", "0").split(",")]   # debug / ablation flags, one run per value
 def run(tag, h, gs):
+    for fl in FLAGS:
+        p.set_debug_flags(fl)
+        run1(f"{tag} flags {fl:#x}", h, gs)
+    p.set_debug_flags(0)
+def run1(tag, h, gs):
     s = CloudSettings(global_scale=gs)
     acc = {}
     for i in range(40):
