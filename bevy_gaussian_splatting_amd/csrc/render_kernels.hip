@@ -841,9 +841,9 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
                                                           FrameCleanup cl) {
     const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
-    // records staged per round: 64 (the whole queue) for the 48-byte records; 32 for the 96-byte surfel
-    // records (4 x 3 KB per workgroup)
-    constexpr uint32_t STAGE = VARIANT == RV_SURFEL ? 32u : 64u;
+    // records staged per round: the whole queue (24 KB of LDS per workgroup for the 96-byte surfel records, five
+    // workgroups per CU at its 5 waves/SIMD; rounds of 32 were 1-5 % slower)
+    constexpr uint32_t STAGE = 64u;
     __shared__ float4 s_rec_all[4][STAGE * REC_V4];
     __shared__ uint32_t s_queue_all[4][64];
 
