@@ -649,7 +649,7 @@ __device__ __forceinline__ bool surfel_negligible_in_tile(const float4 st[6]) {
     const float pyc = fmaf(H, st[2].x + st[2].w, st[1].y), ey = H * (fabsf(st[2].x) + fabsf(st[2].w));
     const float pzc = fmaf(H, st[2].y + st[3].x, st[1].z), ez = H * (fabsf(st[2].y) + fabsf(st[3].x));
     const float lx = fmaxf(fabsf(pxc) - ex, 0.0f), ly = fmaxf(fabsf(pyc) - ey, 0.0f), hz = fabsf(pzc) + ez;
-    const float s3 = fmaf(lx, lx, ly * ly) / (hz * hz);
+    const float s3 = fmaf(lx, lx, ly * ly) * __builtin_amdgcn_rcpf(hz * hz);  // 1 ulp is nothing to a bound with this margin
     const float dx = fmaxf(fabsf(fmaf(H, st[3].z, st[3].y)) - H * fabsf(st[3].z), 0.0f);
     const float dy = fmaxf(fabsf(fmaf(H, st[4].x, st[3].w)) - H * fabsf(st[4].x), 0.0f);
     const float s2 = fmaf(dx, dx, dy * dy);
