@@ -987,7 +987,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
             mark(4);
             launch_tile_ranges(st, L.inst[0], ctl, ranges);
             mark(5);
-            launch_raster(st, fp, L.records, L.inst[0], ranges, L.fb, view->clear_color);
+            launch_raster(st, fp, L.records, L.inst[0], ranges, L.fb, view->clear_color, ctl);
             mark(6);
         }
         // BINNING_SCAN frames get their sRGB8 image from the rasteriser itself (debug flag 0x40000: from the

@@ -117,6 +117,11 @@ struct Control {
     // block of a launch does a returning atomic on its ticket and the L2 retires same-line atomics one
     // at a time (~8 ns), so a load of draw_count queued behind them on a shared line waited for all.
     uint32_t ticket[16][32];
+    // bits of max |r|, |g|, |b| over the frame's drawn records (non-negative floats order like their bits): the
+    // rasterisers scale their transmittance cut-off by it (render_kernels.hip, frame_t_eps). Its own 128-byte
+    // line for the same reason as the tickets: every block of the project kernel polls / bumps it.
+    uint32_t color_max_bits;
+    uint32_t pad1[31];
     uint32_t hist_depth[4][RADIX_BASE];  // global digit histograms of the depth keys
     uint32_t hist_tile[2][RADIX_BASE];   // digit 0 = tile x, digit 1 = tile y
     uint32_t coarse_total[RADIX_BASE];   // scan binning: entries in each supertile's ordered list

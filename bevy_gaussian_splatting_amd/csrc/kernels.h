@@ -142,7 +142,7 @@ void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Contro
 // src/render/mod.rs:944-948).
 void launch_raster(hipStream_t stream, const FrameParams& fp, const void* records,
                    const uint2* instances, const uint2* ranges, float4* framebuffer,
-                   const float clear_color[4]);
+                   const float clear_color[4], const Control* ctl);
 
 // Rgba8UnormSrgb image of the f32 framebuffer (the reference's render-target format).
 // The destination is d_fp->srgb8_target when that is non-zero, else default_out.

@@ -117,11 +117,19 @@ __device__ __forceinline__ ColorInputs frame_color_inputs(const FrameParams& fp,
     return ci;
 }
 
+// The frame's largest colour magnitude (see T_EPS): non-negative floats order like their bits, and after the
+// first few waves of a launch the word already holds a value no later wave exceeds, so most skip the atomic.
+__device__ __forceinline__ void publish_color_max(Control* ctl, const float mag) {
+    const uint32_t bits = __float_as_uint(mag);
+    if (bits > __hip_atomic_load(&ctl->color_max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&ctl->color_max_bits, bits);
+}
+
 template <int FMT, bool SURFEL, bool ANY_MODE>
 __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const CloudPtrs& cloud,
                                                  const uint2 entry, const uint32_t j,
                                                  float4* __restrict__ records, ColorInputs ci,
-                                                 bool& visible) {
+                                                 bool& visible, float& color_mag) {
     const uint32_t si = entry.y;
     const float4 pv = cloud.position_visibility[si];
     float rot[4], so[4], cov[6];
@@ -154,6 +162,8 @@ __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const Cl
         project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{cloud.sh_f32 + (size_t)si * 48u}, ci, pr);
     visible = pr.visible;
     if (!pr.draw) return RECT_EMPTY;
+    // fmaxf drops a NaN: a NaN colour poisons its pixels whatever the cut-off is
+    color_mag = fmaxf(color_mag, fmaxf(fabsf(pr.color[0]), fmaxf(fabsf(pr.color[1]), fabsf(pr.color[2]))));
     const uint32_t rect = (uint32_t)pr.tx0 | ((uint32_t)pr.tx1 << 8) | ((uint32_t)pr.ty0 << 16) |
                           ((uint32_t)pr.ty1 << 24);
     if constexpr (SURFEL) {
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
     s_histx[tid] = 0u;
     s_histy[tid] = 0u;
     uint32_t visible_acc = 0u;
+    float color_mag = 0.0f;  // max |r|, |g|, |b| of the records this thread wrote
     const ColorInputs ci = ANY_MODE ? frame_color_inputs(fp, cloud, draw_list, culled, count)
                                     : ColorInputs{0.0f, 0.0f, 0.0f};
 
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
         if (j < count) {
             // the LAST entry of the draw list is drawn on top => it is the front-most
             bool vis;
-            const uint32_t r = project_rank<FMT, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis);
+            const uint32_t r = project_rank<FMT, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis, color_mag);
             visible_acc += vis ? 1u : 0u;
             if (r != RECT_EMPTY) {
                 rect = r;
@@ -309,8 +320,15 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
         if (hy) atomicAdd(&ctl->hist_tile[1][tid], hy);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) visible_acc += __shfl_down(visible_acc, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        visible_acc += __shfl_down(visible_acc, off, 64);
+        color_mag = fmaxf(color_mag, __shfl_down(color_mag, off, 64));
+    }
     if (lane == 0 && visible_acc) atomicAdd(&ctl->visible_count, visible_acc);
+    __shared__ float s_cmag[4];
+    if (lane == 0) s_cmag[wave] = color_mag;
+    __syncthreads();
+    if (tid == 0) publish_color_max(ctl, fmaxf(fmaxf(s_cmag[0], s_cmag[1]), fmaxf(s_cmag[2], s_cmag[3])));
 }
 
 void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudPtrs& cloud,
@@ -373,6 +391,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
     const uint32_t num_st = sup_x * sup_y;
     const uint32_t my_sy = (uint32_t)tid / sup_x, my_sx = (uint32_t)tid - my_sy * sup_x;  // thread = supertile
     uint32_t visible_acc = 0u;
+    float color_mag = 0.0f;  // max |r|, |g|, |b| of the records this thread wrote
     const bool single_shot = gridDim.x >= num_tiles;  // one ticket per block (see keygen_kernel)
     const ColorInputs ci = ANY_MODE ? frame_color_inputs(fp, cloud, draw_list, culled, count)
                                     : ColorInputs{0.0f, 0.0f, 0.0f};
@@ -389,7 +408,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
             if (fp.debug & 1u) {  // ablation: no projection, a fixed 2x1-tile rectangle
                 rect = 0x01000000u | (j & 63u) | (((j & 63u) + 1u) << 8);
             } else {
-                rect = project_rank<FMT, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis);
+                rect = project_rank<FMT, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis, color_mag);
             }
             visible_acc += vis ? 1u : 0u;
         }
@@ -495,12 +514,20 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
     // waves all arrive here together
     __shared__ uint32_t s_vis[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) visible_acc += __shfl_down(visible_acc, off, 64);
-    if (lane == 0) s_vis[wave] = visible_acc;
+    for (int off = 32; off > 0; off >>= 1) {
+        visible_acc += __shfl_down(visible_acc, off, 64);
+        color_mag = fmaxf(color_mag, __shfl_down(color_mag, off, 64));
+    }
+    __shared__ float s_cmag[4];
+    if (lane == 0) {
+        s_vis[wave] = visible_acc;
+        s_cmag[wave] = color_mag;
+    }
     __syncthreads();
     if (tid == 0) {
         const uint32_t v = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
         if (v) atomicAdd(&ctl->visible_count, v);
+        publish_color_max(ctl, fmaxf(fmaxf(s_cmag[0], s_cmag[1]), fmaxf(s_cmag[2], s_cmag[3])));
     }
 }
 
@@ -554,15 +581,24 @@ void launch_tile_ranges(hipStream_t stream, const uint2* instances, const Contro
 // tile rasteriser
 // ---------------------------------------------------------------------------------------
 constexpr int RV_OBB = 0, RV_AABB3D = 1, RV_SURFEL = 2;
-// A pixel stops compositing once its transmittance is below T_EPS: what the splats behind it could still add is
-// at most T_EPS * max|c| (telescoping sum), 1.2e-4 * max|c| against the 1e-3 tolerance — the cut-off of the 3DGS
-// reference rasteriser (T < 1e-4). Same-box A/B on the headline frame (profiles/r2_notes.md): 2^-16 15.0 k,
-// 2^-13 15.9 k, 2^-12 16.5 k frames/s; the measured error on the dense full-size crops grows from 5e-5 to 2.9e-4
-// at 2^-13 and would be ~5e-4, half the tolerance, at 2^-12.
+// A pixel stops compositing once its transmittance is below the frame's cut-off
+//     t_eps = min(T_EPS, T_BUDGET / cmax),   cmax = the largest colour magnitude among the frame's records
+// (project kernels, Control::color_max_bits). What the splats behind could still add is at most t_eps * cmax
+// (telescoping sum), so the dropped tail is <= T_BUDGET = 2^-11 = 4.9e-4, half the 1e-3 tolerance, whatever the
+// colour range, and <= T_EPS = 2^-13 = 1.2e-4 for colours up to 4; T_EPS is the cut-off of the 3DGS reference
+// rasteriser (T < 1e-4), which only ever sees colours in [0, 1]. SH colours are not clamped and an f32 / Rgba16Float
+// target keeps them, so a fixed cut-off is no bound at all: with a fixed 2^-13 the 200-seed randomized sweep found two
+// frames 3e-3 and 8e-3 off (colours of ~50 behind a stack of alpha-clamped splats). The synthetic benchmark clouds
+// (SH ~ U(-1, 1)) reach |c| = 15: t_eps = 2^-14.9 there. Same-box A/B of FIXED cut-offs on the headline frame
+// (profiles/r2_notes.md): 2^-16 15.0 k, 2^-13 15.9 k, 2^-12 16.5 k frames/s.
 #ifndef BGS_T_EPS_LOG2
 #define BGS_T_EPS_LOG2 13
 #endif
 constexpr float T_EPS = 1.0f / (float)(1u << BGS_T_EPS_LOG2);
+constexpr float T_BUDGET = 1.0f / 2048.0f;
+__device__ __forceinline__ float frame_t_eps(const uint32_t color_max_bits) {
+    return fminf(T_EPS, T_BUDGET / __uint_as_float(color_max_bits));  // cmax = 0 -> T_EPS; inf -> 0: never cut
+}
 
 // One staged record, decoded once per splat and shared by every pixel a lane owns.
 template <int VARIANT>
@@ -659,14 +695,14 @@ __device__ __forceinline__ bool surfel_negligible_in_tile(const float4 st[6]) {
 
 // fs_main + blend for ONE record and ONE pixel (src/render/gaussian.wgsl:438-505,
 // src/render/mod.rs:944-948), front-to-back form, branch-free:
-//     w = covered && T >= T_EPS ? T * alpha : 0;   C += w * c;   T -= w
-// (T - T*alpha == T*(1 - alpha); a pixel stops accumulating once T < T_EPS, a per-pixel rule that
+//     w = covered && T >= t_eps ? T * alpha : 0;   C += w * c;   T -= w
+// (T - T*alpha == T*(1 - alpha); a pixel stops accumulating once T < t_eps (frame_t_eps), a per-pixel rule that
 // does not depend on how splats are batched, so every rasteriser variant gives the same bits).
 // Explicit fmaf so both rasterisers contract identically.
 typedef float v2f __attribute__((ext_vector_type(2)));
 template <int VARIANT>
 __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const float qx, const float qy,
-                                         const float aspect, float& T, v2f& crg, float& cb) {
+                                         const float aspect, const float t_eps, float& T, v2f& crg, float& cb) {
     float alpha, r, g, b;
     bool hit;
     if constexpr (VARIANT == RV_OBB) {
@@ -712,7 +748,7 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
     }
     // a real branch on purpose: it becomes an exec-mask region that a wave skips entirely when none
     // of its 64 pixels (a 16x4 strip in the wave-per-tile rasteriser) is covered
-    if (hit && T >= T_EPS) {
+    if (hit && T >= t_eps) {
         asm volatile("");  // not speculatable: keeps this a branch (the compiler would turn it into selects)
         const float w = T * alpha;
         // red and green as one packed fma on the register pair the record's (r, g) arrive in: left to itself
@@ -758,7 +794,8 @@ template <int VARIANT>
 __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float4* __restrict__ records,
                                                      const uint2* __restrict__ instances,
                                                      const uint2* __restrict__ ranges,
-                                                     float4* __restrict__ fb, float4 clear) {
+                                                     float4* __restrict__ fb, float4 clear,
+                                                     const Control* __restrict__ ctl) {
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     __shared__ float4 s_rec[256 * REC_V4];
 
@@ -774,6 +811,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     const float aspect = fp.viewport_w / fp.viewport_h;
 
     const uint2 range = ranges[(ty << 8) | tx];
+    const float t_eps = frame_t_eps(ctl->color_max_bits);
     float T = in_image ? 1.0f : 0.0f, cb = 0.0f;
     v2f crg = {0.0f, 0.0f};
 
@@ -800,16 +838,16 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
             }
         }
         __syncthreads();
-        if (!__all(T < T_EPS))
+        if (!__all(T < t_eps))
             for (uint32_t k = 0; k < cnt; ++k) {
                 StagedRecord<VARIANT> sr;
                 sr.load(s_rec + k * REC_V4);
                 if constexpr (VARIANT == RV_SURFEL)
                     if (__builtin_amdgcn_readfirstlane(__float_as_uint(sr.a5.y)) == 0u) continue;
-                blend_px<VARIANT>(sr, qx, qy, aspect, T, crg, cb);
+                blend_px<VARIANT>(sr, qx, qy, aspect, t_eps, T, crg, cb);
             }
         // also the barrier that protects s_rec before the next batch overwrites it
-        if (__syncthreads_and(T < T_EPS ? 1 : 0)) break;
+        if (__syncthreads_and(T < t_eps ? 1 : 0)) break;
     }
     if (in_image) {
         // dst = src + dst*(1-src.a) unrolled over the whole list, target cleared to `clear`
@@ -852,6 +890,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
     const uint32_t nblocks = (ntiles + 3u) / 4u;
     const uint32_t tile = xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
     const uint32_t draw_count = ctl->draw_count;
+    const float t_eps = frame_t_eps(__builtin_amdgcn_readfirstlane(ctl->color_max_bits));
     if (cl.other_ctl) {
         // the status words of this frame's chained scans are dead by now: zero the used ones, and
         // the Control block the lane's next frame will use; report this frame's counters to the host
@@ -1014,9 +1053,9 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
                 else keep_flag = __float_as_uint(sr.a5.y);
                 if (__builtin_amdgcn_readfirstlane(keep_flag) == 0u) continue;  // scalar branch
 #pragma unroll
-                for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, T[r], crg[r], cb[r]);
+                for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
             }
-            const bool sat = T[0] < T_EPS && T[1] < T_EPS && T[2] < T_EPS && T[3] < T_EPS;
+            const bool sat = T[0] < t_eps && T[1] < t_eps && T[2] < t_eps && T[3] < t_eps;
             saturated = __all(sat);
             }
             if (saturated) break;
@@ -1073,20 +1112,20 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
 
 void launch_raster(hipStream_t stream, const FrameParams& fp, const void* records,
                    const uint2* instances, const uint2* ranges, float4* framebuffer,
-                   const float clear_color[4]) {
+                   const float clear_color[4], const Control* ctl) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4 clear = make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]);
     const float4* rec = (const float4*)records;
     if (fp.aabb == 0u)
         hipLaunchKernelGGL(raster_kernel<RV_OBB>, dim3(ntiles), dim3(256), 0, stream, fp, rec, instances,
-                           ranges, framebuffer, clear);
+                           ranges, framebuffer, clear, ctl);
     else if (fp.gaussian_mode != 0u)
         hipLaunchKernelGGL(raster_kernel<RV_AABB3D>, dim3(ntiles), dim3(256), 0, stream, fp, rec,
-                           instances, ranges, framebuffer, clear);
+                           instances, ranges, framebuffer, clear, ctl);
     else
         hipLaunchKernelGGL(raster_kernel<RV_SURFEL>, dim3(ntiles), dim3(256), 0, stream, fp, rec,
-                           instances, ranges, framebuffer, clear);
+                           instances, ranges, framebuffer, clear, ctl);
 }
 
 // ---------------------------------------------------------------------------------------

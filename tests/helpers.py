@@ -161,20 +161,29 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
     C = np.zeros((H, W, 3), np.float32)
     out = ShimOut()
     surfel = settings.gaussian_mode == GaussianMode.Gaussian2d and settings.aabb
-    eps = np.float32(1.0 / 8192.0)   # T_EPS of csrc/render_kernels.hip
+    eps = None   # frame_t_eps of csrc/render_kernels.hip, from the largest colour magnitude of the drawn records
     # Depth mode: range from sorted[count-1] and sorted[1] of the FULL entry list (gaussian.wgsl:331-340)
     depth_range = np.zeros(2, np.float32)
     if n > 0:
         i_first, i_last = int(entries[min(1, n - 1)]["index"]), int(entries[n - 1]["index"])
         depth_range[0] = shim().shim_distance_to_camera(ctypes.byref(fpc), _fp(cloud.position_visibility[i_last]))
         depth_range[1] = shim().shim_distance_to_camera(ctypes.byref(fpc), _fp(cloud.position_visibility[i_first]))
-    for j in range(count):
+    def project(j):
         e = entries[count - 1 - j]
         si = int(e["index"])
         shim().shim_project(ctypes.byref(fpc), int(e["key"]), _fp(cloud.position_visibility[si]),
                             _fp(cloud.rotation[si]), _fp(cloud.scale_opacity[si]),
                             _fp(cloud.spherical_harmonic[si]), _fp(depth_range), ctypes.byref(out))
-        if not out.draw:
+        return bool(out.draw)
+    cmax = np.float32(0.0)
+    for j in range(count):
+        if project(j):
+            mags = [abs(np.float32(v)) for v in out.color[:3]]
+            cmax = max([cmax] + [m for m in mags if not np.isnan(m)])   # fmaxf drops a NaN
+    with np.errstate(all="ignore"):
+        eps = np.minimum(np.float32(1.0 / 8192.0), np.float32(1.0 / 2048.0) / np.float32(cmax))
+    for j in range(count):
+        if not project(j):
             continue
         dx = qx - np.float32(out.cx)
         dy = qy - np.float32(out.cy)

@@ -209,6 +209,24 @@ def test_render_10k_config0(plugin, oracle, binning):
     h.free()
 
 
+def test_bright_splats_behind_a_nearly_opaque_stack(plugin, oracle, binning):
+    """The transmittance cut-off scales with the frame's largest colour (frame_t_eps): SH colours are not
+    clamped, so what a fixed cut-off drops behind a nearly opaque stack is only bounded for colours up to 1.
+    Here one splat in a hundred is orders of magnitude brighter than the rest and global_opacity pushes most alphas to
+    the 0.999 clamp (the configuration the 200-seed sweep failed on with a fixed 2^-13)."""
+    c = random_gaussians_3d_seeded(30_000, 91)
+    c.spherical_harmonic[::97] *= 60.0
+    v = View.headless(320, 200)
+    s = CloudSettings(global_opacity=1.7, global_scale=0.5, opacity_adaptive_radius=False)
+    h = plugin.upload(c)
+    got = plugin.render(h, v, s)
+    e = oracle.sort(c, v, s)
+    ref, amb = oracle.render(c, e, v, s, with_ambiguity=True)
+    assert float(np.abs(ref[..., :3]).max()) > 30.0          # the frame really has an HDR range
+    _assert_image(ref, got, amb, what="bright splats")
+    h.free()
+
+
 def test_render_f16_cloud(plugin, oracle, binning):
     c = random_gaussians_3d_seeded(8000, 3)
     c16 = c.to_f16()
