@@ -673,13 +673,14 @@ __device__ __forceinline__ void stage_surfel(const float4* __restrict__ src, con
 // p is affine in the pixel, so over the tile's 16 x 16 pixel centres |p.x| and |p.y| are at least their value
 // at the tile centre minus the half-range of the affine part, |p.z| at most centre plus half-range, the same
 // for the screen-space deltas, and power = min(s3, s2) >= min of the two bounds (interval arithmetic; within
-// 2 % of the exact count). What is dropped is at most 2^-23 opacity per record — 7e-5 if all of a saturated
-// tile's ~600 records were dropped at the threshold, against the 1e-3 tolerance; DESIGN.md "Documented
-// deviations". A NaN anywhere keeps the record.
+// 2 % of the exact count). What is dropped is at most 2^-23 / max(1, cmax) of a record's opacity (cmax: the
+// frame's largest colour magnitude, as for the transmittance cut-off), i.e. <= 1.2e-7 of colour per record —
+// 7e-5 if all of a saturated tile's ~600 records were dropped at the threshold, against the 1e-3 tolerance;
+// DESIGN.md "Documented deviations". A NaN anywhere keeps the record.
 #ifndef BGS_SURFEL_CULL_LOG2
 #define BGS_SURFEL_CULL_LOG2 23
 #endif
-__device__ __forceinline__ bool surfel_negligible_in_tile(const float4 st[6]) {
+__device__ __forceinline__ bool surfel_negligible_in_tile(const float4 st[6], const float limit) {
     constexpr float H = 7.5f;  // pixel centres of a tile: xl, yl in [0, 15]
     const float pxc = fmaf(H, st[1].w + st[2].z, st[1].x), ex = H * (fabsf(st[1].w) + fabsf(st[2].z));
     const float pyc = fmaf(H, st[2].x + st[2].w, st[1].y), ey = H * (fabsf(st[2].x) + fabsf(st[2].w));
@@ -689,8 +690,12 @@ __device__ __forceinline__ bool surfel_negligible_in_tile(const float4 st[6]) {
     const float dx = fmaxf(fabsf(fmaf(H, st[3].z, st[3].y)) - H * fabsf(st[3].z), 0.0f);
     const float dy = fmaxf(fabsf(fmaf(H, st[4].x, st[3].w)) - H * fabsf(st[4].x), 0.0f);
     const float s2 = fmaf(dx, dx, dy * dy);
-    constexpr float LIMIT = (float)BGS_SURFEL_CULL_LOG2;  // staged powers are in exp2 units
-    return s3 >= LIMIT && s2 >= LIMIT;
+    return s3 >= limit && s2 >= limit;  // staged powers are in exp2 units
+}
+// the threshold of the frame: 2^-23 of a record's opacity, lowered by the frame's largest colour magnitude
+// like the transmittance cut-off (what is dropped is alpha * colour)
+__device__ __forceinline__ float frame_surfel_limit(const uint32_t color_max_bits) {
+    return (float)BGS_SURFEL_CULL_LOG2 + __builtin_amdgcn_logf(fmaxf(1.0f, __uint_as_float(color_max_bits)));  // log2
 }
 
 // fs_main + blend for ONE record and ONE pixel (src/render/gaussian.wgsl:438-505,
@@ -812,6 +817,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 
     const uint2 range = ranges[(ty << 8) | tx];
     const float t_eps = frame_t_eps(ctl->color_max_bits);
+    const float surfel_limit = frame_surfel_limit(ctl->color_max_bits);
     float T = in_image ? 1.0f : 0.0f, cb = 0.0f;
     v2f crg = {0.0f, 0.0f};
 
@@ -829,7 +835,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
             } else if constexpr (VARIANT == RV_SURFEL) {
                 float4 st[6];
                 stage_surfel(src, tile_ox, tile_oy, aspect, st);
-                st[5].y = __uint_as_float(surfel_negligible_in_tile(st) && !(fp.debug & 64u) ? 0u : 1u);  // as raster_scan_kernel decides
+                st[5].y = __uint_as_float(surfel_negligible_in_tile(st, surfel_limit) && !(fp.debug & 64u) ? 0u : 1u);  // as raster_scan_kernel decides
 #pragma unroll
                 for (int v = 0; v < 6; ++v) s_rec[tid * REC_V4 + v] = st[v];
             } else {
@@ -890,7 +896,9 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
     const uint32_t nblocks = (ntiles + 3u) / 4u;
     const uint32_t tile = xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
     const uint32_t draw_count = ctl->draw_count;
-    const float t_eps = frame_t_eps(__builtin_amdgcn_readfirstlane(ctl->color_max_bits));
+    const uint32_t cmax_bits = __builtin_amdgcn_readfirstlane(ctl->color_max_bits);
+    const float t_eps = frame_t_eps(cmax_bits);
+    const float surfel_limit = frame_surfel_limit(cmax_bits);
     if (cl.other_ctl) {
         // the status words of this frame's chained scans are dead by now: zero the used ones, and
         // the Control block the lane's next frame will use; report this frame's counters to the host
@@ -1033,7 +1041,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
                 } else {
                     float4 st[6];
                     stage_surfel(src, tile_ox, tile_oy, aspect, st);
-                    keep = keep && !(surfel_negligible_in_tile(st) && !(fp.debug & 64u));
+                    keep = keep && !(surfel_negligible_in_tile(st, surfel_limit) && !(fp.debug & 64u));
                     st[5].y = __uint_as_float(keep ? 1u : 0u);
 #pragma unroll
                     for (int v = 0; v < 6; ++v) s_rec[lane * REC_V4 + v] = st[v];
