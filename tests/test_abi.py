@@ -30,6 +30,16 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert lib.bgs_version() == (0 << 16) | 2
 
 
+def test_integration_doc_binds_every_exported_symbol():
+    """INTEGRATION.md shows the reference-side binding (the `extern "C"` block a maintainer would add): it
+    has to name every entry point the header declares, and nothing the library does not have."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index('extern "C" {'):]
+    block = block[:block.index("\n}")]
+    bound = set(re.findall(r"pub fn (bgs_[a-z0-9_]+)\(", block))
+    assert bound == set(_declared())
+
+
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(BgsView) == (16 * 4 + 8 + 16 + 4) * 4
     assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8 + 1 + 1 + 2 + 8) * 4
