@@ -23,10 +23,11 @@ def run1(tag, h, gs):
                 acc[k] = acc.get(k, 0.0) + x / 20.0
     st = p.stats()
     print(tag, gs, {k: round(x * 1e3, 1) for k, x in acc.items() if x}, "sum", round(sum(acc.values()) * 1e3, 1), st["sort_path"], flush=True)
-h = p.upload(random_gaussians_3d_seeded(1_000_000, 2))
-for gs in (1.0, 0.05):
-    run("1M f32", h, gs)
-h.free()
+if not os.environ.get("SKIP_1M"):
+    h = p.upload(random_gaussians_3d_seeded(1_000_000, 2))
+    for gs in (1.0, 0.05):
+        run("1M f32", h, gs)
+    h.free()
 n5 = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 if n5:
     c = random_gaussians_3d_seeded(n5, 3)
