@@ -7,6 +7,7 @@ from bevy_gaussian_splatting_amd import CloudSettings, GaussianSplattingPlugin, 
 from bevy_gaussian_splatting_amd.gaussian import PlanarGaussian3dF16
 p = GaussianSplattingPlugin(0)
 v = View.headless(1920, 1080)
+GS = [float(a) for a in os.environ.get("GS", "1.0,0.05").split(",")]   # global_scale values
 FLAGS = [int(a, 0) for a in os.environ.get("FLAGS", "0").split(",")]   # debug / ablation flags, one run per value
 def run(tag, h, gs):
     for fl in FLAGS:
@@ -25,12 +26,12 @@ def run1(tag, h, gs):
     print(tag, gs, {k: round(x * 1e3, 1) for k, x in acc.items() if x}, "sum", round(sum(acc.values()) * 1e3, 1), st["sort_path"], flush=True)
 if not os.environ.get("SKIP_1M"):
     h = p.upload(random_gaussians_3d_seeded(1_000_000, 2))
-    for gs in (1.0, 0.05):
+    for gs in GS:
         run("1M f32", h, gs)
     h.free()
 n5 = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 if n5:
     c = random_gaussians_3d_seeded(n5, 3)
     h = p.upload(PlanarGaussian3dF16.from_f32(c))
-    for gs in (1.0, 0.05):
+    for gs in GS:
         run("5M f16", h, gs)
