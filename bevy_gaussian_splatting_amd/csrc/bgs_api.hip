@@ -939,7 +939,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         cl.pass_stride = (uint32_t)(depth_tiles * RADIX_BASE);
         cl.places = bucket ? 0u : places;
         cl.depth_tile = sort_tile_size(large);
-        cl.bucket_chain_words = bucket ? (uint32_t)((n + (n >= (1u << 19) ? 4096u : 2048u) - 1u) / (n >= (1u << 19) ? 4096u : 2048u)) * BUCKET_COUNT : 0u;
+        cl.bucket_chain_words = bucket ? (uint32_t)((n + keygen_tile_splats(n) - 1u) / keygen_tile_splats(n)) * BUCKET_COUNT : 0u;
         cl.sorted = draw_list;
         cl.key_xor = final_xor;
         if (ctx->debug_flags & 0x1000u) cl = FrameCleanup{};  // experiment: classic memset + copy path

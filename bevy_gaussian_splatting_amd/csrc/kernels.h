@@ -73,13 +73,28 @@ struct KeygenLaunch {
     SplitterTable split;      // fp.sort_path == 1: bucket = number of entries <= key
     // filled by prepare(): the launch geometry and the argument vector (points into this object)
     const void* func;
-    uint32_t blocks;
+    uint32_t blocks, threads;
     void* argv[12];
     bool prepare(int max_blocks);  // false: nothing to launch (n == 0)
     hipError_t launch(hipStream_t stream);
     hipError_t update_node(hipGraphExec_t exec, hipGraphNode_t node);  // same launch, as a graph node update
 };
-constexpr uint32_t KEYGEN_TILE = 2048;
+constexpr uint32_t KEYGEN_TILE = 2048;  // the smallest tile: what the chain words are allocated and zeroed for
+// Splats per keygen tile (= per block and ticket) for a cloud of n splats. The chained scans behind a tile cost
+// per TILE, so tiles grow with the cloud: 2048 (256 threads x 8) for small clouds, 4096 (256 x 16) from 2^19 splats.
+// BGS_KEYGEN_WIDE_THREADS = 1024 builds the wide tiles as 1024 threads x 4 (and 8192-splat tiles, 1024 x 8, from
+// 2^22 splats): alone on the chip that keygen is faster (1 M splats 28.6 -> 24.3 us, 5 M 66 -> 62 us), but a
+// 16-wave workgroup needs a whole CU's worth of free wave slots and LDS at once, and with the frames of six lanes
+// in flight it — like a 1024-thread bucket sort, 27.9 -> 15.3 us alone at 600 k pairs — costs throughput:
+// 16.3 k (256 / 256) vs 15.8 k (1024 / 1024) frames/s on the headline frame, 6.9 k vs 6.7 k on the 5 M cloud
+// (same-box A/B, profiles/r2_notes.md). The defaults are what the pipelined frame rate wants.
+#ifndef BGS_KEYGEN_WIDE_THREADS
+#define BGS_KEYGEN_WIDE_THREADS 256
+#endif
+#ifndef BGS_KEYGEN_HUGE_LOG2
+#define BGS_KEYGEN_HUGE_LOG2 (BGS_KEYGEN_WIDE_THREADS == 256 ? 31 : 22)
+#endif
+inline uint32_t keygen_tile_splats(uint32_t n) { return n >= (1u << BGS_KEYGEN_HUGE_LOG2) ? 8192u : (n >= (1u << 19) ? 4096u : 2048u); }
 
 // Standalone digit histograms of existing pairs (used by bgs_radix_sort_pairs).
 void launch_histogram(hipStream_t stream, const uint2* pairs, uint32_t n, uint32_t* hist /*[4][256]*/,

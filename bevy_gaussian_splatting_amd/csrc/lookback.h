@@ -4,8 +4,7 @@
 // its predecessors' words until it meets a STATUS_PREFIX (inclusive prefix). With every tile of a
 // launch resident at once all aggregates appear at about the same time, and a walker consumes B
 // predecessors per L2 round trip: a whole wave per hop (64) where the block has one chain (keygen: one
-// poller wave per block), 4 where each thread owns a chain (one per digit / supertile; 16 beyond ~1000
-// tiles). Wider is NOT better for the per-thread chains: a prefix is usually met within a few words
+// poller wave per block), 4 where each thread owns a chain (one per digit / bucket / supertile). Wider is NOT better for the per-thread chains: a prefix is usually met within a few words
 // and every extra word polled by 256 threads x hundreds of blocks is fabric traffic (one depth pass at
 // 74 tiles: 11.6 us with 4 words per hop, 12.4 with 16, 16.4 with 64).
 // What matters most is how waiting is done: see lb_backoff.

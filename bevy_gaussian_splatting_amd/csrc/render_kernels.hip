@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
             uint32_t excl = 0u;
             if (tile > 0u) {
                 __hip_atomic_store(my_status, STATUS_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                excl = num_tiles > 1024u ? lookback_u32<16>(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u)
-                                         : lookback_u32<4>(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u);
+                // 4 words per hop at every size (2344 blocks of a 5 M-splat frame: 16 per hop 4 % slower, 32: 11 %)
+                excl = lookback_u32<4>(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u);
             }
             __hip_atomic_store(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

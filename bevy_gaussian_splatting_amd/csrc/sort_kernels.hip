@@ -84,22 +84,27 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 // radix pass's machinery] + [arrival order within the tile: a returning LDS atomic]. The sum of the 256
 // exclusive prefixes is the tile's drawable-entry offset, so the partition needs no chain of its own.
 // Order inside a bucket is arbitrary; bucket_sort_kernel orders by (key, index).
-template <int KG_ITEMS, bool BUCKET>  // splats per thread
-__global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
-                                                     uint2* __restrict__ entries,
-                                                     uint2* __restrict__ culled, Control* ctl,
-                                                     uint32_t* part_status, uint32_t places,
-                                                     uint32_t ticket_slot, FrameParams* fp_out,
-                                                     uint2* __restrict__ bucket_slots, uint32_t* bucket_status,
-                                                     SplitterTable split) {
+template <int KG_ITEMS, bool BUCKET, int THREADS>  // splats per thread; 256 or 1024 threads per block
+__global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
+                                                         uint2* __restrict__ entries,
+                                                         uint2* __restrict__ culled, Control* ctl,
+                                                         uint32_t* part_status, uint32_t places,
+                                                         uint32_t ticket_slot, FrameParams* fp_out,
+                                                         uint2* __restrict__ bucket_slots, uint32_t* bucket_status,
+                                                         SplitterTable split) {
+    constexpr int WAVES = THREADS / 64;
+    constexpr int ROWS = KG_ITEMS * WAVES;  // 64-splat rows of a tile, in index order (item, wave)
+    static_assert((THREADS == 256 || THREADS == 1024) && ROWS <= 128, "tile geometry");
     __shared__ uint32_t s_hist[BUCKET ? 1 : 4][RADIX_BASE];
-    __shared__ uint32_t s_cnt[KG_ITEMS][4];  // drawable per (row, wave)
-    __shared__ uint32_t s_keys[256 * KG_ITEMS];  // the tile's drawable keys, compacted (for the histograms / the buckets)
-    __shared__ uint32_t s_idx[BUCKET ? 256 * KG_ITEMS : 1];  // their splat indices (BUCKET)
+    __shared__ uint32_t s_cnt[ROWS];   // drawable splats of each row ...
+    __shared__ uint32_t s_off[ROWS];   // ... and of the rows before it
+    __shared__ uint32_t s_keys[THREADS * KG_ITEMS];  // the tile's drawable keys, compacted (for the histograms / the buckets)
+    __shared__ uint32_t s_idx[BUCKET ? THREADS * KG_ITEMS : 1];  // their splat indices (BUCKET)
     __shared__ uint32_t s_split[BUCKET ? BUCKET_COUNT : 1];
     __shared__ uint32_t s_bcnt[BUCKET ? BUCKET_COUNT : 1];   // pairs of this tile per bucket
     __shared__ uint32_t s_bexcl[BUCKET ? BUCKET_COUNT : 1];  // pairs of earlier tiles per bucket
     __shared__ uint32_t s_tot[4];
+    __shared__ uint32_t s_total;
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,14 +113,16 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
     // a new view by updating this one node's arguments.
     if (fp_out && blockIdx.x == 0 && (uint32_t)tid < (uint32_t)(sizeof(FrameParams) / 4u))
         reinterpret_cast<uint32_t*>(fp_out)[tid] = reinterpret_cast<const uint32_t*>(&fp)[tid];
-    if constexpr (BUCKET) {
-        s_split[tid] = tid < (int)BUCKET_COUNT - 1 ? split.key[tid] : 0xFFFFFFFFu;
-    } else {
+    if (tid < 256) {
+        if constexpr (BUCKET) {
+            s_split[tid] = tid < (int)BUCKET_COUNT - 1 ? split.key[tid] : 0xFFFFFFFFu;
+        } else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
+            for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
+        }
     }
     const uint32_t sentinel = KEY_CULLED >> fp.key_shift;
-    const uint32_t per_tile = 256u * KG_ITEMS;
+    constexpr uint32_t per_tile = (uint32_t)(THREADS * KG_ITEMS);
     const uint32_t num_tiles = (fp.n + per_tile - 1u) / per_tile;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     // Tiles are handed out by ticket so that a tile's predecessors in the chained scan are always owned
@@ -126,30 +133,29 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
 
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
-        if constexpr (BUCKET) s_bcnt[tid] = 0u;
+        if constexpr (BUCKET) { if (tid < (int)BUCKET_COUNT) s_bcnt[tid] = 0u; }
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
         const uint32_t base = tile * per_tile;
         uint32_t key[KG_ITEMS], below[KG_ITEMS];
         // which entries reach the vertex stage: everything unless the radix key is "culled" (out-of-range slots
-        // carry the sentinel too). Re-derived from the key where it is needed: sixteen lane masks kept alive
-        // across the tile cost 32 scalar registers, and this kernel spills them
+        // carry the sentinel too). Re-derived from the key where it is needed: a lane mask per item kept alive
+        // across the tile costs two scalar registers each, and this kernel spills them
         const bool all_draw = fp.sort_mode != SORT_RADIX;
-#define BGS_KG_DRAWN(k) (all_draw ? (base + (uint32_t)(k) * 256u + (uint32_t)tid < fp.n) : (key[k] != sentinel))
-        // all of the tile's position loads are issued before the first key is computed: with one
-        // 4-wave block per CU nothing else hides their latency
+#define BGS_KG_DRAWN(k) (all_draw ? (base + (uint32_t)((k) * THREADS) + (uint32_t)tid < fp.n) : (key[k] != sentinel))
+        // all of the tile's position loads are issued before the first key is computed
         float4 pin[KG_ITEMS];
 #pragma unroll
         for (int k = 0; k < KG_ITEMS; ++k) {
-            const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
+            const uint32_t i = base + (uint32_t)(k * THREADS) + (uint32_t)tid;
             pin[k] = i < fp.n ? pos[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-        // the sort mode is the launch's, not the splat's: one branch around the sixteen keys instead of
-        // sixteen copies of it (each re-reading its matrices from spilled scalar registers)
+        // the sort mode is the launch's, not the splat's: one branch around the keys instead of one inside
+        // each (every copy re-reading its matrices from spilled scalar registers)
 #define BGS_KG_KEYS(KIND)                                                                      \
     _Pragma("unroll") for (int k = 0; k < KG_ITEMS; ++k) {                                     \
-        const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;                          \
+        const uint32_t i = base + (uint32_t)(k * THREADS) + (uint32_t)tid;                     \
         const float4 p = pin[k];                                                               \
         key[k] = i < fp.n ? sort_key_kind<KIND>(fp, V3{p.x, p.y, p.z}) : sentinel;             \
     }
@@ -161,29 +167,37 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
         for (int k = 0; k < KG_ITEMS; ++k) {
             const unsigned long long b = __ballot(BGS_KG_DRAWN(k));
             below[k] = (uint32_t)__popcll(b & lanes_below);
-            if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(b);
+            if (lane == 0) s_cnt[k * WAVES + wave] = (uint32_t)__popcll(b);
         }
         __syncthreads();
-        // exclusive offsets in (row, wave, lane) = index order
-        uint32_t off[KG_ITEMS];
-        uint32_t run = 0u;
-#pragma unroll
-        for (int k = 0; k < KG_ITEMS; ++k) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                if (w == wave) off[k] = run;
-                run += s_cnt[k][w];
+        // exclusive offsets of the rows in (item, wave) = index order: one wave scans the <= 128 row counts
+        if (wave == 0) {
+            const uint32_t c0 = lane < ROWS ? s_cnt[lane] : 0u;
+            const uint32_t c1 = ROWS > 64 && lane + 64 < ROWS ? s_cnt[lane + 64] : 0u;
+            const uint32_t i0 = wave_inclusive_scan(c0, lane);
+            const uint32_t t0 = (uint32_t)__shfl((int)i0, 63, 64);
+            if (lane < ROWS) s_off[lane] = i0 - c0;
+            uint32_t t1 = 0u;
+            if constexpr (ROWS > 64) {
+                const uint32_t i1 = wave_inclusive_scan(c1, lane);
+                t1 = (uint32_t)__shfl((int)i1, 63, 64);
+                if (lane + 64 < ROWS) s_off[lane + 64] = t0 + i1 - c1;
             }
+            if (lane == 0) s_total = t0 + t1;
         }
-        const uint32_t total = run;
+        __syncthreads();
+        uint32_t off[KG_ITEMS];
+#pragma unroll
+        for (int k = 0; k < KG_ITEMS; ++k) off[k] = s_off[k * WAVES + wave];
+        const uint32_t total = s_total;
         // Digit histograms from the COMPACTED keys: with the usual ~12 % of a tile drawable, counting
-        // in place costs 4 LDS atomics on each of the 16 rows of every wave (3.7 us of the kernel);
+        // in place costs 4 LDS atomics on each row of every wave (3.7 us of the kernel);
         // compacted, a tile's ~600 keys are 3 rows.
 #pragma unroll
         for (int k = 0; k < KG_ITEMS; ++k)
             if (BGS_KG_DRAWN(k)) {
                 s_keys[off[k] + below[k]] = key[k];
-                if constexpr (BUCKET) s_idx[off[k] + below[k]] = base + (uint32_t)k * 256u + (uint32_t)tid;
+                if constexpr (BUCKET) s_idx[off[k] + below[k]] = base + (uint32_t)(k * THREADS) + (uint32_t)tid;
             }
         if constexpr (!BUCKET) {
             if (wave == 0) {  // one chain per block: the whole wave walks it, 64 predecessors per hop
@@ -203,18 +217,18 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
                 }
             }
             __syncthreads();
-            for (uint32_t j = (uint32_t)tid; j < total; j += 256u) {
+            for (uint32_t j = (uint32_t)tid; j < total; j += (uint32_t)THREADS) {
                 const uint32_t kk = s_keys[j];
                 for (uint32_t pl = 0; pl < places; ++pl)
                     atomicAdd(&s_hist[pl][(kk >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
             }
         }
-        uint32_t bk[KG_ITEMS], at[KG_ITEMS];  // BUCKET: bucket and arrival slot of compacted pair r * 256 + tid
+        uint32_t bk[KG_ITEMS], at[KG_ITEMS];  // BUCKET: bucket and arrival slot of compacted pair r * THREADS + tid
         if constexpr (BUCKET) {
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < KG_ITEMS; ++r) {
-                const uint32_t j = (uint32_t)r * 256u + (uint32_t)tid;
+                const uint32_t j = (uint32_t)(r * THREADS) + (uint32_t)tid;
                 if (j < total) {
                     const uint32_t kk = s_keys[j];
                     uint32_t lo = 0u;  // number of splitters <= kk (s_split[255] = ~0: never counted unless kk = ~0)
@@ -226,20 +240,29 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
                 }
             }
             __syncthreads();
-            // thread = bucket: chained scan over the tiles, one chain per bucket
-            const uint32_t mine = s_bcnt[tid];
-            uint32_t* const my_status = bucket_status + (size_t)tile * BUCKET_COUNT + tid;
-            uint32_t excl = 0u;
-            if (tile > 0u) {
-                st_agent(my_status, STATUS_AGGREGATE | mine);
-                excl = num_tiles > 1024u ? lookback_u32<16>(bucket_status + tid, tile, BUCKET_COUNT, &ctl->error, 8u)
-                                         : lookback_u32<4>(bucket_status + tid, tile, BUCKET_COUNT, &ctl->error, 8u);
+            // thread = bucket (the first 256 threads): chained scan over the tiles, one chain per bucket
+            uint32_t excl = 0u, mine = 0u;
+            if (tid < (int)BUCKET_COUNT) {
+                mine = s_bcnt[tid];
+                uint32_t* const my_status = bucket_status + (size_t)tile * BUCKET_COUNT + tid;
+                if (tile > 0u) {
+                    st_agent(my_status, STATUS_AGGREGATE | mine);
+                    // 4 words per hop at every size: on a 5 M-splat cloud (1221 tiles) 16 per hop were 5 % slower
+                    excl = lookback_u32<4>(bucket_status + tid, tile, BUCKET_COUNT, &ctl->error, 8u);
+                }
+                st_agent(my_status, STATUS_PREFIX | ((excl + mine) & STATUS_VALUE_MASK));
+                s_bexcl[tid] = excl;
             }
-            st_agent(my_status, STATUS_PREFIX | ((excl + mine) & STATUS_VALUE_MASK));
-            s_bexcl[tid] = excl;
-            uint32_t before_tile;
-            (void)block_exclusive_scan_256(excl, s_tot, before_tile);  // two barriers inside
-            if (tile == num_tiles - 1u) {
+            // the sum of the 256 exclusive prefixes = the drawable entries of the earlier tiles
+            uint32_t before_tile = tid < (int)BUCKET_COUNT ? excl : 0u;
+            if (wave < 4) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) before_tile += (uint32_t)__shfl_xor((int)before_tile, o, 64);
+                if (lane == 0) s_tot[wave] = before_tile;
+            }
+            __syncthreads();
+            before_tile = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+            if (tile == num_tiles - 1u && tid < (int)BUCKET_COUNT) {
                 ctl->bucket_count[tid] = excl + mine;
                 if (tid == 0) {
                     ctl->draw_count = before_tile + total;
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < KG_ITEMS; ++r) {
-                const uint32_t j = (uint32_t)r * 256u + (uint32_t)tid;
+                const uint32_t j = (uint32_t)(r * THREADS) + (uint32_t)tid;
                 if (j < total) {
                     const uint32_t slot = s_bexcl[bk[r]] + at[r];
                     if (slot < BUCKET_CAP)  // a bucket over capacity is seen by bucket_sort_kernel (count > cap)
@@ -261,36 +284,50 @@ __global__ __launch_bounds__(256) void keygen_kernel(FrameParams fp, const float
         const uint32_t vis_base = s_base;
 #pragma unroll
         for (int k = 0; k < KG_ITEMS; ++k) {
-            const uint32_t i = base + (uint32_t)k * 256u + (uint32_t)tid;
+            const uint32_t i = base + (uint32_t)(k * THREADS) + (uint32_t)tid;
             if (i < fp.n) {
                 const uint32_t before = vis_base + off[k] + below[k];  // drawable entries before i
                 if (BGS_KG_DRAWN(k)) { if constexpr (!BUCKET) entries[before] = make_uint2(key[k], i); }
                 else culled[i - before] = make_uint2(key[k], i);
             }
         }
+#undef BGS_KG_DRAWN
         if (single_shot) break;
         __syncthreads();
     }
     if constexpr (!BUCKET) {
-        for (uint32_t pl = 0; pl < places; ++pl) {
-            const uint32_t v = s_hist[pl][tid];
-            if (v) atomicAdd(&ctl->hist_depth[pl][tid], v);
-        }
+        __syncthreads();  // a block that leaves after its one tile comes here straight from the LDS atomics above
+        if (tid < 256)
+            for (uint32_t pl = 0; pl < places; ++pl) {
+                const uint32_t v = s_hist[pl][tid];
+                if (v) atomicAdd(&ctl->hist_depth[pl][tid], v);
+            }
     }
 }
 
 bool KeygenLaunch::prepare(int max_blocks) {
     if (fp.n == 0) return false;
-    // 4096-splat tiles once there are enough splats to fill the chip with them: half the tickets and
-    // chain hops (measured at 1 M splats: 30.8 -> 27.3 us)
-    const bool wide = fp.n >= (1u << 19);
-    const uint32_t per_block = 256u * (wide ? 16u : 8u);
+    // Tile size by cloud size (keygen_tile_splats): every tile is a ticket, a hop in 256 look-back chains and a
+    // round of barriers
+    const uint32_t per_block = keygen_tile_splats(fp.n);
+    const bool bucket = fp.sort_path == 1u;
+#if BGS_KEYGEN_WIDE_THREADS == 256
+    threads = 256u;
+    if (per_block >= 4096u)
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<16, true, 256>) : reinterpret_cast<const void*>(&keygen_kernel<16, false, 256>);
+    else
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<8, true, 256>) : reinterpret_cast<const void*>(&keygen_kernel<8, false, 256>);
+#else
+    threads = per_block >= 4096u ? 1024u : 256u;
+    if (per_block == 8192u)
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<8, true, 1024>) : reinterpret_cast<const void*>(&keygen_kernel<8, false, 1024>);
+    else if (per_block == 4096u)
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<4, true, 1024>) : reinterpret_cast<const void*>(&keygen_kernel<4, false, 1024>);
+    else
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<8, true, 256>) : reinterpret_cast<const void*>(&keygen_kernel<8, false, 256>);
+#endif
     blocks = (fp.n + per_block - 1) / per_block;
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
-    if (fp.sort_path == 1u)
-        func = wide ? reinterpret_cast<const void*>(&keygen_kernel<16, true>) : reinterpret_cast<const void*>(&keygen_kernel<8, true>);
-    else
-        func = wide ? reinterpret_cast<const void*>(&keygen_kernel<16, false>) : reinterpret_cast<const void*>(&keygen_kernel<8, false>);
     argv[0] = &fp; argv[1] = &pos; argv[2] = &entries; argv[3] = &culled; argv[4] = &ctl;
     argv[5] = &part_status; argv[6] = &places; argv[7] = &ticket_slot; argv[8] = &fp_out; argv[9] = &bucket_slots;
     argv[10] = &bucket_status; argv[11] = &split;
@@ -298,14 +335,14 @@ bool KeygenLaunch::prepare(int max_blocks) {
 }
 
 hipError_t KeygenLaunch::launch(hipStream_t stream) {
-    return hipLaunchKernel(func, dim3(blocks), dim3(256), argv, 0, stream);
+    return hipLaunchKernel(func, dim3(blocks), dim3(threads), argv, 0, stream);
 }
 
 hipError_t KeygenLaunch::update_node(hipGraphExec_t exec, hipGraphNode_t node) {
     hipKernelNodeParams np{};
     np.func = const_cast<void*>(func);
     np.gridDim = dim3(blocks);
-    np.blockDim = dim3(256);
+    np.blockDim = dim3(threads);
     np.sharedMemBytes = 0;
     np.kernelParams = argv;
     np.extra = nullptr;
@@ -508,21 +545,31 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
 // capacity, or a key value repeated more than BUCKET_FINE_MAX times (step 4 is quadratic in the ties), sets
 // ctl->sort_overflow and the host re-runs the frame with the onesweep passes.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restrict__ slots,
-                                                          uint2* __restrict__ out, Control* ctl,
-                                                          uint32_t key_xor) {
-    constexpr uint32_t EPT = BUCKET_CAP / 256u;              // pairs per thread (strided)
-    constexpr uint32_t NF = BUCKET_FINE, FPT = NF / 256u;    // fine ranges per thread (contiguous)
-    static_assert(NF == 2048u && BUCKET_COUNT == 256u, "bucket geometry");
+// A bucket is one workgroup. With 1024 threads (4 pairs and 2 fine ranges per thread) instead of 256 a launch puts
+// 16 waves on every CU instead of 4 and is faster alone (600 k pairs of a 5 M-splat cloud 27.9 -> 15.3 us,
+// 120 k pairs 9.9 -> 9.5 us), but slower where it matters, with other frames' kernels sharing the chip
+// (kernels.h, BGS_KEYGEN_WIDE_THREADS): 256 is the default.
+#ifndef BGS_BUCKET_SORT_THREADS
+#define BGS_BUCKET_SORT_THREADS 256
+#endif
+constexpr uint32_t BUCKET_SORT_THREADS = BGS_BUCKET_SORT_THREADS;
+template <uint32_t THREADS>  // 256 or 1024
+__global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __restrict__ slots,
+                                                              uint2* __restrict__ out, Control* ctl,
+                                                              uint32_t key_xor) {
+    constexpr uint32_t WAVES = THREADS / 64u;
+    constexpr uint32_t EPT = BUCKET_CAP / THREADS;              // pairs per thread (strided)
+    constexpr uint32_t NF = BUCKET_FINE, FPT = NF / THREADS;    // fine ranges per thread (contiguous)
+    static_assert(NF == 2048u && BUCKET_COUNT == 256u && (THREADS == 256u || THREADS == 1024u), "bucket geometry");
     __shared__ uint2 s_el[BUCKET_CAP];
     __shared__ uint32_t s_f[NF + 1];
-    __shared__ uint32_t s_tot[4];
-    __shared__ uint32_t s_red[4][2];
+    __shared__ uint32_t s_tot[WAVES];
+    __shared__ uint32_t s_red[WAVES][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
-    const uint32_t cnt = ctl->bucket_count[tid];
-    // offset of this bucket in the sorted list, its own count, the fullest bucket
+    // offset of this bucket in the sorted list, its own count, the fullest bucket (threads 0..255 = buckets)
+    const uint32_t cnt = tid < (int)BUCKET_COUNT ? ctl->bucket_count[tid] : 0u;
     uint32_t before = tid < (int)b ? cnt : 0u, mine = tid == (int)b ? cnt : 0u, mx = cnt;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -532,7 +579,7 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
     }
     if (lane == 0) { s_red[wave][0] = before; s_red[wave][1] = mine; s_tot[wave] = mx; }
 #pragma unroll
-    for (uint32_t j = 0; j < FPT; ++j) s_f[j * 256u + (uint32_t)tid] = 0u;
+    for (uint32_t j = 0; j < FPT; ++j) s_f[j * THREADS + (uint32_t)tid] = 0u;
     __syncthreads();
     const uint32_t base = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
     const uint32_t m = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
@@ -555,7 +602,7 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
     uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < EPT; ++k) {
-        const uint32_t e = k * 256u + (uint32_t)tid;
+        const uint32_t e = k * THREADS + (uint32_t)tid;
         kv[k] = make_uint2(0u, 0u);
         if (e < m) {
             kv[k] = src[e];
@@ -570,8 +617,9 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
     }
     if (lane == 0) { s_red[wave][0] = kmn; s_red[wave][1] = kmx; }
     __syncthreads();
-    kmn = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
-    kmx = max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1]));
+    kmn = 0xFFFFFFFFu; kmx = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; ++w) { kmn = min(kmn, s_red[w][0]); kmx = max(kmx, s_red[w][1]); }
     const uint32_t span = kmx - kmn;
     const uint32_t bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
     const uint32_t fshift = bits > 11u ? bits - 11u : 0u;  // (span >> fshift) < NF = 2^11
@@ -580,7 +628,7 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
     uint32_t slot[EPT];
 #pragma unroll
     for (uint32_t k = 0; k < EPT; ++k) {
-        const uint32_t e = k * 256u + (uint32_t)tid;
+        const uint32_t e = k * THREADS + (uint32_t)tid;
         if (e < m) slot[k] = atomicAdd(&s_f[(kv[k].x - kmn) >> fshift], 1u);
     }
     __syncthreads();
@@ -591,8 +639,13 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
         fmax = max(fmax, f[j]);
         fsum += f[j];
     }
-    uint32_t ftotal;
-    uint32_t fexcl = block_exclusive_scan_256(fsum, s_tot, ftotal);
+    // exclusive scan of fsum over the block (wave scan + the waves' totals through LDS)
+    const uint32_t finc = wave_inclusive_scan(fsum, lane);
+    if (lane == 63) s_tot[wave] = finc;
+    __syncthreads();
+    uint32_t fexcl = finc - fsum;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; ++w) fexcl += w < (uint32_t)wave ? s_tot[w] : 0u;
 #pragma unroll
     for (uint32_t j = 0; j < FPT; ++j) {
         s_f[(uint32_t)tid * FPT + j] = fexcl;
@@ -608,7 +661,7 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
     }
 #pragma unroll
     for (uint32_t k = 0; k < EPT; ++k) {
-        const uint32_t e = k * 256u + (uint32_t)tid;
+        const uint32_t e = k * THREADS + (uint32_t)tid;
         if (e < m) s_el[s_f[(kv[k].x - kmn) >> fshift] + slot[k]] = kv[k];
     }
     __syncthreads();
@@ -616,7 +669,7 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
     // ---- 4. rank among the fine range's pairs by (key, index), write out ----
 #pragma unroll 4
     for (uint32_t k = 0; k < EPT; ++k) {
-        const uint32_t p = k * 256u + (uint32_t)tid;
+        const uint32_t p = k * THREADS + (uint32_t)tid;
         if (p < m) {
             const uint2 el = s_el[p];
             const uint32_t fb = (el.x - kmn) >> fshift;
@@ -632,7 +685,8 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2* __restric
 }
 
 void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor) {
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3(BUCKET_COUNT), dim3(256), 0, stream, bucket_slots, out, ctl, key_xor);
+    hipLaunchKernelGGL(bucket_sort_kernel<BUCKET_SORT_THREADS>, dim3(BUCKET_COUNT), dim3(BUCKET_SORT_THREADS), 0, stream,
+                       bucket_slots, out, ctl, key_xor);
 }
 
 // The 255 keys at the 1/256-quantiles of a sorted draw list, in keygen's key space (key ^ key_xor): the
