@@ -534,10 +534,17 @@ def main():
         dist.barrier()
     handle.free()
     plugin.close()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would come out at
+    # process exit, i.e. AFTER the result: flush it first so that the JSON line is the last line on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
