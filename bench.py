@@ -251,8 +251,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splats", type=int, default=N_SPLATS)
-    ap.add_argument("--depth", type=int, default=6, help="frames in flight (pipeline lanes, 1..8)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--depth", type=int, default=8, help="frames in flight (pipeline lanes, 1..8)")
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the lanes are multiplexed onto (0 = one per lane): frames competing for the chip")
     ap.add_argument("--trials", type=int, default=0,
                     help="timed regions of --steps frames; the median is reported (default: 5, 3 from 2000 steps up)")
@@ -294,8 +294,8 @@ def main():
     DEPTH = max(1, min(8, args.depth))  # frames in flight (lanes); 1 = a single stream
     plugin.set_async(True)
     plugin.set_pipeline_depth(DEPTH)
-    # lane i runs on stream i % STREAMS: with 6 lanes on 3 streams every stream already holds its next
-    # frame while one executes (measured 12.7 k frames/s against 11.8 k with 3 lanes on 3 streams)
+    # lane i runs on stream i % STREAMS: with 8 lanes on 4 streams (one stream per hardware queue of the HIP
+    # runtime, include/bgs.h) every stream already holds its next frame while one executes
     plugin.set_pipeline_streams(max(0, min(8, args.streams)))
     # every kernel of every Nth frame is bracketed by HIP events (a record costs ~4 us of GPU time, so
     # timing every frame would cost ~20 % of the frame rate being measured)
@@ -333,8 +333,7 @@ def main():
 
     # ---- headline: reference distribution, CloudSettings::default() -------------------------
     # with a consumer popping frames the host waits for the oldest frame while the others run: 8 lanes on
-    # 4 streams keep the GPU fed meanwhile (one rank driving this path without peers: 11.8 k frames/s;
-    # 10.6 k with 6 lanes on 3 streams, 10.0 k with 8 on 3)
+    # 4 streams keep the GPU fed meanwhile
     lanes, streams = (8, 4) if gather is not None else (DEPTH, args.streams)
     if os.environ.get("BGS_BENCH_LANES"):
         lanes = max(1, min(8, int(os.environ["BGS_BENCH_LANES"])))  # experiment override

@@ -169,7 +169,8 @@ struct bgs_ctx {
 
     Lane lanes[MAX_LANES];
     hipStream_t streams[MAX_LANES] = {};
-    int num_streams = 3;  // streams the lanes are multiplexed onto, 0 = one per lane
+    hipStream_t queue_holders[3] = {};  // idle streams that make the runtime spread ours over its hardware queues (assign_streams)
+    int num_streams = 4;  // streams the lanes are multiplexed onto, 0 = one per lane (one per hardware queue: include/bgs.h)
     int depth = 1;    // lanes in use
     int next = 0;     // lane the next frame goes to
     int recent = 0;   // lane of the most recently enqueued frame
@@ -259,7 +260,22 @@ int assign_streams(bgs_ctx* ctx) {
         Lane& L = ctx->lanes[i];
         if (!L.done) continue;
         const int si = i < ctx->depth ? i % S : i;
-        if (!ctx->streams[si]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->streams[si], hipStreamNonBlocking));
+        if (!ctx->streams[si]) {
+            // The HIP runtime multiplexes a process's streams onto at most 4 hardware queues per priority
+            // (GPU_MAX_HW_QUEUES), and only queues are concurrent: two streams on one queue run one after the other.
+            // It creates a NEW queue for every new stream until the 4 exist and only then spreads further streams
+            // by reference count — and the process's null stream already holds one. Left alone, our streams 0, 1, 2
+            // get a queue each and stream 3 joins stream 2's (seen in the runtime's log, AMD_LOG_LEVEL=3): four
+            // frames on three queues, two of them serialised — 14.0 k frames/s with 8 lanes on 4 streams where a
+            // process that had initialised RCCL (whose idle streams happen to hold the queues) ran 19.2 k. So the
+            // context parks three idle streams on the queues FIRST; ours are then dealt out evenly over all four,
+            // the null stream's included (8 lanes / 4 streams 18.2 k, 8 / 8 19.0 k; scripts/queues_probe.py).
+            // Priorities other than the default do not help: their queue pools are separate but slower (high:
+            // 13.7 k at 8 / 4, 14.4 k at 6 / 6).
+            if (!ctx->queue_holders[0])
+                for (auto& qh : ctx->queue_holders) HIP_TRY(ctx, hipStreamCreateWithFlags(&qh, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->streams[si], hipStreamNonBlocking));
+        }
         L.stream = ctx->streams[si];
     }
     return BGS_OK;
@@ -1204,6 +1220,7 @@ void bgs_destroy(bgs_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& L : ctx->lanes) lane_destroy(L);
     for (auto st : ctx->streams) if (st) (void)hipStreamDestroy(st);
+    for (auto st : ctx->queue_holders) if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }
 

@@ -333,12 +333,13 @@ int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries_inout, uint32_t n
 int bgs_hbm_probe(bgs_ctx* ctx, uint64_t bytes, uint32_t iters, float* copy_gbs, float* triad_gbs);
 
 /* Streams the lanes run on: lane i uses stream i % min(streams, depth); 0 = one stream per lane.
- * Default 3. With fewer streams than lanes (depth 6 on 3 streams) a stream already holds the next
- * frame of a sibling lane while one executes, so it never idles between frames waiting for the
- * host, and no more than `streams` frames compete for the chip at a time (measured on the headline
- * workload, round 2: 14.8 k frames/s with 3 lanes on 3 streams, 15.3 k with 6 on 3, 15.5 k with 6 on 6, 12.6 k
- * with 8 on 4 — but 16.5 k with 8 on 4 for packed-only frames that are popped one by one: the best pair
- * depends on how the host consumes the frames; measure). Completes the frames in flight. */
+ * Default 4: the HIP runtime multiplexes a process's streams onto 4 hardware queues (per priority), and only
+ * queues run concurrently, so 4 streams — each on its own queue, the library parks idle streams to get them
+ * dealt out that way — is one frame per queue; with more lanes than streams (depth 8 on 4 streams) a stream
+ * already holds the next frame of a sibling lane while one executes and never waits for the host.
+ * Measured on the headline workload (round 2): 8 lanes on 4 streams 19.0 k frames/s, 4 on 4 18.9 k, 8 on 8
+ * 19.0 k, 6 on 3 16.9 k, 6 on 6 17.6 k, and anything that spreads unevenly over the 4 queues loses (8 on 6 16.7 k,
+ * 5 on 5 15.6 k). */
 int bgs_set_pipeline_streams(bgs_ctx* ctx, uint32_t streams);
 
 /* Frame graphs (opt-in, default off). An asynchronous BINNING_SCAN frame (bgs_set_async) in the

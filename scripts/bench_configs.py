@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevy_gaussian_splatting_amd import (CloudSettings, GaussianMode, GaussianSplattingPlugin, View,
                                          random_gaussians_3d_seeded)
 
-def run(p, h, v, s, steps=60, warm=30, depth=6):
-    # throughput with `depth` lanes (on the default 3 streams), no stage events in the timed loop
+def run(p, h, v, s, steps=60, warm=30, depth=8):
+    # throughput with `depth` lanes (on the default 4 streams), no stage events in the timed loop
     p.set_async(True); p.set_pipeline_depth(depth); p.set_profiling(0)
     for _ in range(warm): p.render(h, v, s, download=False)
     p.synchronize()

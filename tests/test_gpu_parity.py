@@ -430,7 +430,7 @@ def test_full_size_f16_5m_sort_and_crop(plugin, oracle):
         plugin.synchronize()
         from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
         assert np.array_equal(framebuffer_as_tensor(plugin, 1080, 1920).cpu().numpy(), got)
-    plugin.set_pipeline_streams(3)  # the default: 6 lanes on 3 streams
+    plugin.set_pipeline_streams(3)  # fewer streams than lanes: 6 lanes on 3 streams
     for _ in range(12):
         plugin.render(h, v, s, download=False)
     plugin.synchronize()
