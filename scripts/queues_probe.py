@@ -56,11 +56,11 @@ p = GaussianSplattingPlugin(0)
 h = p.upload(random_gaussians_3d_seeded(1_000_000, 2))
 v = headless_view(0); s = CloudSettings()
 p.set_async(True); p.set_profiling(0)
-for lanes, streams in ((6, 3), (6, 4), (6, 6), (8, 4), (8, 6), (8, 8), (7, 7), (5, 5), (4, 4), (8, 5)):
+for lanes, streams in ((8, 8), (8, 4), (6, 6), (8, 6)):
     p.set_pipeline_depth(lanes); p.set_pipeline_streams(streams)
     pv = p.prepare(v, s)
     for _ in range(60): p.render(h, pv, download=False)
     p.synchronize(); t0 = time.perf_counter()
     for _ in range(600): p.render(h, pv, download=False)
     p.synchronize(); dt = time.perf_counter() - t0
-    print(f"{what} prio={os.environ.get('BGS_STREAM_PRIORITY')} lanes {lanes} streams {streams}: {600/dt:.0f} fps", flush=True)
+    print(f"{what} maxq={os.environ.get('GPU_MAX_HW_QUEUES')} lanes {lanes} streams {streams}: {600/dt:.0f} fps", flush=True)
