@@ -282,6 +282,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device(f"cuda:{local_rank}"))
+        # RCCL's own (idle) streams already hold the HIP runtime's four hardware queues, which is what the
+        # library's queue-holder streams are for in a process without them (csrc/bgs_api.hip, assign_streams)
+        os.environ.setdefault("BGS_QUEUE_HOLDERS", "0")
 
     from bevy_gaussian_splatting_amd import CloudSettings, GaussianSplattingPlugin, random_gaussians_3d_seeded
     from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor, gather_framebuffers, headless_view

@@ -32,6 +32,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -272,7 +273,12 @@ int assign_streams(bgs_ctx* ctx) {
             // the null stream's included (8 lanes / 4 streams 18.2 k, 8 / 8 19.0 k; scripts/queues_probe.py).
             // Priorities other than the default do not help: their queue pools are separate but slower (high:
             // 13.7 k at 8 / 4, 14.4 k at 6 / 6).
-            if (!ctx->queue_holders[0])
+            // BGS_QUEUE_HOLDERS=0 in the environment switches this off: a process whose other streams already hold
+            // the queues (RCCL's, after a process group was initialised: bench.py's gather path sets it) is better
+            // off without three more co-tenants on them (that path: 18.0 k frames/s without, 13.6 k with).
+            const char* qh_env = std::getenv("BGS_QUEUE_HOLDERS");
+            const bool park = !(qh_env && qh_env[0] == '0');
+            if (park && !ctx->queue_holders[0])
                 for (auto& qh : ctx->queue_holders) HIP_TRY(ctx, hipStreamCreateWithFlags(&qh, hipStreamNonBlocking));
             HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->streams[si], hipStreamNonBlocking));
         }

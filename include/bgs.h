@@ -339,7 +339,8 @@ int bgs_hbm_probe(bgs_ctx* ctx, uint64_t bytes, uint32_t iters, float* copy_gbs,
  * already holds the next frame of a sibling lane while one executes and never waits for the host.
  * Measured on the headline workload (round 2): 8 lanes on 4 streams 19.0 k frames/s, 4 on 4 18.9 k, 8 on 8
  * 19.0 k, 6 on 3 16.9 k, 6 on 6 17.6 k, and anything that spreads unevenly over the 4 queues loses (8 on 6 16.7 k,
- * 5 on 5 15.6 k). */
+ * 5 on 5 15.6 k). BGS_QUEUE_HOLDERS=0 in the environment keeps the library from parking its idle streams: for
+ * processes whose other streams (RCCL's) already hold the queues. */
 int bgs_set_pipeline_streams(bgs_ctx* ctx, uint32_t streams);
 
 /* Frame graphs (opt-in, default off). An asynchronous BINNING_SCAN frame (bgs_set_async) in the
