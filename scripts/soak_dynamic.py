@@ -1,6 +1,6 @@
 """Soak with everything that adapts in motion: an orbiting camera (draw count drifts -> sticky grid hint),
 splat size switching between scene-like and dense (supertile level jumps, list capacities regrow, bucket
-splitters go stale and the frame is re-run), 6 lanes on 3 streams, frame
+splitters go stale and the frame is re-run), 8 lanes on 4 streams, frame
 graphs on for every other phase. Every phase ends with a check against a blocking, directly launched frame.
 python scripts/soak_dynamic.py [frames]"""
 import sys, os, time
@@ -13,7 +13,7 @@ p = GaussianSplattingPlugin(0)
 h = p.upload(random_gaussians_3d_seeded(1_000_000, 2))
 views = [headless_view(g) for g in range(8)]          # camera yawed in 45 degree steps
 p.set_profiling(0)
-p.set_pipeline_depth(6)
+p.set_pipeline_depth(8)
 phase_len = 2000
 t0 = time.perf_counter()
 done = 0
