@@ -1,18 +1,20 @@
 #!/bin/bash
-# rocprofv3 kernel timelines of the pipelined loop (depth 1, 3 and 6 — the last on 3 streams) -> gpurun_out/timeline_depth*.json
+# rocprofv3 kernel timelines of the pipelined loop (1 lane; 3 and 6 lanes on 3 streams; 8 lanes on 4 streams, the
+# default) -> gpurun_out/timeline_depth*.json
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp
-for d in 1 3 6; do
+for d in ${DEPTHS:-1 3 6 8}; do
   rm -rf /tmp/tl$d
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl$d -o t -- python $R/scripts/loop_pipelined.py $d 60 ${1:-1.0} 0 0 3 > /tmp/tl$d.out 2>/tmp/tl$d.err
+  st=3; [ $d -ge 8 ] && st=4
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl$d -o t -- python $R/scripts/loop_pipelined.py $d 60 ${1:-1.0} 0 0 $st > /tmp/tl$d.out 2>/tmp/tl$d.err
   cat /tmp/tl$d.out
   for f in $(find /tmp/tl$d -name "*kernel_trace.csv"); do python $R/scripts/timeline_analysis.py $f 150 > $R/gpurun_out/timeline_depth$d.json; done
 done
 python - <<'PY'
 import json, os
-for d in (1, 3, 6):
+for d in (1, 3, 6, 8):
     p = f"{os.environ['GRAFT_REPO_ROOT']}/gpurun_out/timeline_depth{d}.json"
     if os.path.exists(p):
         t = json.load(open(p))
