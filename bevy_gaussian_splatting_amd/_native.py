@@ -10,6 +10,7 @@ import ctypes
 import os
 from typing import Optional
 
+from . import _build_id
 from .camera import BgsView
 from .settings import BgsSettings
 
@@ -31,6 +32,9 @@ EXPORTED_SYMBOLS = (
     "bgs_destroy",
     "bgs_last_error",
     "bgs_version",
+    "bgs_build_id",
+    "bgs_set_queue_holders",
+    "bgs_selftest_ln_f32",
     "bgs_settings_default",
     "bgs_view_perspective",
     "bgs_cloud_upload_f32",
@@ -93,6 +97,7 @@ class BgsStats(ctypes.Structure):
         ("binning_mode", ctypes.c_uint32),
         ("frames_averaged", ctypes.c_uint32),
         ("list_capacity", ctypes.c_uint32),
+        ("list_entries_allocated", ctypes.c_uint64),
     ]
 
 
@@ -105,17 +110,52 @@ class BgsError(RuntimeError):
 _lib: Optional[ctypes.CDLL] = None
 
 
+def rebuild() -> str:
+    """`make -C csrc` (hipcc cross-compiles gfx950 without a GPU). Returns the build log; raises on failure."""
+    import subprocess
+    p = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "ARCH=gfx950"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0:
+        raise ImportError(f"building libbgs.so failed:\n{p.stdout}")
+    return p.stdout
+
+
+def ensure_current() -> str:
+    """The library on disk must have been compiled from THIS tree's kernel sources (`bgs_build_id()` = SHA-256 of
+    csrc/*.hip + csrc/*.h, `_build_id.py`): a prebuilt libbgs.so that is missing or stale is rebuilt (unless
+    BGS_NO_AUTOBUILD=1), and anything that still does not match is refused. Returns the id."""
+    want = _build_id.kernel_source_sha256()
+    have = _build_id.library_build_id(LIB_PATH) if os.path.exists(LIB_PATH) else None
+    if have != want and os.environ.get("BGS_NO_AUTOBUILD", "0") != "1":
+        rebuild()
+        have = _build_id.library_build_id(LIB_PATH) if os.path.exists(LIB_PATH) else None
+    if have is None:
+        raise ImportError(
+            f"{LIB_PATH} not found (or it carries no build id): build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    if have != want:
+        raise ImportError(f"{LIB_PATH} was built from kernel sources {have[:12]}, this tree is {want[:12]}: rebuild it "
+                          "(make -C bevy_gaussian_splatting_amd/csrc)")
+    return want
+
+
+def build_id() -> str:
+    """`bgs_build_id()` of the loaded library (= the tree's kernel-source hash, load() checked it)."""
+    return load().bgs_build_id().decode()
+
+
 def load() -> ctypes.CDLL:
-    """Load libbgs.so once and declare prototypes. Raises if it has not been built."""
+    """Load libbgs.so once and declare prototypes. Raises if it is not built from this tree's sources and cannot
+    be rebuilt."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            f"{LIB_PATH} not found: build the HIP extension first "
-            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
-        )
+    want = ensure_current()
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib.bgs_build_id.argtypes = []
+    lib.bgs_build_id.restype = ctypes.c_char_p
+    if lib.bgs_build_id().decode() != want:
+        raise ImportError(f"{LIB_PATH}: bgs_build_id() disagrees with the id in the file's bytes")
     vp = ctypes.c_void_p
     u32 = ctypes.c_uint32
     fp = ctypes.POINTER(ctypes.c_float)
@@ -129,6 +169,12 @@ def load() -> ctypes.CDLL:
     lib.bgs_last_error.restype = ctypes.c_char_p
     lib.bgs_version.argtypes = []
     lib.bgs_version.restype = u32
+    lib.bgs_build_id.argtypes = []
+    lib.bgs_build_id.restype = ctypes.c_char_p
+    lib.bgs_set_queue_holders.argtypes = [ctypes.c_int]
+    lib.bgs_set_queue_holders.restype = ctypes.c_int
+    lib.bgs_selftest_ln_f32.argtypes = [vp, u32, u32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)]
+    lib.bgs_selftest_ln_f32.restype = ctypes.c_int
     lib.bgs_settings_default.argtypes = [ctypes.POINTER(BgsSettings)]
     lib.bgs_settings_default.restype = None
     lib.bgs_view_perspective.argtypes = [

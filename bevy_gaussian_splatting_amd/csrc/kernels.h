@@ -168,4 +168,9 @@ void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t
 void launch_triad(hipStream_t stream, float4* a, const float4* b, const float4* c, float s, size_t n4,
                   int blocks);
 
+// Device self-test of ln_f32_cr (exact_log.h) over the binary32 bit patterns first_bits .. first_bits + count - 1:
+// out[i] (may be null) = ln of pattern i; *sum += sum_i mix(bits(in_i), bits(out_i)) (ln_selftest_mix, wrap-around).
+void launch_selftest_ln(hipStream_t stream, uint32_t first_bits, uint32_t count, float* out, unsigned long long* sum,
+                        int blocks);
+
 }  // namespace bgs

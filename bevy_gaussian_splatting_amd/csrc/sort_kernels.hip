@@ -717,6 +717,27 @@ __global__ __launch_bounds__(256) void triad_kernel(float4* __restrict__ a, cons
     }
 }
 
+// ln_f32_cr on the device over a range of binary32 bit patterns (bgs_selftest_ln_f32: the parity tests hold the
+// device build of exact_log.h to the host build and to the oracle's x87 logl on EVERY positive input)
+__global__ void __launch_bounds__(256) selftest_ln_kernel(uint32_t first_bits, uint32_t count, float* __restrict__ out,
+                                                          unsigned long long* __restrict__ sum) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t in_bits = first_bits + (uint32_t)i;
+        const float r = ln_f32_cr(__uint_as_float(in_bits));
+        if (out) out[i] = r;
+        acc += ln_selftest_mix(in_bits, __float_as_uint(r));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+}
+
+void launch_selftest_ln(hipStream_t stream, uint32_t first_bits, uint32_t count, float* out, unsigned long long* sum,
+                        int blocks) {
+    hipLaunchKernelGGL(selftest_ln_kernel, dim3(blocks), dim3(256), 0, stream, first_bits, count, out, sum);
+}
+
 void launch_triad(hipStream_t stream, float4* a, const float4* b, const float4* c, float s, size_t n4,
                   int blocks) {
     if (n4 == 0) return;

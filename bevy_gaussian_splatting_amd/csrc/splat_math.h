@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include "bgs_device.h"
+#include "exact_log.h"
 
 #if defined(__HIPCC__)
 #define BGS_HD __host__ __device__ __forceinline__
@@ -27,13 +28,13 @@
 #define BGS_HD static inline
 #endif
 
-// Transcendentals that feed only colour or the quad SIZE (never a cull decision or a sort key)
-// use the hardware exp2/log2 on the device (~1 ulp); the host build keeps libm.
+// The one transcendental that feeds only a COLOUR (never a cull decision, a sort key or a quad) — the 2.4 power of
+// srgb_to_linear — uses the hardware exp2/log2 on the device (~1 ulp); the host build keeps libm. Everything that
+// reaches a compare is +, -, *, /, sqrt (correctly rounded on gfx950) or ln_f32_cr (exact_log.h): ln(opacity) of
+// the adaptive cutoff goes into the 2DGS degeneracy tests, so it is the correctly rounded value on every side.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define BGS_FAST_LOG(x) (__builtin_amdgcn_logf(x) * 0.6931471805599453f)
 #define BGS_FAST_POW(x, y) __builtin_amdgcn_exp2f((y) * __builtin_amdgcn_logf(x))
 #else
-#define BGS_FAST_LOG(x) logf(x)
 #define BGS_FAST_POW(x, y) powf(x, y)
 #endif
 
@@ -435,7 +436,9 @@ BGS_HD V3 normal_rgb(const FrameParams& fp, const float* rot, const float* scale
 // src/render/gaussian.wgsl:229-235
 BGS_HD float cutoff_radius(const FrameParams& fp, float opacity) {
     if (!fp.adaptive_radius) return 3.0f;
-    return sqrtf(fmaxf(9.0f + 2.0f * BGS_FAST_LOG(opacity), 0.000001f));
+    // ln(opacity) reaches DECISIONS (cutoff^2 -> d, extent -> the `< 1e-4` tests of gaussian_2d.wgsl:49-78,104-132, an
+    // ill-conditioned cancellation): the correctly rounded value, bit-identical on host, device and oracle
+    return sqrtf(fmaxf(9.0f + 2.0f * ln_f32_cr(opacity), 0.000001f));
 }
 
 // The four clip-space quad corners -> pixel-space parallelogram (centre, u axis, v axis).

@@ -370,6 +370,7 @@ class GaussianSplattingPlugin:
             "draw_count": int(st.draw_count),
             "instance_count": int(st.instance_count),
             "instance_capacity": int(st.instance_capacity),
+            "list_entries_allocated": int(st.list_entries_allocated),
             "tiles": (int(st.tiles_x), int(st.tiles_y)),
             "depth_passes": int(st.depth_passes),
             "tile_passes": int(st.tile_passes),

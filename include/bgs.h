@@ -147,8 +147,7 @@ typedef struct bgs_stats {
     uint32_t sort_path;          /* depth sort of the call: 0 = onesweep digit passes, 1 = bucket sort
                                     (one launch; chosen per frame)        */
     uint64_t instance_count;     /* I: (tile, splat) instances emitted                 */
-    uint64_t instance_capacity;  /* BINNING_SORT: tile instances the lane's buffers hold; BINNING_SCAN: 8-byte list
-                                    entries allocated for the lane (all supertile lists together)      */
+    uint64_t instance_capacity;  /* BGS_BINNING_SORT: tile instances the lane's buffers hold (0 until that mode ran) */
     uint32_t tiles_x, tiles_y;
     uint32_t depth_passes;       /* radix digit places used for the depth keys         */
     uint32_t tile_passes;        /* radix passes used for the tile ids                 */
@@ -159,6 +158,8 @@ typedef struct bgs_stats {
     uint32_t frames_averaged;    /* stage_ms/total_ms = mean over this many frames (async: all
                                     frames since the last read-back, at most 64)        */
     uint32_t list_capacity;      /* BGS_BINNING_SCAN: entries each supertile list could hold  */
+    uint64_t list_entries_allocated; /* BGS_BINNING_SCAN: 8-byte list entries allocated for the lane (all supertile
+                                    lists together); instance_count is how many of them the frame filled */
 } bgs_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -166,6 +167,10 @@ int bgs_create(int hip_device, bgs_ctx** out);
 void bgs_destroy(bgs_ctx* ctx);
 const char* bgs_last_error(const bgs_ctx* ctx); /* ctx may be NULL: global message   */
 uint32_t bgs_version(void);                     /* (major << 16) | minor             */
+/* Identity of the kernel sources the library was compiled from: the SHA-256 (64 hex digits) over the HIP
+ * sources and headers of libbgs (csrc/ .hip and .h files). The Python binding, the tests and bench.py refuse a library whose id is not the
+ * tree's (and rebuild it); counter files under profiles/ carry the same stamp. */
+const char* bgs_build_id(void);
 
 /* Fill defaults equal to CloudSettings::default() (src/gaussian/settings.rs:110-131)
  * with an identity transform. */
@@ -332,6 +337,14 @@ int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries_inout, uint32_t n
  * float4 accesses, counting 2 reads + 1 write. Allocates 3 * bytes for the call. */
 int bgs_hbm_probe(bgs_ctx* ctx, uint64_t bytes, uint32_t iters, float* copy_gbs, float* triad_gbs);
 
+/* Device self-test of the correctly rounded natural logarithm behind the adaptive cutoff
+ * (src/render/gaussian.wgsl:229-235; csrc/exact_log.h: the one transcendental that reaches a cull decision).
+ * Evaluates it ON THE DEVICE for the `count` binary32 bit patterns first_bits, first_bits + 1, ...:
+ * host_out (may be NULL) receives the results; checksum_out (may be NULL) the wrap-around sum over the inputs of
+ * mix((in_bits << 32 | out_bits)) with mix(v) = (v * 0x9E3779B97F4A7C15, v ^= v >> 29, v * 0xBF58476D1CE4E5B9),
+ * so that a caller can compare 2^31 results with its own without moving them. */
+int bgs_selftest_ln_f32(bgs_ctx* ctx, uint32_t first_bits, uint32_t count, float* host_out, uint64_t* checksum_out);
+
 /* Streams the lanes run on: lane i uses stream i % min(streams, depth); 0 = one stream per lane.
  * Default 4: the HIP runtime multiplexes a process's streams onto 4 hardware queues (per priority), and only
  * queues run concurrently, so 4 streams — each on its own queue, the library parks idle streams to get them
@@ -342,6 +355,12 @@ int bgs_hbm_probe(bgs_ctx* ctx, uint64_t bytes, uint32_t iters, float* copy_gbs,
  * 5 on 5 15.6 k). BGS_QUEUE_HOLDERS=0 in the environment keeps the library from parking its idle streams: for
  * processes whose other streams (RCCL's) already hold the queues. */
 int bgs_set_pipeline_streams(bgs_ctx* ctx, uint32_t streams);
+/* The library parks three idle "queue holder" streams per DEVICE (process-global, created once, however many
+ * contexts the process has) before a context creates its own streams, so that the HIP runtime deals those out one per
+ * hardware queue (see above). 0 switches that off for contexts that have not created their streams yet — for a
+ * process whose other streams already hold the queues (e.g. RCCL's after a process group was initialised); 1 forces
+ * it on; -1 (default) follows the environment variable BGS_QUEUE_HOLDERS (unset or non-zero: on). Never fails. */
+int bgs_set_queue_holders(int enabled);
 
 /* Frame graphs (opt-in, default off). An asynchronous BINNING_SCAN frame (bgs_set_async) in the
  * steady state is replayed from a hipGraph captured once per (lane, parity): the frame's first kernel

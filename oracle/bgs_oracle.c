@@ -26,6 +26,35 @@ typedef struct { float m[9]; } m3; /* column-major: m[3*c + r] */
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+/* ln(x) correctly rounded to binary32. WGSL leaves the precision of `log` open; the arithmetic contract pins it to
+ * the correctly rounded value because ln(opacity) reaches DECISIONS through the adaptive cutoff (gaussian.wgsl:229-235
+ * -> gaussian_2d.wgsl:49-78,104-132, an ill-conditioned cancellation). Here: x87 `logl` (64-bit significand, error
+ * < 2^-63) rounded once — an implementation independent of the product's (csrc/exact_log.h: binary64 arithmetic with a
+ * table); scripts/exact_log/check_exhaustive.cpp compares the two on all 2 139 095 039 positive finite inputs (equal
+ * everywhere, and no input lies closer than 2^-57.8 to a rounding boundary, so the 2^-63 cannot decide one). */
+static inline float ln_correctly_rounded(float x) { return (float)logl((long double)x); }
+float oracle_ln_f32(float x) { return ln_correctly_rounded(x); }
+void oracle_ln_f32_array(const float* x, uint32_t n, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = ln_correctly_rounded(x[i]);
+}
+/* the sum bgs_selftest_ln_f32 forms on the device (include/bgs.h), over the bit patterns first_bits .. + count - 1 */
+uint64_t oracle_ln_f32_checksum(uint32_t first_bits, uint32_t count) {
+    uint64_t sum = 0;
+#pragma omp parallel for schedule(static) reduction(+ : sum)
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        uint32_t in_bits = first_bits + (uint32_t)i, out_bits;
+        float x, r;
+        memcpy(&x, &in_bits, 4);
+        r = ln_correctly_rounded(x);
+        memcpy(&out_bits, &r, 4);
+        uint64_t v = ((uint64_t)in_bits << 32 | out_bits) * 0x9E3779B97F4A7C15ull;
+        v ^= v >> 29;
+        sum += v * 0xBF58476D1CE4E5B9ull;
+    }
+    return sum;
+}
+
 static inline float dot2(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
 static inline float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 static inline v3 v3mul(v3 a, v3 b) { v3 r = {a.x * b.x, a.y * b.y, a.z * b.z}; return r; }
@@ -637,7 +666,7 @@ static int vs_impl(const oracle_cloud* cloud, bgs_sort_entry entry, const bgs_vi
     float opacity = so[3];
     float cutoff = 3.0f;
     if (s->opacity_adaptive_radius)                                  /* :231-235 */
-        cutoff = sqrtf(fmaxf(9.0f + 2.0f * logf(opacity), 0.000001f));
+        cutoff = sqrtf(fmaxf(9.0f + 2.0f * ln_correctly_rounded(opacity), 0.000001f));
     o->cutoff = cutoff;
 
     if (s->gaussian_mode == BGS_GAUSSIAN_2D) {                       /* :237-255 */

@@ -71,6 +71,11 @@ int oracle_radix_defines(uint32_t depth_bits, uint32_t* digit_places, uint32_t* 
 
 /* tests/radix.rs:96-106 helper pair: dist2 (scalar L->R) and the key derived from it. */
 float oracle_distance_squared(const float position[3], const float camera[3]);
+/* ln(x) correctly rounded to binary32 (x87 logl rounded once): the log of the adaptive cutoff, gaussian.wgsl:229-235 */
+float oracle_ln_f32(float x);
+void oracle_ln_f32_array(const float* x, uint32_t n, float* out);
+/* the wrap-around sum bgs_selftest_ln_f32 (include/bgs.h) forms on the device, from the oracle's log */
+uint64_t oracle_ln_f32_checksum(uint32_t first_bits, uint32_t count);
 uint32_t oracle_radix_depth_key(float dist2, uint32_t key_shift);
 
 /* radix_sort_a keygen (src/sort/radix.wgsl:86-101) for SORT_RADIX;

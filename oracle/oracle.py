@@ -96,6 +96,10 @@ def lib() -> ctypes.CDLL:
         l.oracle_radix_defines.restype = ctypes.c_int
         l.oracle_distance_squared.argtypes = [fp, fp]
         l.oracle_distance_squared.restype = ctypes.c_float
+        l.oracle_ln_f32_array.argtypes = [fp, u32, fp]
+        l.oracle_ln_f32_array.restype = None
+        l.oracle_ln_f32_checksum.argtypes = [u32, u32]
+        l.oracle_ln_f32_checksum.restype = ctypes.c_uint64
         l.oracle_radix_depth_key.argtypes = [ctypes.c_float, u32]
         l.oracle_radix_depth_key.restype = u32
         l.oracle_keygen.argtypes = [fp, u32, vp, sp, ep]
@@ -306,3 +310,17 @@ def max_threads() -> int:
 
 def set_threads(n: int) -> None:
     lib().oracle_set_threads(int(n))
+
+
+def ln_f32(x: np.ndarray) -> np.ndarray:
+    """ln(x) correctly rounded to binary32 (x87 logl rounded once): the log of the adaptive cutoff."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().oracle_ln_f32_array(x.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), x.size,
+                              out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
+
+
+def ln_f32_checksum(first_bits: int, count: int) -> int:
+    """The sum `bgs_selftest_ln_f32` forms on the device, computed from the oracle's log."""
+    return int(lib().oracle_ln_f32_checksum(first_bits, count))

@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """The library under test is the one built from THIS tree's kernel sources: `_native.load()` compares
+    `bgs_build_id()` with the SHA-256 of csrc/*.hip + csrc/*.h and rebuilds (or refuses) a stale binary."""
+    try:
+        from bevy_gaussian_splatting_amd import _native
+        return f"libbgs build id {_native.build_id()} (= kernel sources of this tree)"
+    except Exception as e:  # noqa: BLE001 - the tests themselves will fail loudly
+        return f"libbgs: NOT LOADABLE ({e})"
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure; built on demand with gcc)."""

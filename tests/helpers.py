@@ -73,16 +73,20 @@ def shim() -> ctypes.CDLL:
     global _shim
     if _shim is not None:
         return _shim
-    deps = [SHIM_SRC] + [os.path.join(CSRC, f) for f in ("splat_math.h", "bgs_device.h", "frame_params.h")]
+    deps = [SHIM_SRC] + [os.path.join(CSRC, f) for f in ("splat_math.h", "exact_log.h", "bgs_device.h", "frame_params.h")]
     if not os.path.exists(SHIM_LIB) or any(os.path.getmtime(d) > os.path.getmtime(SHIM_LIB) for d in deps):
         subprocess.run(
-            ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC",
+            ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared", "-fPIC",
              "-Wno-unknown-pragmas", SHIM_SRC, "-o", SHIM_LIB], check=True, capture_output=True)
     l = ctypes.CDLL(SHIM_LIB)
     fp = ctypes.POINTER(ctypes.c_float)
     l.shim_fill_params.argtypes = [ctypes.c_uint32, ctypes.POINTER(BgsView), ctypes.POINTER(BgsSettings),
                                    ctypes.POINTER(FrameParamsC)]
     l.shim_fill_params.restype = None
+    l.shim_ln_f32.argtypes = [fp, ctypes.c_uint32, fp]
+    l.shim_ln_f32.restype = None
+    l.shim_ln_f32_checksum.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    l.shim_ln_f32_checksum.restype = ctypes.c_uint64
     l.shim_supertile_div.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     l.shim_supertile_div.restype = ctypes.c_uint32
     l.shim_next_supertile_level.argtypes = [ctypes.c_double, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),

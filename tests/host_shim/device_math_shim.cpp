@@ -33,6 +33,22 @@ void shim_fill_params(uint32_t n, const bgs_view* view, const bgs_settings* s, F
     fill_frame_params(n, view, s, *fp);
 }
 
+// csrc/exact_log.h: the correctly rounded ln of the adaptive cutoff, host build (the device runs the same operations)
+void shim_ln_f32(const float* x, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = ln_f32_cr(x[i]);
+}
+
+uint64_t shim_ln_f32_checksum(uint32_t first_bits, uint32_t count) {
+    uint64_t sum = 0;
+#pragma omp parallel for schedule(static) reduction(+ : sum)
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        const uint32_t in_bits = first_bits + (uint32_t)i;
+        float x; memcpy(&x, &in_bits, 4);
+        sum += ln_selftest_mix(in_bits, f2u(ln_f32_cr(x)));
+    }
+    return sum;
+}
+
 uint32_t shim_frame_params_size(void) { return (uint32_t)sizeof(FrameParams); }
 
 // supertile index of a tile for a supertile edge (bgs_device.h: reciprocal multiply)

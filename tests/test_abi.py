@@ -44,7 +44,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(BgsView) == (16 * 4 + 8 + 16 + 4) * 4
     assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8 + 1 + 1 + 2 + 8) * 4
     assert ctypes.sizeof(_native.BgsSortEntry) == 8
-    assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 4 * 4 + 8 + 8 + 8
+    assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 4 * 4 + 8 + 8 + 8 + 8
     # the ctypes images include natural padding exactly like the C structs
     assert _native.BgsStats.instance_count.offset % 8 == 0
 
@@ -114,3 +114,34 @@ def test_header_is_plain_c_and_the_cpp_layer_is_standard_cpp17(tmp_path):
     cpp.write_text('#include "bgs_host.hpp"\nint main() { bgs::CloudSettings s; return (int)s.to_native().sh_degree - 3; }\n')
     subprocess.run(["g++", "-std=c++17", "-pedantic", "-Wall", "-Wextra", "-Wshadow", "-Werror", "-I",
                     os.path.join(root, "include"), "-c", str(cpp), "-o", str(tmp_path / "host.o")], check=True)
+
+
+def test_library_is_built_from_this_trees_kernel_sources(tmp_path):
+    """`bgs_build_id()` = SHA-256 over csrc/*.hip + csrc/*.h (`_build_id.py`), compiled in by the Makefile; the id is
+    also readable from the file's bytes without loading it, and a library carrying another id is refused."""
+    from bevy_gaussian_splatting_amd import _build_id
+    lib = _native.load()
+    want = _build_id.kernel_source_sha256()
+    assert lib.bgs_build_id().decode() == want and len(want) == 64
+    assert _build_id.library_build_id(_native.LIB_PATH) == want
+    stale = tmp_path / "libbgs_stale.so"
+    data = open(_native.LIB_PATH, "rb").read()
+    stale.write_bytes(data.replace(want.encode(), b"0" * 64))
+    assert _build_id.library_build_id(str(stale)) == "0" * 64
+    assert _build_id.library_build_id(str(tmp_path / "missing.so")) is None
+    # the loader's verdict on such a file (auto-build off): refused, with both ids in the message
+    import importlib
+    old_path, old_env = _native.LIB_PATH, os.environ.get("BGS_NO_AUTOBUILD")
+    os.environ["BGS_NO_AUTOBUILD"] = "1"
+    _native.LIB_PATH = str(stale)
+    try:
+        with pytest.raises(ImportError) as ei:
+            _native.ensure_current()
+        assert "000000000000" in str(ei.value) and want[:12] in str(ei.value)
+    finally:
+        _native.LIB_PATH = old_path
+        if old_env is None:
+            del os.environ["BGS_NO_AUTOBUILD"]
+        else:
+            os.environ["BGS_NO_AUTOBUILD"] = old_env
+    assert _native.ensure_current() == want

@@ -537,7 +537,7 @@ def test_full_size_f16_5m_default_scale_crops(plugin, oracle):
                 fresh.render(h2, v, s2, download=False)
             fresh.synchronize()
             st, level = fresh.stats(), fresh.adaptive_counters()["supertile_level"]
-            lane_bytes = st["instance_capacity"] * 8     # list entries allocated for one lane
+            lane_bytes = st["list_entries_allocated"] * 8     # list entries allocated for one lane
             print(f"[5M f16 gs={gs}] supertile level {level}: {lane_bytes / 2**20:.0f} MiB of lists per lane "
                   f"({st['instance_count']} entries in use, capacity {st['list_capacity']} per list)")
             assert 8 * lane_bytes < 8 * 2**30
