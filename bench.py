@@ -29,13 +29,14 @@ Prints ONE JSON line on rank 0. `value` = whole-job frames/s. Extra objects:
 from __future__ import annotations
 
 import argparse
-import hashlib
 import json
 import os
 import statistics
 import subprocess
 import sys
 import time
+
+import math
 
 import numpy as np
 
@@ -50,16 +51,11 @@ GATHER_BATCH = 8  # frames per framebuffer gather (N > 1)
 
 
 def kernel_source_sha256() -> str:
-    """Identity of the kernels a counter file was measured on: SHA-256 over the HIP sources and headers of
-    libbgs (not the commit id, which also changes with every documentation commit)."""
-    d = os.path.join(ROOT, "bevy_gaussian_splatting_amd", "csrc")
-    h = hashlib.sha256()
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(f.read())
-    return h.hexdigest()
+    """Identity of the kernels a counter file was measured on — and of the library this run loads: SHA-256 over the
+    HIP sources and headers of libbgs (`bgs_build_id()`; not the commit id, which also changes with every
+    documentation commit)."""
+    from bevy_gaussian_splatting_amd import _build_id
+    return _build_id.kernel_source_sha256()
 
 
 def load_pmc():
@@ -127,8 +123,11 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
     }
 
 
+FRAMES_ISSUED = [0]  # every frame any measure() call enqueued (the gather path checks it against what rank 0 received)
+
+
 def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=None, depth=1, trials=1,
-            busy_warm_frames=0):
+            busy_warm_frames=0, views=None):
     """W untimed + K timed steps. A step ENQUEUES one frame: the scan pipeline needs no host round
     trip, and the context keeps `depth` frames in flight (lanes, multiplexed onto a few HIP streams). With a
     `gather` callback (N > 1 ranks) the oldest frame is popped and handed to it as soon as `depth`
@@ -141,12 +140,20 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
     Returns (seconds of the median trial, per-stage ms averaged by the library over the timed frames' HIP
     events, stats[, every trial's seconds])."""
     prepared = plugin.prepare(view, settings)  # marshal the C structs once, like a caller's per-view cache
+    # `views`: a list of prepared views, one per frame, cycled (a moving camera; marshalled outside the timed region
+    # like `prepared`, so the host cost per frame is the same as for the static view)
+    cursor = [0]
 
     def run(k):
         for _ in range(k):
             if gather is not None and hasattr(gather, "before_render"):
                 gather.before_render()
-            plugin.render(handle, prepared, download=False)
+            if views is not None:
+                plugin.render(handle, views[cursor[0] % len(views)], download=False)
+                cursor[0] += 1
+            else:
+                plugin.render(handle, prepared, download=False)
+            FRAMES_ISSUED[0] += 1
             if gather is not None and plugin.frames_in_flight() >= depth:
                 gather(*plugin.pipeline_pop())
         if gather is not None:
@@ -178,7 +185,44 @@ def measure(plugin, handle, view, settings, steps, warmup, gather=None, barrier=
     return dts[0], dict(st["stage_ms"]), st
 
 
-def cpu_baseline(cloud, view, settings):
+def whole_frame_parity(oracle, cloud, entries, view, settings, ref, got):
+    """The GPU frame against the oracle's whole frame (which `cpu_baseline` renders anyway), all W x H pixels, at the
+    tolerance of the parity tests: |gpu - oracle| <= 1e-3 + 1e-4 |oracle| per channel, plus the oracle's per-pixel
+    ambiguity bound where a coverage decision lies within rounding distance of a quad edge. The timed oracle frame
+    carries no ambiguity map (that would change what is timed), so the map is computed afterwards and only for the
+    48 x 48 cells that hold a value beyond the strict bound. OUTSIDE every timed region."""
+    err = np.abs(got.astype(np.float64) - ref)
+    strict = err <= 1e-3 + 1e-4 * np.abs(ref)
+    bad = np.argwhere(~strict.all(axis=-1))
+    cells = sorted({(int(y) // 48, int(x) // 48) for y, x in bad})
+    out = {"checked": f"whole {ref.shape[1]}x{ref.shape[0]} frame vs the oracle (every pixel, every channel)",
+           "pixels": int(ref.shape[0] * ref.shape[1]), "max_abs_err": float(err.max()),
+           "tolerance": "1e-3 + 1e-4*|ref| per channel (+ the oracle's ambiguity bound on quad-edge pixels)",
+           "values_beyond_strict_tolerance": int((~strict).sum()), "values_on_ambiguity_slack": 0, "ok": True}
+    if len(cells) > 256:
+        out["ok"] = False
+        out["why"] = f"{len(cells)} cells of 48x48 px hold values beyond the strict tolerance"
+        return out
+    on_slack = 0
+    for cy, cx in cells:
+        x0, y0 = cx * 48, cy * 48
+        x1, y1 = min(x0 + 48, ref.shape[1]), min(y0 + 48, ref.shape[0])
+        r, amb = oracle.render(cloud, entries, view, settings, window=(x0, y0, x1, y1), with_ambiguity=True)
+        g = got[y0:y1, x0:x1]
+        e = np.abs(g.astype(np.float64) - r)
+        lim = 1e-3 + 1e-4 * np.abs(r)
+        on_slack += int((e > lim).sum())
+        if not (e <= lim + amb[..., None]).all():
+            out["ok"] = False
+            out["why"] = f"cell ({x0},{y0}): max |err| {float(e.max()):.3e} beyond tolerance + ambiguity bound"
+    out["values_on_ambiguity_slack"] = on_slack
+    if on_slack > 0.0005 * strict.size:
+        out["ok"] = False
+        out["why"] = "the ambiguity slack is used by more than 0.05 % of the values"
+    return out
+
+
+def cpu_baseline(cloud, view, settings, gpu_frame=None, gpu_entries=None):
     """The oracle (C restatement, OpenMP) on a bounded sample of the SAME workload:
     all host cores this process is granted (affinity capped by the cgroup quota): the full 1M-splat sort (both reference sorts: the radix semantics and the
     rayon/std descending-f32 semantics) + the vertex stage for every splat + the raster of the
@@ -198,6 +242,8 @@ def cpu_baseline(cloud, view, settings):
     oracle.build()
     all_cores = oracle.max_threads()  # already capped to the CPUs the cgroup grants this process (oracle.effective_cpus)
 
+    kept = {}
+
     def frame(window_w, window_h):
         t0 = time.perf_counter()
         entries = oracle.sort(cloud, view, settings)
@@ -207,12 +253,23 @@ def cpu_baseline(cloud, view, settings):
         t_vs = time.perf_counter() - t0
         x0, y0 = (WIDTH - window_w) // 2, (HEIGHT - window_h) // 2
         t0 = time.perf_counter()
-        oracle.render(cloud, entries, view, settings, window=(x0, y0, x0 + window_w, y0 + window_h))
+        img = oracle.render(cloud, entries, view, settings, window=(x0, y0, x0 + window_w, y0 + window_h))
         t_win = max(time.perf_counter() - t0 - t_vs, 1e-6)
         scale = (WIDTH * HEIGHT) / float(window_w * window_h)
+        if window_w == WIDTH and window_h == HEIGHT:
+            kept["entries"], kept["image"] = entries, img
         return t_sort, t_vs, t_win, scale
 
     t_sort, t_vs, t_win, scale = frame(WIDTH, HEIGHT)
+    parity = None
+    if gpu_frame is not None:
+        # the whole oracle frame the baseline just paid for is also the checker of the frame this run benchmarked
+        parity = whole_frame_parity(oracle, cloud, kept["entries"], view, settings, kept["image"], gpu_frame)
+        if gpu_entries is not None:
+            parity["sort_entries_bit_exact"] = bool(np.array_equal(gpu_entries["key"], kept["entries"]["key"]) and
+                                                    np.array_equal(gpu_entries["index"], kept["entries"]["index"]))
+            parity["ok"] = parity["ok"] and parity["sort_entries_bit_exact"]
+    kept.clear()
     t0 = time.perf_counter()
     oracle.sort(cloud, view, CloudSettings(sort_mode=SortMode.Rayon))
     t_sort_std = time.perf_counter() - t0
@@ -225,6 +282,7 @@ def cpu_baseline(cloud, view, settings):
         oracle.set_threads(all_cores)
     t_frame1 = s1 + v1 + sc1 * w1
     return {
+        "parity": parity,
         "value": 1.0 / t_frame,
         "unit": "frames/s",
         "cores": all_cores,
@@ -285,6 +343,8 @@ def main():
         # RCCL's own (idle) streams already hold the HIP runtime's four hardware queues, which is what the
         # library's queue-holder streams are for in a process without them (csrc/bgs_api.hip, assign_streams)
         os.environ.setdefault("BGS_QUEUE_HOLDERS", "0")
+        from bevy_gaussian_splatting_amd import _native
+        _native.load().bgs_set_queue_holders(0)   # the same switch through the API (process-global)
 
     from bevy_gaussian_splatting_amd import CloudSettings, GaussianSplattingPlugin, random_gaussians_3d_seeded
     from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor, gather_framebuffers, headless_view
@@ -347,15 +407,43 @@ def main():
     # the headline region runs without stage events (each record is a packet on the stream; timing every
     # 16th frame cost ~5 % of the rate being measured); the per-stage numbers come from separate passes
     plugin.set_profiling(0)
+    # Trials: at least 5 (3 from 2000 steps up), and as many as it takes to put >= 0.5 s of GPU time inside timed
+    # regions (20 steps are ~1 ms: the driver's utilisation sampling cannot see five of those). The count comes from
+    # a pilot region and is agreed between the ranks (max over ranks), so every rank issues the same collectives.
     trials = args.trials if args.trials > 0 else (5 if args.steps < 2000 else 3)
+    if args.trials <= 0:
+        pilot, _, _ = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, lanes,
+                              busy_warm_frames=3000)
+        if dist is not None:
+            t = torch.tensor([pilot], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pilot = float(t.item())
+        trials = int(max(trials, min(1000, math.ceil(0.5 / max(pilot, 1e-6)))))
     _, _, _, dts = measure(plugin, handle, view, settings, args.steps, args.warmup, gather, barrier, lanes,
-                           trials=max(trials, 2), busy_warm_frames=3000)
+                           trials=max(trials, 2), busy_warm_frames=0 if args.trials <= 0 else 3000)
+    issued_main = FRAMES_ISSUED[0]
     plugin.set_profiling(2)
     plugin.set_packed_only(False)
+    per_rank = None
     if dist is not None:  # a trial lasts as long as its slowest rank
         t = torch.tensor(dts, dtype=torch.float64, device="cuda")
+        mine = torch.tensor([statistics.median(dts)], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dts = [float(x) for x in t.tolist()]
+        frame_bytes8 = WIDTH * HEIGHT * 4
+        per_rank = [{"rank": r, "frames_per_s": round(args.steps / float(e.item()), 2),
+                     "gather_bytes_per_trial": args.steps * frame_bytes8 if r != 0 else 0,
+                     # what the rank's link carried while it rendered: its frames' bytes over ITS OWN median region
+                     "link_GBps": round(args.steps * frame_bytes8 / float(e.item()) / 1e9, 2) if r != 0 else None}
+                    for r, e in enumerate(every)]
+        if rank == 0 and batcher is not None:
+            # every frame every rank issued on this path has arrived on rank 0 (flush() waits for all collectives)
+            want = world * issued_main
+            if batcher.frames_received != want:
+                raise SystemExit(f"gather check failed: rank 0 received {batcher.frames_received} frames, "
+                                 f"{world} ranks issued {want}")
     dt = statistics.median(dts)
     fps = world * args.steps / dt
 
@@ -426,24 +514,50 @@ def main():
         roofline_main["measured_peak"] = roofline["measured_peak"]
         roofline_main["frac_of_measured"] = round(roofline_main["achieved"] / measured, 4) if measured else None
         roofline_main["measured_on"] = "single-stream frames (HIP events, every kernel of every Nth frame)"
-        # the kernel is VALU-issue bound, not HBM bound: its vector instruction count (SQ_INSTS_VALU from the
-        # committed PMC pass) against what 1024 SIMDs issue at 4 clocks per wave64 fp32 instruction, 2.4 GHz max clock
-        wi = pmc_kernels.get(roofline_main["kernel"], {}).get("valu_wave_instructions")
-        if wi:
-            min_ms = wi * 4.0 / (4 * 256) / 2.4e9 * 1e3
-            roofline_main["valu"] = {"wave_instructions_per_launch": int(wi), "issue_bound_ms": round(min_ms, 4),
-                                     "frac_of_issue_peak": round(min_ms / roofline_main["launch_ms"], 3)}
-            # the whole frame against the same bound: every kernel's vector instructions x its launches per
+        # What binds the kernel is vector-instruction ISSUE, not HBM. The floor: every wave-level vector instruction
+        # the launch executes (SQ_INSTS_VALU of the committed PMC pass), priced per class at the rates of
+        # MI355X_MICROARCH.md — a wave64 instruction issues over 2 clocks on the SIMD-32 (157.3 TFLOP/s fp32 peak),
+        # transcendentals (v_exp / v_log / v_rcp / v_sqrt ...) at a quarter of that (8 clocks), fp64 at half (4) —
+        # on 1024 SIMDs at the 2.4 GHz peak clock. (Round 2 priced every instruction at 4 clocks, which is the
+        # ACHIEVED rate of this instruction mix — SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU — not a bound.)
+        def issue_floor_ms(k):
+            pk = pmc_kernels.get(k, {})
+            wi = pk.get("valu_wave_instructions")
+            if not wi:
+                return None, None
+            trans = pk.get("valu_trans_wave_instructions") or 0.0
+            f64 = pk.get("valu_f64_wave_instructions") or 0.0
+            clocks = 2.0 * (wi - trans - f64) + 8.0 * trans + 4.0 * f64
+            return clocks / (4 * 256) / 2.4e9 * 1e3, {"wave_instructions": int(wi), "transcendental": int(trans), "fp64": int(f64),
+                                                       "classes_measured": pk.get("valu_trans_wave_instructions") is not None}
+        floor_ms, mix = issue_floor_ms(roofline_main["kernel"])
+        if floor_ms:
+            roofline_main["valu"] = {"wave_instructions_per_launch": mix["wave_instructions"],
+                                     "transcendental_per_launch": mix["transcendental"], "fp64_per_launch": mix["fp64"],
+                                     "per_class_counters": mix["classes_measured"],
+                                     "clocks_per_instruction": "2 (wave64 on a SIMD-32), transcendental 8, fp64 4; 1024 SIMDs x 2.4 GHz",
+                                     "issue_floor_ms": round(floor_ms, 4),
+                                     "frac_of_issue_peak": round(floor_ms / roofline_main["launch_ms"], 3)}
+            # the whole frame against the same floor: every kernel's vector instructions x its launches per
             # frame, at the frame rate of the timed region — the chip-wide VALU-issue utilisation
             per_frame = {"keygen_kernel": 1, kernel_names["depth_sort"]: table["depth_sort"]["launches"],
                          "project_bin_kernel": 1, "raster_scan_kernel": 1}
-            if scan_mode and all(pmc_kernels.get(k, {}).get("valu_wave_instructions") for k in per_frame):
-                fw = sum(pmc_kernels[k]["valu_wave_instructions"] * m for k, m in per_frame.items())
-                frame_issue_ms = fw * 4.0 / (4 * 256) / 2.4e9 * 1e3
+            floors = {k: issue_floor_ms(k)[0] for k in per_frame}
+            if scan_mode and all(floors.values()):
+                frame_issue_ms = sum(floors[k] * m for k, m in per_frame.items())
                 roofline_main["valu"]["frame"] = {
-                    "wave_instructions_per_frame": int(fw), "issue_bound_ms": round(frame_issue_ms, 4),
+                    "wave_instructions_per_frame": int(sum(pmc_kernels[k]["valu_wave_instructions"] * m for k, m in per_frame.items())),
+                    "issue_floor_ms": round(frame_issue_ms, 4),
                     "ms_per_frame": round(1e3 * dt / args.steps, 4),
                     "frac_of_issue_peak": round(frame_issue_ms / (1e3 * dt / args.steps), 3)}
+        # `bound` names what binds: the HBM figures stay what the contract defines (algorithmic bytes of the launch /
+        # its duration against the 8 TB/s peak), `valu` is the floor the kernel is actually nearest to
+        hbm_frac = roofline_main["frac"]
+        valu_frac = roofline_main.get("valu", {}).get("frac_of_issue_peak")
+        roofline_main["bound"] = "valu" if (valu_frac is None or valu_frac >= hbm_frac) else "hbm"
+        roofline_main["bound_note"] = ("achieved / peak / frac are the HBM figures of the contract (algorithmic bytes per launch / launch "
+                                       "duration / 8 TB/s); the kernel is nearest to the vector-issue floor (`valu`), and its launch lasts "
+                                       "about twice its mean wave life (`tail`): neither HBM nor MFMA binds this algorithm")
         roofline_main["in_flight"] = roofline
 
         # "Msplats/s sorted": keygen + depth sort only (blocking calls, every one timed)
@@ -470,6 +584,44 @@ def main():
         plugin.set_pipeline_depth(1)
         dt2s, _, _ = measure(plugin, handle, view, s2, args.steps, args.warmup)
 
+        # ---- moving camera (the reference's use case: an interactive camera re-sorts whenever it moves,
+        # src/sort/mod.rs:153-194). The static view above is the best case for everything the context learns from
+        # completed frames (bucket-sort splitters, draw-count hint, list capacity, supertile level); here the camera
+        # yaws 0.25 degrees per frame about the headless pose and makes a hard cut of 137 degrees every 500 frames.
+        # Same lanes / streams as the headline; views marshalled outside the timed region.
+        from bevy_gaussian_splatting_amd import View
+        base_yaw = rank * math.pi / 4.0
+        orbit_frames = 2000
+        orbit_views = []
+        for i in range(orbit_frames):
+            deg = 0.25 * i + 137.0 * (i // 500)
+            orbit_views.append(plugin.prepare(View.headless(WIDTH, HEIGHT, yaw=base_yaw + math.radians(deg)), settings))
+        plugin.set_pipeline_depth(lanes)
+        plugin.set_pipeline_streams(streams)
+        plugin.set_profiling(0)
+        k_orbit = max(args.steps, 250)
+        ac0 = plugin.adaptive_counters()
+        _, _, st_o, dts_o = measure(plugin, handle, view, settings, k_orbit, min(args.warmup, 20), depth=lanes, trials=8,
+                                    views=orbit_views)
+        ac1 = plugin.adaptive_counters()
+        plugin.set_profiling(2)
+        dt_o = statistics.median(dts_o)
+        orbit = {"value": round(k_orbit / dt_o, 2), "unit": "frames/s", "vs_static": round((k_orbit / dt_o) / (fps / world), 3),
+                 "camera": "yaw += 0.25 deg per frame about the headless pose, a 137-deg cut every 500 frames",
+                 "frames_per_trial": k_orbit, "trials_ms": [round(1e3 * x, 3) for x in dts_o],
+                 "lanes": lanes, "streams": streams,
+                 "adaptive_counters_delta": {k: ac1[k] - ac0[k] for k in ("bucket_frames", "onesweep_frames", "reruns_sort",
+                                                                         "reruns_lists", "reruns_instances", "level_changes")},
+                 "supertile_level_at_end": ac1["supertile_level"], "visible_splats_last_frame": st_o["visible_count"]}
+        plugin.reset_adaptive_state()
+
+        # one blocking frame of the benchmarked view for the whole-frame parity check (download outside any timing)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        gpu_frame = plugin.render(handle, view, settings)
+        gpu_entries = plugin.sort(handle, view, settings)
+        plugin.set_async(True)
+
         # the named instance-sort pipeline (tile-major|depth radix sort) on the same workload
         plugin.set_binning("sort")
         plugin.set_profiling_stride(1)  # blocking frames: time every one
@@ -483,26 +635,36 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "timing": {"trials_ms": [round(1e3 * x, 4) for x in dts], "reported": "median trial",
-                       "note": "every trial is a barrier + sync, --steps frames, barrier + sync; 3000 untimed "
-                               "frames (~0.2 s) precede the first one"},
+            "timing": {"trials": len(dts), "trials_ms_min_median_max": [round(1e3 * min(dts), 4), round(1e3 * dt, 4), round(1e3 * max(dts), 4)],
+                       "trials_ms_first_10": [round(1e3 * x, 4) for x in dts[:10]], "reported": "median trial",
+                       "gpu_seconds_in_timed_regions": round(sum(dts), 3),
+                       "note": "every trial is a barrier + sync, --steps frames, barrier + sync; 3000 untimed frames (~0.2 s) and a "
+                               "pilot region precede the first one; the number of trials puts >= 0.5 s inside timed regions"},
             "config": {"workload": f"{args.splats}-splat 3DGS f32 planar cloud (seed {SEED}, reference random_gaussians_3d "
                                    "distributions), 1920x1080, SH degree 3, CloudSettings::default(), "
                                    "examples/headless.rs camera; one camera per GPU",
                        "parallelism": f"views{world}", "sort": "radix32", "global_scale": 1.0,
                        "frames_in_flight": lanes, "lanes": lanes, "streams": streams},
+            "build_id": plugin.build_id(),
             "single_stream": single,
+            "orbit": orbit,
+            "per_rank": per_rank,
             "roofline": roofline_main,
             "frame": {"device_ms": round(frame_ms, 4), "algorithmic_GB": round(frame_bytes / 1e9, 4),
                       "GBps": round(frame_gbs, 1), "pct_hbm_peak": round(100 * frame_gbs / HBM_PEAK_GBS, 2),
                       "effective_GBps": round(eff_gbs, 1),
                       "effective_pct_hbm_peak": round(100 * eff_gbs / HBM_PEAK_GBS, 2),
                       "effective_pct_measured_peak": round(100 * eff_gbs / measured, 2) if measured else None,
-                      "visible_splats": st["visible_count"], "tile_instances": st["instance_count"],
+                      "visible_splats": st["visible_count"], "coarse_entries": st["instance_count"],
+                      "tile_instances": st3["instance_count"],
+                      "tile_instances_note": ("V visible splats overlap I (tile, splat) pairs (counted by the instance-sort pipeline "
+                                              "below); the default pipeline bins them into `coarse_entries` (rank, tile-rect) list "
+                                              "entries and expands lazily, only as far as a tile composites"),
                       "gather_ms_per_step": round(gather_ms[0] / max(args.steps + args.warmup, 1), 4),
                       "gathered_format": "Rgba8UnormSrgb (packed-only frames: no f32 target)" if dist is not None else None,
                       "gather_batch_frames": GATHER_BATCH if dist is not None else None,
-                      "frames_gathered_on_rank0": batcher.frames_received if batcher is not None else None},
+                      "frames_gathered_on_rank0": batcher.frames_received if batcher is not None else None,
+                      "frames_issued_per_rank": issued_main},
             "stages": stages,
             "sort_msplats_per_s": round(args.splats / (sort_dev_ms * 1e-3) / 1e6, 1) if sort_dev_ms > 0 else None,
             "sort": {"device_ms": round(sort_dev_ms, 4), "wall_ms": round(sort_wall * 1e3, 4),
@@ -510,20 +672,21 @@ def main():
             "scene_like": {"global_scale": 0.05, "value": round(args.steps / dt2, 2), "unit": "frames/s",
                            "single_stream_value": round(args.steps / dt2s, 2),
                            "device_ms": round(ms2, 4), "visible_splats": st2["visible_count"],
-                           "tile_instances": st2["instance_count"],
+                           "coarse_entries": st2["instance_count"], "tile_instances": st4["instance_count"],
                            "GBps": round(st2["algorithmic_bytes"] / (ms2 * 1e-3) / 1e9, 1) if ms2 > 0 else None},
             "binning": st["binning"], "sort_path": st.get("sort_path"),
             "instance_sort_pipeline": {
                 "note": "bgs_set_binning(SORT): (tile,splat) instances + stable radix sort on tile ids + ranges",
                 "value": round(max(args.steps // 3, 3) / dt3, 2), "unit": "frames/s",
-                "tile_instances": st3["instance_count"],
+                "visible_splats": st3["visible_count"], "tile_instances": st3["instance_count"],
                 "stage_ms": {k: round(v, 4) for k, v in stage3.items()},
                 "GBps": round(st3["algorithmic_bytes"] / (max(sum(stage3.values()), 1e-9) * 1e-3) / 1e9, 1),
                 "scene_like_value": round(max(args.steps // 3, 3) / dt4, 2),
                 "scene_like_stage_ms": {k: round(v, 4) for k, v in stage4.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cloud, view, settings)
+            out["cpu_baseline"] = cpu_baseline(cloud, view, settings, gpu_frame, gpu_entries)
+            out["parity"] = out["cpu_baseline"].pop("parity")
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)
             cb = out["cpu_baseline"]
             cb["sort_msplats_per_s"] = round(cb["sort_msplats_per_s"], 2)
@@ -547,6 +710,8 @@ def main():
         pass
     if rank == 0:
         print(json.dumps(out), flush=True)
+        if out.get("parity") and not out["parity"]["ok"]:
+            raise SystemExit(f"bench.py: the benchmarked frame FAILED the whole-frame parity check: {out['parity']}")
 
 
 if __name__ == "__main__":

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = (
     "bgs_version",
     "bgs_build_id",
     "bgs_set_queue_holders",
+    "bgs_set_tile_trace",
     "bgs_selftest_ln_f32",
     "bgs_settings_default",
     "bgs_view_perspective",
@@ -171,6 +172,8 @@ def load() -> ctypes.CDLL:
     lib.bgs_version.restype = u32
     lib.bgs_build_id.argtypes = []
     lib.bgs_build_id.restype = ctypes.c_char_p
+    lib.bgs_set_tile_trace.argtypes = [vp, vp]
+    lib.bgs_set_tile_trace.restype = ctypes.c_int
     lib.bgs_set_queue_holders.argtypes = [ctypes.c_int]
     lib.bgs_set_queue_holders.restype = ctypes.c_int
     lib.bgs_selftest_ln_f32.argtypes = [vp, u32, u32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)]

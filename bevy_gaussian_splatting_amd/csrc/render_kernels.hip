@@ -875,14 +875,22 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 // The surfel variant carries a 24-dword staged record through a 30-slot blend: it spills at 64 registers
 // (14 VGPRs) and at 72 / 80; same-box A/B of the dense 1 M-surfel frame: 5 waves/SIMD (90 VGPRs, no spill)
 // 0.49 ms, 6: 0.54, 7: 0.55, 8: 0.51 (and 0.13 instead of 0.09 ms scene-like).
-template <int VARIANT>
+// TRACE (bgs_set_tile_trace, diagnostics only): every tile's wave also writes two uint4 to trace[2 * tile]:
+//   { s_memtime at wave start (lo, hi), s_memtime at wave end (lo, hi) },
+//   { HW_ID register, XCC_ID register, candidates scanned, records blended | records staged << 16 }
+// — where a tile ran (XCD / SE / CU / SIMD / wave slot), for how long, and on how much work: what the analysis of
+// the launch's tail (scripts/tile_trace.py) is made from. The production instantiation carries none of it.
+template <int VARIANT, bool TRACE = false>
 __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_mul,
                                                           uint32_t sup_x, Control* ctl,
                                                           float4* __restrict__ fb,
                                                           uint32_t* __restrict__ fb8_default, uint32_t want_srgb8,
-                                                          FrameCleanup cl) {
+                                                          FrameCleanup cl, uint4* __restrict__ trace = nullptr) {
+    unsigned long long trace_t0 = 0ull;
+    uint32_t trace_scanned = 0u, trace_blended = 0u, trace_staged = 0u;
+    if constexpr (TRACE) trace_t0 = __builtin_amdgcn_s_memtime();
     const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     // records staged per round: the whole queue (24 KB of LDS per workgroup for the 96-byte surfel records, five
@@ -992,6 +1000,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
             if (hit)
                 s_queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = rank_cur;
             qn += hits;
+            if constexpr (TRACE) trace_scanned += min(64u, total - base);
             rank_cur = rank_nxt; rect_cur = rect_nxt;
             rank_nxt = rank_nn; rect_nxt = rect_nn;
             base += 64u;
@@ -1059,7 +1068,9 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
                 if constexpr (VARIANT == RV_OBB) keep_flag = __float_as_uint(sr.a1.z);
                 else if constexpr (VARIANT == RV_AABB3D) keep_flag = __float_as_uint(sr.a2.w);
                 else keep_flag = __float_as_uint(sr.a5.y);
+                if constexpr (TRACE) trace_staged += 1u;
                 if (__builtin_amdgcn_readfirstlane(keep_flag) == 0u) continue;  // scalar branch
+                if constexpr (TRACE) trace_blended += 1u;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
             }
@@ -1106,6 +1117,15 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
             }
         }
     }
+    if constexpr (TRACE) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && trace) {
+            const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID, all 32 bits
+            const uint32_t xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+            trace[2u * tile] = make_uint4((uint32_t)trace_t0, (uint32_t)(trace_t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
+            trace[2u * tile + 1u] = make_uint4(hw_id, xcc_id, trace_scanned, min(trace_blended, 0xFFFFu) | (min(trace_staged, 0xFFFFu) << 16));
+        }
+    }
     }  // tile < ntiles
 
 }
@@ -1113,15 +1133,21 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
-                        uint32_t out_format, const FrameCleanup& cleanup) {
+                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4* rec = (const float4*)records;
     const uint32_t sup = sup_edge, sup_mul = supertile_mul(sup_edge);
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
 #define BGS_LAUNCH_RS(V)                                                                          \
-    hipLaunchKernelGGL(raster_scan_kernel<V>, dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,      \
-                       coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup)
+    do {                                                                                          \
+        if (tile_trace)                                                                           \
+            hipLaunchKernelGGL((raster_scan_kernel<V, true>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
+                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, tile_trace); \
+        else                                                                                      \
+            hipLaunchKernelGGL((raster_scan_kernel<V, false>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
+                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (uint4*)nullptr); \
+    } while (0)
     if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
     else BGS_LAUNCH_RS(RV_SURFEL);

@@ -253,6 +253,19 @@ class GaussianSplattingPlugin:
         self._check(self._lib.bgs_hbm_probe(self._ctx, int(nbytes), int(iters), ctypes.byref(c), ctypes.byref(t)))
         return float(c.value), float(t.value)
 
+    def selftest_ln(self, first_bits: int, count: int, download: Optional[bool] = None):
+        """`bgs_selftest_ln_f32`: the correctly rounded ln of the adaptive cutoff evaluated ON THE DEVICE for the
+        binary32 bit patterns first_bits .. first_bits + count - 1. Returns (results or None, checksum); the results
+        are downloaded for count <= 2^24 unless `download` says otherwise."""
+        if download is None:
+            download = count <= (1 << 24)
+        out = np.empty(count, np.float32) if download else None
+        chk = ctypes.c_uint64()
+        self._check(self._lib.bgs_selftest_ln_f32(
+            self._ctx, int(first_bits), int(count),
+            out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if download else None, ctypes.byref(chk)))
+        return out, int(chk.value)
+
     def set_pipeline_streams(self, streams: int) -> None:
         """HIP streams the lanes are multiplexed onto (0 = one per lane); see bgs_set_pipeline_streams."""
         self._check(self._lib.bgs_set_pipeline_streams(self._ctx, int(streams)))
@@ -335,6 +348,15 @@ class GaussianSplattingPlugin:
     def set_debug_flags(self, flags: int) -> None:
         """Kernel-ablation switches for experiments only (non-zero => wrong images)."""
         self._check(self._lib.bgs_set_debug_flags(self._ctx, int(flags)))
+
+    def set_tile_trace(self, device_ptr: Optional[int]) -> None:
+        """`bgs_set_tile_trace`: per-tile timing / placement trace of the rasteriser into a caller-owned device buffer
+        (tiles_x * tiles_y * 32 bytes); None switches it off."""
+        self._check(self._lib.bgs_set_tile_trace(self._ctx, ctypes.c_void_p(device_ptr or 0)))
+
+    def build_id(self) -> str:
+        """`bgs_build_id()`: SHA-256 of the kernel sources the loaded library was compiled from."""
+        return self._lib.bgs_build_id().decode()
 
     def adaptive_counters(self) -> dict:
         """Cumulative counters of the adaptive machinery (bgs_adaptive_counters)."""

@@ -362,6 +362,14 @@ int bgs_set_pipeline_streams(bgs_ctx* ctx, uint32_t streams);
  * it on; -1 (default) follows the environment variable BGS_QUEUE_HOLDERS (unset or non-zero: on). Never fails. */
 int bgs_set_queue_holders(int enabled);
 
+/* Diagnostics: per-tile trace of the default (BGS_BINNING_SCAN) rasteriser. With a non-NULL device buffer of
+ * tiles_x * tiles_y * 32 bytes, every following frame runs the rasteriser's instrumented instantiation, in which each
+ * tile's wave writes 8 uint32: s_memtime at its start (lo, hi) and end (lo, hi), the HW_ID and XCC_ID registers (which
+ * XCD / SE / CU / SIMD / wave slot it ran on), the list candidates it scanned, and records blended | staged << 16.
+ * scripts/tile_trace.py turns that into the launch's per-SIMD occupancy picture (the "tail"). NULL switches it off.
+ * Completes the frames in flight; the buffer stays the caller's. Costs ~10 % of the rasteriser's time while on. */
+int bgs_set_tile_trace(bgs_ctx* ctx, void* device_ptr);
+
 /* Frame graphs (opt-in, default off). An asynchronous BINNING_SCAN frame (bgs_set_async) in the
  * steady state is replayed from a hipGraph captured once per (lane, parity): the frame's first kernel
  * receives the new view/settings as its arguments (one graph-node update) and leaves them in device

@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC counters per kernel for one workload: bash scripts/gpu_pmc.sh <global_scale> <tag>
+# PMC counters per kernel for one workload: bash scripts/gpu_pmc.sh <what> <tag>   (<what>: see scripts/loop_render.py)
+# Every group is its own rocprofv3 run with --pmc only (never combined with trace domains).
 GS=$1; TAG=$2
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -7,7 +8,9 @@ mkdir -p $R/gpurun_out/pmc_$TAG; rm -f $R/gpurun_out/pmc_$TAG/counters.txt
 cd /tmp
 for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" \
-           "GRBM_GUI_ACTIVE SQ_LEVEL_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU" \
+           "GRBM_GUI_ACTIVE SQ_LEVEL_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU" \
+           "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32" \
+           "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $pmc | tr ' ' '_' | cut -c1-30)
   rm -rf /tmp/p_$tag

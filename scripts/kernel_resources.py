@@ -2,7 +2,7 @@
 python scripts/kernel_resources.py [file.hip ...]   (default: every csrc/*.hip)"""
 import os, re, subprocess, sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bevy_gaussian_splatting_amd", "csrc")
-files = sys.argv[1:] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+files = [os.path.abspath(a) for a in sys.argv[1:]] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
 for f in files:
     p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", f,
                         "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=CSRC)

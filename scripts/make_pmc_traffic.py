@@ -14,7 +14,7 @@ from bench import kernel_source_sha256  # noqa: E402
 vals = collections.defaultdict(dict)
 for line in open(sys.argv[1]):
     m = re.match(r"\s*(?:void )?(?:bgs::)?([a-z_]+kernel)(?:<[^>]*>)?\s+(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|"
-                 r"SQ_ACTIVE_INST_VALU|SQ_WAVE_CYCLES|GRBM_GUI_ACTIVE)\s+calls\s+(\d+)\s+mean\s+([\d.]+)", line)
+                 r"SQ_ACTIVE_INST_VALU|SQ_WAVE_CYCLES|GRBM_GUI_ACTIVE|SQ_INSTS_VALU_[A-Z0-9_]+)\s+calls\s+(\d+)\s+mean\s+([\d.]+)", line)
     if m:
         vals[m.group(1)][m.group(2)] = float(m.group(4))
         vals[m.group(1)]["calls"] = int(m.group(3))
@@ -31,6 +31,13 @@ for k, v in vals.items():
         out["kernels"][k] = {"fetch_size_kb": v["FETCH_SIZE"], "write_size_kb": v["WRITE_SIZE"],
                              "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024),
                              "valu_wave_instructions": v.get("SQ_INSTS_VALU"),
+                             # per-class counts (bench.py prices them: transcendental 8 clocks, fp64 4, the rest 2);
+                             # None when the class pass did not run
+                             "valu_trans_wave_instructions": v.get("SQ_INSTS_VALU_TRANS_F32"),
+                             "valu_f64_wave_instructions": (None if "SQ_INSTS_VALU_FMA_F64" not in v else
+                                                            v.get("SQ_INSTS_VALU_FMA_F64", 0) + v.get("SQ_INSTS_VALU_ADD_F64", 0) +
+                                                            v.get("SQ_INSTS_VALU_MUL_F64", 0) + v.get("SQ_INSTS_VALU_TRANS_F64", 0)),
+                             "valu_classes": {k[len("SQ_INSTS_VALU_"):].lower(): x for k, x in v.items() if k.startswith("SQ_INSTS_VALU_")},
                              "gui_active_cycles": v.get("GRBM_GUI_ACTIVE"), "launches_sampled": v.get("calls")}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out["kernels"]))

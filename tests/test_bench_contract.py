@@ -72,14 +72,27 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    # `bound` names what binds the kernel ("valu": vector-instruction issue — there is no dense contraction and the
+    # lazily terminating rasteriser is not HBM-bound); achieved / peak / frac stay the contract's HBM figures
+    assert rf["bound"] in ("hbm", "mfma", "valu") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert d["value"] > 1000.0     # BASELINE.json's target on this config, with a wide margin to the measured 12 k
-    assert len(d["timing"]["trials_ms"]) >= 5 and "traffic_source" in rf
+    assert d["timing"]["trials"] >= 5 and "traffic_source" in rf
+    assert d["timing"]["gpu_seconds_in_timed_regions"] >= 0.45          # enough for the driver's utilisation sampling
+    from bevy_gaussian_splatting_amd import _build_id
+    assert d["build_id"] == _build_id.kernel_source_sha256()             # the library that ran = this tree's sources
+    # the whole benchmarked frame was checked against the oracle frame the CPU baseline renders anyway
+    assert d["parity"]["ok"] is True and d["parity"]["pixels"] == 1920 * 1080 and d["parity"]["sort_entries_bit_exact"] is True
+    # moving camera next to the static view, with what the adaptive machinery did meanwhile
+    ob = d["orbit"]
+    assert ob["value"] > 1000.0 and ob["adaptive_counters_delta"]["bucket_frames"] + ob["adaptive_counters_delta"]["onesweep_frames"] >= 8 * ob["frames_per_trial"]
+    # V and I beside the fps numbers
+    assert d["frame"]["visible_splats"] > 0 and d["frame"]["tile_instances"] > d["frame"]["coarse_entries"] > 0
+    assert d["scene_like"]["tile_instances"] > 0
 
 
 @pytest.mark.gpu
@@ -100,5 +113,9 @@ def test_bench_gather_path_runs_with_one_rank():
     assert "Rgba8UnormSrgb" in d["frame"]["gathered_format"] and d["frame"]["gather_batch_frames"] in (8, None)
     lanes = d["config"]["lanes"]
     chunk = max(24, 4 * lanes)
-    expected = lanes + 4 + -(-3000 // chunk) * chunk + len(d["timing"]["trials_ms"]) * 24
-    assert d["frame"]["frames_gathered_on_rank0"] == expected
+    # pilot region (lanes + warm-up + ~3000 busy-warm frames + 24) and the timed trials (lanes + warm-up + 24 each)
+    expected = (lanes + 4 + -(-3000 // chunk) * chunk + 24) + (lanes + 4 + d["timing"]["trials"] * 24)
+    assert d["frame"]["frames_issued_per_rank"] == expected
+    assert d["frame"]["frames_gathered_on_rank0"] == d["n_gpus"] * expected
+    pr = d["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["frames_per_s"] > 1000.0 and pr[0]["link_GBps"] is None

@@ -1206,6 +1206,139 @@ def test_multi_camera_sorted_entries_layout(plugin, oracle):
     h.free()
 
 
+
+# ---------------------------------------------------------------------------------------------
+# the correctly rounded ln of the adaptive cutoff, device build
+# ---------------------------------------------------------------------------------------------
+def test_exact_log_on_the_device_every_positive_input(plugin, oracle):
+    """ln_f32_cr (csrc/exact_log.h) ON THE DEVICE against the oracle's x87 logl (and the host build of the same header)
+    for EVERY positive finite binary32 input, subnormals included: 2 139 095 039 values compared through wrap-around
+    checksums per 2^28-pattern chunk (bgs_selftest_ln_f32), plus a direct element-wise comparison of the patterns an
+    opacity can take near the known ill-conditioned case, the special values and the hard cases of the exhaustive run."""
+    first, last = 1, 0x7F7FFFFF
+    chunk = 1 << 28
+    total = 0
+    b = first
+    while b <= last:
+        count = min(chunk, last - b + 1)
+        dev = plugin.selftest_ln(b, count)[1]
+        assert dev == oracle.ln_f32_checksum(b, count), f"device ln differs from the oracle in patterns {b:#x}..{b + count - 1:#x}"
+        assert dev == int(H.shim().shim_ln_f32_checksum(b, count)), f"device ln differs from the host build in {b:#x}.."
+        total += count
+        b += count
+    assert total == 2_139_095_039
+    # element-wise: [0.0078, 1.0001] consecutively (opacities), specials and the nearest-to-a-boundary inputs
+    lo = int(np.array([0.0078125], np.float32).view(np.uint32)[0])
+    hi = int(np.array([1.0001], np.float32).view(np.uint32)[0])
+    got = plugin.selftest_ln(lo, hi - lo + 1)[0]
+    x = np.arange(lo, hi + 1, dtype=np.uint32).view(np.float32)
+    assert np.array_equal(got.view(np.uint32), oracle.ln_f32(x).view(np.uint32))
+    for pattern in (0x65d890d3, 0x4c5d65a5, 0x4d604ebe, 0x41178feb, 0x3c413d3a, 0x6f31a8ec, 1, 0x007FFFFF, 0x00800000, 0x3F800000):
+        g = plugin.selftest_ln(pattern, 1)[0]
+        with np.errstate(all="ignore"):
+            assert g.view(np.uint32)[0] == oracle.ln_f32(np.array([pattern], np.uint32).view(np.float32)).view(np.uint32)[0]
+    for pattern, want in ((0, -np.inf), (0x80000000, -np.inf), (0x7F800000, np.inf)):
+        assert plugin.selftest_ln(pattern, 1)[0][0] == want
+    for pattern in (0xBF800000, 0x7FC00000, 0xFF800000):
+        assert np.isnan(plugin.selftest_ln(pattern, 1)[0][0])
+
+
+# ---------------------------------------------------------------------------------------------
+# WHOLE-FRAME parity at every BASELINE.json config (all 2 073 600 pixels against the oracle)
+# ---------------------------------------------------------------------------------------------
+def _whole_frame_parity(plugin, oracle, dec, handle, v, s, what):
+    """Every pixel of the 1920x1080 frame against the oracle's frame of the same inputs (the crops of the tests above
+    stay as the fast path). The oracle rasterises every quad in full, back to front: seconds to minutes of CPU."""
+    import time
+    got = plugin.render(handle, v, s)
+    st = plugin.stats()
+    t0 = time.time()
+    e = oracle.sort(dec, v, s)
+    ref, amb = oracle.render(dec, e, v, s, with_ambiguity=True)
+    t_oracle = time.time() - t0
+    assert got.shape == ref.shape == (v.height, v.width, 4)
+    strict, err = H.tolerance_mask(ref, got, None)
+    _assert_image(ref, got, amb, frac_slack=0.0005, what=what)
+    print(f"[whole frame: {what}] {ref.shape[0] * ref.shape[1]} pixels, {st['visible_count']} visible splats, max |err| "
+          f"{err.max():.2e}, values on ambiguity slack {int((~strict).sum())} of {strict.size}, oracle {t_oracle:.0f} s")
+    return got
+
+
+@pytest.mark.parametrize("global_scale", [1.0, 0.05])
+def test_whole_frame_parity_1m_3dgs(plugin, oracle, cloud_1m, global_scale):
+    """configs[1] (the headline): 1 M f32 splats, 1920x1080, SH3, CloudSettings::default(); dense and scene-like."""
+    h = plugin.upload(cloud_1m)
+    _whole_frame_parity(plugin, oracle, cloud_1m, h, View.headless(1920, 1080), CloudSettings(global_scale=global_scale),
+                        f"cfg1 1M 3DGS f32 gs={global_scale}")
+    h.free()
+
+
+@pytest.mark.parametrize("global_scale", [1.0, 0.05])
+def test_whole_frame_parity_5m_f16(plugin, oracle, global_scale):
+    """configs[2]: 5 M-splat f16 planar cloud at 1080p; dense and scene-like."""
+    c = random_gaussians_3d_seeded(5_000_000, 3).to_f16()
+    dec = oracle.decode_f16(c)
+    h = plugin.upload(c)
+    _whole_frame_parity(plugin, oracle, dec, h, View.headless(1920, 1080), CloudSettings(global_scale=global_scale),
+                        f"cfg2 5M f16 gs={global_scale}")
+    h.free()
+
+
+@pytest.mark.parametrize("aabb", [True, False])
+def test_whole_frame_parity_1m_2dgs(plugin, oracle, cloud_1m, aabb):
+    """configs[3]: 1 M-splat 2DGS cloud at the benchmarked setting (global_scale 1): the true surfel path (aabb) and
+    the default OBB quad."""
+    h = plugin.upload(cloud_1m)
+    _whole_frame_parity(plugin, oracle, cloud_1m, h, View.headless(1920, 1080),
+                        CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, aabb=aabb), f"cfg3 1M 2DGS aabb={aabb}")
+    h.free()
+
+
+def test_rerun_keeps_the_output_state_the_frame_was_enqueued_with(plugin):
+    """A frame whose supertile lists overflow is re-run when its lane completes. If the caller changed the packed
+    output format in between (bgs_set_output_rgba16f / _srgb8 / _packed_only complete nothing), the re-run must still
+    produce what the frame was ENQUEUED for: an Rgba8UnormSrgb image of w*h*4 bytes in the caller's target — not
+    8 B per pixel of Rgba16Float written past its end."""
+    import torch
+    c = random_gaussians_3d_seeded(120_000, 19)
+    v = View.headless(640, 360)
+    s = CloudSettings()
+    h = plugin.upload(c)
+    plugin.reset_adaptive_state()
+    plugin.set_output_srgb8(True)
+    plugin.render(h, v, s)
+    from bevy_gaussian_splatting_amd.multiview import device_ptr_as_tensor
+    p8, _ = plugin.framebuffer_srgb8_device_ptr()
+    want8 = device_ptr_as_tensor(p8, (360, 640, 4), "|u1", "cuda:0").cpu().numpy().copy()
+    assert want8.any()
+    plugin.reset_adaptive_state()
+    target = torch.zeros((2, 360, 640, 4), dtype=torch.uint8, device="cuda:0")   # second half = guard zone
+    try:
+        plugin.set_debug_flags(0x100000)          # lists start at 64 entries: this frame WILL overflow and be re-run
+        plugin.set_async(True)
+        plugin.set_pipeline_depth(2)
+        plugin.set_srgb8_target(target[0].data_ptr())
+        plugin.render(h, v, s, download=False)
+        # while it is in flight: another format, packed-only, and the flag that made it overflow cleared
+        plugin.set_output_srgb8(False)
+        plugin.set_output_rgba16f(True)
+        plugin.set_packed_only(True)
+        plugin.set_debug_flags(0)
+        plugin.synchronize()
+        assert plugin.stats()["regrow_count"] >= 1
+        got = target.cpu().numpy()
+        assert np.array_equal(got[0], want8)
+        assert not got[1].any()                   # nothing was written past the 4 B/px image
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.set_packed_only(False)
+        plugin.set_output_rgba16f(False)
+        plugin.set_output_srgb8(False)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.reset_adaptive_state()
+    h.free()
+
 # ---------------------------------------------------------------------------------------------
 # randomized sweep over camera / transform / settings combinations
 # ---------------------------------------------------------------------------------------------
@@ -1227,7 +1360,15 @@ def test_randomized_configurations(plugin, oracle, seed):
     h.free()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BGS_RANDOM_MEDIUM_SEEDS", "3"))))
+def _medium_seeds():
+    """12 seeds by default plus seed 321 — round 2's one parity failure (an ill-conditioned 2DGS degeneracy decision that
+    a 1-ulp difference in ln(opacity) flipped; since round 3 the log is correctly rounded on every side), kept in the
+    default suite for good. BGS_RANDOM_MEDIUM_SEEDS=N widens the range (evidence runs: 350)."""
+    n = int(os.environ.get("BGS_RANDOM_MEDIUM_SEEDS", "12"))
+    return list(range(n)) + ([321] if n <= 321 else [])
+
+
+@pytest.mark.parametrize("seed", _medium_seeds())
 def test_randomized_configurations_medium(plugin, oracle, seed):
     """The same sweep at 40-250 k splats and up to 1280x720: many tiles and supertiles, ticket loops, both
     supertile rules (BGS_RANDOM_MEDIUM_SEEDS=N widens it; a 60-seed run is in profiles/)."""
