@@ -108,7 +108,8 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
         # I = coarse (supertile) list entries (rank + tile rect, 8 B): written once by project_bin, read
         # once by the rasteriser, which also reads each visible record at least once
         return {
-            "keygen": {"bytes": N * 16 + N * 8, "launches": 1},
+            # keygen reads N positions and writes the D drawable pairs (the culled tail has no reader in a Color frame)
+            "keygen": {"bytes": N * 16 + D * 8, "launches": 1},
             "depth_sort": sort_stage,
             "project": {"bytes": V * 8 + V * (B - 16) + V * rec_bytes + I * 8, "launches": 1},
             "raster": {"bytes": I * 8 + V * rec_bytes + P * 16, "launches": 1},

@@ -91,43 +91,6 @@ inline uint32_t next_supertile_level(double ratio, uint32_t lv, const uint32_t e
     return target;
 }
 
-// Multiplier of the rasteriser's work-item permutation (render_kernels.hip, xcd_remap_spread): workgroup g of an XCD's
-// band of G items takes item (g * mult) % G. The hardware deals an XCD's workgroups to its CUs round-robin, so a CU's
-// resident workgroups are g, g + cus, g + 2 cus, ...: mult is the unit of Z_G (a permutation) for which that step,
-// (cus * mult) % G, is closest to the golden section of the band (0.382 G: successive items of a CU then sample the
-// band with low discrepancy) — among units that also keep neighbouring workgroups at least a CU-stride of items
-// apart. 1 (no permutation) for bands too short to matter. Pure host arithmetic; the result only moves work between
-// CUs, never changes an image.
-inline uint32_t spread_multiplier_uncached(uint32_t G, uint32_t cus) {
-    if (G < 4u * cus || cus == 0u) return 1u;
-    uint32_t best = 1u;
-    double best_cost = 1e30;
-    for (uint32_t m = 2u; m < G; ++m) {
-        uint32_t a = m, b = G;
-        while (b) { const uint32_t t = a % b; a = b; b = t; }
-        if (a != 1u) continue;
-        const uint32_t step = (uint32_t)(((uint64_t)cus * m) % G);
-        const double frac = (double)step / (double)G;
-        double cost = frac > 0.381966 ? frac - 0.381966 : 0.381966 - frac;
-        // neighbouring workgroups (the other XCD-local CUs) should not land on neighbouring items either
-        const uint32_t near = m < G - m ? m : G - m;
-        if (near < 8u) cost += 1.0;
-        if (cost < best_cost) { best_cost = cost; best = m; }
-    }
-    return best;
-}
-inline uint32_t spread_multiplier(uint32_t G, uint32_t cus) {
-    // (two band sizes per frame geometry: a few entries cover a context's life; the search is ~G gcds)
-    struct Entry { uint32_t G, cus, mult; };
-    static thread_local Entry cache[8] = {};
-    static thread_local uint32_t next = 0;
-    for (const Entry& e : cache)
-        if (e.G == G && e.cus == cus && e.mult) return e.mult;
-    const uint32_t m = spread_multiplier_uncached(G, cus);
-    cache[next++ % 8u] = Entry{G, cus, m};
-    return m;
-}
-
 // A splitter table is usable only if it is ascending: bucket(key) = number of splitters <= key is monotone in
 // the key exactly then, and the bucket sort's ORDER (not just its balance) rests on that.
 inline bool splitters_ascending(const uint32_t* key, uint32_t count) {

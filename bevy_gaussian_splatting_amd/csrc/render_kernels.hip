@@ -24,7 +24,6 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
-#include "frame_params.h"
 #include "kernels.h"
 #include "lookback.h"
 #include "splat_math.h"
@@ -681,41 +680,17 @@ __device__ __forceinline__ void stage_surfel(const float4* __restrict__ src, con
 #ifndef BGS_SURFEL_CULL_LOG2
 #define BGS_SURFEL_CULL_LOG2 23
 #endif
-// The bound over ANY axis-aligned pixel rectangle of the tile: centres xl in [cx - hx, cx + hx], yl in [cy - hy, cy + hy]
-// (the whole tile is (7.5, 7.5, 7.5, 7.5); row strip r of the wave-per-tile rasteriser — rows 4r .. 4r+3, the 64 pixels
-// one blend_px call evaluates — is (7.5, 7.5, 4r + 1.5, 1.5)).
-__device__ __forceinline__ bool surfel_negligible_in_rect(const float4 st[6], const float limit, const float cx, const float hx,
-                                                          const float cy, const float hy) {
-    const float pxc = fmaf(cy, st[2].z, fmaf(cx, st[1].w, st[1].x)), ex = fmaf(hy, fabsf(st[2].z), hx * fabsf(st[1].w));
-    const float pyc = fmaf(cy, st[2].w, fmaf(cx, st[2].x, st[1].y)), ey = fmaf(hy, fabsf(st[2].w), hx * fabsf(st[2].x));
-    const float pzc = fmaf(cy, st[3].x, fmaf(cx, st[2].y, st[1].z)), ez = fmaf(hy, fabsf(st[3].x), hx * fabsf(st[2].y));
+__device__ __forceinline__ bool surfel_negligible_in_tile(const float4 st[6], const float limit) {
+    constexpr float H = 7.5f;  // pixel centres of a tile: xl, yl in [0, 15]
+    const float pxc = fmaf(H, st[1].w + st[2].z, st[1].x), ex = H * (fabsf(st[1].w) + fabsf(st[2].z));
+    const float pyc = fmaf(H, st[2].x + st[2].w, st[1].y), ey = H * (fabsf(st[2].x) + fabsf(st[2].w));
+    const float pzc = fmaf(H, st[2].y + st[3].x, st[1].z), ez = H * (fabsf(st[2].y) + fabsf(st[3].x));
     const float lx = fmaxf(fabsf(pxc) - ex, 0.0f), ly = fmaxf(fabsf(pyc) - ey, 0.0f), hz = fabsf(pzc) + ez;
     const float s3 = fmaf(lx, lx, ly * ly) * __builtin_amdgcn_rcpf(hz * hz);  // 1 ulp is nothing to a bound with this margin
-    const float dx = fmaxf(fabsf(fmaf(cx, st[3].z, st[3].y)) - hx * fabsf(st[3].z), 0.0f);
-    const float dy = fmaxf(fabsf(fmaf(cy, st[4].x, st[3].w)) - hy * fabsf(st[4].x), 0.0f);
+    const float dx = fmaxf(fabsf(fmaf(H, st[3].z, st[3].y)) - H * fabsf(st[3].z), 0.0f);
+    const float dy = fmaxf(fabsf(fmaf(H, st[4].x, st[3].w)) - H * fabsf(st[4].x), 0.0f);
     const float s2 = fmaf(dx, dx, dy * dy);
     return s3 >= limit && s2 >= limit;  // staged powers are in exp2 units
-}
-__device__ __forceinline__ bool surfel_negligible_in_tile(const float4 st[6], const float limit) {
-    return surfel_negligible_in_rect(st, limit, 7.5f, 7.5f, 7.5f, 7.5f);
-}
-// Which of the tile's four row strips (rows 4r .. 4r+3) a staged surfel record can contribute to: bit r is clear when the
-// quad's v range misses the strip's rows or no pixel of the strip can receive more than the frame's threshold of the
-// record's opacity. A surfel strip costs ~30 issue slots per pixel row (three FMAs, a reciprocal, the 2D fallback, exp2),
-// so one scalar branch per strip pays — unlike for the 6-instruction reject path of an OBB record, where it was measured
-// not to. 0 = the record is not blended in this tile at all. Both rasterisers use this mask (the workgroup-per-tile one
-// has wave w own strip w), so their images stay bit-identical.
-__device__ __forceinline__ uint32_t surfel_strip_mask(const float4 st[6], const float limit, const bool cull, const bool per_strip) {
-    if (!per_strip) return cull && surfel_negligible_in_tile(st, limit) ? 0u : 15u;  // A/B (debug flag 0x2000000): round 2's all-or-nothing test
-    uint32_t mask = 0u;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float v0 = fmaf(st[0].w, (float)(4 * r), st[0].z), v1 = fmaf(st[0].w, (float)(4 * r + 3), st[0].z);
-        const bool outside = (v0 > 1.0001f && v1 > 1.0001f) || (v0 < -1.0001f && v1 < -1.0001f);
-        const bool drop = cull && (outside || surfel_negligible_in_rect(st, limit, 7.5f, 7.5f, (float)(4 * r) + 1.5f, 1.5f));
-        mask |= drop ? 0u : (1u << r);
-    }
-    return mask;
 }
 // the threshold of the frame: 2^-23 of a record's opacity, lowered by the frame's largest colour magnitude
 // like the transmittance cut-off (what is dropped is alpha * colour)
@@ -818,21 +793,6 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
 }
 
-// The same band per XCD, but the band's work items are dealt to the XCD's workgroups through a multiplicative
-// permutation: the hardware hands workgroup g of an XCD to CU g % (CUs per XCD), so a CU's eight resident workgroups
-// were 32 items apart — at 1080p a diagonal of eight 4-tile groups one row and eight tiles apart — and the heavy
-// tiles of a frame are neighbours (round 3's per-tile trace of the dense headline frame: the bottom-right corner
-// stages 114 records per tile where the median tile stages 61; those 60 tiles sat on 17 CUs and the launch lasted
-// 112.6 k clocks where the median SIMD was done after 85 k). With item (g * mult) % G, mult coprime to G and
-// (CUs-per-XCD * mult) % G near 0.382 G, a CU's workgroups sample the whole band (golden-ratio steps), so every SIMD
-// gets the band's mix of heavy and light tiles. mult = 1 is the plain band order.
-__device__ __forceinline__ uint32_t xcd_remap_spread(uint32_t b, uint32_t n, uint32_t mult_q1, uint32_t mult_q) {
-    const uint32_t q = n / 8u, r = n % 8u, xcd = b % 8u, g = b / 8u;
-    const bool big = xcd < r;
-    const uint32_t G = big ? q + 1u : q, start = big ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    return start + (uint32_t)(((unsigned long long)g * (big ? mult_q1 : mult_q)) % G);
-}
-
 // BINNING_SORT rasteriser: one workgroup per tile, one pixel per thread; the tile's instances are
 // a contiguous range of the tile-sorted list, staged 256 records at a time in LDS.
 template <int VARIANT>
@@ -875,7 +835,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
             } else if constexpr (VARIANT == RV_SURFEL) {
                 float4 st[6];
                 stage_surfel(src, tile_ox, tile_oy, aspect, st);
-                st[5].y = __uint_as_float(surfel_strip_mask(st, surfel_limit, !(fp.debug & 64u), !(fp.debug & 0x2000000u)));  // as raster_scan_kernel decides
+                st[5].y = __uint_as_float(surfel_negligible_in_tile(st, surfel_limit) && !(fp.debug & 64u) ? 0u : 1u);  // as raster_scan_kernel decides
 #pragma unroll
                 for (int v = 0; v < 6; ++v) s_rec[tid * REC_V4 + v] = st[v];
             } else {
@@ -888,8 +848,8 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
             for (uint32_t k = 0; k < cnt; ++k) {
                 StagedRecord<VARIANT> sr;
                 sr.load(s_rec + k * REC_V4);
-                if constexpr (VARIANT == RV_SURFEL)  // wave w of the workgroup owns rows 4w .. 4w+3 = strip w of the mask
-                    if (!((__builtin_amdgcn_readfirstlane(__float_as_uint(sr.a5.y)) >> (tid >> 6)) & 1u)) continue;
+                if constexpr (VARIANT == RV_SURFEL)
+                    if (__builtin_amdgcn_readfirstlane(__float_as_uint(sr.a5.y)) == 0u) continue;
                 blend_px<VARIANT>(sr, qx, qy, aspect, t_eps, T, crg, cb);
             }
         // also the barrier that protects s_rec before the next batch overwrites it
@@ -927,7 +887,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
                                                           uint32_t sup_x, Control* ctl,
                                                           float4* __restrict__ fb,
                                                           uint32_t* __restrict__ fb8_default, uint32_t want_srgb8,
-                                                          FrameCleanup cl, uint4* __restrict__ trace, uint32_t mult_q1, uint32_t mult_q) {
+                                                          FrameCleanup cl, uint4* __restrict__ trace) {
     unsigned long long trace_t0 = 0ull;
     uint32_t trace_scanned = 0u, trace_blended = 0u, trace_staged = 0u;
     if constexpr (TRACE) trace_t0 = __builtin_amdgcn_s_memtime();
@@ -942,7 +902,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     const uint32_t nblocks = (ntiles + 3u) / 4u;
-    const uint32_t tile = xcd_remap_spread(blockIdx.x, nblocks, mult_q1, mult_q) * 4u + (uint32_t)wave;
+    const uint32_t tile = xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
     const uint32_t draw_count = ctl->draw_count;
     const uint32_t cmax_bits = __builtin_amdgcn_readfirstlane(ctl->color_max_bits);
     const float t_eps = frame_t_eps(cmax_bits);
@@ -1023,6 +983,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
     // list fills the queue with its first group, so nothing changes there.
     constexpr uint32_t FLUSH_AT = 32u;
     uint32_t qn = 0u;  // ranks waiting in s_queue (wave-uniform)
+    uint32_t prio_rounds = 0u;
     uint32_t base = 0u;
     for (;;) {
         const bool have = base < total;
@@ -1090,7 +1051,8 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
                 } else {
                     float4 st[6];
                     stage_surfel(src, tile_ox, tile_oy, aspect, st);
-                    st[5].y = __uint_as_float(keep ? surfel_strip_mask(st, surfel_limit, !(fp.debug & 64u), !(fp.debug & 0x2000000u)) : 0u);
+                    keep = keep && !(surfel_negligible_in_tile(st, surfel_limit) && !(fp.debug & 64u));
+                    st[5].y = __uint_as_float(keep ? 1u : 0u);
 #pragma unroll
                     for (int v = 0; v < 6; ++v) s_rec[lane * REC_V4 + v] = st[v];
                 }
@@ -1110,18 +1072,16 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
                 if constexpr (TRACE) trace_staged += 1u;
                 if (__builtin_amdgcn_readfirstlane(keep_flag) == 0u) continue;  // scalar branch
                 if constexpr (TRACE) trace_blended += 1u;
-                if constexpr (VARIANT == RV_SURFEL) {
-                    const uint32_t strips = __builtin_amdgcn_readfirstlane(keep_flag);  // scalar: one s_bitcmp + branch per strip
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((strips >> r) & 1u) blend_px<VARIANT>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
-                }
+                for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
             }
             const bool sat = T[0] < t_eps && T[1] < t_eps && T[2] < t_eps && T[3] < t_eps;
             saturated = __all(sat);
+            if (fp.debug & 0x4000000u) {  // experiment: a tile that needs more rounds than its neighbours gets issue priority
+                if (++prio_rounds == 1u) __builtin_amdgcn_s_setprio(1);
+                else if (prio_rounds == 2u) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+            }
             }
             if (saturated) break;
             __builtin_amdgcn_wave_barrier();  // blend reads of s_rec / s_queue done before they are rewritten
@@ -1179,24 +1139,20 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
-                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace, uint32_t cus_per_xcd) {
+                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4* rec = (const float4*)records;
     const uint32_t sup = sup_edge, sup_mul = supertile_mul(sup_edge);
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
-    const uint32_t nblocks = (ntiles + 3u) / 4u;
-    const bool plain = (fp.debug & 0x1000000u) != 0u;  // A/B: the plain band order
-    const uint32_t mult_q1 = plain ? 1u : spread_multiplier(nblocks / 8u + 1u, cus_per_xcd);
-    const uint32_t mult_q = plain ? 1u : spread_multiplier(nblocks / 8u, cus_per_xcd);
 #define BGS_LAUNCH_RS(V)                                                                          \
     do {                                                                                          \
         if (tile_trace)                                                                           \
             hipLaunchKernelGGL((raster_scan_kernel<V, true>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
-                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, tile_trace, mult_q1, mult_q); \
+                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, tile_trace); \
         else                                                                                      \
             hipLaunchKernelGGL((raster_scan_kernel<V, false>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
-                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (uint4*)nullptr, mult_q1, mult_q); \
+                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (uint4*)nullptr); \
     } while (0)
     if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);

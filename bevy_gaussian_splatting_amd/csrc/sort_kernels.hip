@@ -288,7 +288,8 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
             if (i < fp.n) {
                 const uint32_t before = vis_base + off[k] + below[k];  // drawable entries before i
                 if (BGS_KG_DRAWN(k)) { if constexpr (!BUCKET) entries[before] = make_uint2(key[k], i); }
-                else {  // streaming store: the culled tail is only read when somebody asks for the whole list
+                else if (culled) {  // null in frames nobody reads the tail of (see enqueue_frame): 8 B per culled splat saved
+                    // streaming store: the culled tail is only read when somebody asks for the whole list
                     typedef uint32_t v2u __attribute__((ext_vector_type(2)));
                     __builtin_nontemporal_store((v2u){key[k], i}, reinterpret_cast<v2u*>(culled + (i - before)));
                 }

@@ -2,6 +2,9 @@
 # PMC counters per kernel for one workload: bash scripts/gpu_pmc.sh <what> <tag>   (<what>: see scripts/loop_render.py)
 # Every group is its own rocprofv3 run with --pmc only (never combined with trace domains).
 GS=$1; TAG=$2
+# PMC_GROUPS="0 3 5 6" picks counter groups by position (default: all); 12 blocking frames per run
+SEL=" ${PMC_GROUPS:-0 1 2 3 4 5 6} "
+GI=-1
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/pmc_$TAG; rm -f $R/gpurun_out/pmc_$TAG/counters.txt
@@ -12,6 +15,7 @@ for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32" \
            "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64" \
            "FETCH_SIZE" "WRITE_SIZE"; do
+  GI=$((GI+1)); case "$SEL" in *" $GI "*) ;; *) continue;; esac
   tag=$(echo $pmc | tr ' ' '_' | cut -c1-30)
   rm -rf /tmp/p_$tag
   rocprofv3 --pmc $pmc --output-format csv -d /tmp/p_$tag -o pmc -- python $R/scripts/loop_render.py $GS 12 > /dev/null 2> /tmp/pmc_$tag.err

@@ -92,8 +92,6 @@ def shim() -> ctypes.CDLL:
     l.shim_next_supertile_level.argtypes = [ctypes.c_double, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
                                             ctypes.POINTER(ctypes.c_double)]
     l.shim_next_supertile_level.restype = ctypes.c_uint32
-    l.shim_spread_multiplier.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
-    l.shim_spread_multiplier.restype = ctypes.c_uint32
     l.shim_pow2_ceil.argtypes = [ctypes.c_uint64]
     l.shim_pow2_ceil.restype = ctypes.c_uint32
     l.shim_splitters_ascending.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32]

@@ -58,7 +58,6 @@ uint32_t shim_supertile_div(uint32_t tile, uint32_t edge) { return supertile_div
 uint32_t shim_next_supertile_level(double ratio, uint32_t lv, const uint32_t* edges, double* longer_out) {
     return next_supertile_level(ratio, lv, edges, longer_out);
 }
-uint32_t shim_spread_multiplier(uint32_t G, uint32_t cus) { return spread_multiplier(G, cus); }
 uint32_t shim_pow2_ceil(uint64_t v) { return pow2_ceil_u32(v); }
 int shim_splitters_ascending(const uint32_t* key, uint32_t count) { return splitters_ascending(key, count) ? 1 : 0; }
 

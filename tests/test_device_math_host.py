@@ -373,24 +373,3 @@ def test_2dgs_degeneracy_decision_agrees_on_the_known_ill_conditioned_case():
             assert abs(out.radius - vs.radius[0]) <= 1e-6 * abs(vs.radius[0]), float(o)
         flips.add(bool(out.draw))
     assert flips == {True, False}   # the neighbourhood really is on the edge: both outcomes occur, always on both sides
-
-
-def test_rasteriser_work_item_permutation_is_a_permutation_that_spreads_a_cus_items():
-    """xcd_remap_spread (render_kernels.hip): workgroup g of an XCD's band of G work items takes item (g * mult) % G.
-    `spread_multiplier` must return a unit of Z_G (so that every item is taken exactly once — the image cannot
-    depend on it), and the items of one CU (workgroups g, g + cus, g + 2 cus, ...) must sample the band evenly."""
-    l = H.shim()
-    for G, cus in ((255, 32), (256, 32), (2048, 32), (1020, 32), (127, 32), (128, 32), (5, 32), (0, 32), (1, 32), (509, 38)):
-        m = int(l.shim_spread_multiplier(G, cus))
-        if G < 4 * cus:
-            assert m == 1
-            continue
-        items = (np.arange(G, dtype=np.int64) * m) % G
-        assert np.array_equal(np.sort(items), np.arange(G))            # a permutation
-        for c in (0, 7, cus - 1):
-            mine = np.sort(items[c::cus])                                # what CU c works on
-            gaps = np.diff(np.concatenate([mine, [mine[0] + G]]))
-            assert gaps.max() <= 3.0 * G / len(mine), (G, cus, m, gaps.max())   # no large hole in the band
-            assert gaps.min() >= 0.2 * G / len(mine), (G, cus, m, gaps.min())   # and no clump
-    # 1080p: 2040 four-tile groups, 255 per XCD
-    assert int(l.shim_spread_multiplier(255, 32)) not in (0, 1)
