@@ -8,19 +8,33 @@
 
 namespace bgs {
 
-// Device pointers of an uploaded planar cloud (src/gaussian/formats/planar_3d.rs:45-54).
+// Device image of an uploaded planar cloud (src/gaussian/formats/planar_3d.rs:45-54). At the boundary the cloud is
+// the reference's planes; in HBM it is TWO arrays, laid out for who reads what:
+//   position_visibility[n]   16 B per splat, read by keygen for ALL n splats, coalesced (the only plane the sort touches)
+//   packed[n][stride]        everything the vertex stage needs for ONE splat in one aligned record, read by project_*
+//                            for the VISIBLE splats only, at sorted (= random) indices. The memory side fetches whole
+//                            128-byte lines (round 3's gather calibration, profiles/r3_*/gather_fetch_calibration.txt:
+//                            a 16-byte gather moves 128 B, FETCH_SIZE tallies it as 64), so three gathers from three
+//                            planes (position 16 B, rotation + scale 32 B, SH 192 / 96 B) cost 4 lines per f32 splat and
+//                            3-4 per f16 splat — 2.1x / 3.1x the bytes asked for (measured: 5 M-splat f16 frame, 288 MB
+//                            fetched for 93 MB of gathers, project+bin at 3.2 TB/s). One record per splat is
+//                              f32:   pos_vis | rotation | scale_opacity | sh[48] | pad   = 256 B = 2 lines
+//                              cov3d: pos_vis | cov3d[6] opacity pad     | sh[48] | pad   = 256 B = 2 lines
+//                              f16:   pos_vis | rot scale opacity (8 x f16) | sh[48] f16  = 128 B = 1 line
+//                            (the position is duplicated into the record so the vertex stage needs no second line).
+// Memory: 272 B per f32 splat instead of 240, 144 instead of 128 for f16 — on a 288 GB device the price of the
+// duplicate position plane is nothing next to a halved (f32) or thirded (f16) gather traffic.
 struct CloudPtrs {
     const float4* position_visibility;  // n
-    const float* sh_f32;                // n*48      (f32 format)
-    const float4* rot_scale;            // n*2       (f32 format) rotation [w,x,y,z] then scale_opacity, interleaved at
-                                        //           upload: one 32-byte gather (one cache line) per visible splat
-                                        //           instead of two 16-byte gathers from two planes
-    const uint32_t* sh_f16;             // n*24      (f16 format)
-    const uint4* rot_scale_opacity_f16; // n         (f16 format)
-    const float4* cov3d_opacity;        // n*2       (cov3d format: Covariance3dOpacity = cov3d[6], opacity, pad)
+    const uint4* packed;                // n * packed_v4 16-byte words, record i at packed + i * packed_v4 (aligned to its size)
+    uint32_t packed_v4;                 // 16 (f32, cov3d: 256-byte records) or 8 (f16: 128-byte records)
     uint32_t n;
     uint32_t format;                    // cloud format: 0 = f32 planes, 1 = f16 planes, 2 = f32 with precomputed covariance
 };
+// 16-byte word offsets inside a packed record
+constexpr uint32_t PACK_ROT = 1u, PACK_SCALE_OPACITY = 2u, PACK_SH_F32 = 3u;   // f32
+constexpr uint32_t PACK_COV3D = 1u;                                            // cov3d (2 words), SH at PACK_SH_F32
+constexpr uint32_t PACK_RSO_F16 = 1u, PACK_SH_F16 = 2u;                        // f16
 constexpr uint32_t CLOUD_F32 = 0, CLOUD_F16 = 1, CLOUD_COV3D = 2;
 
 // What the rasteriser of a BINNING_SCAN frame tidies up so that the NEXT frame of the same lane needs
@@ -163,6 +177,12 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
 // The destination is d_fp->srgb8_target when that is non-zero, else default_out.
 void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* default_out, uint32_t pixels,
                          const FrameParams* d_fp, uint32_t out_format = 1u);
+
+// One-time re-layout at upload: the boundary's planes (device copies) -> packed records (see CloudPtrs). Word w of
+// record i is pos[i] for w = 0, then the v4_a / v4_b / v4_c 16-byte words of splat i from planes a, b, c in that order,
+// then zero padding up to stride_v4. Coalesced reads and writes.
+void launch_pack_cloud(hipStream_t stream, const uint4* pos, const uint4* a, uint32_t v4_a, const uint4* b, uint32_t v4_b,
+                       const uint4* c, uint32_t v4_c, uint4* out, uint32_t stride_v4, uint32_t n);
 
 // STREAM-triad on float4: a = b + s * c (HBM ceiling probe, bgs_hbm_probe).
 void launch_triad(hipStream_t stream, float4* a, const float4* b, const float4* c, float s, size_t n4,

@@ -21,6 +21,8 @@
 //
 // Front-to-back vs the reference's back-to-front "over" is the same polynomial evaluated in
 // the opposite association order; the difference is f32 rounding (<< 1e-3).
+#include <algorithm>
+
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
@@ -131,35 +133,37 @@ __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const Cl
                                                  float4* __restrict__ records, ColorInputs ci,
                                                  bool& visible, float& color_mag) {
     const uint32_t si = entry.y;
-    const float4 pv = cloud.position_visibility[si];
+    // ONE aligned record per splat (CloudPtrs): every load below falls into the same one or two 128-byte lines
+    const uint4* __restrict__ rec = cloud.packed + (size_t)si * cloud.packed_v4;
+    const float4 pv = *reinterpret_cast<const float4*>(rec);
     float rot[4], so[4], cov[6];
     if constexpr (FMT == (int)CLOUD_COV3D) {
         // Covariance3dOpacity (src/gaussian/f32.rs:218-251): cov3d[6], opacity, pad
-        const float4 c0 = cloud.cov3d_opacity[2u * si], c1 = cloud.cov3d_opacity[2u * si + 1u];
+        const float4 c0 = *reinterpret_cast<const float4*>(rec + PACK_COV3D), c1 = *reinterpret_cast<const float4*>(rec + PACK_COV3D + 1u);
         cov[0] = c0.x; cov[1] = c0.y; cov[2] = c0.z; cov[3] = c0.w; cov[4] = c1.x; cov[5] = c1.y;
         rot[0] = 1.0f; rot[1] = rot[2] = rot[3] = 0.0f;
         so[0] = so[1] = so[2] = 0.0f; so[3] = c1.z;
     } else if constexpr (FMT == (int)CLOUD_F16) {
         // src/render/planar.wgsl:154-176: first value of each pair in the HIGH half
-        const uint4 raw = cloud.rot_scale_opacity_f16[si];
+        const uint4 raw = rec[PACK_RSO_F16];
         rot[0] = half_hi(raw.x); rot[1] = half_lo(raw.x);
         rot[2] = half_hi(raw.y); rot[3] = half_lo(raw.y);
         so[0] = half_hi(raw.z); so[1] = half_lo(raw.z);
         so[2] = half_hi(raw.w); so[3] = half_lo(raw.w);
     } else {
-        const float4 r4 = cloud.rot_scale[2u * si];
-        const float4 s4 = cloud.rot_scale[2u * si + 1u];
+        const float4 r4 = *reinterpret_cast<const float4*>(rec + PACK_ROT);
+        const float4 s4 = *reinterpret_cast<const float4*>(rec + PACK_SCALE_OPACITY);
         rot[0] = r4.x; rot[1] = r4.y; rot[2] = r4.z; rot[3] = r4.w;
         so[0] = s4.x; so[1] = s4.y; so[2] = s4.z; so[3] = s4.w;
     }
     Projected pr;
     ci.visibility = pv.w;
     if constexpr (FMT == (int)CLOUD_F16)
-        project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF16{cloud.sh_f16 + (size_t)si * 24u}, ci, pr);
+        project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF16{reinterpret_cast<const uint32_t*>(rec + PACK_SH_F16)}, ci, pr);
     else if constexpr (FMT == (int)CLOUD_COV3D)
-        project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{cloud.sh_f32 + (size_t)si * 48u}, ci, pr, cov);
+        project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{reinterpret_cast<const float*>(rec + PACK_SH_F32)}, ci, pr, cov);
     else
-        project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{cloud.sh_f32 + (size_t)si * 48u}, ci, pr);
+        project_splat<ANY_MODE>(fp, entry.x, V3{pv.x, pv.y, pv.z}, rot, so, ShF32{reinterpret_cast<const float*>(rec + PACK_SH_F32)}, ci, pr);
     visible = pr.visible;
     if (!pr.draw) return RECT_EMPTY;
     // fmaxf drops a NaN: a NaN colour poisons its pixels whatever the cut-off is
@@ -1194,6 +1198,32 @@ __global__ __launch_bounds__(256) void encode_srgb8_kernel(const float4* __restr
         if (out_format & OUT_RGBA16F) reinterpret_cast<uint2*>(out)[i] = pack_rgba16f(c);
         else out[i] = pack_srgb8(c);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// upload-time re-layout: planes -> one aligned record per splat (CloudPtrs)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_cloud_kernel(const uint4* __restrict__ pos, const uint4* __restrict__ a, uint32_t v4_a,
+                                                         const uint4* __restrict__ b, uint32_t v4_b, const uint4* __restrict__ c,
+                                                         uint32_t v4_c, uint4* __restrict__ out, uint32_t stride_v4, uint32_t n) {
+    const size_t words = (size_t)n * stride_v4;
+    for (size_t g = (size_t)blockIdx.x * 256u + threadIdx.x; g < words; g += (size_t)gridDim.x * 256u) {
+        const uint32_t i = (uint32_t)(g / stride_v4), w = (uint32_t)(g - (size_t)i * stride_v4);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (w == 0u) v = pos[i];
+        else if (w < 1u + v4_a) v = a[(size_t)i * v4_a + (w - 1u)];
+        else if (w < 1u + v4_a + v4_b) v = b[(size_t)i * v4_b + (w - 1u - v4_a)];
+        else if (w < 1u + v4_a + v4_b + v4_c) v = c[(size_t)i * v4_c + (w - 1u - v4_a - v4_b)];
+        out[g] = v;
+    }
+}
+
+void launch_pack_cloud(hipStream_t stream, const uint4* pos, const uint4* a, uint32_t v4_a, const uint4* b, uint32_t v4_b,
+                       const uint4* c, uint32_t v4_c, uint4* out, uint32_t stride_v4, uint32_t n) {
+    if (n == 0) return;
+    const size_t words = (size_t)n * stride_v4;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((words + 255u) / 256u, 65536u);
+    hipLaunchKernelGGL(pack_cloud_kernel, dim3(blocks), dim3(256), 0, stream, pos, a, v4_a, b, v4_b, c, v4_c, out, stride_v4, n);
 }
 
 void launch_encode_srgb8(hipStream_t stream, const float4* framebuffer, uint32_t* default_out, uint32_t pixels,
