@@ -606,74 +606,57 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     constexpr uint32_t NF = BUCKET_FINE, FPT = NF / THREADS;    // fine ranges per thread (contiguous)
     static_assert(NF == 2048u && BUCKET_COUNT == 256u && (THREADS == 256u || THREADS == 1024u), "bucket geometry");
     __shared__ uint2 s_el[BUCKET_CAP];
-    __shared__ uint16_t s_tp[GROUPED ? BUCKET_GROUPED_MAX_TILES + 2u : 2u];  // grouped: this bucket's pairs in the tiles before tile t
     __shared__ uint32_t s_f[NF + 1];
     __shared__ uint32_t s_tot[WAVES];
     __shared__ uint32_t s_red[WAVES][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x;
     uint32_t base, m;
     if constexpr (GROUPED) {
-        static_assert(THREADS == 256u, "grouped bucket sort");
-        // ---- 1. this bucket's column of the count rows -> per-tile exclusive prefix in LDS; its sum = the bucket's size.
-        // Buckets are taken by ticket, so that the buckets below a running workgroup's have always started: the
-        // output offset comes from a 256-word look-back over the buckets' sizes (ctl->bucket_count doubles as the status
-        // words; one poller wave per workgroup, 64 predecessors per hop, as in keygen's partition chain).
-        if (tid == 0) s_tot[0] = atomicAdd(&ctl->ticket[0][0], 1u);   // ticket slot 0: the depth passes do not run in this frame
-        const uint8_t* const count_bytes = reinterpret_cast<const uint8_t*>(count_rows);
-        const uint32_t CH = (num_tiles + THREADS - 1u) / THREADS;      // tiles per thread (contiguous chunk), <= 32
+        static_assert(THREADS == 256u, "grouped bucket sort: 4 rows of 64 dwords per sweep");
+        // ---- 1. sizes from the count rows: row t = 64 dwords, byte k of dword w = bucket 4w + k ----
+        const uint32_t w = (uint32_t)lane;
+        const int below = (int)b - 4 * (int)w;   // how many of this dword's four buckets lie below b
+        const uint32_t lowmask = below >= 4 ? 0xFFFFFFFFu : (below <= 0 ? 0u : ((1u << (8 * below)) - 1u));
+        const bool has_mine = (b >> 2) == w;
+        const uint32_t myshift = 8u * (b & 3u);
+        uint32_t before = 0u, mine = 0u;
+        for (uint32_t t = (uint32_t)wave; t < num_tiles; t += WAVES) {
+            const uint32_t x = count_rows[(size_t)t * (BUCKET_COUNT / 4u) + w];
+            before = __builtin_amdgcn_sad_u8(x & lowmask, 0u, before);   // += the four bytes
+            if (has_mine) mine += (x >> myshift) & 255u;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            before += (uint32_t)__shfl_xor((int)before, off, 64);
+            mine += (uint32_t)__shfl_xor((int)mine, off, 64);
+        }
+        if (lane == 0) { s_red[wave][0] = before; s_red[wave][1] = mine; }
+        if (tid == 0) s_tot[0] = 0u;   // the gather's LDS cursor (s_tot[1..] unused until step 3)
 #pragma unroll
         for (uint32_t j = 0; j < FPT; ++j) s_f[j * THREADS + (uint32_t)tid] = 0u;
         __syncthreads();
-        b = s_tot[0];
-        const uint32_t t0 = (uint32_t)tid * CH;
-        uint32_t csum = 0u;
-        for (uint32_t i = 0; i < CH; ++i) {
-            const uint32_t t = t0 + i;
-            csum += t < num_tiles ? (uint32_t)count_bytes[(size_t)t * BUCKET_COUNT + b] : 0u;
-        }
-        const uint32_t cinc = wave_inclusive_scan(csum, lane);
-        __syncthreads();                      // s_tot[0] (the ticket) has been read by everyone
-        if (lane == 63) s_tot[wave] = cinc;
-        __syncthreads();
-        uint32_t run = cinc - csum;
-#pragma unroll
-        for (uint32_t w = 0; w < WAVES; ++w) run += w < (uint32_t)wave ? s_tot[w] : 0u;
-        m = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-        for (uint32_t i = 0; i < CH; ++i) {   // (the byte loads are L1 / L2 hits the second time)
-            const uint32_t t = t0 + i;
-            if (t < num_tiles) {
-                s_tp[t] = (uint16_t)min(run, 0xFFFFu);
-                run += (uint32_t)count_bytes[(size_t)t * BUCKET_COUNT + b];
-            }
-        }
-        if (tid == 0) s_tp[num_tiles] = (uint16_t)min(m, 0xFFFFu);
-        // ---- offset of this bucket: look-back over the lower buckets' sizes ----
-        if (wave == 0) {
-            uint32_t* const my_status = ctl->bucket_count + b;
-            uint32_t excl = 0u;
-            if (b > 0u) {
-                if (lane == 0) st_agent(my_status, STATUS_AGGREGATE | min(m, STATUS_VALUE_MASK));
-                excl = lookback_wave(ctl->bucket_count, b, lane, &ctl->error, 16u);
-            }
-            if (lane == 0) {
-                st_agent(my_status, STATUS_PREFIX | ((excl + m) & STATUS_VALUE_MASK));
-                s_red[0][0] = excl;
-            }
-        }
-        __syncthreads();
-        base = s_red[0][0];
+        base = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+        m = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
         const bool group_overflow = (__hip_atomic_load(&ctl->sort_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) != 0u;  // keygen's, before this launch
         if (m > BUCKET_CAP && tid == 0) atomicOr(&ctl->sort_overflow, 1u);
-        // draw_count: the last bucket knows the total. A voided frame (any overflow bit) is kept away from the unwritten
-        // stretches of the list by the consumers, which read sort_overflow next to draw_count.
+        // draw_count: only this kernel's last bucket knows the total. A voided frame (any overflow bit) is kept away
+        // from the unwritten stretches of the list by the consumers, which read sort_overflow next to draw_count.
         if (b == BUCKET_COUNT - 1u && tid == 0) {
             ctl->draw_count = group_overflow ? 0u : base + min(m, BUCKET_CAP);
-            ctl->bucket_max = m;   // (stats: the last bucket's size; no single workgroup sees the fullest one)
+            ctl->bucket_max = m;   // (stats: the last bucket's size; the fullest one is not known to any one workgroup)
         }
         if (m == 0u || m > BUCKET_CAP || group_overflow) return;
-        __syncthreads();  // s_red / s_tot are reused below
+        // ---- 2. gather this bucket's groups: slot s = tile * 16 + j is valid iff j < count[tile][b] ----
+        const uint8_t* const count_bytes = reinterpret_cast<const uint8_t*>(count_rows);
+        const uint32_t total_slots = num_tiles * BUCKET_GROUP;
+        for (uint32_t s0 = 0u; s0 < total_slots; s0 += THREADS) {
+            const uint32_t sidx = s0 + (uint32_t)tid, t = sidx / BUCKET_GROUP, j = sidx % BUCKET_GROUP;
+            if (sidx < total_slots && j < (uint32_t)count_bytes[(size_t)t * BUCKET_COUNT + b])
+                s_el[atomicAdd(&s_tot[0], 1u)] = slots[((size_t)t * BUCKET_COUNT + b) * BUCKET_GROUP + j];
+        }
+        __syncthreads();
     } else {
     // offset of this bucket in the sorted list, its own count, the fullest bucket (threads 0..255 = buckets)
     const uint32_t cnt = tid < (int)BUCKET_COUNT ? ctl->bucket_count[tid] : 0u;
@@ -713,15 +696,8 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
         const uint32_t e = k * THREADS + (uint32_t)tid;
         kv[k] = make_uint2(0u, 0u);
         if (e < m) {
-            if constexpr (GROUPED) {
-                // entry e of the bucket lives in the group of the tile t with s_tp[t] <= e < s_tp[t + 1]
-                uint32_t lo = 0u, hi = num_tiles - 1u;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi + 1u) >> 1;
-                    if ((uint32_t)s_tp[mid] <= e) lo = mid; else hi = mid - 1u;
-                }
-                kv[k] = slots[((size_t)lo * BUCKET_COUNT + b) * BUCKET_GROUP + (e - (uint32_t)s_tp[lo])];
-            } else kv[k] = src[e];
+            if constexpr (GROUPED) kv[k] = s_el[e];   // gathered into LDS above (rewritten in sorted order in step 3)
+            else kv[k] = src[e];
             kmn = min(kmn, kv[k].x);
             kmx = max(kmx, kv[k].x);
         }
