@@ -97,7 +97,6 @@ static_assert(sizeof(RecordSurfel) == 96, "RecordSurfel must be 96 bytes");
 // view changes slowly, and monotone in the key whatever the table holds (order never depends on it).
 constexpr uint32_t BUCKET_COUNT = 256;       // = the 256 chains of the look-back (thread = bucket)
 constexpr uint32_t BUCKET_CAP = 4096;        // pairs per bucket: 32 KB of LDS
-constexpr uint32_t BUCKET_GROUP = 16;        // grouped placement (sort_path 2): slots per (keygen tile, bucket) = one 128-byte line
 constexpr uint32_t BUCKET_FINE = 2048;       // fine key ranges inside a bucket (counting sort + rank among equals)
 constexpr uint32_t BUCKET_FINE_MAX = 1024;   // more pairs than this in one fine range: give up (ties), onesweep re-run
 struct SplitterTable { uint32_t key[BUCKET_COUNT]; };  // key[0..254] ascending; key[255] unused

@@ -130,11 +130,7 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
 // to out[] at its offset; out[0 .. draw_count) is then bit-identical to what the stable LSD passes
 // produce. Sets ctl->sort_overflow instead when a bucket holds more than BUCKET_CAP pairs or one key value
 // repeats more than BUCKET_FINE_MAX times (the host re-runs the frame with the onesweep passes).
-// count_rows != null: grouped placement (keygen BUCKET == 2): bucket_slots is the group image
-// [num_tiles][BUCKET_COUNT][BUCKET_GROUP], count_rows the byte counts [num_tiles][BUCKET_COUNT]; the kernel derives the
-// bucket offsets and draw_count itself.
-void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor,
-                        const uint32_t* count_rows = nullptr, uint32_t num_tiles = 0u);
+void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor);
 // ctl->splitters = the 255 quantile keys of the sorted draw list (for frames without a cleaning rasteriser).
 void launch_splitters(hipStream_t stream, const uint2* sorted, Control* ctl, uint32_t key_xor);
 

@@ -217,8 +217,7 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // (a bucket-sort frame that gave up leaves unwritten stretches in the list: sort_overflow voids it, the host re-runs the frame)
-    const uint32_t count = ctl->sort_overflow ? 0u : ctl->draw_count;
+    const uint32_t count = ctl->draw_count;
     const uint32_t num_tiles = (count + 255u) / 256u;
     if (num_tiles == 0u) return;
     s_histx[tid] = 0u;
@@ -390,8 +389,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // (a bucket-sort frame that gave up leaves unwritten stretches in the list: sort_overflow voids it, the host re-runs the frame)
-    const uint32_t count = ctl->sort_overflow ? 0u : ctl->draw_count;
+    const uint32_t count = ctl->draw_count;
     const uint32_t num_tiles = (count + 255u) / 256u;
     if (num_tiles == 0u) return;
     const uint32_t num_st = sup_x * sup_y;

@@ -84,19 +84,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 // radix pass's machinery] + [arrival order within the tile: a returning LDS atomic]. The sum of the 256
 // exclusive prefixes is the tile's drawable-entry offset, so the partition needs no chain of its own.
 // Order inside a bucket is arbitrary; bucket_sort_kernel orders by (key, index).
-//
-// BUCKET == 2 (fp.sort_path == 2, "grouped"): the same buckets WITHOUT any chain. Because order inside a bucket is
-// arbitrary, a pair's slot only has to be unique, not ranked: every (tile, bucket) pair owns a fixed GROUP of
-// BUCKET_GROUP = 16 slots (one 128-byte line), the tile's 256 groups are contiguous (one coalesced 32 KB write per
-// tile, built in LDS), and a 256-byte row of counts per tile tells bucket_sort_kernel how full each group is — it
-// sums the rows itself (its output offset = the counts of all lower buckets over all tiles). Nothing in this
-// kernel then depends on another workgroup: no look-back (the ~7 us a tile waited for its slowest predecessor's
-// aggregate), no status words to publish, poll and clean up, and no ticket either (tile = block index: with no
-// chain there is no forward-progress order to protect). Needs: nobody reads the culled tail (its ordered partition
-// is what the chain's sum was for), a drawable share of at most ~1/5 of the cloud (mean group fill <= 3.2 of 16)
-// and a cloud whose memory order is not depth order; a group over capacity sets sort_overflow bit 4, the frame is
-// re-run with the digit passes and the context stays on the chained buckets for a while (bgs_api.hip).
-template <int KG_ITEMS, int BUCKET, int THREADS>  // splats per thread; 256 or 1024 threads per block
+template <int KG_ITEMS, bool BUCKET, int THREADS>  // splats per thread; 256 or 1024 threads per block
 __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
                                                          uint2* __restrict__ entries,
                                                          uint2* __restrict__ culled, Control* ctl,
@@ -104,8 +92,6 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                                                          uint32_t ticket_slot, FrameParams* fp_out,
                                                          uint2* __restrict__ bucket_slots, uint32_t* bucket_status,
                                                          SplitterTable split) {
-    // BUCKET == 2: bucket_slots = the group image [tile][BUCKET_COUNT][BUCKET_GROUP] pairs, bucket_status = the count
-    // rows [tile][BUCKET_COUNT] bytes (as dwords)
     constexpr int WAVES = THREADS / 64;
     constexpr int ROWS = KG_ITEMS * WAVES;  // 64-splat rows of a tile, in index order (item, wave)
     static_assert((THREADS == 256 || THREADS == 1024) && ROWS <= 128, "tile geometry");
@@ -116,8 +102,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     __shared__ uint32_t s_idx[BUCKET ? THREADS * KG_ITEMS : 1];  // their splat indices (BUCKET)
     __shared__ uint32_t s_split[BUCKET ? BUCKET_COUNT : 1];
     __shared__ uint32_t s_bcnt[BUCKET ? BUCKET_COUNT : 1];   // pairs of this tile per bucket
-    __shared__ uint32_t s_bexcl[BUCKET == 1 ? BUCKET_COUNT : 1];  // pairs of earlier tiles per bucket
-    __shared__ uint2 s_img[BUCKET == 2 ? BUCKET_COUNT * BUCKET_GROUP : 1];  // grouped: the tile's 256 groups, copied out in one piece
+    __shared__ uint32_t s_bexcl[BUCKET ? BUCKET_COUNT : 1];  // pairs of earlier tiles per bucket
     __shared__ uint32_t s_tot[4];
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_base;
@@ -146,14 +131,11 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     // after its tile instead of queueing for a second ticket only to be told there is nothing left.
     const bool single_shot = gridDim.x >= num_tiles;
 
-    if constexpr (BUCKET == 2) {
-        if (blockIdx.x == 0 && tid == 0) ctl->splat_count = fp.n;   // draw_count comes from bucket_sort_kernel
-    }
-    for (uint32_t iter = 0u;; ++iter) {
-        if constexpr (BUCKET != 2) { if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u); }
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
         if constexpr (BUCKET) { if (tid < (int)BUCKET_COUNT) s_bcnt[tid] = 0u; }
         __syncthreads();
-        const uint32_t tile = BUCKET == 2 ? blockIdx.x + iter * gridDim.x : s_tile;  // grouped: no chain, so no ticket
+        const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
         const uint32_t base = tile * per_tile;
         uint32_t key[KG_ITEMS], below[KG_ITEMS];
@@ -255,29 +237,9 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                         if (s_split[lo + step - 1u] <= kk) lo += step;
                     bk[r] = min(lo, BUCKET_COUNT - 1u);
                     at[r] = atomicAdd(&s_bcnt[bk[r]], 1u);
-                    if constexpr (BUCKET == 2) {   // straight into the tile's group image (a full group drops the pair: overflow below)
-                        if (at[r] < BUCKET_GROUP) s_img[bk[r] * BUCKET_GROUP + at[r]] = make_uint2(kk, s_idx[j]);
-                    }
                 }
             }
             __syncthreads();
-            if constexpr (BUCKET == 2) {
-                // counts: one byte per bucket, the tile's row as 64 dwords; a group over capacity voids the frame
-                uint32_t* const rows = bucket_status + (size_t)tile * (BUCKET_COUNT / 4u);
-                if (tid < (int)(BUCKET_COUNT / 4u)) {
-                    const uint32_t c0 = s_bcnt[4 * tid], c1 = s_bcnt[4 * tid + 1], c2 = s_bcnt[4 * tid + 2], c3 = s_bcnt[4 * tid + 3];
-                    if (max(max(c0, c1), max(c2, c3)) > BUCKET_GROUP) atomicOr(&ctl->sort_overflow, 4u);
-                    rows[tid] = min(c0, BUCKET_GROUP) | (min(c1, BUCKET_GROUP) << 8) | (min(c2, BUCKET_GROUP) << 16) | (min(c3, BUCKET_GROUP) << 24);
-                }
-                // the image: 4096 pairs = 2048 x 16 B, contiguous in HBM (slots past a group's count are never read)
-                uint4* const dst = reinterpret_cast<uint4*>(bucket_slots + (size_t)tile * (BUCKET_COUNT * BUCKET_GROUP));
-                const uint4* const src = reinterpret_cast<const uint4*>(s_img);
-#pragma unroll
-                for (uint32_t q = (uint32_t)tid; q < BUCKET_COUNT * BUCKET_GROUP / 2u; q += (uint32_t)THREADS) dst[q] = src[q];
-                if (gridDim.x >= num_tiles) break;   // one tile per block: done
-                __syncthreads();                      // s_img / s_bcnt / s_keys are rewritten by the next tile
-                continue;
-            }
             // thread = bucket (the first 256 threads): chained scan over the tiles, one chain per bucket
             uint32_t excl = 0u, mine = 0u;
             if (tid < (int)BUCKET_COUNT) {
@@ -352,18 +314,22 @@ bool KeygenLaunch::prepare(int max_blocks) {
     // Tile size by cloud size (keygen_tile_splats): every tile is a ticket, a hop in 256 look-back chains and a
     // round of barriers
     const uint32_t per_block = keygen_tile_splats(fp.n);
-    const bool bucket = fp.sort_path == 1u, grouped = fp.sort_path == 2u;
-#define BGS_KG_PICK(ITEMS, THR)                                                                         \
-    (grouped ? reinterpret_cast<const void*>(&keygen_kernel<ITEMS, 2, THR>)                             \
-             : bucket ? reinterpret_cast<const void*>(&keygen_kernel<ITEMS, 1, THR>) : reinterpret_cast<const void*>(&keygen_kernel<ITEMS, 0, THR>))
+    const bool bucket = fp.sort_path == 1u;
 #if BGS_KEYGEN_WIDE_THREADS == 256
     threads = 256u;
-    func = per_block >= 4096u ? BGS_KG_PICK(16, 256) : BGS_KG_PICK(8, 256);
+    if (per_block >= 4096u)
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<16, true, 256>) : reinterpret_cast<const void*>(&keygen_kernel<16, false, 256>);
+    else
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<8, true, 256>) : reinterpret_cast<const void*>(&keygen_kernel<8, false, 256>);
 #else
     threads = per_block >= 4096u ? 1024u : 256u;
-    func = per_block == 8192u ? BGS_KG_PICK(8, 1024) : (per_block == 4096u ? BGS_KG_PICK(4, 1024) : BGS_KG_PICK(8, 256));
+    if (per_block == 8192u)
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<8, true, 1024>) : reinterpret_cast<const void*>(&keygen_kernel<8, false, 1024>);
+    else if (per_block == 4096u)
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<4, true, 1024>) : reinterpret_cast<const void*>(&keygen_kernel<4, false, 1024>);
+    else
+        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<8, true, 256>) : reinterpret_cast<const void*>(&keygen_kernel<8, false, 256>);
 #endif
-#undef BGS_KG_PICK
     blocks = (fp.n + per_block - 1) / per_block;
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
     argv[0] = &fp; argv[1] = &pos; argv[2] = &entries; argv[3] = &culled; argv[4] = &ctl;
@@ -591,16 +557,10 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
 #define BGS_BUCKET_SORT_THREADS 256
 #endif
 constexpr uint32_t BUCKET_SORT_THREADS = BGS_BUCKET_SORT_THREADS;
-// GROUPED (sort_path 2): keygen left the pairs in per-(tile, bucket) groups of BUCKET_GROUP slots and a row of 256
-// byte counts per tile (keygen_kernel, BUCKET == 2). Step 1 then sums the count rows — everything below this
-// bucket over all tiles is the output offset, this bucket's column its size — and step 2 gathers the bucket's
-// groups (one 128-byte line per tile) into LDS; the rest is the same. The workgroup of the last bucket knows the
-// total and publishes it as draw_count. Still no workgroup waits for another one.
-template <uint32_t THREADS, bool GROUPED>  // 256 or 1024
+template <uint32_t THREADS>  // 256 or 1024
 __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __restrict__ slots,
                                                               uint2* __restrict__ out, Control* ctl,
-                                                              uint32_t key_xor, const uint32_t* __restrict__ count_rows,
-                                                              uint32_t num_tiles) {
+                                                              uint32_t key_xor) {
     constexpr uint32_t WAVES = THREADS / 64u;
     constexpr uint32_t EPT = BUCKET_CAP / THREADS;              // pairs per thread (strided)
     constexpr uint32_t NF = BUCKET_FINE, FPT = NF / THREADS;    // fine ranges per thread (contiguous)
@@ -612,52 +572,6 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
-    uint32_t base, m;
-    if constexpr (GROUPED) {
-        static_assert(THREADS == 256u, "grouped bucket sort: 4 rows of 64 dwords per sweep");
-        // ---- 1. sizes from the count rows: row t = 64 dwords, byte k of dword w = bucket 4w + k ----
-        const uint32_t w = (uint32_t)lane;
-        const int below = (int)b - 4 * (int)w;   // how many of this dword's four buckets lie below b
-        const uint32_t lowmask = below >= 4 ? 0xFFFFFFFFu : (below <= 0 ? 0u : ((1u << (8 * below)) - 1u));
-        const bool has_mine = (b >> 2) == w;
-        const uint32_t myshift = 8u * (b & 3u);
-        uint32_t before = 0u, mine = 0u;
-        for (uint32_t t = (uint32_t)wave; t < num_tiles; t += WAVES) {
-            const uint32_t x = count_rows[(size_t)t * (BUCKET_COUNT / 4u) + w];
-            before = __builtin_amdgcn_sad_u8(x & lowmask, 0u, before);   // += the four bytes
-            if (has_mine) mine += (x >> myshift) & 255u;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            before += (uint32_t)__shfl_xor((int)before, off, 64);
-            mine += (uint32_t)__shfl_xor((int)mine, off, 64);
-        }
-        if (lane == 0) { s_red[wave][0] = before; s_red[wave][1] = mine; }
-        if (tid == 0) s_tot[0] = 0u;   // the gather's LDS cursor (s_tot[1..] unused until step 3)
-#pragma unroll
-        for (uint32_t j = 0; j < FPT; ++j) s_f[j * THREADS + (uint32_t)tid] = 0u;
-        __syncthreads();
-        base = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-        m = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
-        const bool group_overflow = (__hip_atomic_load(&ctl->sort_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) != 0u;  // keygen's, before this launch
-        if (m > BUCKET_CAP && tid == 0) atomicOr(&ctl->sort_overflow, 1u);
-        // draw_count: only this kernel's last bucket knows the total. A voided frame (any overflow bit) is kept away
-        // from the unwritten stretches of the list by the consumers, which read sort_overflow next to draw_count.
-        if (b == BUCKET_COUNT - 1u && tid == 0) {
-            ctl->draw_count = group_overflow ? 0u : base + min(m, BUCKET_CAP);
-            ctl->bucket_max = m;   // (stats: the last bucket's size; the fullest one is not known to any one workgroup)
-        }
-        if (m == 0u || m > BUCKET_CAP || group_overflow) return;
-        // ---- 2. gather this bucket's groups: slot s = tile * 16 + j is valid iff j < count[tile][b] ----
-        const uint8_t* const count_bytes = reinterpret_cast<const uint8_t*>(count_rows);
-        const uint32_t total_slots = num_tiles * BUCKET_GROUP;
-        for (uint32_t s0 = 0u; s0 < total_slots; s0 += THREADS) {
-            const uint32_t sidx = s0 + (uint32_t)tid, t = sidx / BUCKET_GROUP, j = sidx % BUCKET_GROUP;
-            if (sidx < total_slots && j < (uint32_t)count_bytes[(size_t)t * BUCKET_COUNT + b])
-                s_el[atomicAdd(&s_tot[0], 1u)] = slots[((size_t)t * BUCKET_COUNT + b) * BUCKET_GROUP + j];
-        }
-        __syncthreads();
-    } else {
     // offset of this bucket in the sorted list, its own count, the fullest bucket (threads 0..255 = buckets)
     const uint32_t cnt = tid < (int)BUCKET_COUNT ? ctl->bucket_count[tid] : 0u;
     uint32_t before = tid < (int)b ? cnt : 0u, mine = tid == (int)b ? cnt : 0u, mx = cnt;
@@ -671,8 +585,8 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
 #pragma unroll
     for (uint32_t j = 0; j < FPT; ++j) s_f[j * THREADS + (uint32_t)tid] = 0u;
     __syncthreads();
-    base = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-    m = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
+    const uint32_t base = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+    const uint32_t m = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
     mx = max(max(s_tot[0], s_tot[1]), max(s_tot[2], s_tot[3]));
     if (b == 0u && tid == 0) {
         ctl->bucket_max = mx;
@@ -685,7 +599,6 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     }
     if (m == 0u || mx > BUCKET_CAP) return;
     __syncthreads();  // s_red / s_tot are reused below
-    }
 
     // ---- 2. load ----
     const uint2* __restrict__ src = slots + (size_t)b * BUCKET_CAP;
@@ -696,8 +609,7 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
         const uint32_t e = k * THREADS + (uint32_t)tid;
         kv[k] = make_uint2(0u, 0u);
         if (e < m) {
-            if constexpr (GROUPED) kv[k] = s_el[e];   // gathered into LDS above (rewritten in sorted order in step 3)
-            else kv[k] = src[e];
+            kv[k] = src[e];
             kmn = min(kmn, kv[k].x);
             kmx = max(kmx, kv[k].x);
         }
@@ -747,8 +659,7 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     if (__syncthreads_or(fmax > BUCKET_FINE_MAX ? 1 : 0)) {  // step 4 is quadratic in equal keys: give up
         if (tid == 0) {
             atomicOr(&ctl->sort_overflow, 2u);
-            if constexpr (!GROUPED) ctl->draw_count = 0u;  // this bucket's stretch of the list stays unwritten: see above
-            // (grouped: draw_count is the last bucket's to write; the consumers read sort_overflow next to it)
+            ctl->draw_count = 0u;  // this bucket's stretch of the list stays unwritten: see above
         }
         return;
     }
@@ -777,14 +688,9 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     }
 }
 
-void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor,
-                        const uint32_t* count_rows, uint32_t num_tiles) {
-    if (count_rows)   // grouped placement (sort_path 2)
-        hipLaunchKernelGGL((bucket_sort_kernel<256u, true>), dim3(BUCKET_COUNT), dim3(256), 0, stream, bucket_slots, out, ctl,
-                           key_xor, count_rows, num_tiles);
-    else
-        hipLaunchKernelGGL((bucket_sort_kernel<BUCKET_SORT_THREADS, false>), dim3(BUCKET_COUNT), dim3(BUCKET_SORT_THREADS), 0, stream,
-                           bucket_slots, out, ctl, key_xor, (const uint32_t*)nullptr, 0u);
+void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor) {
+    hipLaunchKernelGGL(bucket_sort_kernel<BUCKET_SORT_THREADS>, dim3(BUCKET_COUNT), dim3(BUCKET_SORT_THREADS), 0, stream,
+                       bucket_slots, out, ctl, key_xor);
 }
 
 // The 255 keys at the 1/256-quantiles of a sorted draw list, in keygen's key space (key ^ key_xor): the

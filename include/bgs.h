@@ -144,10 +144,8 @@ typedef struct bgs_stats {
     uint32_t visible_count;      /* V: splats that pass the frustum test               */
     uint32_t draw_count;         /* D: entries that go through the radix passes / reach the
                                     vertex stage (key != culled sentinel)               */
-    uint32_t sort_path;          /* depth sort of the call: 0 = onesweep digit passes; bucket sort (one launch, pairs
-                                    placed into 256 key-range buckets by keygen): 1 = placed by per-bucket chained
-                                    scans over the keygen tiles, 2 = placed into fixed (tile, bucket) groups, no chain
-                                    (rendered frames whose culled tail nobody reads, drawable share <= 1/5) */
+    uint32_t sort_path;          /* depth sort of the call: 0 = onesweep digit passes, 1 = bucket sort
+                                    (one launch; chosen per frame)        */
     uint64_t instance_count;     /* I: (tile, splat) instances emitted                 */
     uint64_t instance_capacity;  /* BGS_BINNING_SORT: tile instances the lane's buffers hold (0 until that mode ran) */
     uint32_t tiles_x, tiles_y;

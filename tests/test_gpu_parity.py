@@ -679,89 +679,6 @@ def test_splitter_tables_are_kept_per_view(plugin, oracle):
     plugin.reset_adaptive_state()
 
 
-
-def test_grouped_bucket_placement_is_bit_exact_and_falls_back(plugin, oracle):
-    """Rendered frames whose culled tail nobody reads place the drawable pairs into fixed (keygen tile, bucket) groups —
-    no look-back chain, no ticket (sort_path 2, stats["bucket_placement"] == "grouped"). The draw list such a frame
-    leaves must be the oracle's drawable prefix bit for bit, its image the image of the chained placement (debug flag
-    0x1000000) and of the digit passes (0x80000); RasterizeMode::Depth (which reads the tail) and bgs_sort stay on the
-    chained placement; and a cloud whose MEMORY ORDER follows depth — every keygen tile then crowds its drawable
-    splats into a few buckets — overflows a group: that frame is re-run, the result is still exact, and the context
-    falls back to the chained placement."""
-    c = random_gaussians_3d_seeded(700_000, 91)
-    v = View.headless(1280, 720)
-    s = CloudSettings(global_scale=0.4)
-    h = plugin.upload(c)
-    ref = oracle.sort(c, v, s)
-    drawable = ref[ref["key"] != 0xFFFFFFFF]
-    plugin.reset_adaptive_state()
-    try:
-        plugin.set_debug_flags(0x80000)
-        img_passes = plugin.render(h, v, s)
-        plugin.set_debug_flags(0x1000000)
-        plugin.render(h, v, s)
-        img_chained = plugin.render(h, v, s)
-        assert plugin.stats()["bucket_placement"] == "chained"
-        plugin.set_debug_flags(0)
-        for _ in range(3):
-            img = plugin.render(h, v, s)
-        st = plugin.stats()
-        assert st["bucket_placement"] == "grouped" and st["regrow_count"] == 0, st
-        assert np.array_equal(img, img_chained) and np.array_equal(img, img_passes)
-        got = plugin.draw_list()
-        assert len(got) == len(drawable) and np.array_equal(got["key"], drawable["key"]) and np.array_equal(got["index"], drawable["index"])
-        # pipelined, with and without graphs
-        from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
-        plugin.set_async(True)
-        plugin.set_pipeline_depth(4)
-        for graphs in (False, True):
-            plugin.set_graphs(graphs)
-            plugin.set_profiling(0 if graphs else 2)
-            for _ in range(16):
-                plugin.render(h, v, s, download=False)
-            plugin.synchronize()
-            assert np.array_equal(framebuffer_as_tensor(plugin, 720, 1280).cpu().numpy(), img)
-            assert plugin.stats()["bucket_placement"] == "grouped"
-        plugin.set_graphs(False)
-        plugin.set_profiling(2)
-        plugin.set_async(False)
-        plugin.set_pipeline_depth(1)
-        # readers of the culled tail keep the chained placement
-        full = plugin.sort(h, v, s)
-        assert plugin.stats()["bucket_placement"] == "chained" and _sort_equal(full, ref)
-        sd = CloudSettings(global_scale=0.4, rasterize_mode=RasterizeMode.Depth)
-        plugin.render(h, v, sd)
-        plugin.render(h, v, sd)
-        assert plugin.stats()["bucket_placement"] == "chained"
-    finally:
-        plugin.set_debug_flags(0)
-        plugin.set_graphs(False)
-        plugin.set_profiling(2)
-        plugin.set_async(False)
-        plugin.set_pipeline_depth(1)
-    h.free()
-
-    # memory order = depth order: the same splats, stored front to back
-    cam = np.asarray(v.world_from_view, np.float64)[:3, 3]
-    order = np.argsort(((c.position_visibility[:, :3].astype(np.float64) - cam) ** 2).sum(1), kind="stable")
-    cs = PlanarGaussian3d(c.position_visibility[order], c.spherical_harmonic[order], c.rotation[order], c.scale_opacity[order])
-    hs = plugin.upload(cs)
-    refs = oracle.sort(cs, v, s)
-    drawable_s = refs[refs["key"] != 0xFFFFFFFF]
-    plugin.reset_adaptive_state()
-    before = plugin.adaptive_counters()["reruns_sort"]
-    imgs = [plugin.render(hs, v, s) for _ in range(4)]
-    after = plugin.adaptive_counters()["reruns_sort"]
-    assert after > before                                   # a group overflowed: the frame was re-run on the digit passes ...
-    got = plugin.draw_list()
-    assert np.array_equal(got["key"], drawable_s["key"]) and np.array_equal(got["index"], drawable_s["index"])
-    assert all(np.array_equal(imgs[0], im) for im in imgs)  # ... every frame is the same image ...
-    assert plugin.stats()["bucket_placement"] == "chained"  # ... and the context stays on the chained placement
-    ref_img, amb = oracle.render(cs, refs, v, s, window=(616, 336, 664, 384), with_ambiguity=True)
-    _assert_image(ref_img, imgs[-1][336:384, 616:664], amb, frac_slack=0.01, what="depth-ordered cloud")
-    hs.free()
-    plugin.reset_adaptive_state()
-
 def test_bucket_and_onesweep_frames_are_bit_identical(plugin):
     """Pipelined frames (6 lanes on 3 streams, with and without frame graphs) on either sort path give the
     same bits as a blocking frame."""
