@@ -987,7 +987,6 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
     // list fills the queue with its first group, so nothing changes there.
     constexpr uint32_t FLUSH_AT = 32u;
     uint32_t qn = 0u;  // ranks waiting in s_queue (wave-uniform)
-    uint32_t prio_rounds = 0u;
     uint32_t base = 0u;
     for (;;) {
         const bool have = base < total;
@@ -1081,11 +1080,6 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
             }
             const bool sat = T[0] < t_eps && T[1] < t_eps && T[2] < t_eps && T[3] < t_eps;
             saturated = __all(sat);
-            if (fp.debug & 0x4000000u) {  // experiment: a tile that needs more rounds than its neighbours gets issue priority
-                if (++prio_rounds == 1u) __builtin_amdgcn_s_setprio(1);
-                else if (prio_rounds == 2u) __builtin_amdgcn_s_setprio(2);
-                else __builtin_amdgcn_s_setprio(3);
-            }
             }
             if (saturated) break;
             __builtin_amdgcn_wave_barrier();  // blend reads of s_rec / s_queue done before they are rewritten

@@ -349,6 +349,16 @@ class GaussianSplattingPlugin:
         """Kernel-ablation switches for experiments only (non-zero => wrong images)."""
         self._check(self._lib.bgs_set_debug_flags(self._ctx, int(flags)))
 
+    def draw_list(self) -> np.ndarray:
+        """The sorted entries the last call left on the device (`bgs_sorted_entries_device_ptr` + `bgs_download`): after
+        `sort` all n entries, after `render` the drawable prefix (what reaches the vertex stage, back to front)."""
+        p, n = ctypes.c_void_p(), ctypes.c_uint32()
+        self._check(self._lib.bgs_sorted_entries_device_ptr(self._ctx, ctypes.byref(p), ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.dtype([("key", np.uint32), ("index", np.uint32)]))
+        if n.value:
+            self._check(self._lib.bgs_download(self._ctx, p, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+        return out
+
     def set_tile_trace(self, device_ptr: Optional[int]) -> None:
         """`bgs_set_tile_trace`: per-tile timing / placement trace of the rasteriser into a caller-owned device buffer
         (tiles_x * tiles_y * 32 bytes); None switches it off."""

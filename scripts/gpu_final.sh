@@ -1,15 +1,34 @@
 #!/bin/bash
-# Round-end evidence run: smoke, all GPU tests, bench, other configs, rocprofv3 stats + PMC, timelines.
+# Round-end evidence run on the FINAL tree (one set per round): smoke, all GPU tests, the wide randomized sweeps, bench
+# (default + the driver's flags twice), the other configs, rocprofv3 kernel stats + PMC passes (dense headline frame:
+# all groups; the two slowest configs: VALU / classes / FETCH / WRITE), timelines, per-tile traces, gather calibration.
+#   bash scripts/gpu_final.sh <tag>      then copy gpurun_out/<tag> to profiles/<tag> and its pmc_traffic.json to profiles/
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r2_final}
+TAG=${1:-r3_final}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
-echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-echo "== pytest gpu"; timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -s 2>&1 | grep -E "passed|failed|error|ambiguity slack used" | tee $OUT/pytest_gpu_summary.log | tail -8
-echo "== bench"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json; tail -2 $OUT/bench.err
-echo "== other configs"; timeout 900 python scripts/bench_configs.py > $OUT/bench_other_configs.json 2> $OUT/bench_other.err; tail -c 1500 $OUT/bench_other_configs.json; tail -2 $OUT/bench_other.err
-echo "== rocprof"; bash scripts/gpu_profile.sh > $OUT/profile.log 2>&1; cp $R/gpurun_out/prof/* $OUT/ 2>/dev/null; tail -30 $OUT/profile.log
-python $R/scripts/make_pmc_traffic.py "$R/gpurun_out/pmc_dense/counters.txt" "$OUT/pmc_traffic.json" "$TAG"
-echo "== timelines"; bash scripts/gpu_timeline.sh 2>&1 | tail -6; cp $R/gpurun_out/timeline_depth*.json $OUT/
-ls -la $OUT
+cd $R
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log
+echo "== pytest gpu"; timeout 1800 python -m pytest tests -m gpu -q --timeout 1200 -s 2>&1 | grep -E "passed|failed|error|Error|ambiguity slack used|whole frame|libbgs build id" | tee $OUT/pytest_gpu_summary.log | tail -14
+echo "== sweeps"; SMALL=2000 MEDIUM=350 SURFEL=120 bash scripts/gpu_sweeps.sh $TAG 2>&1 | tail -8
+echo "== bench"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench.json; tail -2 $OUT/bench.err
+for i in 1 2; do timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_flags_$i.json 2>/dev/null; cut -c1-160 $OUT/bench_driver_flags_$i.json; done
+echo "== other configs"; timeout 900 python scripts/bench_configs.py > $OUT/bench_other_configs.json 2> $OUT/bench_other.err; grep -E "frames_per_s" $OUT/bench_other_configs.json | head -20
+echo "== rocprof"; bash scripts/gpu_profile.sh > $OUT/profile.log 2>&1; cp $R/gpurun_out/prof/* $OUT/ 2>/dev/null; tail -12 $OUT/profile.log
+python $R/scripts/make_pmc_traffic.py "$R/gpurun_out/pmc_dense/counters.txt" "$OUT/pmc_traffic.json" "$TAG" | cut -c1-400
+for w in surfel 5m_scene; do
+  PMC_GROUPS="0 3 5 6" bash scripts/gpu_pmc.sh $w $w > /dev/null 2>&1; cp $R/gpurun_out/pmc_$w/counters.txt $OUT/${w}_pmc_counters.txt
+  cd /tmp; rm -rf /tmp/p_$w
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$w -o trace -- python $R/scripts/loop_render.py $w 40 > /dev/null 2> /tmp/$w.err
+  for f in $(find /tmp/p_$w -name "*kernel_stats.csv"); do cp $f $OUT/${w}_kernel_stats.csv; done
+  cd $R
+done
+echo "== bench with the PMC stamp"; cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json; timeout 900 python bench.py --no-cpu-baseline > $OUT/bench_stamped.json 2>/dev/null; python -c "
+import json,sys
+d=json.load(open('$OUT/bench_stamped.json')); print(d['value'], json.dumps(d['roofline'].get('valu'))[:700], d['roofline'].get('traffic'))"
+echo "== timelines"; bash scripts/gpu_timeline.sh 2>&1 | tail -4; cp $R/gpurun_out/timeline_depth*.json $OUT/ 2>/dev/null
+echo "== tile traces"; for c in dense surfel 5m_scene; do timeout 300 python scripts/tile_trace.py $c $OUT/tile_trace_$c.json > /dev/null 2>&1; done
+echo "== gather calibration"; bash scripts/gpu_gather_fetch.sh $OUT 2>&1 | tail -7
+python scripts/isa_mix.py > $OUT/isa_mix_raster_scan_obb.txt 2>&1
+ls $OUT | head -60
