@@ -317,6 +317,8 @@ def main():
                     help="timed regions of --steps frames; the median is reported (default: 5, 3 from 2000 steps up)")
     args = ap.parse_args()
 
+    if os.environ.get("BGS_LIB_OVERRIDE"):
+        raise SystemExit("bench.py measures the library built from this tree's sources: unset BGS_LIB_OVERRIDE")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("BGS_BENCH_FORCE_DIST") != "1":
         raise SystemExit(launch_ranks(args.gpus))
 

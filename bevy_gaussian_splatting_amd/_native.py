@@ -151,12 +151,23 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    want = ensure_current()
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-    lib.bgs_build_id.argtypes = []
-    lib.bgs_build_id.restype = ctypes.c_char_p
-    if lib.bgs_build_id().decode() != want:
-        raise ImportError(f"{LIB_PATH}: bgs_build_id() disagrees with the id in the file's bytes")
+    override = os.environ.get("BGS_LIB_OVERRIDE")
+    if override:
+        # EXPERIMENTS ONLY (scripts/ab_variants.sh: same-box A/B of library variants built from modified sources): the
+        # named library is loaded as it is, whatever it was built from. Said loudly; bench.py and the tests refuse it.
+        import sys
+        print(f"bevy_gaussian_splatting_amd: BGS_LIB_OVERRIDE={override} — NOT the library of this tree "
+              f"(build id {_build_id.library_build_id(override)})", file=sys.stderr)
+        lib = ctypes.CDLL(override, mode=ctypes.RTLD_GLOBAL)
+        lib.bgs_build_id.argtypes = []
+        lib.bgs_build_id.restype = ctypes.c_char_p
+    else:
+        want = ensure_current()
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        lib.bgs_build_id.argtypes = []
+        lib.bgs_build_id.restype = ctypes.c_char_p
+        if lib.bgs_build_id().decode() != want:
+            raise ImportError(f"{LIB_PATH}: bgs_build_id() disagrees with the id in the file's bytes")
     vp = ctypes.c_void_p
     u32 = ctypes.c_uint32
     fp = ctypes.POINTER(ctypes.c_float)

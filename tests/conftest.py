@@ -11,6 +11,8 @@ for p in (ROOT, os.path.dirname(__file__)):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("BGS_LIB_OVERRIDE"):
+        raise pytest.UsageError("the tests check the library built from this tree's sources: unset BGS_LIB_OVERRIDE")
 
 
 def pytest_report_header(config):
