@@ -560,7 +560,8 @@ def main():
         roofline_main["bound"] = "valu" if (valu_frac is None or valu_frac >= hbm_frac) else "hbm"
         roofline_main["bound_note"] = ("achieved / peak / frac are the HBM figures of the contract (algorithmic bytes per launch / launch "
                                        "duration / 8 TB/s); the kernel is nearest to the vector-issue floor (`valu`), and its launch lasts "
-                                       "about twice its mean wave life (`tail`): neither HBM nor MFMA binds this algorithm")
+                                       "about twice its mean wave life (per-tile trace: profiles/r3_notes.md section 1): neither HBM nor "
+                                       "MFMA binds this algorithm")
         roofline_main["in_flight"] = roofline
 
         # "Msplats/s sorted": keygen + depth sort only (blocking calls, every one timed)
