@@ -21,11 +21,16 @@
  *     pair of tools/compare_aabb_obb.rs); every covered pixel of an anisotropic splat against the projected
  *     Gaussian; SH degree 0-3 against scipy's spherical harmonics at 1000 directions; the 2DGS
  *     local_to_pixel / mean_2d / extent against a ray-plane linear solve and the sampled cutoff ellipse, and
- *     the surfel image against the same solve; a three-splat stack against the closed-form "over" sum; plus
+ *     the surfel image against the same solve; a three-splat stack against the closed-form "over" sum; a WHOLE
+ *     random scene (120 overlapping splats, SH3, sRGB, adaptive radius, a third culled; OBB and AABB) against an
+ *     independent numpy float64 renderer, every pixel off the quad edges to 1e-6; plus
  *     the coarse thresholds of tests/visibility_render.rs:245-274 applied to the oracle's image. Where the
  *     reference itself departs from the geometric truth (OBB falloff tied to the quad, the 2DGS frame's doubled
  *     focal factor and half-size quad, the on-axis OBB NaN) the oracle follows the reference and the tests
  *     say so.
+ *   - ln(opacity) of the adaptive cutoff is the CORRECTLY ROUNDED binary32 logarithm (x87 logl rounded once;
+ *     checked against the product's binary64 implementation on all 2 139 095 039 positive inputs): it reaches the
+ *     2DGS degeneracy decisions, and WGSL leaves the precision of log open.
  *   - STILL PARITY UNPINNED: third-party arithmetic outside the reference tree — Bevy's projection matrix
  *     helper, wgpu's rasterisation rules / blend unit, glam, bevy_render 0.19.0's hsv_to_rgb (Classification
  *     and OpticalFlow colour variants) — restated and labelled where used.
