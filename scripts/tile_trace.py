@@ -59,14 +59,18 @@ hw, xcc = t[:, 4], t[:, 5] & 0xF
 scanned, blended, staged = t[:, 6], t[:, 7] & 0xFFFF, t[:, 7] >> 16
 wave_slot, simd, cu, sh, se = hw & 0xF, (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
 dur = (t1 - t0).astype(np.float64)
-# per XCD the launch starts when its first wave starts; the span of the whole launch in ticks
-start = np.array([t0[xcc == x].min() if (xcc == x).any() else 0 for x in range(16)])
-rel_end = (t1 - start[xcc]).astype(np.float64)
-rel_start = (t0 - start[xcc]).astype(np.float64)
+# s_memtime is a PER-CU time base (counters of different CUs are millions of ticks apart): a launch's timeline is taken
+# relative to the first wave of the same CU; one tick is one shader clock
+cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+cu_ids, cu_inv = np.unique(cu_key, return_inverse=True)
+start = np.full(len(cu_ids), np.iinfo(np.int64).max)
+np.minimum.at(start, cu_inv, t0)
+rel_end = (t1 - start[cu_inv]).astype(np.float64)
+rel_start = (t0 - start[cu_inv]).astype(np.float64)
 span_ticks = rel_end.max()
 launch_us = float(np.median(raster_ms)) * 1e3
-tick_us = launch_us / span_ticks   # calibrated on this launch (s_memtime is a fixed-rate counter)
-simd_key = ((xcc * 8 + se) * 2 + sh) * 16 * 4 + cu * 4 + simd
+tick_us = launch_us / span_ticks   # calibrated on this launch: the clock the kernel actually ran at
+simd_key = cu_key * 4 + simd
 keys, inv = np.unique(simd_key, return_inverse=True)
 tiles_per_simd = np.bincount(inv)
 blended_per_simd = np.bincount(inv, weights=blended)
@@ -77,7 +81,7 @@ q = lambda a, f: float(np.quantile(a, f))  # noqa: E731
 res = {
     "config": cfg, "tiles": int(tx * ty), "visible_splats": st["visible_count"], "coarse_entries": st["instance_count"],
     "raster_ms_traced_median": float(np.median(raster_ms)), "raster_ms_untraced_median": float(np.median(untraced)),
-    "tick_ns": tick_us * 1e3, "launch_span_us": launch_us,
+    "tick_ns": tick_us * 1e3, "clock_GHz": 1e-3 / tick_us, "launch_span_ticks": float(span_ticks), "launch_span_us": launch_us,
     "wave_life_us": {k: q(dur, f) * tick_us for k, f in (("p10", .1), ("p50", .5), ("p90", .9), ("p99", .99), ("max", 1.0))}
     | {"mean": float(dur.mean()) * tick_us},
     "wave_start_us": {"p50": q(rel_start, .5) * tick_us, "p99": q(rel_start, .99) * tick_us, "max": float(rel_start.max()) * tick_us},
@@ -87,7 +91,7 @@ res = {
                  "blended": [q(blended, .5), q(blended, .99), float(blended.max())], "columns": "p50, p99, max"},
     "corr_duration_vs": {"blended": float(np.corrcoef(dur, blended)[0, 1]), "staged": float(np.corrcoef(dur, staged)[0, 1]),
                          "scanned": float(np.corrcoef(dur, scanned)[0, 1])},
-    "simds_used": int(len(keys)), "xcds": sorted(int(x) for x in np.unique(xcc)),
+    "simds_used": int(len(keys)), "cus_used": int(len(cu_ids)), "xcds": sorted(int(x) for x in np.unique(xcc)),
     "per_simd": {"tiles": [int(tiles_per_simd.min()), float(np.median(tiles_per_simd)), int(tiles_per_simd.max())],
                  "blended_records": [float(blended_per_simd.min()), float(np.median(blended_per_simd)), float(blended_per_simd.max())],
                  "last_wave_ends_us": [q(last_end_per_simd, f) * tick_us for f in (.0, .1, .5, .9, 1.0)],
