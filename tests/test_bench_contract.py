@@ -119,3 +119,40 @@ def test_bench_gather_path_runs_with_one_rank():
     assert d["frame"]["frames_gathered_on_rank0"] == d["n_gpus"] * expected
     pr = d["per_rank"]
     assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["frames_per_s"] > 1000.0 and pr[0]["link_GBps"] is None
+
+
+def test_the_benchs_parity_checker_can_fail():
+    """bench.whole_frame_parity (the benchmarked frame against the oracle frame the CPU baseline renders): a checker that
+    cannot fail checks nothing. With a stand-in oracle whose ambiguity map is zero except at one marked pixel: a value
+    inside the tolerance passes, one beyond it fails and names the cell, the marked pixel may use its slack, and a frame
+    that is wrong everywhere is refused."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import bench
+
+    rng = np.random.default_rng(1)
+    ref = rng.uniform(0.0, 2.0, (96, 144, 4)).astype(np.float32)
+    amb_full = np.zeros((96, 144), np.float32)
+    amb_full[50, 70] = 0.05
+
+    class FakeOracle:
+        calls = 0
+
+        def render(self, cloud, entries, view, settings, window=None, with_ambiguity=False):
+            FakeOracle.calls += 1
+            x0, y0, x1, y1 = window
+            return ref[y0:y1, x0:x1].astype(np.float64), amb_full[y0:y1, x0:x1]
+
+    o = FakeOracle()
+    got = ref.copy()
+    got[10, 10, 1] += 5e-4                       # inside 1e-3 + 1e-4 |ref|
+    r = bench.whole_frame_parity(o, None, None, None, None, ref.astype(np.float64), got)
+    assert r["ok"] and r["values_beyond_strict_tolerance"] == 0 and r["pixels"] == 96 * 144 and FakeOracle.calls == 0
+    got[50, 70, 2] += 0.03                       # beyond the strict bound, inside this pixel's ambiguity slack
+    r = bench.whole_frame_parity(o, None, None, None, None, ref.astype(np.float64), got)
+    assert r["ok"] and r["values_on_ambiguity_slack"] == 1 and FakeOracle.calls == 1
+    got[20, 100, 0] += 0.01                      # a plain error: no slack there
+    r = bench.whole_frame_parity(o, None, None, None, None, ref.astype(np.float64), got)
+    assert not r["ok"] and "cell (96,0)" in r["why"], r
+    r = bench.whole_frame_parity(o, None, None, None, None, ref.astype(np.float64), ref + 0.5)
+    assert not r["ok"] and r["values_beyond_strict_tolerance"] == ref.size
