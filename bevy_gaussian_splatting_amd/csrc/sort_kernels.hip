@@ -103,6 +103,8 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     __shared__ uint32_t s_split[BUCKET ? BUCKET_COUNT : 1];
     __shared__ uint32_t s_bcnt[BUCKET ? BUCKET_COUNT : 1];   // pairs of this tile per bucket
     __shared__ uint32_t s_bexcl[BUCKET ? BUCKET_COUNT : 1];  // pairs of earlier tiles per bucket
+    __shared__ uint16_t s_at[BUCKET ? THREADS * KG_ITEMS : 1];  // arrival slot of compacted pair j inside its bucket (this tile)
+    __shared__ uint8_t s_bk[BUCKET ? THREADS * KG_ITEMS : 1];   // its bucket
     __shared__ uint32_t s_tot[4];
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_base;
@@ -223,7 +225,6 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                     atomicAdd(&s_hist[pl][(kk >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
             }
         }
-        uint32_t bk[KG_ITEMS], at[KG_ITEMS];  // BUCKET: bucket and arrival slot of compacted pair r * THREADS + tid
         if constexpr (BUCKET) {
             __syncthreads();
 #pragma unroll
@@ -235,8 +236,11 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
 #pragma unroll
                     for (uint32_t step = BUCKET_COUNT / 2u; step > 0u; step >>= 1)
                         if (s_split[lo + step - 1u] <= kk) lo += step;
-                    bk[r] = min(lo, BUCKET_COUNT - 1u);
-                    at[r] = atomicAdd(&s_bcnt[bk[r]], 1u);
+                    // bucket and arrival slot wait in LDS for the chain (16 + 16 registers per thread otherwise: typically
+                    // only the first two of the 16 rounds hold pairs, but the registers are reserved for all)
+                    const uint32_t bkt = min(lo, BUCKET_COUNT - 1u);
+                    s_bk[j] = (uint8_t)bkt;
+                    s_at[j] = (uint16_t)min(atomicAdd(&s_bcnt[bkt], 1u), 0xFFFFu);
                 }
             }
             __syncthreads();
@@ -275,12 +279,14 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
             for (int r = 0; r < KG_ITEMS; ++r) {
                 const uint32_t j = (uint32_t)(r * THREADS) + (uint32_t)tid;
                 if (j < total) {
-                    const uint32_t slot = s_bexcl[bk[r]] + at[r];
+                    const uint32_t bkt = s_bk[j];
+                    const uint32_t slot = s_bexcl[bkt] + (uint32_t)s_at[j];
                     if (slot < BUCKET_CAP)  // a bucket over capacity is seen by bucket_sort_kernel (count > cap)
-                        bucket_slots[(size_t)bk[r] * BUCKET_CAP + slot] = make_uint2(s_keys[j], s_idx[j]);
+                        bucket_slots[(size_t)bkt * BUCKET_CAP + slot] = make_uint2(s_keys[j], s_idx[j]);
                 }
             }
         }
+        {
         const uint32_t vis_base = s_base;
 #pragma unroll
         for (int k = 0; k < KG_ITEMS; ++k) {
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                     __builtin_nontemporal_store((v2u){key[k], i}, reinterpret_cast<v2u*>(culled + (i - before)));
                 }
             }
+        }
         }
 #undef BGS_KG_DRAWN
         if (single_shot) break;
@@ -315,21 +322,16 @@ bool KeygenLaunch::prepare(int max_blocks) {
     // round of barriers
     const uint32_t per_block = keygen_tile_splats(fp.n);
     const bool bucket = fp.sort_path == 1u;
+#define BGS_KG_PICK(ITEMS, THR) \
+    (bucket ? reinterpret_cast<const void*>(&keygen_kernel<ITEMS, true, THR>) : reinterpret_cast<const void*>(&keygen_kernel<ITEMS, false, THR>))
 #if BGS_KEYGEN_WIDE_THREADS == 256
     threads = 256u;
-    if (per_block >= 4096u)
-        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<16, true, 256>) : reinterpret_cast<const void*>(&keygen_kernel<16, false, 256>);
-    else
-        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<8, true, 256>) : reinterpret_cast<const void*>(&keygen_kernel<8, false, 256>);
+    func = per_block >= 4096u ? BGS_KG_PICK(16, 256) : BGS_KG_PICK(8, 256);
 #else
     threads = per_block >= 4096u ? 1024u : 256u;
-    if (per_block == 8192u)
-        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<8, true, 1024>) : reinterpret_cast<const void*>(&keygen_kernel<8, false, 1024>);
-    else if (per_block == 4096u)
-        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<4, true, 1024>) : reinterpret_cast<const void*>(&keygen_kernel<4, false, 1024>);
-    else
-        func = bucket ? reinterpret_cast<const void*>(&keygen_kernel<8, true, 256>) : reinterpret_cast<const void*>(&keygen_kernel<8, false, 256>);
+    func = per_block == 8192u ? BGS_KG_PICK(8, 1024) : (per_block == 4096u ? BGS_KG_PICK(4, 1024) : BGS_KG_PICK(8, 256));
 #endif
+#undef BGS_KG_PICK
     blocks = (fp.n + per_block - 1) / per_block;
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
     argv[0] = &fp; argv[1] = &pos; argv[2] = &entries; argv[3] = &culled; argv[4] = &ctl;
