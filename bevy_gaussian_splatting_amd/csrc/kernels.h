@@ -158,7 +158,8 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
-                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace = nullptr);
+                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace = nullptr,
+                        bool midround_exit = false);
 // out_format bits: which packed image the rasteriser writes next to (or instead of) the f32 target
 constexpr uint32_t OUT_SRGB8 = 1u;     // Rgba8UnormSrgb, 4 B per pixel
 constexpr uint32_t OUT_RGBA16F = 2u;   // Rgba16Float, 8 B per pixel (the reference's hdr target)

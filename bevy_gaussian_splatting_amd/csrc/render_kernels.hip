@@ -884,7 +884,17 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 //   { HW_ID register, XCC_ID register, candidates scanned, records blended | records staged << 16 }
 // — where a tile ran (XCD / SE / CU / SIMD / wave slot), for how long, and on how much work: what the analysis of
 // the launch's tail (scripts/tile_trace.py) is made from. The production instantiation carries none of it.
-template <int VARIANT, bool TRACE = false>
+// MIDROUND_EXIT: look for saturation inside a staging round as well (every 4th record), not only at its end. A tile
+// of a DENSE frame saturates somewhere inside a round of up to 64 records, and the records behind that point each still
+// pay the four strips' reject path: leaving early changes no bit (saturated pixels never accumulate) and saves 7 % of
+// the rasteriser's time on the dense 1 M frame, 18 % on the dense 5 M frame. On frames whose tiles rarely saturate
+// (small splats; surfels, which need ~300 records per tile) the four compares, the ballot and the extra loop exit
+// only cost: +18 % / +21 % / +14 % on the scene-like 1 M / 5 M and the dense surfel frame. So it is an instantiation
+// the launcher picks per frame (supertile level >= 2, i.e. splats larger than a supertile, and not the surfel variant).
+#ifndef BGS_MIDROUND_PERIOD
+#define BGS_MIDROUND_PERIOD 4u
+#endif
+template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false>
 __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_mul,
@@ -1077,6 +1087,8 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
                 if constexpr (TRACE) trace_blended += 1u;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
+                if constexpr (MIDROUND_EXIT)
+                    if ((k & (BGS_MIDROUND_PERIOD - 1u)) == BGS_MIDROUND_PERIOD - 1u && __all(T[0] < t_eps && T[1] < t_eps && T[2] < t_eps && T[3] < t_eps)) break;
             }
             const bool sat = T[0] < t_eps && T[1] < t_eps && T[2] < t_eps && T[3] < t_eps;
             saturated = __all(sat);
@@ -1137,24 +1149,24 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
-                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace) {
+                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace, bool midround_exit) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4* rec = (const float4*)records;
     const uint32_t sup = sup_edge, sup_mul = supertile_mul(sup_edge);
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
-#define BGS_LAUNCH_RS(V)                                                                          \
+#define BGS_LAUNCH_RS(V, X)                                                                       \
     do {                                                                                          \
         if (tile_trace)                                                                           \
-            hipLaunchKernelGGL((raster_scan_kernel<V, true>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
+            hipLaunchKernelGGL((raster_scan_kernel<V, true, X>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
                                coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, tile_trace); \
         else                                                                                      \
-            hipLaunchKernelGGL((raster_scan_kernel<V, false>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
+            hipLaunchKernelGGL((raster_scan_kernel<V, false, X>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
                                coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (uint4*)nullptr); \
     } while (0)
-    if (fp.aabb == 0u) BGS_LAUNCH_RS(RV_OBB);
-    else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RS(RV_AABB3D);
-    else BGS_LAUNCH_RS(RV_SURFEL);
+    if (fp.aabb == 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_OBB, true); else BGS_LAUNCH_RS(RV_OBB, false); }
+    else if (fp.gaussian_mode != 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_AABB3D, true); else BGS_LAUNCH_RS(RV_AABB3D, false); }
+    else BGS_LAUNCH_RS(RV_SURFEL, false);
 #undef BGS_LAUNCH_RS
 }
 
