@@ -99,6 +99,8 @@ class BgsStats(ctypes.Structure):
         ("frames_averaged", ctypes.c_uint32),
         ("list_capacity", ctypes.c_uint32),
         ("list_entries_allocated", ctypes.c_uint64),
+        ("strip_tiles", ctypes.c_uint32),
+        ("reserved_stats", ctypes.c_uint32),
     ]
 
 

@@ -112,7 +112,8 @@ struct Control {
     uint32_t splat_count;     // N, parked on the device so the sort kernels read every size the same way
     uint32_t sort_overflow;   // bucket sort gave up (1 bucket over capacity, 2 too many equal keys): re-run with onesweep
     uint32_t bucket_max;      // fullest bucket (stats)
-    uint32_t pad0[22];        // the read-mostly header owns its 128-byte line (see ticket)
+    uint32_t strip_tiles;     // tiles this frame's rasteriser drew with four strip waves (the consumed heavy-tile list; stats)
+    uint32_t pad0[21];        // the read-mostly header owns its 128-byte line (see ticket)
     // dynamic tile ids, one word per kernel launch of the frame, each in its OWN 128-byte line: every
     // block of a launch does a returning atomic on its ticket and the L2 retires same-line atomics one
     // at a time (~8 ns), so a load of draw_count queued behind them on a shared line waited for all.
@@ -129,7 +130,7 @@ struct Control {
     uint32_t splitters[BUCKET_COUNT];    // quantile keys of THIS frame's sorted list (keygen key space): the
                                          // host hands them to later frames' keygen (SplitterTable)
 };
-constexpr uint32_t CONTROL_HEADER_WORDS = 10;  // draw_count .. bucket_max: what a frame reports to the host
+constexpr uint32_t CONTROL_HEADER_WORDS = 11;  // draw_count .. strip_tiles: what a frame reports to the host
 
 
 // packed tile rectangle x0 | x1 << 8 | y0 << 16 | y1 << 24 (inclusive); x0 > x1 = touches no tile

@@ -85,10 +85,11 @@ struct KeygenLaunch {
     uint2* bucket_slots;  // fp.sort_path == 1: [BUCKET_COUNT][BUCKET_CAP] slot regions
     uint32_t* bucket_status;  // fp.sort_path == 1: zeroed look-back words [keygen tiles][BUCKET_COUNT]
     SplitterTable split;      // fp.sort_path == 1: bucket = number of entries <= key
+    uint32_t* zero_word;      // a word the frame needs zeroed before its later kernels run (the rasteriser's heavy-tile count), or null
     // filled by prepare(): the launch geometry and the argument vector (points into this object)
     const void* func;
     uint32_t blocks, threads;
-    void* argv[12];
+    void* argv[13];
     bool prepare(int max_blocks);  // false: nothing to launch (n == 0)
     hipError_t launch(hipStream_t stream);
     hipError_t update_node(hipGraphExec_t exec, hipGraphNode_t node);  // same launch, as a graph node update
@@ -159,7 +160,14 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
                         uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace = nullptr,
-                        bool midround_exit = false);
+                        bool midround_exit = false, const uint8_t* heavy_in = nullptr, uint8_t* heavy_out = nullptr);
+// HeavyFeedback: what the rasteriser of a dense frame (midround_exit) leaves for the frames behind it — the tiles that
+// did not saturate inside their first staging round, as a list (for the strip workgroups) and as a flag per tile (for the
+// regular waves, which step aside). One buffer: [count (own 128-byte line) | list u16[HEAVY_CAP] | flag u8[tiles]].
+// The count is zeroed by the producing frame's keygen; a frame only ever reads the buffer of a COMPLETED frame
+// (bgs_api.hip hands out the pointer in finish_lane), so list, flags and count are consistent by construction.
+constexpr uint32_t HEAVY_CAP = 256u, HEAVY_LIST_OFFSET = 128u, HEAVY_FLAGS_OFFSET = HEAVY_LIST_OFFSET + 2u * HEAVY_CAP;
+inline size_t heavy_feedback_bytes(uint32_t tiles) { return (size_t)HEAVY_FLAGS_OFFSET + tiles; }
 // out_format bits: which packed image the rasteriser writes next to (or instead of) the f32 target
 constexpr uint32_t OUT_SRGB8 = 1u;     // Rgba8UnormSrgb, 4 B per pixel
 constexpr uint32_t OUT_RGBA16F = 2u;   // Rgba16Float, 8 B per pixel (the reference's hdr target)

@@ -894,86 +894,44 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 #ifndef BGS_MIDROUND_PERIOD
 #define BGS_MIDROUND_PERIOD 4u
 #endif
-template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false>
-__global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
-                                                          const uint32_t* __restrict__ coarse,
-                                                          uint32_t coarse_cap, uint32_t sup_mul,
-                                                          uint32_t sup_x, Control* ctl,
-                                                          float4* __restrict__ fb,
-                                                          uint32_t* __restrict__ fb8_default, uint32_t want_srgb8,
-                                                          FrameCleanup cl, uint4* __restrict__ trace) {
-    unsigned long long trace_t0 = 0ull;
-    uint32_t trace_scanned = 0u, trace_blended = 0u, trace_staged = 0u;
-    if constexpr (TRACE) trace_t0 = __builtin_amdgcn_s_memtime();
-    const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
+// One tile — or, with ROWS == 1, one 16 x 4 ROW STRIP of a tile (rows row0 .. row0 + 3, one pixel per lane) — by one wave.
+// A wave that owns a whole tile has four pixels per lane (rows row0 + (lane >> 4) + {0, 4, 8, 12}, row0 = 0) and runs
+// the four strips' chains one after the other, ~950 clocks per record whether it shares its SIMD or not; a strip wave
+// runs one chain per record. The arithmetic per pixel is the same (records are staged relative to the TILE's first
+// pixel either way), so which of the two shapes draws a pixel changes no bit. Returns the staging rounds it blended.
+template <int ROWS>
+__device__ __forceinline__ bool all_saturated(const float (&T)[ROWS], const float t_eps) {
+    bool s = true;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) s = s && T[r] < t_eps;
+    return s;
+}
+template <int VARIANT, bool TRACE, bool MIDROUND_EXIT, int ROWS>
+__device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const float4* __restrict__ records,
+                                               const uint32_t* __restrict__ coarse, const uint32_t coarse_cap,
+                                               const uint32_t sup_mul, const uint32_t sup_x, Control* ctl,
+                                               float4* __restrict__ fb, uint32_t* __restrict__ fb8_default,
+                                               const uint32_t want_srgb8, const float t_eps, const float surfel_limit,
+                                               float4* const s_rec, uint32_t* const s_queue, const int lane,
+                                               const uint32_t tile, const int row0, uint32_t& trace_scanned,
+                                               uint32_t& trace_blended, uint32_t& trace_staged) {
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
-    // records staged per round: the whole queue (24 KB of LDS per workgroup for the 96-byte surfel records, five
-    // workgroups per CU at its 5 waves/SIMD; rounds of 32 were 1-5 % slower)
     constexpr uint32_t STAGE = 64u;
-    __shared__ float4 s_rec_all[4][STAGE * REC_V4];
-    __shared__ uint32_t s_queue_all[4][64];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
-    const uint32_t nblocks = (ntiles + 3u) / 4u;
-    const uint32_t tile = xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
-    const uint32_t draw_count = ctl->draw_count;
-    const uint32_t cmax_bits = __builtin_amdgcn_readfirstlane(ctl->color_max_bits);
-    const float t_eps = frame_t_eps(cmax_bits);
-    const float surfel_limit = frame_surfel_limit(cmax_bits);
-    if (cl.other_ctl) {
-        // the status words of this frame's chained scans are dead by now: zero the used ones, and
-        // the Control block the lane's next frame will use; report this frame's counters to the host
-        const uint32_t g = blockIdx.x * 256u + (uint32_t)tid, gn = nblocks * 256u;
-        uint32_t* zc = reinterpret_cast<uint32_t*>(cl.other_ctl);
-        for (uint32_t i = g; i < (uint32_t)(sizeof(Control) / 4u); i += gn) zc[i] = 0u;
-        if (blockIdx.x == nblocks - 1u) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
-            uint32_t* host = reinterpret_cast<uint32_t*>(cl.host_ctl);
-            constexpr uint32_t HEADER_WORDS = CONTROL_HEADER_WORDS;  // draw_count .. bucket_max
-            constexpr uint32_t COARSE_OFF = (uint32_t)(offsetof(Control, coarse_total) / 4u);
-            constexpr uint32_t SPLIT_OFF = (uint32_t)(offsetof(Control, splitters) / 4u);
-            if ((uint32_t)tid < HEADER_WORDS) host[tid] = src[tid];
-            host[COARSE_OFF + (uint32_t)tid] = src[COARSE_OFF + (uint32_t)tid];
-            // the 1/256-quantile keys of this frame's sorted list: later frames' bucket splitters
-            host[SPLIT_OFF + (uint32_t)tid] =
-                (draw_count != 0u && (uint32_t)tid < BUCKET_COUNT - 1u)
-                    ? (cl.sorted[(uint32_t)(((unsigned long long)((uint32_t)tid + 1u) * draw_count) >> 8)].x ^ cl.key_xor)
-                    : 0xFFFFFFFFu;
-        }
-        const uint32_t part_words = (fp.n + KEYGEN_TILE - 1u) / KEYGEN_TILE;
-        for (uint32_t i = g; i < part_words; i += gn) cl.part_status[i] = 0u;
-        const uint32_t depth_v4 = ((draw_count + cl.depth_tile - 1u) / cl.depth_tile) * (RADIX_BASE / 4u);
-        for (uint32_t p = 0u; p < cl.places; ++p) {
-            uint4* dst = reinterpret_cast<uint4*>(cl.depth_status + (size_t)p * cl.pass_stride);
-            for (uint32_t i = g; i < depth_v4; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        {   // bucket-sort frames: keygen's per-bucket chains live at the start of the depth status words
-            uint4* dst = reinterpret_cast<uint4*>(cl.depth_status);
-            for (uint32_t i = g; i < cl.bucket_chain_words / 4u; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        const uint32_t bin_v4 = ((draw_count + 255u) / 256u) * (MAX_SUPERTILES / 4u);
-        uint4* bdst = reinterpret_cast<uint4*>(cl.bin_status);
-        for (uint32_t i = g; i < bin_v4; i += gn) bdst[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    if (tile < ntiles) {  // whole wave; nothing in here synchronises across waves
-    float4* const s_rec = s_rec_all[wave];
-    uint32_t* const s_queue = s_queue_all[wave];  // plain LDS accesses, ordered by the wave barriers + fences below
 
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
-    const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + (lane >> 4);
+    const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + row0 + (lane >> 4);
     // OBB and surfel records are staged tile-local (stage_obb / stage_surfel): pixels are then addressed inside the tile
     const float qx = VARIANT != RV_AABB3D ? (float)(lane & 15) : (float)px + 0.5f;
     const float aspect = fp.viewport_w / fp.viewport_h;
     const float tile_cx = (float)((int)tx * TILE_PX + 8), tile_cy = (float)((int)ty * TILE_PX + 8);
     const float tile_ox = (float)((int)tx * TILE_PX) + 0.5f, tile_oy = (float)((int)ty * TILE_PX) + 0.5f;
 
-    float T[4], cb[4], qy[4];
-    v2f crg[4];
+    float T[ROWS], cb[ROWS], qy[ROWS];
+    v2f crg[ROWS];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < ROWS; ++r) {
         const int py = py0 + 4 * r;
-        qy[r] = VARIANT != RV_AABB3D ? (float)((lane >> 4) + 4 * r) : (float)py + 0.5f;
+        qy[r] = VARIANT != RV_AABB3D ? (float)(row0 + (lane >> 4) + 4 * r) : (float)py + 0.5f;
         T[r] = (px < fp.width && py < fp.height) ? 1.0f : 0.0f;
         crg[r] = (v2f){0.0f, 0.0f};
         cb[r] = 0.0f;
@@ -997,6 +955,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
     // list fills the queue with its first group, so nothing changes there.
     constexpr uint32_t FLUSH_AT = 32u;
     uint32_t qn = 0u;  // ranks waiting in s_queue (wave-uniform)
+    uint32_t rounds = 0u;  // staging rounds blended so far (a dense frame's heavy tiles: more than one)
     uint32_t base = 0u;
     for (;;) {
         const bool have = base < total;
@@ -1086,12 +1045,12 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
                 if (__builtin_amdgcn_readfirstlane(keep_flag) == 0u) continue;  // scalar branch
                 if constexpr (TRACE) trace_blended += 1u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
+                for (int r = 0; r < ROWS; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
                 if constexpr (MIDROUND_EXIT)
-                    if ((k & (BGS_MIDROUND_PERIOD - 1u)) == BGS_MIDROUND_PERIOD - 1u && __all(T[0] < t_eps && T[1] < t_eps && T[2] < t_eps && T[3] < t_eps)) break;
+                    if ((k & (BGS_MIDROUND_PERIOD - 1u)) == BGS_MIDROUND_PERIOD - 1u && __all(all_saturated(T, t_eps))) break;
             }
-            const bool sat = T[0] < t_eps && T[1] < t_eps && T[2] < t_eps && T[3] < t_eps;
-            saturated = __all(sat);
+            saturated = __all(all_saturated(T, t_eps));
+            ++rounds;
             }
             if (saturated) break;
             __builtin_amdgcn_wave_barrier();  // blend reads of s_rec / s_queue done before they are rewritten
@@ -1104,9 +1063,9 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
         // indices alive across the blend loop costs registers the loop needs (they were spilled)
         int lw = lane;
         asm volatile("" : "+v"(lw));
-        const int pxw = (int)tx * TILE_PX + (lw & 15), pyw = (int)ty * TILE_PX + (lw >> 4);
+        const int pxw = (int)tx * TILE_PX + (lw & 15), pyw = (int)ty * TILE_PX + row0 + (lw >> 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < ROWS; ++r) {
             const int py = pyw + 4 * r;
             if (pxw < fp.width && py < fp.height) {
                 const float4 c = make_float4(fmaf(T[r], fp.clear[0], crg[r].x), fmaf(T[r], fp.clear[1], crg[r].y),
@@ -1133,23 +1092,139 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
             }
         }
     }
-    if constexpr (TRACE) {
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        if (lane == 0 && trace) {
-            const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID, all 32 bits
-            const uint32_t xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
-            trace[2u * tile] = make_uint4((uint32_t)trace_t0, (uint32_t)(trace_t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
-            trace[2u * tile + 1u] = make_uint4(hw_id, xcc_id, trace_scanned, min(trace_blended, 0xFFFFu) | (min(trace_staged, 0xFFFFu) << 16));
+    return rounds;
+}
+
+template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false>
+__global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
+                                                          const uint32_t* __restrict__ coarse,
+                                                          uint32_t coarse_cap, uint32_t sup_mul,
+                                                          uint32_t sup_x, Control* ctl,
+                                                          float4* __restrict__ fb,
+                                                          uint32_t* __restrict__ fb8_default, uint32_t want_srgb8,
+                                                          FrameCleanup cl, uint4* __restrict__ trace,
+                                                          const uint8_t* __restrict__ heavy_in, uint8_t* __restrict__ heavy_out) {
+    unsigned long long trace_t0 = 0ull;
+    uint32_t trace_scanned = 0u, trace_blended = 0u, trace_staged = 0u;
+    if constexpr (TRACE) trace_t0 = __builtin_amdgcn_s_memtime();
+    const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
+    constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
+    // records staged per round: the whole queue (24 KB of LDS per workgroup for the 96-byte surfel records, five
+    // workgroups per CU at its 5 waves/SIMD; rounds of 32 were 1-5 % slower)
+    constexpr uint32_t STAGE = 64u;
+    __shared__ float4 s_rec_all[4][STAGE * REC_V4];
+    __shared__ uint32_t s_queue_all[4][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
+    const uint32_t nblocks = (ntiles + 3u) / 4u;
+    // HEAVY TILES (MIDROUND_EXIT instantiations, i.e. dense frames; kernels.h HeavyFeedback): the workgroups behind the
+    // regular grid each take ONE tile of the list a completed frame left — a tile that needed more than one staging round
+    // there — and give each of its four 16 x 4 row strips a wave of its own; the regular wave of such a tile steps aside.
+    const bool strip_block = MIDROUND_EXIT && blockIdx.x >= nblocks;
+    uint32_t tile = strip_block ? 0xFFFFFFFFu : xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
+    if constexpr (MIDROUND_EXIT) {
+        if (strip_block) {
+            const uint32_t have = heavy_in ? min(*reinterpret_cast<const uint32_t*>(heavy_in), HEAVY_CAP) : 0u;
+            const uint32_t sb = blockIdx.x - nblocks;
+            if (sb >= have) return;
+            tile = reinterpret_cast<const uint16_t*>(heavy_in + HEAVY_LIST_OFFSET)[sb];
+        } else if (heavy_in && tile < ntiles && heavy_in[HEAVY_FLAGS_OFFSET + tile]) {
+            tile = 0xFFFFFFFFu;   // a strip block draws this tile
         }
     }
-    }  // tile < ntiles
+    const uint32_t draw_count = ctl->draw_count;
+    const uint32_t cmax_bits = __builtin_amdgcn_readfirstlane(ctl->color_max_bits);
+    const float t_eps = frame_t_eps(cmax_bits);
+    const float surfel_limit = frame_surfel_limit(cmax_bits);
+    if (cl.other_ctl && !strip_block) {
+        // the status words of this frame's chained scans are dead by now: zero the used ones, and
+        // the Control block the lane's next frame will use; report this frame's counters to the host
+        const uint32_t g = blockIdx.x * 256u + (uint32_t)tid, gn = nblocks * 256u;
+        uint32_t* zc = reinterpret_cast<uint32_t*>(cl.other_ctl);
+        for (uint32_t i = g; i < (uint32_t)(sizeof(Control) / 4u); i += gn) zc[i] = 0u;
+        if (blockIdx.x == nblocks - 1u) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl);
+            uint32_t* host = reinterpret_cast<uint32_t*>(cl.host_ctl);
+            constexpr uint32_t HEADER_WORDS = CONTROL_HEADER_WORDS;  // draw_count .. strip_tiles
+            constexpr uint32_t COARSE_OFF = (uint32_t)(offsetof(Control, coarse_total) / 4u);
+            constexpr uint32_t SPLIT_OFF = (uint32_t)(offsetof(Control, splitters) / 4u);
+            static_assert(offsetof(Control, strip_tiles) / 4u == HEADER_WORDS - 1u, "strip_tiles is the header's last word");
+            if ((uint32_t)tid < HEADER_WORDS - 1u) host[tid] = src[tid];
+            if ((uint32_t)tid == HEADER_WORDS - 1u) {   // how many tiles this launch draws with strip workgroups (known at its start)
+                uint32_t strips = 0u;
+                if constexpr (MIDROUND_EXIT) strips = heavy_in ? min(*reinterpret_cast<const uint32_t*>(heavy_in), HEAVY_CAP) : 0u;
+                host[tid] = strips;
+            }
+            host[COARSE_OFF + (uint32_t)tid] = src[COARSE_OFF + (uint32_t)tid];
+            // the 1/256-quantile keys of this frame's sorted list: later frames' bucket splitters
+            host[SPLIT_OFF + (uint32_t)tid] =
+                (draw_count != 0u && (uint32_t)tid < BUCKET_COUNT - 1u)
+                    ? (cl.sorted[(uint32_t)(((unsigned long long)((uint32_t)tid + 1u) * draw_count) >> 8)].x ^ cl.key_xor)
+                    : 0xFFFFFFFFu;
+        }
+        const uint32_t part_words = (fp.n + KEYGEN_TILE - 1u) / KEYGEN_TILE;
+        for (uint32_t i = g; i < part_words; i += gn) cl.part_status[i] = 0u;
+        const uint32_t depth_v4 = ((draw_count + cl.depth_tile - 1u) / cl.depth_tile) * (RADIX_BASE / 4u);
+        for (uint32_t p = 0u; p < cl.places; ++p) {
+            uint4* dst = reinterpret_cast<uint4*>(cl.depth_status + (size_t)p * cl.pass_stride);
+            for (uint32_t i = g; i < depth_v4; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        {   // bucket-sort frames: keygen's per-bucket chains live at the start of the depth status words
+            uint4* dst = reinterpret_cast<uint4*>(cl.depth_status);
+            for (uint32_t i = g; i < cl.bucket_chain_words / 4u; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const uint32_t bin_v4 = ((draw_count + 255u) / 256u) * (MAX_SUPERTILES / 4u);
+        uint4* bdst = reinterpret_cast<uint4*>(cl.bin_status);
+        for (uint32_t i = g; i < bin_v4; i += gn) bdst[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint32_t tile_done = 0xFFFFFFFFu;
+    if (tile < ntiles) {  // whole wave; nothing in here synchronises across waves
+        uint32_t rounds;
+        bool reports = true;   // which wave speaks for the tile in the feedback
+        if (MIDROUND_EXIT && strip_block) {
+            rounds = raster_tile<VARIANT, false, MIDROUND_EXIT, 1>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
+                                                                   t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], lane, tile, 4 * wave,
+                                                                   trace_scanned, trace_blended, trace_staged);
+            reports = wave == 0;
+        } else {
+            rounds = raster_tile<VARIANT, TRACE, MIDROUND_EXIT, 4>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
+                                                                   t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], lane, tile, 0,
+                                                                   trace_scanned, trace_blended, trace_staged);
+            tile_done = tile;
+        }
+        if constexpr (MIDROUND_EXIT) {
+            // feedback for the frames behind this one: a tile that did not saturate inside its first staging round is
+            // heavy (parameter-free: the median tile of a dense frame saturates after ~35 of the round's <= 64 records)
+            if (heavy_out && reports && lane == 0) {
+                bool heavy = rounds >= 2u;
+                if (heavy) {
+                    const uint32_t at = atomicAdd(reinterpret_cast<uint32_t*>(heavy_out), 1u);
+                    if (at < HEAVY_CAP) reinterpret_cast<uint16_t*>(heavy_out + HEAVY_LIST_OFFSET)[at] = (uint16_t)tile;
+                    else heavy = false;   // a flagged tile must be in the list: somebody has to draw it
+                }
+                heavy_out[HEAVY_FLAGS_OFFSET + tile] = heavy ? 1u : 0u;
+            }
+        }
+    }
 
+    if constexpr (TRACE) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && trace && tile_done != 0xFFFFFFFFu) {
+            const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID, all 32 bits
+            const uint32_t xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+            trace[2u * tile_done] = make_uint4((uint32_t)trace_t0, (uint32_t)(trace_t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
+            trace[2u * tile_done + 1u] = make_uint4(hw_id, xcc_id, trace_scanned, min(trace_blended, 0xFFFFu) | (min(trace_staged, 0xFFFFu) << 16));
+        }
+    }
 }
 
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
-                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace, bool midround_exit) {
+                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace, bool midround_exit,
+                        const uint8_t* heavy_in, uint8_t* heavy_out) {
+    if (!midround_exit) { heavy_in = nullptr; heavy_out = nullptr; }
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4* rec = (const float4*)records;
@@ -1157,12 +1232,13 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
 #define BGS_LAUNCH_RS(V, X)                                                                       \
     do {                                                                                          \
+        const uint32_t grid = (ntiles + 3u) / 4u + ((X) && heavy_in ? HEAVY_CAP : 0u);            \
         if (tile_trace)                                                                           \
-            hipLaunchKernelGGL((raster_scan_kernel<V, true, X>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
-                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, tile_trace); \
+            hipLaunchKernelGGL((raster_scan_kernel<V, true, X>), dim3(grid), dim3(256), 0, stream, d_fp, rec,  \
+                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, tile_trace, heavy_in, heavy_out); \
         else                                                                                      \
-            hipLaunchKernelGGL((raster_scan_kernel<V, false, X>), dim3((ntiles + 3u) / 4u), dim3(256), 0, stream, d_fp, rec,  \
-                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (uint4*)nullptr); \
+            hipLaunchKernelGGL((raster_scan_kernel<V, false, X>), dim3(grid), dim3(256), 0, stream, d_fp, rec,  \
+                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (uint4*)nullptr, heavy_in, heavy_out); \
     } while (0)
     if (fp.aabb == 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_OBB, true); else BGS_LAUNCH_RS(RV_OBB, false); }
     else if (fp.gaussian_mode != 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_AABB3D, true); else BGS_LAUNCH_RS(RV_AABB3D, false); }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                                                          uint32_t* part_status, uint32_t places,
                                                          uint32_t ticket_slot, FrameParams* fp_out,
                                                          uint2* __restrict__ bucket_slots, uint32_t* bucket_status,
-                                                         SplitterTable split) {
+                                                         SplitterTable split, uint32_t* zero_word) {
     constexpr int WAVES = THREADS / 64;
     constexpr int ROWS = KG_ITEMS * WAVES;  // 64-splat rows of a tile, in index order (item, wave)
     static_assert((THREADS == 256 || THREADS == 1024) && ROWS <= 128, "tile geometry");
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     // a new view by updating this one node's arguments.
     if (fp_out && blockIdx.x == 0 && (uint32_t)tid < (uint32_t)(sizeof(FrameParams) / 4u))
         reinterpret_cast<uint32_t*>(fp_out)[tid] = reinterpret_cast<const uint32_t*>(&fp)[tid];
+    if (zero_word && blockIdx.x == 0 && tid == 0) *zero_word = 0u;
     if (tid < 256) {
         if constexpr (BUCKET) {
             s_split[tid] = tid < (int)BUCKET_COUNT - 1 ? split.key[tid] : 0xFFFFFFFFu;
@@ -336,7 +337,7 @@ bool KeygenLaunch::prepare(int max_blocks) {
     if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
     argv[0] = &fp; argv[1] = &pos; argv[2] = &entries; argv[3] = &culled; argv[4] = &ctl;
     argv[5] = &part_status; argv[6] = &places; argv[7] = &ticket_slot; argv[8] = &fp_out; argv[9] = &bucket_slots;
-    argv[10] = &bucket_status; argv[11] = &split;
+    argv[10] = &bucket_status; argv[11] = &split; argv[12] = &zero_word;
     return true;
 }
 

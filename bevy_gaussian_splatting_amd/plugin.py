@@ -403,6 +403,7 @@ class GaussianSplattingPlugin:
             "instance_count": int(st.instance_count),
             "instance_capacity": int(st.instance_capacity),
             "list_entries_allocated": int(st.list_entries_allocated),
+            "strip_tiles": int(st.strip_tiles),
             "tiles": (int(st.tiles_x), int(st.tiles_y)),
             "depth_passes": int(st.depth_passes),
             "tile_passes": int(st.tile_passes),

@@ -160,6 +160,9 @@ typedef struct bgs_stats {
     uint32_t list_capacity;      /* BGS_BINNING_SCAN: entries each supertile list could hold  */
     uint64_t list_entries_allocated; /* BGS_BINNING_SCAN: 8-byte list entries allocated for the lane (all supertile
                                     lists together); instance_count is how many of them the frame filled */
+    uint32_t strip_tiles;        /* tiles of the frame that were drawn by four strip waves instead of one wave (dense
+                                    frames: the tiles a completed frame found heavy); 0 otherwise */
+    uint32_t reserved_stats;
 } bgs_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */

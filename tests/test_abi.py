@@ -44,7 +44,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(BgsView) == (16 * 4 + 8 + 16 + 4) * 4
     assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8 + 1 + 1 + 2 + 8) * 4
     assert ctypes.sizeof(_native.BgsSortEntry) == 8
-    assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 4 * 4 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 4 * 4 + 8 + 8 + 8 + 8 + 8
     # the ctypes images include natural padding exactly like the C structs
     assert _native.BgsStats.instance_count.offset % 8 == 0
 

@@ -1294,6 +1294,72 @@ def test_whole_frame_parity_1m_2dgs(plugin, oracle, cloud_1m, aabb):
     h.free()
 
 
+
+@pytest.mark.parametrize("what", ["1m_f32", "2dgs_obb", "aabb3d"])
+def test_heavy_tiles_drawn_by_strip_waves_give_the_same_bits(plugin, oracle, cloud_1m, what):
+    """Dense frames (supertile level >= 2) run the rasteriser's mid-round-exit instantiation, and the tiles a completed
+    frame found heavy (more than one staging round) are drawn by a workgroup of four strip waves in the frames behind it
+    while their regular wave steps aside (`stats()["strip_tiles"]`). Whichever shape draws a pixel, its arithmetic is the
+    same: every frame of the sequence — first frame (level 1, nothing of this), the frames while the level climbs, the
+    frames with strips, the same frames pipelined on 8 lanes (strips off by default there, forced on as well) — is
+    bit-identical to the frame with both switched off
+    (debug flags 0x1000000 | 0x2000000), and the frame agrees with the oracle on crops in the heavy corner."""
+    from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
+    kw = {"1m_f32": {}, "2dgs_obb": {"gaussian_mode": GaussianMode.Gaussian2d}, "aabb3d": {"aabb": True}}[what]
+    v = View.headless(1920, 1080)
+    s = CloudSettings(**kw)
+    h = plugin.upload(cloud_1m)
+    plugin.reset_adaptive_state()
+    try:
+        plugin.set_debug_flags(0x1000000 | 0x2000000)
+        for _ in range(4):
+            plain = plugin.render(h, v, s)
+        assert plugin.stats()["strip_tiles"] == 0
+        plugin.set_debug_flags(0)
+        plugin.reset_adaptive_state()
+        strips = []
+        for k in range(8):
+            img = plugin.render(h, v, s)
+            strips.append(plugin.stats()["strip_tiles"])
+            assert np.array_equal(img, plain), (what, k, strips)
+        assert strips[0] == 0 and strips[-1] > 0, strips          # the feedback kicks in after the level has climbed
+        assert strips[-1] < 2000                                     # ... for a few per cent of the 8160 tiles
+        print(f"[heavy tiles {what}] strip tiles per frame: {strips}")
+        # with several frames in flight the strips are off by default (the tail is filled by the other lanes' kernels):
+        # forced on (debug flag 0x4000000) they must still give the same bits, whichever lane's list a frame reads
+        plugin.set_async(True)
+        plugin.set_pipeline_depth(8)
+        for flags, want_strips in ((0, False), (0x4000000, True)):
+            plugin.set_debug_flags(flags)
+            for _ in range(40):
+                plugin.render(h, v, s, download=False)
+            plugin.synchronize()
+            assert (plugin.stats()["strip_tiles"] > 0) == want_strips, (flags, plugin.stats()["strip_tiles"])
+            assert np.array_equal(framebuffer_as_tensor(plugin, 1080, 1920).cpu().numpy(), plain)
+        plugin.set_debug_flags(0)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        # a moving camera: the list is stale by a few frames — balance, never pixels
+        for k in range(6):
+            vk = View.headless(1920, 1080, yaw=0.02 * (k + 1))
+            a = plugin.render(h, vk, s)
+            used = plugin.stats()["strip_tiles"]
+            plugin.set_debug_flags(0x1000000 | 0x2000000)
+            b = plugin.render(h, vk, s)
+            plugin.set_debug_flags(0)
+            assert np.array_equal(a, b), (what, k, used)
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+    e = oracle.sort(cloud_1m, v, s)
+    for (x0, y0) in ((1860, 1020), (1780, 940)):
+        win = (x0, y0, x0 + 48, y0 + 48)
+        ref, amb = oracle.render(cloud_1m, e, v, s, window=win, with_ambiguity=True)
+        _assert_image(ref, plain[y0:y0 + 48, x0:x0 + 48], amb, frac_slack=0.01, what=f"heavy corner {what} {win}")
+    h.free()
+    plugin.reset_adaptive_state()
+
 def test_rerun_keeps_the_output_state_the_frame_was_enqueued_with(plugin):
     """A frame whose supertile lists overflow is re-run when its lane completes. If the caller changed the packed
     output format in between (bgs_set_output_rgba16f / _srgb8 / _packed_only complete nothing), the re-run must still
