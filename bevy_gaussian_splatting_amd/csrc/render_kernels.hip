@@ -797,6 +797,15 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
 }
 
+// The same with S contiguous runs per XCD, dealt round-robin (run j of 8 S belongs to XCD j % 8): an XCD's tiles
+// come from S places of the image instead of one band, so that a frame whose work varies over the image (edges of a
+// dense cloud are heavier than its middle) loads the XCDs alike. Work item b / 8 of XCD b % 8 is found by walking the
+// XCD's runs (scalar integer work, <= 8 S steps, once per workgroup). A bijection of [0, n) for every n
+// (splat_math.h: xcd_runs_item, checked on the host by tests/test_device_math_host.py).
+__device__ __forceinline__ uint32_t xcd_remap_runs(const uint32_t b, const uint32_t n, const uint32_t S) {
+    return xcd_runs_item(b, n, S);
+}
+
 // BINNING_SORT rasteriser: one workgroup per tile, one pixel per thread; the tile's instances are
 // a contiguous range of the tile-sorted list, staged 256 records at a time in LDS.
 template <int VARIANT>
@@ -1122,7 +1131,12 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(
     // regular grid each take ONE tile of the list a completed frame left — a tile that needed more than one staging round
     // there — and give each of its four 16 x 4 row strips a wave of its own; the regular wave of such a tile steps aside.
     const bool strip_block = MIDROUND_EXIT && blockIdx.x >= nblocks;
-    uint32_t tile = strip_block ? 0xFFFFFFFFu : xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
+    // Surfel frames: four runs per XCD. A surfel tile is ~10x the work of an ellipse tile and only 5120 of the 8160 tile
+    // waves are resident at once, so an XCD whose band is the image's (heavier) top or bottom edge ends the launch:
+    // dense 1 M surfel frame 544 -> 492 us (runs 2 / 4 / 8: 520 / 492 / 508). The ellipse variants keep one band per XCD:
+    // their tiles share lists and records with their neighbours and the split only costs (scene-like 61.5 -> 63.6 us).
+    constexpr uint32_t RUNS = VARIANT == RV_SURFEL ? 4u : 1u;
+    uint32_t tile = strip_block ? 0xFFFFFFFFu : (RUNS == 1u ? xcd_remap(blockIdx.x, nblocks) : xcd_remap_runs(blockIdx.x, nblocks, RUNS)) * 4u + (uint32_t)wave;
     if constexpr (MIDROUND_EXIT) {
         if (strip_block) {
             const uint32_t have = heavy_in ? min(*reinterpret_cast<const uint32_t*>(heavy_in), HEAVY_CAP) : 0u;

@@ -28,6 +28,30 @@
 #define BGS_HD static inline
 #endif
 
+// Work order of the rasteriser's grid with S contiguous runs per XCD (render_kernels.hip: xcd_remap_runs): workgroup b
+// runs on XCD b % 8 (observed dispatch; a speed assumption only) and is the (b / 8)-th of that XCD's q + (xcd < r)
+// work items, n = 8 q + r. The items [0, n) are cut into 8 S runs dealt round-robin — run (s, x) belongs to XCD x and
+// holds cnt_x / S (+ 1 for the first cnt_x % S runs) items — and the XCD's items are its runs one after the other.
+// A bijection of [0, n) onto itself for every n and S >= 1.
+BGS_HD uint32_t xcd_runs_item(const uint32_t b, const uint32_t n, const uint32_t S) {
+    const uint32_t q = n / 8u, r = n % 8u, xcd = b % 8u;
+    uint32_t i = b / 8u, start = 0u;
+    for (uint32_t s = 0u; s < S; ++s) {
+        uint32_t mine = 0u, before = 0u, row = 0u;
+        for (uint32_t x = 0u; x < 8u; ++x) {
+            const uint32_t cnt = q + (x < r ? 1u : 0u);
+            const uint32_t len = cnt / S + (s < cnt % S ? 1u : 0u);
+            if (x < xcd) before += len;
+            if (x == xcd) mine = len;
+            row += len;
+        }
+        if (i < mine) return start + before + i;
+        i -= mine;
+        start += row;
+    }
+    return n;   // not reached for b < n
+}
+
 // The one transcendental that feeds only a COLOUR (never a cull decision, a sort key or a quad) — the 2.4 power of
 // srgb_to_linear — uses the hardware exp2/log2 on the device (~1 ulp); the host build keeps libm. Everything that
 // reaches a compare is +, -, *, /, sqrt (correctly rounded on gfx950) or ln_f32_cr (exact_log.h): ln(opacity) of

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The three randomized parity sweeps (defaults 600 small, 200 medium, 120 medium forced onto the surfel path; evidence size since round 3: SMALL=2000 MEDIUM=350 SURFEL=120):
-# bash scripts/gpu_sweeps.sh <tag>   -> gpurun_out/<tag>/randomized_*.log   (SMALL= MEDIUM= SURFEL= override the seed counts;
+# bash scripts/gpu_sweeps.sh <tag>   -> gpurun_out/<tag>/randomized_*.log   (SMALL= MEDIUM= SURFEL= override the seed counts, BGS_RANDOM_SEED_BASE=B starts at seed B;
 # MEDIUM=350 includes seed 321, round 2's one failure (fixed in round 3 by the correctly rounded log)
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-sweeps}; mkdir -p $OUT

@@ -87,6 +87,8 @@ def shim() -> ctypes.CDLL:
     l.shim_ln_f32.restype = None
     l.shim_ln_f32_checksum.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     l.shim_ln_f32_checksum.restype = ctypes.c_uint64
+    l.shim_xcd_runs_items.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    l.shim_xcd_runs_items.restype = None
     l.shim_supertile_div.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     l.shim_supertile_div.restype = ctypes.c_uint32
     l.shim_next_supertile_level.argtypes = [ctypes.c_double, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),

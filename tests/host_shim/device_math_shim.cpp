@@ -34,6 +34,11 @@ void shim_fill_params(uint32_t n, const bgs_view* view, const bgs_settings* s, F
 }
 
 // csrc/exact_log.h: the correctly rounded ln of the adaptive cutoff, host build (the device runs the same operations)
+// the rasteriser's work order with S runs per XCD, for every workgroup of a grid of n
+void shim_xcd_runs_items(uint32_t n, uint32_t S, uint32_t* out) {
+    for (uint32_t b = 0; b < n; ++b) out[b] = xcd_runs_item(b, n, S);
+}
+
 void shim_ln_f32(const float* x, uint32_t n, float* out) {
     for (uint32_t i = 0; i < n; ++i) out[i] = ln_f32_cr(x[i]);
 }

@@ -279,6 +279,28 @@ def test_supertile_index_by_reciprocal_multiply_is_exact():
             assert l.shim_supertile_div(tile, edge) == tile // edge, (tile, edge)
 
 
+def test_xcd_runs_work_order_is_a_bijection_made_of_runs():
+    """splat_math.h xcd_runs_item (the surfel rasteriser's work order: four runs per XCD): every work item exactly once
+    for every grid size — a tile nobody draws or a tile drawn twice would be a wrong image — and XCD b % 8 really gets
+    S contiguous runs."""
+    import ctypes
+    l = H.shim()
+    for n in list(range(1, 70)) + [255, 256, 257, 2040, 2041, 2047, 4093, 16384, 65535]:
+        for S in (1, 2, 3, 4, 8):
+            out = np.empty(n, np.uint32)
+            l.shim_xcd_runs_items(n, S, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+            assert np.array_equal(np.sort(out), np.arange(n, dtype=np.uint32)), (n, S)
+            for xcd in range(min(8, n)):
+                mine = out[xcd::8].astype(np.int64)          # this XCD's items in its dispatch order
+                assert np.all(np.diff(mine) > 0), (n, S, xcd)  # ascending: runs are walked front to back
+                assert int((np.diff(mine) != 1).sum()) <= S - 1, (n, S, xcd)
+    # one run per XCD is the contiguous-band order (render_kernels.hip xcd_remap)
+    n = 2040
+    out = np.empty(n, np.uint32)
+    l.shim_xcd_runs_items(n, 1, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    assert np.array_equal(out[0::8], np.arange(0, 255, dtype=np.uint32)) and out[1] == 255
+
+
 LN_HARD_CASES = (0x65d890d3, 0x4c5d65a5, 0x4d604ebe, 0x41178feb, 0x3c413d3a, 0x6f31a8ec)
 
 
