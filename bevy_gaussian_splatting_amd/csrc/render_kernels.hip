@@ -887,7 +887,9 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 // 1024 SIMDs x 8 slots, so at 7 waves/SIMD a second, nearly empty round of waves appears.
 // The surfel variant carries a 24-dword staged record through a 30-slot blend: it spills at 64 registers
 // (14 VGPRs) and at 72 / 80; same-box A/B of the dense 1 M-surfel frame: 5 waves/SIMD (90 VGPRs, no spill)
-// 0.49 ms, 6: 0.54, 7: 0.55, 8: 0.51 (and 0.13 instead of 0.09 ms scene-like).
+// 0.49 ms, 6: 0.54, 7: 0.55, 8: 0.51 (and 0.13 instead of 0.09 ms scene-like). Round 3: the kernel has since come
+// down to 84 registers and fits 80 without a spill: 6 waves/SIMD (6 x 25.6 KB of LDS per CU) is +2 % frames/s with
+// frames in flight on both the dense and the scene-like surfel frame and +-2 % on a frame alone on the chip.
 // TRACE (bgs_set_tile_trace, diagnostics only): every tile's wave also writes two uint4 to trace[2 * tile]:
 //   { s_memtime at wave start (lo, hi), s_memtime at wave end (lo, hi) },
 //   { HW_ID register, XCC_ID register, candidates scanned, records blended | records staged << 16 }
@@ -1105,7 +1107,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
 }
 
 template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false>
-__global__ __launch_bounds__(256, VARIANT == 2 ? 5 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
+__global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_mul,
                                                           uint32_t sup_x, Control* ctl,
