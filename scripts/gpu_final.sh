@@ -2,7 +2,8 @@
 # Round-end evidence run on the FINAL tree (one set per round): smoke, all GPU tests, the wide randomized sweeps, bench
 # (default + the driver's flags twice), the other configs, rocprofv3 kernel stats + PMC passes (dense headline frame:
 # all groups; the two slowest configs: VALU / classes / FETCH / WRITE), timelines, per-tile traces, gather calibration.
-#   bash scripts/gpu_final.sh <tag>      then copy gpurun_out/<tag> to profiles/<tag> and its pmc_traffic.json to profiles/
+#   [EXPLORE=<first seed>] bash scripts/gpu_final.sh <tag>      (EXPLORE adds 4000 + 700 + 300 configurations from that seed on)
+#   then copy gpurun_out/<tag> to profiles/<tag> and its pmc_traffic.json to profiles/
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r3_final}
@@ -12,6 +13,7 @@ cd $R
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log
 echo "== pytest gpu"; timeout 1800 python -m pytest tests -m gpu -q --timeout 1200 -s 2>&1 | grep -E "passed|failed|error|Error|ambiguity slack used|whole frame|libbgs build id" | tee $OUT/pytest_gpu_summary.log | tail -14
 echo "== sweeps"; SMALL=2000 MEDIUM=350 SURFEL=120 bash scripts/gpu_sweeps.sh $TAG 2>&1 | tail -8
+if [ -n "$EXPLORE" ]; then echo "== exploratory sweeps (seeds $EXPLORE ..)"; BGS_RANDOM_SEED_BASE=$EXPLORE SMALL=4000 MEDIUM=700 SURFEL=300 bash scripts/gpu_sweeps.sh $TAG/explore_$EXPLORE 2>&1 | tail -8; fi
 echo "== bench"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench.json; tail -2 $OUT/bench.err
 for i in 1 2; do timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_flags_$i.json 2>/dev/null; cut -c1-160 $OUT/bench_driver_flags_$i.json; done
 echo "== other configs"; timeout 900 python scripts/bench_configs.py > $OUT/bench_other_configs.json 2> $OUT/bench_other.err; grep -E "frames_per_s" $OUT/bench_other_configs.json | head -20
