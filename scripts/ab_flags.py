@@ -35,7 +35,10 @@ def run(p, h, v, s, steps, warm=40, depth=8):
     dt1 = time.perf_counter() - t0
     st1 = p.stats()
     p.set_async(False)
-    return best, steps / dt1, {k: round(1e3 * x, 1) for k, x in st1["stage_ms"].items() if x}
+    stages = {k: round(1e3 * x, 1) for k, x in st1["stage_ms"].items() if x}
+    if st1.get("strip_tiles"):
+        stages["feedback_tiles"] = st1["strip_tiles"]
+    return best, steps / dt1, stages
 
 
 CLOUDS = {}
