@@ -86,6 +86,7 @@ struct KeygenLaunch {
     uint32_t* bucket_status;  // fp.sort_path == 1: zeroed look-back words [keygen tiles][BUCKET_COUNT]
     SplitterTable split;      // fp.sort_path == 1: bucket = number of entries <= key
     uint32_t* zero_word;      // a word the frame needs zeroed before its later kernels run (the rasteriser's heavy-tile count), or null
+    bool wide = false;        // the frame is alone on the chip (pipeline depth 1): chainless tiles as 1024-thread workgroups
     // filled by prepare(): the launch geometry and the argument vector (points into this object)
     const void* func;
     uint32_t blocks, threads;

@@ -84,7 +84,18 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 // radix pass's machinery] + [arrival order within the tile: a returning LDS atomic]. The sum of the 256
 // exclusive prefixes is the tile's drawable-entry offset, so the partition needs no chain of its own.
 // Order inside a bucket is arbitrary; bucket_sort_kernel orders by (key, index).
-template <int KG_ITEMS, bool BUCKET, int THREADS>  // splats per thread; 256 or 1024 threads per block
+// ORDERED = false (BUCKET frames that write no culled tail, i.e. every rendered frame): nothing downstream needs the
+// drawable pairs or the culled ones in index order — bucket_sort_kernel orders every bucket by (key, index) whatever
+// the order inside its slots — so the tile needs no ticket, no row scan and, above all, NO CHAIN: the 256 per-bucket
+// look-backs are replaced by one returning atomicAdd per (tile, bucket) on the bucket's running count. With the
+// chains, all 245 tiles of a 1 M-splat cloud reach the look-back within a microsecond of each other and the
+// inclusive prefixes then travel tile by tile: s_memtime stamps put the wait at 50 ns per predecessor — 6 us for
+// tile 120, 12 us for tile 244, half of the kernel (profiles/r3_notes.md section 10).
+#ifndef BGS_KG_GROUP
+#define BGS_KG_GROUP 2   // splats of a thread whose keys are computed together (divides every KG_ITEMS): 2 / 4 / 8 / 16 ->
+                         // 1 M keygen 20.6 / 21.2 / 22.2 / 23.5 us, 5 M 51 / 53 / 64 / 88 us (registers: 153 / 164 / 206 / 256)
+#endif
+template <int KG_ITEMS, bool BUCKET, int THREADS, bool ORDERED = true>  // splats per thread; 256 or 1024 threads per block
 __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
                                                          uint2* __restrict__ entries,
                                                          uint2* __restrict__ culled, Control* ctl,
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                                                          SplitterTable split, uint32_t* zero_word) {
     constexpr int WAVES = THREADS / 64;
     constexpr int ROWS = KG_ITEMS * WAVES;  // 64-splat rows of a tile, in index order (item, wave)
-    static_assert((THREADS == 256 || THREADS == 1024) && ROWS <= 128, "tile geometry");
+    static_assert((THREADS == 256 || THREADS == 512 || THREADS == 1024) && ROWS <= 128, "tile geometry");
     __shared__ uint32_t s_hist[BUCKET ? 1 : 4][RADIX_BASE];
     __shared__ uint32_t s_cnt[ROWS];   // drawable splats of each row ...
     __shared__ uint32_t s_off[ROWS];   // ... and of the rows before it
@@ -134,6 +145,101 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     // after its tile instead of queueing for a second ticket only to be told there is nothing left.
     const bool single_shot = gridDim.x >= num_tiles;
 
+    if constexpr (BUCKET && !ORDERED) {
+        if (blockIdx.x == 0 && tid == 0) ctl->splat_count = fp.n;
+        for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+            if (tid < (int)BUCKET_COUNT) s_bcnt[tid] = 0u;
+            if (tid == 0) s_total = 0u;
+            __syncthreads();   // (first tile: s_split is in place as well)
+            const uint32_t base = tile * per_tile;
+            float4 pin[KG_ITEMS];
+#pragma unroll
+            for (int k = 0; k < KG_ITEMS; ++k) {
+                const uint32_t i = base + (uint32_t)(k * THREADS) + (uint32_t)tid;
+                pin[k] = i < fp.n ? pos[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            uint32_t key[KG_ITEMS], below[KG_ITEMS], rowoff[KG_ITEMS];
+            const bool all_draw = fp.sort_mode != SORT_RADIX;
+#define BGS_KG_KEYS(KIND)                                                                      \
+    _Pragma("unroll") for (int k0 = 0; k0 < KG_ITEMS; k0 += BGS_KG_GROUP) {                    \
+        /* BGS_KG_GROUP splats at a time: straight-line keys (independent chains the compiler interleaves; all 16 at once \
+           cost 256 registers), then ONE rare branch for the splats whose frustum verdict needs the divisions */ \
+        uint32_t unsure_mask = 0u;                                                             \
+        _Pragma("unroll") for (int k = k0; k < k0 + BGS_KG_GROUP; ++k) {                       \
+            const uint32_t i = base + (uint32_t)(k * THREADS) + (uint32_t)tid;                 \
+            const float4 p = pin[k];                                                           \
+            bool unsure;                                                                       \
+            const uint32_t kf = sort_key_fast<KIND>(fp, V3{p.x, p.y, p.z}, unsure);            \
+            key[k] = i < fp.n ? kf : sentinel;                                                 \
+            unsure_mask |= (unsure && i < fp.n) ? (1u << (k - k0)) : 0u;                       \
+        }                                                                                      \
+        if (unsure_mask) {                                                                     \
+            _Pragma("unroll") for (int k = k0; k < k0 + BGS_KG_GROUP; ++k)                     \
+                if ((unsure_mask >> (k - k0)) & 1u) key[k] = sort_key_kind<KIND>(fp, V3{pin[k].x, pin[k].y, pin[k].z}); \
+        }                                                                                      \
+    }
+            if (fp.sort_mode == SORT_RADIX) { BGS_KG_KEYS(1) }
+            else if (fp.sort_mode == SORT_NONE) { BGS_KG_KEYS(0) }
+            else { BGS_KG_KEYS(2) }
+#undef BGS_KG_KEYS
+#define BGS_KG_DRAWN(k) (all_draw ? (base + (uint32_t)((k) * THREADS) + (uint32_t)tid < fp.n) : (key[k] != sentinel))
+            // the wave's drawable pairs go to one contiguous piece of the tile's compacted arrays: ONE LDS atomic per wave
+            uint32_t run = 0u;
+#pragma unroll
+            for (int k = 0; k < KG_ITEMS; ++k) {
+                const unsigned long long b = __ballot(BGS_KG_DRAWN(k));
+                below[k] = (uint32_t)__popcll(b & lanes_below);
+                rowoff[k] = run;
+                run += (uint32_t)__popcll(b);
+            }
+            uint32_t wbase = 0u;
+            if (lane == 0 && run) wbase = atomicAdd(&s_total, run);
+            wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+#pragma unroll
+            for (int k = 0; k < KG_ITEMS; ++k)
+                if (BGS_KG_DRAWN(k)) {
+                    const uint32_t j = wbase + rowoff[k] + below[k];
+                    s_keys[j] = key[k];
+                    s_idx[j] = base + (uint32_t)(k * THREADS) + (uint32_t)tid;
+                }
+#undef BGS_KG_DRAWN
+            __syncthreads();
+            const uint32_t total = s_total;
+#pragma unroll
+            for (int r = 0; r < KG_ITEMS; ++r) {
+                const uint32_t j = (uint32_t)(r * THREADS) + (uint32_t)tid;
+                if (j < total) {
+                    const uint32_t kk = s_keys[j];
+                    uint32_t lo = 0u;  // number of splitters <= kk (s_split[255] = ~0: never counted unless kk = ~0)
+#pragma unroll
+                    for (uint32_t step = BUCKET_COUNT / 2u; step > 0u; step >>= 1)
+                        if (s_split[lo + step - 1u] <= kk) lo += step;
+                    const uint32_t bkt = min(lo, BUCKET_COUNT - 1u);
+                    s_bk[j] = (uint8_t)bkt;
+                    s_at[j] = (uint16_t)min(atomicAdd(&s_bcnt[bkt], 1u), 0xFFFFu);
+                }
+            }
+            __syncthreads();
+            // thread = bucket: the tile's pairs of a bucket take the next `mine` slots of the bucket, whoever comes first
+            if (tid < (int)BUCKET_COUNT) {
+                const uint32_t mine = s_bcnt[tid];
+                s_bexcl[tid] = mine ? atomicAdd(&ctl->bucket_count[tid], mine) : 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < KG_ITEMS; ++r) {
+                const uint32_t j = (uint32_t)(r * THREADS) + (uint32_t)tid;
+                if (j < total) {
+                    const uint32_t bkt = s_bk[j];
+                    const uint32_t slot = s_bexcl[bkt] + (uint32_t)s_at[j];
+                    if (slot < BUCKET_CAP)  // a bucket over capacity is seen by bucket_sort_kernel (count > cap)
+                        bucket_slots[(size_t)bkt * BUCKET_CAP + slot] = make_uint2(s_keys[j], s_idx[j]);
+                }
+            }
+        }
+        return;
+    }
+
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
         if constexpr (BUCKET) { if (tid < (int)BUCKET_COUNT) s_bcnt[tid] = 0u; }
@@ -157,10 +263,22 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
         // the sort mode is the launch's, not the splat's: one branch around the keys instead of one inside
         // each (every copy re-reading its matrices from spilled scalar registers)
 #define BGS_KG_KEYS(KIND)                                                                      \
-    _Pragma("unroll") for (int k = 0; k < KG_ITEMS; ++k) {                                     \
-        const uint32_t i = base + (uint32_t)(k * THREADS) + (uint32_t)tid;                     \
-        const float4 p = pin[k];                                                               \
-        key[k] = i < fp.n ? sort_key_kind<KIND>(fp, V3{p.x, p.y, p.z}) : sentinel;             \
+    _Pragma("unroll") for (int k0 = 0; k0 < KG_ITEMS; k0 += BGS_KG_GROUP) {                    \
+        /* BGS_KG_GROUP splats at a time: straight-line keys (independent chains the compiler interleaves; all 16 at once \
+           cost 256 registers), then ONE rare branch for the splats whose frustum verdict needs the divisions */ \
+        uint32_t unsure_mask = 0u;                                                             \
+        _Pragma("unroll") for (int k = k0; k < k0 + BGS_KG_GROUP; ++k) {                       \
+            const uint32_t i = base + (uint32_t)(k * THREADS) + (uint32_t)tid;                 \
+            const float4 p = pin[k];                                                           \
+            bool unsure;                                                                       \
+            const uint32_t kf = sort_key_fast<KIND>(fp, V3{p.x, p.y, p.z}, unsure);            \
+            key[k] = i < fp.n ? kf : sentinel;                                                 \
+            unsure_mask |= (unsure && i < fp.n) ? (1u << (k - k0)) : 0u;                       \
+        }                                                                                      \
+        if (unsure_mask) {                                                                     \
+            _Pragma("unroll") for (int k = k0; k < k0 + BGS_KG_GROUP; ++k)                     \
+                if ((unsure_mask >> (k - k0)) & 1u) key[k] = sort_key_kind<KIND>(fp, V3{pin[k].x, pin[k].y, pin[k].z}); \
+        }                                                                                      \
     }
         if (fp.sort_mode == SORT_RADIX) { BGS_KG_KEYS(1) }
         else if (fp.sort_mode == SORT_NONE) { BGS_KG_KEYS(0) }
@@ -321,10 +439,16 @@ bool KeygenLaunch::prepare(int max_blocks) {
     if (fp.n == 0) return false;
     // Tile size by cloud size (keygen_tile_splats): every tile is a ticket, a hop in 256 look-back chains and a
     // round of barriers
-    const uint32_t per_block = keygen_tile_splats(fp.n);
     const bool bucket = fp.sort_path == 1u;
+    const bool unordered = bucket && culled == nullptr;   // no culled tail wanted: bucket placement without chains
+#ifndef BGS_KG_UNORDERED_TILE
+#define BGS_KG_UNORDERED_TILE 0   // 0: the size rule of the chained tiles
+#endif
+    const uint32_t per_block = (unordered && BGS_KG_UNORDERED_TILE) ? (uint32_t)BGS_KG_UNORDERED_TILE : keygen_tile_splats(fp.n);
 #define BGS_KG_PICK(ITEMS, THR) \
-    (bucket ? reinterpret_cast<const void*>(&keygen_kernel<ITEMS, true, THR>) : reinterpret_cast<const void*>(&keygen_kernel<ITEMS, false, THR>))
+    (bucket ? (unordered ? reinterpret_cast<const void*>(&keygen_kernel<ITEMS, true, THR, false>)                       \
+                         : reinterpret_cast<const void*>(&keygen_kernel<ITEMS, true, THR, true>))                       \
+            : reinterpret_cast<const void*>(&keygen_kernel<ITEMS, false, THR, true>))
 #if BGS_KEYGEN_WIDE_THREADS == 256
     threads = 256u;
     func = per_block >= 4096u ? BGS_KG_PICK(16, 256) : BGS_KG_PICK(8, 256);
@@ -332,9 +456,19 @@ bool KeygenLaunch::prepare(int max_blocks) {
     threads = per_block >= 4096u ? 1024u : 256u;
     func = per_block == 8192u ? BGS_KG_PICK(8, 1024) : (per_block == 4096u ? BGS_KG_PICK(4, 1024) : BGS_KG_PICK(8, 256));
 #endif
+    // A frame that is ALONE on the chip (pipeline depth 1: a blocking caller) runs its chainless 4096-splat tiles as
+    // 1024 threads x 4 splats instead of 256 x 16: four waves per SIMD instead of one on the tile's CU, a quarter of
+    // every thread's chain (keygen 17.6 -> 12.5 us at 1 M). With frames in flight the narrow tile wins (21.0 vs 20.2 k
+    // frames/s: a 16-wave workgroup needs a CU's worth of free slots at once, and there the other frames' kernels are
+    // what hides a tile's latency) — the same trade as in round 2, now decided per frame.
+    if (unordered && wide && per_block == 4096u) {
+        threads = 1024u;
+        func = reinterpret_cast<const void*>(&keygen_kernel<4, true, 1024, false>);
+    }
 #undef BGS_KG_PICK
     blocks = (fp.n + per_block - 1) / per_block;
-    if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
+    // (tiles without chains depend on nobody: one workgroup per tile, dispatched as slots come free)
+    if (!unordered && blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
     argv[0] = &fp; argv[1] = &pos; argv[2] = &entries; argv[3] = &culled; argv[4] = &ctl;
     argv[5] = &part_status; argv[6] = &places; argv[7] = &ticket_slot; argv[8] = &fp_out; argv[9] = &bucket_slots;
     argv[10] = &bucket_status; argv[11] = &split; argv[12] = &zero_word;
@@ -600,6 +734,9 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
             ctl->draw_count = 0u;
         }
     }
+    // the length of the list: the last bucket's offset + its pairs (a keygen without chains leaves only the per-bucket
+    // counts; one with chains has written the same number already)
+    if (b == BUCKET_COUNT - 1u && tid == 0 && mx <= BUCKET_CAP) ctl->draw_count = base + m;
     if (m == 0u || mx > BUCKET_CAP) return;
     __syncthreads();  // s_red / s_tot are reused below
 

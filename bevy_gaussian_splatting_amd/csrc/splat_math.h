@@ -125,6 +125,43 @@ BGS_HD bool in_frustum(V4 c) {
     return fabsf(c.x) < 1.1f && fabsf(c.y) < 1.1f && fabsf(c.z - 0.5f) < 0.5f;
 }
 
+// in_frustum(world_to_clip(fp, p)) — the SAME verdict, bit for bit — without the three IEEE divisions wherever the
+// verdict is clear. keygen runs one wave per SIMD and the divisions of a thread's 16 splats queue behind each other
+// (v_div_scale -> v_div_fmas goes through VCC): they were half of the kernel's arithmetic time.
+//   q~ = h * rcp(d) differs from fl(h / d) by less than 2^-22 relative for a normal d (v_rcp_f32: 1 ulp, the product:
+//   half an ulp, the correctly rounded quotient: half an ulp), so with a guard band of 2^-20 around each threshold
+//     |q~x|, |q~y| < 1.1 (1 - 2^-20)  and  2^-20 < q~z < 1 - 2^-20      =>  every compare of in_frustum is true,
+//     |q~x| or |q~y| > 1.1 (1 + 2^-20)  or  q~z < -2^-20  or  q~z > 1 + 2^-20  =>  one of them is false
+//   (fabsf(c.z - 0.5f) < 0.5f is true on [2^-20, 1 - 2^-20] with 2^-25 of rounding to spare and false for every c.z < 0
+//   and every c.z > 1). Anything else — a value inside a band, a NaN, a d outside [2^-100, 2^100] (where rcp or the
+//   product could leave the normal range) — takes the divisions. tests/test_gpu_parity.py puts a million points
+//   within a few ulp of every threshold.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BGS_RCP_APPROX(x) __builtin_amdgcn_rcpf(x)
+#else
+#define BGS_RCP_APPROX(x) (1.0f / (x))
+#endif
+// Returns 1 (inside), 0 (outside) or 2 (not clear: the caller takes the divisions, in_frustum(world_to_clip(..))).
+// Straight-line on purpose — no branch, bitwise combinations of the compares (each false for a NaN) — so that the
+// splats a thread owns are independent chains the compiler interleaves.
+BGS_HD uint32_t frustum_verdict_fast(const FrameParams& fp, V3 world_pos) {
+    const V4 h = m4_mul_point(fp.clip_from_world, world_pos);
+    const float d = h.w + 0.000000001f;
+    const float ad = fabsf(d);
+    constexpr float E = 0x1p-20f, LO = 1.1f * (1.0f - 0x1p-20f), HI = 1.1f * (1.0f + 0x1p-20f);
+    const float r = BGS_RCP_APPROX(d);
+    const float qx = fabsf(h.x * r), qy = fabsf(h.y * r), qz = h.z * r;
+    const bool normal = (ad >= 0x1p-100f) & (ad <= 0x1p100f);
+    const bool out = normal & ((qx > HI) | (qy > HI) | (qz < -E) | (qz > 1.0f + E));
+    const bool in = normal & (qx < LO) & (qy < LO) & (qz > E) & (qz < 1.0f - E);
+    return in ? 1u : (out ? 0u : 2u);
+}
+BGS_HD bool in_frustum_of_world(const FrameParams& fp, V3 world_pos) {
+    const uint32_t v = frustum_verdict_fast(fp, world_pos);
+    if (v != 2u) return v == 1u;
+    return in_frustum(world_to_clip(fp, world_pos));
+}
+
 // Sort key of one splat for every SortMode.
 //   SORT_RADIX: src/sort/radix.wgsl:86-101 (cull + inverted distance bits, >> key_shift)
 //   SORT_RAYON/STD: src/sort/rayon.rs:91-97 stores bits(dist2) and sorts DESCENDING; the
@@ -149,13 +186,31 @@ BGS_HD uint32_t sort_key_kind(const FrameParams& fp, V3 pos) {
             return 0xFFFFFFFFu - bits;
         } else {
             uint32_t key = KEY_CULLED;
-            V4 clip = world_to_clip(fp, tp);
             V3 diff = sub3(tp, cam);
             float dist2 = dot3(diff, diff);
             uint32_t key_distance = 0xFFFFFFFFu - f2u(dist2);
-            if (in_frustum(clip)) key = key_distance;
+            if (in_frustum_of_world(fp, tp)) key = key_distance;   // = in_frustum(world_to_clip(fp, tp))
             return key >> fp.key_shift;
         }
+    }
+}
+// The same key in two steps, for a thread that owns several splats (keygen): sort_key_fast is straight-line code and
+// says `unsure` where the frustum verdict needs the divisions; the caller then asks sort_key_kind for those splats.
+template <int KIND>
+BGS_HD uint32_t sort_key_fast(const FrameParams& fp, V3 pos, bool& unsure) {
+    unsure = false;
+    if constexpr (KIND != 1) {
+        return sort_key_kind<KIND>(fp, pos);
+    } else {
+        V4 t4 = m4_mul_point(fp.transform, pos);
+        V3 tp{t4.x, t4.y, t4.z};
+        V3 cam{fp.cam[0], fp.cam[1], fp.cam[2]};
+        V3 diff = sub3(tp, cam);
+        float dist2 = dot3(diff, diff);
+        const uint32_t key_distance = 0xFFFFFFFFu - f2u(dist2);
+        const uint32_t v = frustum_verdict_fast(fp, tp);
+        unsure = v == 2u;
+        return (v == 1u ? key_distance : KEY_CULLED) >> fp.key_shift;
     }
 }
 BGS_HD uint32_t sort_key(const FrameParams& fp, V3 pos) {
