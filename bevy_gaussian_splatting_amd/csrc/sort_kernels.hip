@@ -263,22 +263,12 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
         // the sort mode is the launch's, not the splat's: one branch around the keys instead of one inside
         // each (every copy re-reading its matrices from spilled scalar registers)
 #define BGS_KG_KEYS(KIND)                                                                      \
-    _Pragma("unroll") for (int k0 = 0; k0 < KG_ITEMS; k0 += BGS_KG_GROUP) {                    \
-        /* BGS_KG_GROUP splats at a time: straight-line keys (independent chains the compiler interleaves; all 16 at once \
-           cost 256 registers), then ONE rare branch for the splats whose frustum verdict needs the divisions */ \
-        uint32_t unsure_mask = 0u;                                                             \
-        _Pragma("unroll") for (int k = k0; k < k0 + BGS_KG_GROUP; ++k) {                       \
-            const uint32_t i = base + (uint32_t)(k * THREADS) + (uint32_t)tid;                 \
-            const float4 p = pin[k];                                                           \
-            bool unsure;                                                                       \
-            const uint32_t kf = sort_key_fast<KIND>(fp, V3{p.x, p.y, p.z}, unsure);            \
-            key[k] = i < fp.n ? kf : sentinel;                                                 \
-            unsure_mask |= (unsure && i < fp.n) ? (1u << (k - k0)) : 0u;                       \
-        }                                                                                      \
-        if (unsure_mask) {                                                                     \
-            _Pragma("unroll") for (int k = k0; k < k0 + BGS_KG_GROUP; ++k)                     \
-                if ((unsure_mask >> (k - k0)) & 1u) key[k] = sort_key_kind<KIND>(fp, V3{pin[k].x, pin[k].y, pin[k].z}); \
-        }                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < KG_ITEMS; ++k) {                                     \
+        /* the tiles with chains keep the reference's own key (three divisions per splat, no branch: the compiler    \
+           interleaves a thread's splats): with the two-step key of the chainless tiles this kernel was 3 us slower */ \
+        const uint32_t i = base + (uint32_t)(k * THREADS) + (uint32_t)tid;                     \
+        const float4 p = pin[k];                                                               \
+        key[k] = i < fp.n ? sort_key_kind<KIND>(fp, V3{p.x, p.y, p.z}) : sentinel;             \
     }
         if (fp.sort_mode == SORT_RADIX) { BGS_KG_KEYS(1) }
         else if (fp.sort_mode == SORT_NONE) { BGS_KG_KEYS(0) }

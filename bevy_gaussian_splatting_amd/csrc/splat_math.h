@@ -126,7 +126,7 @@ BGS_HD bool in_frustum(V4 c) {
 }
 
 // in_frustum(world_to_clip(fp, p)) — the SAME verdict, bit for bit — without the three IEEE divisions wherever the
-// verdict is clear. keygen runs one wave per SIMD and the divisions of a thread's 16 splats queue behind each other
+// verdict is clear (sort_key_fast below; sort_key_kind is the reference's statement as it stands). keygen runs one wave per SIMD and the divisions of a thread's 16 splats queue behind each other
 // (v_div_scale -> v_div_fmas goes through VCC): they were half of the kernel's arithmetic time.
 //   q~ = h * rcp(d) differs from fl(h / d) by less than 2^-22 relative for a normal d (v_rcp_f32: 1 ulp, the product:
 //   half an ulp, the correctly rounded quotient: half an ulp), so with a guard band of 2^-20 around each threshold
@@ -156,12 +156,6 @@ BGS_HD uint32_t frustum_verdict_fast(const FrameParams& fp, V3 world_pos) {
     const bool in = normal & (qx < LO) & (qy < LO) & (qz > E) & (qz < 1.0f - E);
     return in ? 1u : (out ? 0u : 2u);
 }
-BGS_HD bool in_frustum_of_world(const FrameParams& fp, V3 world_pos) {
-    const uint32_t v = frustum_verdict_fast(fp, world_pos);
-    if (v != 2u) return v == 1u;
-    return in_frustum(world_to_clip(fp, world_pos));
-}
-
 // Sort key of one splat for every SortMode.
 //   SORT_RADIX: src/sort/radix.wgsl:86-101 (cull + inverted distance bits, >> key_shift)
 //   SORT_RAYON/STD: src/sort/rayon.rs:91-97 stores bits(dist2) and sorts DESCENDING; the
@@ -186,10 +180,11 @@ BGS_HD uint32_t sort_key_kind(const FrameParams& fp, V3 pos) {
             return 0xFFFFFFFFu - bits;
         } else {
             uint32_t key = KEY_CULLED;
+            V4 clip = world_to_clip(fp, tp);
             V3 diff = sub3(tp, cam);
             float dist2 = dot3(diff, diff);
             uint32_t key_distance = 0xFFFFFFFFu - f2u(dist2);
-            if (in_frustum_of_world(fp, tp)) key = key_distance;   // = in_frustum(world_to_clip(fp, tp))
+            if (in_frustum(clip)) key = key_distance;
             return key >> fp.key_shift;
         }
     }
