@@ -102,6 +102,9 @@ def shim() -> ctypes.CDLL:
     l.shim_frame_params_size.restype = ctypes.c_uint32
     l.shim_sort_keys.argtypes = [ctypes.POINTER(FrameParamsC), fp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
     l.shim_sort_keys.restype = None
+    l.shim_sort_keys_two_step.argtypes = [ctypes.POINTER(FrameParamsC), fp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
+                                          ctypes.POINTER(ctypes.c_uint32)]
+    l.shim_sort_keys_two_step.restype = None
     l.shim_project.argtypes = [ctypes.POINTER(FrameParamsC), ctypes.c_uint32, fp, fp, fp, fp, fp, ctypes.POINTER(ShimOut)]
     l.shim_project.restype = None
     l.shim_distance_to_camera.argtypes = [ctypes.POINTER(FrameParamsC), fp]
@@ -129,6 +132,17 @@ def device_keys(cloud: PlanarGaussian3d, view: View, settings: CloudSettings) ->
     shim().shim_sort_keys(ctypes.byref(fpc), _fp(cloud.position_visibility), len(cloud),
                           keys.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
     return keys
+
+
+def device_keys_two_step(cloud: PlanarGaussian3d, view: View, settings: CloudSettings):
+    """The same keys computed the way the chainless keygen tiles do (straight-line frustum verdict, divisions only where
+    it is unsure), and how many splats took the divisions."""
+    fpc = frame_params(len(cloud), view, settings)
+    keys = np.empty(len(cloud), np.uint32)
+    unsure = ctypes.c_uint32(0)
+    shim().shim_sort_keys_two_step(ctypes.byref(fpc), _fp(cloud.position_visibility), len(cloud),
+                                   keys.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ctypes.byref(unsure))
+    return keys, int(unsure.value)
 
 
 def device_sorted_entries(cloud, view, settings) -> np.ndarray:
@@ -346,3 +360,38 @@ def random_case(seed: int, medium: bool = False):
         num_classes=int(rng.integers(1, 6)), position_min=mn, position_max=mx, transform=tr,
         draw_mode=DrawMode(int(rng.choice([0, 0, 0, 1, 2]))))
     return c, v, s
+
+
+def frustum_boundary_cloud(view, n_per_case, seed):
+    """Points whose clip coordinates sit within a few ulp of every threshold of in_frustum (|x/w|, |y/w| = 1.1;
+    z/w = 1, the near plane; z/w -> 0 far away; w ~ 0) and of the guard bands of the device's division-free verdict
+    (splat_math.h in_frustum_of_world: 1.1 (1 +- 2^-20), 2^-20, 1 +- 2^-20), built by un-projecting in float64."""
+    rng = np.random.default_rng(seed)
+    inv = np.linalg.inv(np.asarray(view.clip_from_world, np.float64))
+    near = float(np.asarray(view.clip_from_view, np.float64)[2, 3])     # infinite reverse-z: clip.z = near, clip.w = distance
+    parts = []
+
+    def unproject(ndc_x, ndc_y, dist):
+        clip = np.stack([ndc_x * dist, ndc_y * dist, np.full_like(dist, near), dist], axis=1)
+        w = clip @ inv.T
+        return (w[:, :3] / w[:, 3:4]).astype(np.float32)
+    m = n_per_case
+    for centre in (1.1, 1.1 * (1 - 2.0 ** -20), 1.1 * (1 + 2.0 ** -20)):
+        for axis in (0, 1):
+            for sign in (-1.0, 1.0):
+                edge = sign * centre * (1.0 + rng.uniform(-3e-6, 3e-6, m))
+                other = rng.uniform(-1.05, 1.05, m)
+                dist = np.exp(rng.uniform(np.log(0.2), np.log(200.0), m))
+                parts.append(unproject(edge if axis == 0 else other, other if axis == 0 else edge, dist))
+    for centre in (1.0, 1.0 - 2.0 ** -20, 1.0 + 2.0 ** -20):               # z/w = near/dist around 1: the near plane
+        dist = near / (centre * (1.0 + rng.uniform(-3e-6, 3e-6, 2 * m)))
+        parts.append(unproject(rng.uniform(-1.0, 1.0, 2 * m), rng.uniform(-1.0, 1.0, 2 * m), dist))
+    dist = near / (2.0 ** -20 * (1.0 + rng.uniform(-3e-6, 3e-6, 2 * m)))   # z/w around 2^-20: ~100 km away
+    parts.append(unproject(rng.uniform(-1.0, 1.0, 2 * m), rng.uniform(-1.0, 1.0, 2 * m), dist))
+    dist = rng.uniform(-1e-7, 1e-7, 2 * m)                                  # w within 1e-7 of 0, either side
+    parts.append(unproject(rng.uniform(-1.0, 1.0, 2 * m), rng.uniform(-1.0, 1.0, 2 * m), np.where(dist == 0, 1e-9, dist)))
+    pos = np.concatenate(parts)
+    pv = np.concatenate([pos, np.ones((len(pos), 1), np.float32)], axis=1).astype(np.float32)
+    n = len(pv)
+    return PlanarGaussian3d(pv, np.zeros((n, 48), np.float32), np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1)),
+                            np.tile(np.array([0.01, 0.01, 0.01, 0.5], np.float32), (n, 1)))

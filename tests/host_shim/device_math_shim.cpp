@@ -72,6 +72,23 @@ void shim_sort_keys(const FrameParams* fp, const float* pos_vis, uint32_t n, uin
         keys_out[i] = sort_key(*fp, V3{pos_vis[4 * i], pos_vis[4 * i + 1], pos_vis[4 * i + 2]});
 }
 
+// the same keys the way the chainless keygen tiles compute them: the straight-line verdict first (sort_key_fast), the
+// reference's divisions only for the splats it is unsure about. `unsure_out` counts those.
+void shim_sort_keys_two_step(const FrameParams* fp, const float* pos_vis, uint32_t n, uint32_t* keys_out, uint32_t* unsure_out) {
+    uint32_t unsure_count = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const V3 p{pos_vis[4 * i], pos_vis[4 * i + 1], pos_vis[4 * i + 2]};
+        bool unsure = false;
+        uint32_t k;
+        if (fp->sort_mode == SORT_NONE) k = sort_key_fast<0>(*fp, p, unsure);
+        else if (fp->sort_mode != SORT_RADIX) k = sort_key_fast<2>(*fp, p, unsure);
+        else k = sort_key_fast<1>(*fp, p, unsure);
+        if (unsure) { k = sort_key(*fp, p); ++unsure_count; }
+        keys_out[i] = k;
+    }
+    *unsure_out = unsure_count;
+}
+
 // pos = position_visibility row (4 floats); depth_range = {min_distance, max_distance}
 void shim_project(const FrameParams* fp, uint32_t key, const float* pos, const float* rot,
                   const float* so, const float* sh48, const float* depth_range, ShimOut* out) {

@@ -301,6 +301,31 @@ def test_xcd_runs_work_order_is_a_bijection_made_of_runs():
     assert np.array_equal(out[0::8], np.arange(0, 255, dtype=np.uint32)) and out[1] == 255
 
 
+@pytest.mark.parametrize("yaw", [0.0, 0.37])
+def test_two_step_keys_are_the_reference_keys_at_every_frustum_threshold(oracle, yaw):
+    """splat_math.h sort_key_fast + the divisions for the splats it is unsure about (what the chainless keygen tiles
+    run) against sort_key (the reference's statement) and the oracle, on points within a few ulp of every threshold of
+    in_frustum and of every guard band. Host build: the reciprocal is the correctly rounded one here and v_rcp_f32
+    (1 ulp) on the device, which the 2^-20 bands cover with a factor of four to spare; the device itself is held to
+    the same cloud by tests/test_gpu_parity.py."""
+    v = View.headless(1920, 1080, yaw=yaw)
+    c = H.frustum_boundary_cloud(v, 20_000, 5 + int(100 * yaw))
+    s = CloudSettings()
+    plain = H.device_keys(c, v, s)
+    two_step, unsure = H.device_keys_two_step(c, v, s)
+    assert np.array_equal(plain, two_step)
+    e = oracle.sort(c, v, s)
+    by_index = np.empty(len(c), np.uint32)
+    by_index[e["index"]] = e["key"]
+    assert np.array_equal(by_index, two_step)
+    drawn = int((two_step != 0xFFFFFFFF).sum())
+    assert 0.2 * len(c) < drawn < 0.8 * len(c)
+    assert 0.05 * len(c) < unsure < 0.6 * len(c), unsure      # a fair share inside the bands, most of the cloud outside
+    for mode in (SortMode.Rayon, SortMode.NONE):              # no frustum test in these keys: never unsure
+        k2, u2 = H.device_keys_two_step(c, v, CloudSettings(sort_mode=mode))
+        assert u2 == 0 and np.array_equal(k2, H.device_keys(c, v, CloudSettings(sort_mode=mode)))
+
+
 LN_HARD_CASES = (0x65d890d3, 0x4c5d65a5, 0x4d604ebe, 0x41178feb, 0x3c413d3a, 0x6f31a8ec)
 
 

@@ -66,41 +66,6 @@ def test_sort_bit_exact_modes_and_depth_bits(plugin, oracle, mode, bits):
     h.free()
 
 
-def _frustum_boundary_cloud(view, n_per_case, seed):
-    """Points whose clip coordinates sit within a few ulp of every threshold of in_frustum (|x/w|, |y/w| = 1.1;
-    z/w = 1, the near plane; z/w -> 0 far away; w ~ 0) and of the guard bands of the device's division-free verdict
-    (splat_math.h in_frustum_of_world: 1.1 (1 +- 2^-20), 2^-20, 1 +- 2^-20), built by un-projecting in float64."""
-    rng = np.random.default_rng(seed)
-    inv = np.linalg.inv(np.asarray(view.clip_from_world, np.float64))
-    near = float(np.asarray(view.clip_from_view, np.float64)[2, 3])     # infinite reverse-z: clip.z = near, clip.w = distance
-    parts = []
-
-    def unproject(ndc_x, ndc_y, dist):
-        clip = np.stack([ndc_x * dist, ndc_y * dist, np.full_like(dist, near), dist], axis=1)
-        w = clip @ inv.T
-        return (w[:, :3] / w[:, 3:4]).astype(np.float32)
-    m = n_per_case
-    for centre in (1.1, 1.1 * (1 - 2.0 ** -20), 1.1 * (1 + 2.0 ** -20)):
-        for axis in (0, 1):
-            for sign in (-1.0, 1.0):
-                edge = sign * centre * (1.0 + rng.uniform(-3e-6, 3e-6, m))
-                other = rng.uniform(-1.05, 1.05, m)
-                dist = np.exp(rng.uniform(np.log(0.2), np.log(200.0), m))
-                parts.append(unproject(edge if axis == 0 else other, other if axis == 0 else edge, dist))
-    for centre in (1.0, 1.0 - 2.0 ** -20, 1.0 + 2.0 ** -20):               # z/w = near/dist around 1: the near plane
-        dist = near / (centre * (1.0 + rng.uniform(-3e-6, 3e-6, 2 * m)))
-        parts.append(unproject(rng.uniform(-1.0, 1.0, 2 * m), rng.uniform(-1.0, 1.0, 2 * m), dist))
-    dist = near / (2.0 ** -20 * (1.0 + rng.uniform(-3e-6, 3e-6, 2 * m)))   # z/w around 2^-20: ~100 km away
-    parts.append(unproject(rng.uniform(-1.0, 1.0, 2 * m), rng.uniform(-1.0, 1.0, 2 * m), dist))
-    dist = rng.uniform(-1e-7, 1e-7, 2 * m)                                  # w within 1e-7 of 0, either side
-    parts.append(unproject(rng.uniform(-1.0, 1.0, 2 * m), rng.uniform(-1.0, 1.0, 2 * m), np.where(dist == 0, 1e-9, dist)))
-    pos = np.concatenate(parts)
-    pv = np.concatenate([pos, np.ones((len(pos), 1), np.float32)], axis=1).astype(np.float32)
-    n = len(pv)
-    return PlanarGaussian3d(pv, np.zeros((n, 48), np.float32), np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1)),
-                            np.tile(np.array([0.01, 0.01, 0.01, 0.5], np.float32), (n, 1)))
-
-
 @pytest.mark.parametrize("yaw", [0.0, 0.37])
 def test_frustum_verdict_without_divisions_is_the_verdict_with_them(plugin, oracle, yaw):
     """keygen decides in_frustum(world_to_clip(p)) from h * rcp(h.w) wherever that is clear of the thresholds by 2^-20
@@ -108,7 +73,7 @@ def test_frustum_verdict_without_divisions_is_the_verdict_with_them(plugin, orac
     a few ulp of every threshold and of every guard band, on both sides: keys and order bit-exact with the oracle,
     which always divides."""
     v = View.headless(1920, 1080, yaw=yaw)
-    c = _frustum_boundary_cloud(v, 60_000, 17 + int(100 * yaw))
+    c = H.frustum_boundary_cloud(v, 60_000, 17 + int(100 * yaw))
     s = CloudSettings()
     h = plugin.upload(c)
     got = plugin.sort(h, v, s)
