@@ -130,8 +130,19 @@ def ensure_current() -> str:
     want = _build_id.kernel_source_sha256()
     have = _build_id.library_build_id(LIB_PATH) if os.path.exists(LIB_PATH) else None
     if have != want and os.environ.get("BGS_NO_AUTOBUILD", "0") != "1":
-        rebuild()
-        have = _build_id.library_build_id(LIB_PATH) if os.path.exists(LIB_PATH) else None
+        # One builder at a time: bench.py's ranks and pytest-xdist workers import the package concurrently, and N
+        # `make` processes in one directory corrupt each other's objects. The id is looked at again under the lock —
+        # whoever waited finds the library its predecessor built.
+        import fcntl
+        with open(os.path.join(_HERE, "csrc", ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                have = _build_id.library_build_id(LIB_PATH) if os.path.exists(LIB_PATH) else None
+                if have != want:
+                    rebuild()
+                    have = _build_id.library_build_id(LIB_PATH) if os.path.exists(LIB_PATH) else None
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     if have is None:
         raise ImportError(
             f"{LIB_PATH} not found (or it carries no build id): build the HIP extension first "

@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void project_emit_kernel(FrameParams fp, Cloud
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t count = ctl->draw_count;
+    // a bucket sort that gave up has voided the list, whatever a later block of it wrote to draw_count (sticky)
+    const uint32_t count = ctl->sort_overflow ? 0u : ctl->draw_count;
     const uint32_t num_tiles = (count + 255u) / 256u;
     if (num_tiles == 0u) return;
     s_histx[tid] = 0u;
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t count = ctl->draw_count;
+    // a bucket sort that gave up has voided the list, whatever a later block of it wrote to draw_count (sticky)
+    const uint32_t count = ctl->sort_overflow ? 0u : ctl->draw_count;
     const uint32_t num_tiles = (count + 255u) / 256u;
     if (num_tiles == 0u) return;
     const uint32_t num_st = sup_x * sup_y;
@@ -1149,7 +1151,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
             tile = 0xFFFFFFFFu;   // a strip block draws this tile
         }
     }
-    const uint32_t draw_count = ctl->draw_count;
+    const uint32_t draw_count = ctl->sort_overflow ? 0u : ctl->draw_count;   // as the project kernel read it
     const uint32_t cmax_bits = __builtin_amdgcn_readfirstlane(ctl->color_max_bits);
     const float t_eps = frame_t_eps(cmax_bits);
     const float surfel_limit = frame_surfel_limit(cmax_bits);

@@ -789,7 +789,9 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     if (__syncthreads_or(fmax > BUCKET_FINE_MAX ? 1 : 0)) {  // step 4 is quadratic in equal keys: give up
         if (tid == 0) {
             atomicOr(&ctl->sort_overflow, 2u);
-            ctl->draw_count = 0u;  // this bucket's stretch of the list stays unwritten: see above
+            // this bucket's stretch of the list stays unwritten: the kernels behind this one read sort_overflow != 0
+            // as "no draw list" (block 255 may publish draw_count AFTER this store: the flag is what is sticky)
+            ctl->draw_count = 0u;
         }
         return;
     }
