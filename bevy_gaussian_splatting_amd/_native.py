@@ -72,6 +72,9 @@ EXPORTED_SYMBOLS = (
     "bgs_set_output_rgba16f",
     "bgs_framebuffer_rgba16f_device_ptr",
     "bgs_set_packed_only",
+    "bgs_device_alloc",
+    "bgs_device_free",
+    "bgs_upload",
 )
 
 
@@ -275,6 +278,12 @@ def load() -> ctypes.CDLL:
     lib.bgs_set_packed_only.restype = ctypes.c_int
     lib.bgs_framebuffer_rgba16f_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
     lib.bgs_framebuffer_rgba16f_device_ptr.restype = ctypes.c_int
+    lib.bgs_device_alloc.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp)]
+    lib.bgs_device_alloc.restype = ctypes.c_int
+    lib.bgs_device_free.argtypes = [vp, vp]
+    lib.bgs_device_free.restype = ctypes.c_int
+    lib.bgs_upload.argtypes = [vp, vp, vp, ctypes.c_uint64]
+    lib.bgs_upload.restype = ctypes.c_int
     lib.bgs_adaptive_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.bgs_adaptive_counters.restype = ctypes.c_int
     lib.bgs_reset_adaptive_state.argtypes = [vp]

@@ -32,7 +32,10 @@ class BgsView(ctypes.Structure):
         ("clear_color", ctypes.c_float * 4),
         ("previous_clip_from_world", ctypes.c_float * 16),
         ("delta_time", ctypes.c_float),
-        ("reserved", ctypes.c_float * 3),
+        ("sample_count", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32 * 2),
+        ("depth_device_ptr", ctypes.c_uint64),
+        ("reserved_ptr", ctypes.c_uint64),
     ]
 
 
@@ -97,6 +100,14 @@ class View:
     previous_clip_from_world: Optional[np.ndarray] = None
     delta_time: float = 1.0 / 60.0
     camera: GaussianCamera = field(default_factory=GaussianCamera)
+    # The camera's `Msaa` component (Bevy: required component of Camera, default Msaa::Sample4) as the pipeline is
+    # specialised on it: CloudPipelineKey.sample_count = msaa.samples() (src/render/mod.rs:357,412,422,975-979).
+    # 1 = Msaa::Off, 4 = Msaa::Sample4. Nothing in the reference sets it, so its cameras all run with 4.
+    msaa_samples: int = 4
+    # Device address of the view's depth attachment (Depth32Float, reverse-Z; [y][x][sample] floats) the draw is tested
+    # against with GreaterEqual (src/render/mod.rs:959-974), or 0: no scene depth. GaussianSplattingPlugin.upload_depth
+    # puts a host array there.
+    depth_device_ptr: int = 0
 
     @property
     def width(self) -> int:
@@ -119,6 +130,7 @@ class View:
         near: float = 0.1,
         clear_color=(0.0, 0.0, 0.0, 1.0),
         order: int = 0,
+        msaa_samples: int = 4,
     ) -> "View":
         wfv = np.asarray(world_from_view, dtype=np.float32)
         vfw = np.linalg.inv(wfv.astype(np.float64)).astype(np.float32)
@@ -132,14 +144,16 @@ class View:
             viewport=(0.0, 0.0, float(width), float(height)),
             clear_color=tuple(float(c) for c in clear_color),
             camera=GaussianCamera(order=order),
+            msaa_samples=int(msaa_samples),
         )
 
     @staticmethod
-    def headless(width: int = 1920, height: int = 1080, yaw: float = 0.0, order: int = 0) -> "View":
+    def headless(width: int = 1920, height: int = 1080, yaw: float = 0.0, order: int = 0, msaa_samples: int = 4) -> "View":
         """examples/headless.rs:177-184 camera, optionally yawed about +Y in place
-        (SURVEY 8(d) cfg 5: camera g = this camera yawed by g * 45 degrees)."""
+        (SURVEY 8(d) cfg 5: camera g = this camera yawed by g * 45 degrees). The example spawns `Camera3d::default()`
+        without an `Msaa` component of its own, so it renders with Bevy's default, Msaa::Sample4."""
         wfv = transform_from((0.0, 1.5, 5.0), rotation_y(yaw))
-        return View.perspective(wfv, width, height, order=order)
+        return View.perspective(wfv, width, height, order=order, msaa_samples=msaa_samples)
 
     def to_native(self) -> BgsView:
         v = BgsView()
@@ -151,4 +165,6 @@ class View:
         prev = self.clip_from_world if self.previous_clip_from_world is None else self.previous_clip_from_world
         v.previous_clip_from_world[:] = np.asarray(prev, dtype=np.float32).T.reshape(16).tolist()
         v.delta_time = float(self.delta_time)
+        v.sample_count = int(self.msaa_samples)
+        v.depth_device_ptr = int(self.depth_device_ptr)
         return v

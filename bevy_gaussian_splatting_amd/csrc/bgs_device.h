@@ -47,7 +47,11 @@ struct FrameParams {
     // Depth-sort path of the frame (sort_kernels.hip): 0 = onesweep digit passes, 1 = bucket sort (keygen
     // places the drawable pairs into key-range buckets, one kernel sorts each bucket in LDS)
     uint32_t sort_path;
-    uint32_t pad_sort;
+    // MultisampleState.count of the pipeline = Msaa::samples() of the camera (src/render/mod.rs:357-424,975-979): 1 or 4
+    uint32_t sample_count;
+    // the view's depth attachment (Depth32Float, reverse-Z, [y][x][sample] floats) the quads are tested against with
+    // GreaterEqual (src/render/mod.rs:959-974), as a device address; 0 = none
+    uint64_t depth_ptr;
 };
 static_assert(sizeof(FrameParams) % 8 == 0 && sizeof(FrameParams) / 4 <= 256, "keygen copies it with one block");
 
@@ -68,12 +72,15 @@ struct ColorInputs {
 //   AABB 3D:        p = {m00, m11, A, B, C}: uv = (m00*dx, m11*dy) and
 //                   power = -0.5*(A*u*u + C*v*v) + B*u*v with (A,B,C) = conic * radius_px^2
 //                   (fs_main uses d = -major_minor = -radius_px * uv, gaussian.wgsl:456-458)
-// rect = inclusive tile bounds x0 | x1 << 8 | y0 << 16 | y1 << 24 (tiles_x, tiles_y <= 256).
+// z = the quad's depth: position.z / position.w of src/render/gaussian.wgsl:429-433, constant over the quad, in (0, 1)
+// for everything that passes in_frustum (reverse-Z: 1 = near plane); what the depth test compares
+// (src/render/mod.rs:959-974). The packed tile rectangle travels in the coarse list entries / the emit kernel's LDS,
+// not in the record.
 struct Record {
     float cx, cy;       // quad centre in pixels (viewport origin at 0,0, y down)
     float p[5];
     float r, g, b, a;   // colour (linear, unclamped) and opacity * global_opacity
-    uint32_t rect;
+    float z;
 };
 static_assert(sizeof(Record) == 48, "Record must be 48 bytes");
 
@@ -85,7 +92,7 @@ struct RecordSurfel {
     float mean_x, mean_y;
     float T[9];         // A = T1 x T2, B = T2 x T0, C = T0 x T1 of local_to_pixel's columns (render_kernels.hip: stage_surfel)
     float r, g, b, a;
-    uint32_t rect;
+    float z;            // the quad's depth (see Record)
     uint32_t pad[3];
 };
 static_assert(sizeof(RecordSurfel) == 96, "RecordSurfel must be 96 bytes");

@@ -49,7 +49,8 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     memcpy(fp.clear, view->clear_color, sizeof fp.clear);
     fp.srgb8_target = 0;
     fp.sort_path = 0;  // chosen per frame by the host (bgs_api.hip)
-    fp.pad_sort = 0;
+    fp.sample_count = view->sample_count;
+    fp.depth_ptr = view->depth_device_ptr;
     for (int i = 0; i < 3; ++i) {
         fp.pos_min[i] = s->position_min[i];
         fp.pos_max[i] = s->position_max[i];

@@ -22,6 +22,7 @@
 // Front-to-back vs the reference's back-to-front "over" is the same polynomial evaluated in
 // the opposite association order; the difference is f32 rounding (<< 1e-3).
 #include <algorithm>
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
@@ -29,6 +30,13 @@
 #include "kernels.h"
 #include "lookback.h"
 #include "splat_math.h"
+
+// Kernel-ablation bits (fp.debug & 1 .. 64: parts of kernels switched off, WRONG images; scripts/ablate.py) exist only in
+// builds with -DBGS_ABLATION=1 (scripts/ab_variants.sh builds those into gpurun_variants/); the production
+// instantiations carry none of them.
+#ifndef BGS_ABLATION
+#define BGS_ABLATION 0
+#endif
 
 namespace bgs {
 
@@ -186,12 +194,12 @@ __device__ __forceinline__ uint32_t project_rank(const FrameParams& fp, const Cl
         dst[3] = make_float4((float)(T2x * T0y - T2y * T0x), (float)(T0y * T1z - T0z * T1y),
                              (float)(T0z * T1x - T0x * T1z), (float)(T0x * T1y - T0y * T1x));
         dst[4] = make_float4(pr.color[0], pr.color[1], pr.color[2], pr.color[3]);
-        dst[5] = make_float4(__uint_as_float(rect), 0.0f, 0.0f, 0.0f);
+        dst[5] = make_float4(pr.ndc_z, 0.0f, 0.0f, 0.0f);
     } else {
         float4* dst = records + (size_t)j * 3u;
         dst[0] = make_float4(pr.quad.cx, pr.quad.cy, pr.p[0], pr.p[1]);
         dst[1] = make_float4(pr.p[2], pr.p[3], pr.p[4], pr.color[0]);
-        dst[2] = make_float4(pr.color[1], pr.color[2], pr.color[3], __uint_as_float(rect));
+        dst[2] = make_float4(pr.color[1], pr.color[2], pr.color[3], pr.ndc_z);
     }
     return rect;
 }
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
         uint32_t rect = RECT_EMPTY;
         if (j < count) {
             bool vis = false;
-            if (fp.debug & 1u) {  // ablation: no projection, a fixed 2x1-tile rectangle
+            if (BGS_ABLATION && (fp.debug & 1u)) {  // ablation: no projection, a fixed 2x1-tile rectangle
                 rect = 0x01000000u | (j & 63u) | (((j & 63u) + 1u) << 8);
             } else {
                 rect = project_rank<FMT, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis, color_mag);
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
         }
         s_rect[tid] = rect;
         if (tid == 0) s_block_hits = 0u;
-        if (fp.debug & 2u) {  // ablation: no coarse binning at all
+        if (BGS_ABLATION && (fp.debug & 2u)) {  // ablation: no coarse binning at all
             __syncthreads();
             continue;
         }
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
             }
         }
         __syncthreads();
-        if (fp.debug & 4u) {  // ablation: ballots only
+        if (BGS_ABLATION && (fp.debug & 4u)) {  // ablation: ballots only
             __syncthreads();
             continue;
         }
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
         // scene-like workload: ~2 per supertile) lets one thread per supertile walk its bits (2 us).
         // entry = (rank, its packed tile rectangle): the rasteriser's candidate scan then is one coalesced
         // 8-byte stream instead of a rank stream plus a 64-line gather of rects[rank].
-        if (fp.debug & 8u) {
+        if (BGS_ABLATION && (fp.debug & 8u)) {
             // ablation bit 8: chain but no list writes
         } else if (s_block_hits >= 8u * num_st) {
             const uint32_t r0 = s_rect[lane], r1 = s_rect[64 + lane], r2 = s_rect[128 + lane], r3 = s_rect[192 + lane];
@@ -711,9 +719,12 @@ __device__ __forceinline__ float frame_surfel_limit(const uint32_t color_max_bit
 // does not depend on how splats are batched, so every rasteriser variant gives the same bits).
 // Explicit fmaf so both rasterisers contract identically.
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <int VARIANT>
+// DEPTH: the fragment is also tested against the pixel's scene depth `dpx` (src/render/mod.rs:959-974: GreaterEqual on
+// a reverse-Z Depth32Float attachment, no write); `z` is the quad's constant depth.
+template <int VARIANT, bool DEPTH = false>
 __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const float qx, const float qy,
-                                         const float aspect, const float t_eps, float& T, v2f& crg, float& cb) {
+                                         const float aspect, const float t_eps, float& T, v2f& crg, float& cb,
+                                         const float z = 0.0f, const float dpx = 0.0f) {
     float alpha, r, g, b;
     bool hit;
     if constexpr (VARIANT == RV_OBB) {
@@ -757,6 +768,7 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
         alpha = fminf(__builtin_amdgcn_exp2f(-fminf(s3, s2)) * s.a5.x, 0.999f);
         r = s.a4.y; g = s.a4.z; b = s.a4.w;
     }
+    if constexpr (DEPTH) hit = hit && z >= dpx;
     // a real branch on purpose: it becomes an exec-mask region that a wave skips entirely when none
     // of its 64 pixels (a 16x4 strip in the wave-per-tile rasteriser) is covered
     if (hit && T >= t_eps) {
@@ -767,6 +779,99 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
         crg = __builtin_elementwise_fma((v2f){w, w}, (v2f){r, g}, crg);
         cb = fmaf(w, b, cb);
         T -= w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 4x multisampling: MultisampleState { count: key.sample_count } with sample_count = Msaa::samples() of the camera
+// (src/render/mod.rs:357,412,422,975-979; Bevy's default is Msaa::Sample4 and nothing in the reference sets another).
+// The fixed-function pipeline then decides COVERAGE (and the depth test) per sample, runs fs_main ONCE per pixel with
+// the interpolants taken at the pixel centre (`@interpolate(linear)`: centre sampling, gaussian.wgsl:146-162;
+// extrapolated when the centre itself is outside the quad), blends the same source colour into every covered sample,
+// and resolves to the mean of the samples. So per pixel alpha and colour are shared and only the transmittance is per
+// sample: C += alpha c mean_s(cov_s T_s);  T_s *= 1 - alpha for the covered samples; the resolved pixel is
+// C + clear * mean_s(T_s). Sample positions: the standard 4x pattern (Vulkan / D3D / Metal), relative to the centre
+//     s0 (-1/8, -3/8)   s1 (+3/8, -1/8)   s2 (-3/8, +1/8) = -s1   s3 (+1/8, +3/8) = -s0.
+// State of a pixel: T_s = S * r[s]. A record that covers ALL samples of a pixel — nearly every (record, pixel) pair
+// away from the quad edges — only scales S (one fma, like the single-sample path); only a pixel the quad's edge passes
+// through scales its covered r[s]. rb = mean_s r[s] rides along so that the mean transmittance S * rb costs one
+// multiplication. A pixel stops accumulating once S * rb < t_eps: what the splats behind could still add is at most
+// mean_s(T_s) * cmax, the bound of the single-sample rule.
+// Which of the two updates a pixel takes is decided per WAVE (the general one runs as soon as one active pixel of the
+// wave needs it; it is correct for fully covered pixels as well): both rasterisers give a wave the same 16 x 4 pixels,
+// so their images stay bit-identical.
+// ---------------------------------------------------------------------------------------
+struct PxMs { float S, rb, r0, r1, r2, r3; };
+constexpr float MS_OX0 = -0.125f, MS_OY0 = -0.375f, MS_OX1 = 0.375f, MS_OY1 = -0.125f;
+// largest |change of u| between the pixel centre and one of its samples, u = a x + b y (staged coefficients)
+__device__ __forceinline__ float ms_margin(const float a, const float b) {
+    return fmaxf(fabsf(fmaf(b, MS_OY0, a * MS_OX0)), fabsf(fmaf(b, MS_OY1, a * MS_OX1)));
+}
+template <int VARIANT, bool DEPTH>
+__device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, const float qx, const float qy,
+                                            const float aspect, const float t_eps, PxMs& t, v2f& crg, float& cb,
+                                            const float z, const bool zmixed, const float4 dpx) {
+    float u, v, lim, m, alpha, r, g, b, du0, du1, dv0, dv1;
+    bool ok = true;
+    if constexpr (VARIANT == RV_OBB) {
+        // staged by stage_obb: a0 = U0' V0' m00' m01' | a1 = m10' m11' margin r | a2 = g b a keepz
+        u = fmaf(s.a0.w, qy, fmaf(s.a0.z, qx, s.a0.x));
+        v = fmaf(s.a1.y, qy, fmaf(s.a1.x, qx, s.a0.y));
+        lim = OBB_C;
+        m = s.a1.z;
+        const float e = __builtin_amdgcn_exp2f(-fmaf(u, u, v * v));
+        alpha = fminf(e * s.a2.z, 0.999f);
+        r = s.a1.w; g = s.a2.x; b = s.a2.y;
+        du0 = fmaf(s.a0.w, MS_OY0, s.a0.z * MS_OX0); du1 = fmaf(s.a0.w, MS_OY1, s.a0.z * MS_OX1);
+        dv0 = fmaf(s.a1.y, MS_OY0, s.a1.x * MS_OX0); dv1 = fmaf(s.a1.y, MS_OY1, s.a1.x * MS_OX1);
+    } else if constexpr (VARIANT == RV_AABB3D) {
+        const float dx = qx - s.a0.x, dy = qy - s.a0.y;
+        u = s.a0.z * dx; v = s.a0.w * dy;
+        lim = 1.0f;
+        m = 0.375f * fmaxf(fabsf(s.a0.z), fabsf(s.a0.w));
+        const float power = fmaf(s.a1.y * u, v, -0.5f * fmaf(s.a1.x * u, u, s.a1.z * v * v));
+        ok = !(power > 0.0f);   // fs_main's discard: the fragment — all its samples — is dropped
+        alpha = fminf(__expf(power) * s.a2.z, 0.999f);
+        r = s.a1.w; g = s.a2.x; b = s.a2.y;
+        du0 = s.a0.z * MS_OX0; du1 = s.a0.z * MS_OX1; dv0 = s.a0.w * MS_OY0; dv1 = s.a0.w * MS_OY1;
+    } else {
+        u = fmaf(s.a0.y, qx, s.a0.x); v = fmaf(s.a0.w, qy, s.a0.z);
+        lim = 1.0f;
+        m = 0.375f * fmaxf(fabsf(s.a0.y), fabsf(s.a0.w));
+        const float px = fmaf(s.a2.z, qy, fmaf(s.a1.w, qx, s.a1.x));
+        const float py = fmaf(s.a2.w, qy, fmaf(s.a2.x, qx, s.a1.y));
+        const float pz = fmaf(s.a3.x, qy, fmaf(s.a2.y, qx, s.a1.z));
+        const float icz = __builtin_amdgcn_rcpf(pz);
+        const float us = px * icz, vs = py * icz;
+        const float ddx = fmaf(s.a3.z, qx, s.a3.y), ddy = fmaf(s.a4.x, qy, s.a3.w);
+        const float s3 = fmaf(us, us, vs * vs);
+        const float s2 = fmaf(ddx, ddx, ddy * ddy);
+        alpha = fminf(__builtin_amdgcn_exp2f(-fminf(s3, s2)) * s.a5.x, 0.999f);
+        r = s.a4.y; g = s.a4.z; b = s.a4.w;
+        du0 = s.a0.y * MS_OX0; du1 = s.a0.y * MS_OX1; dv0 = s.a0.w * MS_OY0; dv1 = s.a0.w * MS_OY1;
+    }
+    const float gmax = fmaxf(fabsf(u), fabsf(v));
+    // beyond lim + m no sample of the pixel is covered; within lim - m all four are
+    if (gmax <= lim + m && ok && t.S * t.rb >= t_eps) {
+        asm volatile("");  // keeps this a branch (see blend_px)
+        const bool full = gmax <= lim - m;
+        float w;
+        if (!(DEPTH && zmixed) && __builtin_amdgcn_ballot_w64(!full) == 0ull) {
+            w = (t.S * t.rb) * alpha;
+            t.S = fmaf(-alpha, t.S, t.S);
+        } else {
+            bool c0 = fmaxf(fabsf(u + du0), fabsf(v + dv0)) <= lim, c1 = fmaxf(fabsf(u + du1), fabsf(v + dv1)) <= lim;
+            bool c2 = fmaxf(fabsf(u - du1), fabsf(v - dv1)) <= lim, c3 = fmaxf(fabsf(u - du0), fabsf(v - dv0)) <= lim;
+            if constexpr (DEPTH) { c0 = c0 && z >= dpx.x; c1 = c1 && z >= dpx.y; c2 = c2 && z >= dpx.z; c3 = c3 && z >= dpx.w; }
+            const float t0 = c0 ? t.r0 : 0.0f, t1 = c1 ? t.r1 : 0.0f, t2 = c2 ? t.r2 : 0.0f, t3 = c3 ? t.r3 : 0.0f;
+            const float sum = (t0 + t1) + (t2 + t3), aq = 0.25f * alpha;
+            w = (t.S * aq) * sum;
+            t.r0 = fmaf(-alpha, t0, t.r0); t.r1 = fmaf(-alpha, t1, t.r1);
+            t.r2 = fmaf(-alpha, t2, t.r2); t.r3 = fmaf(-alpha, t3, t.r3);
+            t.rb = fmaf(-aq, sum, t.rb);
+        }
+        crg = __builtin_elementwise_fma((v2f){w, w}, (v2f){r, g}, crg);
+        cb = fmaf(w, b, cb);
     }
 }
 
@@ -808,9 +913,35 @@ __device__ __forceinline__ uint32_t xcd_remap_runs(const uint32_t b, const uint3
     return xcd_runs_item(b, n, S);
 }
 
+// Staging-time extras of a record for the tile that blends it (both rasterisers go through these, so that their
+// staged records — and with them their images — stay bit-identical):
+//   OBB, multisampled: the margin of blend_px_ms in the spare dword of the second vector;
+//   keepz: the quad's depth, or -1 for a record the tile does not need to blend at all (the exact quad-vs-tile test
+//   failed, a surfel that is negligible in this tile, a quad behind everything the tile's depth buffer holds).
+//   A kept record's depth is > 0 (in_frustum), so the sign bit is the flag.
+template <int MSAA>
+__device__ __forceinline__ void stage_obb_margin(const float4& r0, float4& r1) {
+    r1.z = MSAA == 4 ? fmaxf(ms_margin(r0.z, r0.w), ms_margin(r1.x, r1.y)) : 0.0f;
+}
+__device__ __forceinline__ float keepz_of(const bool keep, const float z) { return keep ? z : -1.0f; }
+__device__ __forceinline__ bool keepz_keeps(const float keepz) { return (int32_t)__float_as_uint(keepz) >= 0; }
+
+// min / max over a wave (all 64 lanes take part)
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 // BINNING_SORT rasteriser: one workgroup per tile, one pixel per thread; the tile's instances are
 // a contiguous range of the tile-sorted list, staged 256 records at a time in LDS.
-template <int VARIANT>
+// MSAA: samples per pixel (1 or 4, blend_px_ms); DEPTH: test against the view's depth buffer (fp.depth_ptr).
+template <int VARIANT, int MSAA, bool DEPTH>
 __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float4* __restrict__ records,
                                                      const uint2* __restrict__ instances,
                                                      const uint2* __restrict__ ranges,
@@ -818,6 +949,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
                                                      const Control* __restrict__ ctl) {
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     __shared__ float4 s_rec[256 * REC_V4];
+    __shared__ float s_zr[4][2];
 
     const uint32_t tile = xcd_remap(blockIdx.x, (uint32_t)(fp.tiles_x * fp.tiles_y));
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
@@ -834,7 +966,27 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     const float t_eps = frame_t_eps(ctl->color_max_bits);
     const float surfel_limit = frame_surfel_limit(ctl->color_max_bits);
     float T = in_image ? 1.0f : 0.0f, cb = 0.0f;
+    PxMs tm{T, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
     v2f crg = {0.0f, 0.0f};
+    // the pixel's scene depth(s) and the tile's range of them (what a record's constant depth is compared with first)
+    float4 dpx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float tile_dmin = 0.0f, tile_dmax = 0.0f;
+    if constexpr (DEPTH) {
+        float lo = INFINITY, hi = -INFINITY;
+        if (in_image) {
+            const float* dsrc = reinterpret_cast<const float*>(fp.depth_ptr) + ((size_t)py * (size_t)fp.width + (size_t)px) * MSAA;
+            if constexpr (MSAA == 4) dpx = *reinterpret_cast<const float4*>(dsrc);
+            else dpx.x = dpx.y = dpx.z = dpx.w = dsrc[0];
+            lo = fminf(fminf(dpx.x, dpx.y), fminf(dpx.z, dpx.w));
+            hi = fmaxf(fmaxf(dpx.x, dpx.y), fmaxf(dpx.z, dpx.w));
+        }
+        lo = wave_min(lo); hi = wave_max(hi);
+        if ((tid & 63) == 0) { s_zr[tid >> 6][0] = lo; s_zr[tid >> 6][1] = hi; }
+        __syncthreads();
+        tile_dmin = fminf(fminf(s_zr[0][0], s_zr[1][0]), fminf(s_zr[2][0], s_zr[3][0]));
+        tile_dmax = fmaxf(fmaxf(s_zr[0][1], s_zr[1][1]), fmaxf(s_zr[2][1], s_zr[3][1]));
+    }
+    auto saturated = [&]() { return MSAA == 4 ? tm.S * tm.rb < t_eps : T < t_eps; };
 
     for (uint32_t base = range.x; base < range.y; base += 256u) {
         const uint32_t cnt = min(256u, range.y - base);
@@ -842,39 +994,49 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
             const uint32_t rank = instances[base + (uint32_t)tid].y;
             const float4* src = records + (size_t)rank * REC_V4;
             if constexpr (VARIANT == RV_OBB) {
-                float4 r0 = src[0], r1 = src[1];
+                float4 r0 = src[0], r1 = src[1], r2 = src[2];
                 stage_obb(r0, r1, tile_ox, tile_oy);
+                stage_obb_margin<MSAA>(r0, r1);
+                r2.w = keepz_of(!DEPTH || r2.w >= tile_dmin, r2.w);
                 s_rec[tid * REC_V4 + 0] = r0;
                 s_rec[tid * REC_V4 + 1] = r1;
-                s_rec[tid * REC_V4 + 2] = src[2];
+                s_rec[tid * REC_V4 + 2] = r2;
             } else if constexpr (VARIANT == RV_SURFEL) {
                 float4 st[6];
                 stage_surfel(src, tile_ox, tile_oy, aspect, st);
-                st[5].y = __uint_as_float(surfel_negligible_in_tile(st, surfel_limit) && !(fp.debug & 64u) ? 0u : 1u);  // as raster_scan_kernel decides
+                const float z = src[5].x;
+                st[5].y = keepz_of(!surfel_negligible_in_tile(st, surfel_limit) && (!DEPTH || z >= tile_dmin), z);  // as raster_scan_kernel decides
 #pragma unroll
                 for (int v = 0; v < 6; ++v) s_rec[tid * REC_V4 + v] = st[v];
             } else {
-#pragma unroll
-                for (int v = 0; v < REC_V4; ++v) s_rec[tid * REC_V4 + v] = src[v];
+                float4 r2 = src[2];
+                r2.w = keepz_of(!DEPTH || r2.w >= tile_dmin, r2.w);
+                s_rec[tid * REC_V4 + 0] = src[0];
+                s_rec[tid * REC_V4 + 1] = src[1];
+                s_rec[tid * REC_V4 + 2] = r2;
             }
         }
         __syncthreads();
-        if (!__all(T < t_eps))
+        if (!__all(saturated()))
             for (uint32_t k = 0; k < cnt; ++k) {
                 StagedRecord<VARIANT> sr;
                 sr.load(s_rec + k * REC_V4);
-                if constexpr (VARIANT == RV_SURFEL)
-                    if (__builtin_amdgcn_readfirstlane(__float_as_uint(sr.a5.y)) == 0u) continue;
-                blend_px<VARIANT>(sr, qx, qy, aspect, t_eps, T, crg, cb);
+                const float keepz = VARIANT == RV_SURFEL ? sr.a5.y : sr.a2.w;
+                const float zr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(keepz)));
+                if (!keepz_keeps(zr)) continue;
+                if constexpr (MSAA == 4) blend_px_ms<VARIANT, DEPTH>(sr, qx, qy, aspect, t_eps, tm, crg, cb, zr, DEPTH && zr < tile_dmax, dpx);
+                else blend_px<VARIANT, DEPTH>(sr, qx, qy, aspect, t_eps, T, crg, cb, zr, dpx.x);
             }
         // also the barrier that protects s_rec before the next batch overwrites it
-        if (__syncthreads_and(T < t_eps ? 1 : 0)) break;
+        if (__syncthreads_and(saturated() ? 1 : 0)) break;
     }
     if (in_image) {
-        // dst = src + dst*(1-src.a) unrolled over the whole list, target cleared to `clear`
+        // dst = src + dst*(1-src.a) unrolled over the whole list, target cleared to `clear`; multisampled: the mean
+        // of the samples, C + clear * mean_s(T_s)
+        const float Tf = MSAA == 4 ? tm.S * tm.rb : T;
         fb[(size_t)py * (size_t)fp.width + (size_t)px] =
-            make_float4(fmaf(T, clear.x, crg.x), fmaf(T, clear.y, crg.y), fmaf(T, clear.z, cb),
-                        fmaf(T, clear.w, 1.0f - T));
+            make_float4(fmaf(Tf, clear.x, crg.x), fmaf(Tf, clear.y, crg.y), fmaf(Tf, clear.z, cb),
+                        fmaf(Tf, clear.w, 1.0f - Tf));
     }
 }
 
@@ -919,17 +1081,32 @@ __device__ __forceinline__ bool all_saturated(const float (&T)[ROWS], const floa
     for (int r = 0; r < ROWS; ++r) s = s && T[r] < t_eps;
     return s;
 }
-template <int VARIANT, bool TRACE, bool MIDROUND_EXIT, int ROWS>
+template <int ROWS>
+__device__ __forceinline__ bool all_saturated(const PxMs (&T)[ROWS], const float t_eps) {
+    bool s = true;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) s = s && T[r].S * T[r].rb < t_eps;
+    return s;
+}
+// MSAA: samples per pixel, 1 or 4 (blend_px_ms). DEPTH: the quads are tested against the view's depth buffer
+// (fp.depth_ptr: [y][x][sample] floats, GreaterEqual, no write; src/render/mod.rs:959-974) — the tile's depths are read
+// once (single-sampled: a register per pixel; 4x: 4 KB of the wave's LDS, s_depth), a record is compared with the
+// tile's [min, max] first: behind everything -> dropped at staging, in front of everything -> the plain path, in between
+// -> the per-sample path.
+template <int VARIANT, bool TRACE, bool MIDROUND_EXIT, int ROWS, int MSAA, bool DEPTH>
 __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const float4* __restrict__ records,
                                                const uint32_t* __restrict__ coarse, const uint32_t coarse_cap,
                                                const uint32_t sup_mul, const uint32_t sup_x, Control* ctl,
                                                float4* __restrict__ fb, uint32_t* __restrict__ fb8_default,
                                                const uint32_t want_srgb8, const float t_eps, const float surfel_limit,
-                                               float4* const s_rec, uint32_t* const s_queue, const int lane,
+                                               float4* const s_rec, uint32_t* const s_queue, float4* const s_depth, const int lane,
                                                const uint32_t tile, const int row0, uint32_t& trace_scanned,
                                                uint32_t& trace_blended, uint32_t& trace_staged) {
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     constexpr uint32_t STAGE = 64u;
+    constexpr bool ABLATE = BGS_ABLATION != 0;
+    // half extent of the box the tile's sample positions span around the tile centre (the exact quad-vs-tile test)
+    constexpr float HALF = MSAA == 4 ? 7.875f : 7.5f;
 
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
     const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + row0 + (lane >> 4);
@@ -939,15 +1116,42 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     const float tile_cx = (float)((int)tx * TILE_PX + 8), tile_cy = (float)((int)ty * TILE_PX + 8);
     const float tile_ox = (float)((int)tx * TILE_PX) + 0.5f, tile_oy = (float)((int)ty * TILE_PX) + 0.5f;
 
-    float T[ROWS], cb[ROWS], qy[ROWS];
+    // per-pixel transmittance: one number (single-sampled target) or PxMs (4x)
+    typedef typename std::conditional<MSAA == 4, PxMs, float>::type Trans;
+    Trans T[ROWS];
+    float cb[ROWS], qy[ROWS], dpx[ROWS];
     v2f crg[ROWS];
+    float tile_dmin = 0.0f, tile_dmax = 0.0f;
+    {
+        float lo = INFINITY, hi = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const int py = py0 + 4 * r;
-        qy[r] = VARIANT != RV_AABB3D ? (float)(row0 + (lane >> 4) + 4 * r) : (float)py + 0.5f;
-        T[r] = (px < fp.width && py < fp.height) ? 1.0f : 0.0f;
-        crg[r] = (v2f){0.0f, 0.0f};
-        cb[r] = 0.0f;
+        for (int r = 0; r < ROWS; ++r) {
+            const int py = py0 + 4 * r;
+            qy[r] = VARIANT != RV_AABB3D ? (float)(row0 + (lane >> 4) + 4 * r) : (float)py + 0.5f;
+            const bool inside = px < fp.width && py < fp.height;
+            if constexpr (MSAA == 4) T[r] = PxMs{inside ? 1.0f : 0.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+            else T[r] = inside ? 1.0f : 0.0f;
+            crg[r] = (v2f){0.0f, 0.0f};
+            cb[r] = 0.0f;
+            dpx[r] = 0.0f;
+            if constexpr (DEPTH) {
+                float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (inside) {
+                    const float* dsrc = reinterpret_cast<const float*>(fp.depth_ptr) + ((size_t)py * (size_t)fp.width + (size_t)px) * MSAA;
+                    if constexpr (MSAA == 4) d = *reinterpret_cast<const float4*>(dsrc);
+                    else d.x = d.y = d.z = d.w = dsrc[0];
+                    lo = fminf(lo, fminf(fminf(d.x, d.y), fminf(d.z, d.w)));
+                    hi = fmaxf(hi, fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w)));
+                }
+                if constexpr (MSAA == 4) s_depth[r * 64 + lane] = d;
+                else dpx[r] = d.x;
+            }
+        }
+        if constexpr (DEPTH) {
+            // (a ROWS == 1 strip wave sees its strip's range only: a tighter, equally valid pre-test)
+            tile_dmin = wave_min(lo);
+            tile_dmax = wave_max(hi);
+        }
     }
 
     const uint32_t st = supertile_div(ty, sup_mul) * sup_x + supertile_div(tx, sup_mul);
@@ -992,7 +1196,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             base += 64u;
         }
         const bool end = base >= total;
-        if (qn && (qn >= FLUSH_AT || !fits || end) && !(fp.debug & 32u)) {  // ablation bit 32: scan only
+        if (qn && (qn >= FLUSH_AT || !fits || end) && !(ABLATE && (fp.debug & 32u))) {  // ablation bit 32: scan only
             const uint32_t cnt = qn;
             qn = 0u;
             bool saturated = false;
@@ -1003,41 +1207,45 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                 const float4* src = records + (size_t)s_queue[c0 + (uint32_t)lane] * REC_V4;
                 float4 r0 = src[0], r1 = src[1];
                 // exact test the tile rect cannot do: the quad is the parallelogram |u|,|v| <= 1, so
-                // it misses the tile iff the tile's pixel-centre box lies wholly beyond one of its
+                // it misses the tile iff the box of the tile's sample positions (its pixel centres for a
+                // single-sampled target) lies wholly beyond one of its
                 // two axes (the box's own axes are the rect test). The verdict rides in a spare
-                // dword of the staged record and the blend loop skips rejected records.
+                // dword of the staged record (keepz_of) and the blend loop skips rejected records.
                 bool keep;
                 if constexpr (VARIANT == RV_OBB) {
                     stage_obb(r0, r1, tile_ox, tile_oy);
-                    // tile centre = first pixel + (7.5, 7.5), half extent 7.5 in both axes
+                    // tile centre = first pixel + (7.5, 7.5), half extent HALF in both axes
                     const float uc = fmaf(r0.w, 7.5f, fmaf(r0.z, 7.5f, r0.x));
                     const float vc = fmaf(r1.y, 7.5f, fmaf(r1.x, 7.5f, r0.y));
-                    const float eu = 7.5f * (fabsf(r0.z) + fabsf(r0.w));
-                    const float ev = 7.5f * (fabsf(r1.x) + fabsf(r1.y));
+                    const float eu = HALF * (fabsf(r0.z) + fabsf(r0.w));
+                    const float ev = HALF * (fabsf(r1.x) + fabsf(r1.y));
                     keep = !(fabsf(uc) - eu > 1.0001f * OBB_C) && !(fabsf(vc) - ev > 1.0001f * OBB_C);
                 } else {  // axis-aligned square: uv = (m00 * dx, m11 * dy)
                     const float dcx = tile_cx - r0.x, dcy = tile_cy - r0.y;
                     const float uc = r0.z * dcx, vc = r0.w * dcy;
-                    const float eu = 7.5f * fabsf(r0.z), ev = 7.5f * fabsf(r0.w);
+                    const float eu = HALF * fabsf(r0.z), ev = HALF * fabsf(r0.w);
                     keep = !(fabsf(uc) - eu > 1.0001f) && !(fabsf(vc) - ev > 1.0001f);
                 }
-                keep = keep || (fp.debug & 64u);
+                if constexpr (ABLATE) keep = keep || (fp.debug & 64u);
                 if constexpr (VARIANT == RV_OBB) {
+                    float4 r2 = src[2];
+                    stage_obb_margin<MSAA>(r0, r1);   // p[4] is unused by the OBB record
+                    r2.w = keepz_of(keep && (!DEPTH || r2.w >= tile_dmin), r2.w);
                     s_rec[lane * REC_V4 + 0] = r0;
-                    r1.z = __uint_as_float(keep ? 1u : 0u);  // p[4] is unused by the OBB record
                     s_rec[lane * REC_V4 + 1] = r1;
-                    s_rec[lane * REC_V4 + 2] = src[2];
+                    s_rec[lane * REC_V4 + 2] = r2;
                 } else if constexpr (VARIANT == RV_AABB3D) {
                     s_rec[lane * REC_V4 + 0] = r0;
                     s_rec[lane * REC_V4 + 1] = r1;
                     float4 r2 = src[2];
-                    r2.w = __uint_as_float(keep ? 1u : 0u);  // rect dword
+                    r2.w = keepz_of(keep && (!DEPTH || r2.w >= tile_dmin), r2.w);
                     s_rec[lane * REC_V4 + 2] = r2;
                 } else {
                     float4 st[6];
                     stage_surfel(src, tile_ox, tile_oy, aspect, st);
-                    keep = keep && !(surfel_negligible_in_tile(st, surfel_limit) && !(fp.debug & 64u));
-                    st[5].y = __uint_as_float(keep ? 1u : 0u);
+                    keep = keep && !(surfel_negligible_in_tile(st, surfel_limit) && !(ABLATE && (fp.debug & 64u)));
+                    const float z = src[5].x;
+                    st[5].y = keepz_of(keep && (!DEPTH || z >= tile_dmin), z);
 #pragma unroll
                     for (int v = 0; v < 6; ++v) s_rec[lane * REC_V4 + v] = st[v];
                 }
@@ -1046,19 +1254,27 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t kend = (fp.debug & 16u) ? min(ccnt, 1u) : ccnt;  // ablation bit 16: stage, blend 1
+            const uint32_t kend = (ABLATE && (fp.debug & 16u)) ? min(ccnt, 1u) : ccnt;  // ablation bit 16: stage, blend 1
             for (uint32_t k = 0; k < kend; ++k) {
                 StagedRecord<VARIANT> sr;
                 sr.load(s_rec + k * REC_V4);
-                uint32_t keep_flag;
-                if constexpr (VARIANT == RV_OBB) keep_flag = __float_as_uint(sr.a1.z);
-                else if constexpr (VARIANT == RV_AABB3D) keep_flag = __float_as_uint(sr.a2.w);
-                else keep_flag = __float_as_uint(sr.a5.y);
+                const float keepz = VARIANT == RV_SURFEL ? sr.a5.y : sr.a2.w;
                 if constexpr (TRACE) trace_staged += 1u;
-                if (__builtin_amdgcn_readfirstlane(keep_flag) == 0u) continue;  // scalar branch
+                // the record's depth, or the "skip" flag in its sign bit: wave-uniform, a scalar branch
+                const float zr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(keepz)));
+                if (!keepz_keeps(zr)) continue;
                 if constexpr (TRACE) trace_blended += 1u;
+                const bool zmixed = DEPTH && zr < tile_dmax;
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r) blend_px<VARIANT>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
+                for (int r = 0; r < ROWS; ++r) {
+                    if constexpr (MSAA == 4) {
+                        float4 d4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if constexpr (DEPTH) if (zmixed) d4 = s_depth[r * 64 + lane];
+                        blend_px_ms<VARIANT, DEPTH>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, zmixed, d4);
+                    } else {
+                        blend_px<VARIANT, DEPTH>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, dpx[r]);
+                    }
+                }
                 if constexpr (MIDROUND_EXIT)
                     if ((k & (BGS_MIDROUND_PERIOD - 1u)) == BGS_MIDROUND_PERIOD - 1u && __all(all_saturated(T, t_eps))) break;
             }
@@ -1068,7 +1284,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             if (saturated) break;
             __builtin_amdgcn_wave_barrier();  // blend reads of s_rec / s_queue done before they are rewritten
         }
-        if (fp.debug & 32u) qn = 0u;
+        if constexpr (ABLATE) if (fp.debug & 32u) qn = 0u;
         if (end && qn == 0u) break;
     }
     {
@@ -1081,8 +1297,11 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
         for (int r = 0; r < ROWS; ++r) {
             const int py = pyw + 4 * r;
             if (pxw < fp.width && py < fp.height) {
-                const float4 c = make_float4(fmaf(T[r], fp.clear[0], crg[r].x), fmaf(T[r], fp.clear[1], crg[r].y),
-                                             fmaf(T[r], fp.clear[2], cb[r]), fmaf(T[r], fp.clear[3], 1.0f - T[r]));
+                // (multisampled: the resolve — the mean of the samples is C + clear * mean_s(T_s))
+                float Tf;
+                if constexpr (MSAA == 4) Tf = T[r].S * T[r].rb; else Tf = T[r];
+                const float4 c = make_float4(fmaf(Tf, fp.clear[0], crg[r].x), fmaf(Tf, fp.clear[1], crg[r].y),
+                                             fmaf(Tf, fp.clear[2], cb[r]), fmaf(Tf, fp.clear[3], 1.0f - Tf));
                 const size_t at = (size_t)py * (size_t)fp.width + (size_t)pxw;
                 // Streaming stores: a frame's 33 MB target is written once and read by nobody on this chip before
                 // the next frames have pushed it out anyway; kept out of the L2 / Infinity Cache allocation the
@@ -1108,8 +1327,13 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     return rounds;
 }
 
-template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false>
-__global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
+// Waves per SIMD: 8 for the single-sampled ellipse variants (<= 64 VGPRs), 6 for the surfel variant; the multisampled
+// instantiations carry six transmittance words per pixel instead of one (5 / 4 waves).
+constexpr int raster_waves_per_simd(const int variant, const int msaa, const bool depth) {
+    return msaa == 4 ? (variant == 2 ? (depth ? 3 : 4) : 5) : (variant == 2 ? (depth ? 5 : 6) : (depth ? 7 : 8));
+}
+template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false, int MSAA = 1, bool DEPTH = false>
+__global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_mul,
                                                           uint32_t sup_x, Control* ctl,
@@ -1127,6 +1351,7 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
     constexpr uint32_t STAGE = 64u;
     __shared__ float4 s_rec_all[4][STAGE * REC_V4];
     __shared__ uint32_t s_queue_all[4][64];
+    __shared__ float4 s_depth_all[4][DEPTH && MSAA == 4 ? 256 : 1];   // the tile's depth samples (raster_tile)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
@@ -1201,13 +1426,13 @@ __global__ __launch_bounds__(256, VARIANT == 2 ? 6 : 8) void raster_scan_kernel(
         uint32_t rounds;
         bool reports = true;   // which wave speaks for the tile in the feedback
         if (MIDROUND_EXIT && strip_block) {
-            rounds = raster_tile<VARIANT, false, MIDROUND_EXIT, 1>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
-                                                                   t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], lane, tile, 4 * wave,
+            rounds = raster_tile<VARIANT, false, MIDROUND_EXIT, 1, MSAA, DEPTH>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
+                                                                   t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 4 * wave,
                                                                    trace_scanned, trace_blended, trace_staged);
             reports = wave == 0;
         } else {
-            rounds = raster_tile<VARIANT, TRACE, MIDROUND_EXIT, 4>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
-                                                                   t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], lane, tile, 0,
+            rounds = raster_tile<VARIANT, TRACE, MIDROUND_EXIT, 4, MSAA, DEPTH>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
+                                                                   t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 0,
                                                                    trace_scanned, trace_blended, trace_staged);
             tile_done = tile;
         }
@@ -1248,20 +1473,24 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
     const float4* rec = (const float4*)records;
     const uint32_t sup = sup_edge, sup_mul = supertile_mul(sup_edge);
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
+    // instantiations: variant x mid-round exit x samples per pixel; the per-tile trace exists for the variants without a
+    // depth buffer, the depth test for the untraced ones
+    const bool msaa4 = fp.sample_count == 4u, depth = fp.depth_ptr != 0ull;
+#define BGS_LAUNCH_RS4(V, X, TR, MS, DP)                                                          \
+    hipLaunchKernelGGL((raster_scan_kernel<V, TR, X, MS, DP>), dim3(grid), dim3(256), 0, stream, d_fp, rec, coarse,      \
+                       coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (TR) ? tile_trace : (uint4*)nullptr, heavy_in, heavy_out)
 #define BGS_LAUNCH_RS(V, X)                                                                       \
     do {                                                                                          \
         const uint32_t grid = (ntiles + 3u) / 4u + ((X) && heavy_in ? HEAVY_CAP : 0u);            \
-        if (tile_trace)                                                                           \
-            hipLaunchKernelGGL((raster_scan_kernel<V, true, X>), dim3(grid), dim3(256), 0, stream, d_fp, rec,  \
-                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, tile_trace, heavy_in, heavy_out); \
-        else                                                                                      \
-            hipLaunchKernelGGL((raster_scan_kernel<V, false, X>), dim3(grid), dim3(256), 0, stream, d_fp, rec,  \
-                               coarse, coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (uint4*)nullptr, heavy_in, heavy_out); \
+        if (depth) { if (msaa4) BGS_LAUNCH_RS4(V, X, false, 4, true); else BGS_LAUNCH_RS4(V, X, false, 1, true); } \
+        else if (tile_trace) { if (msaa4) BGS_LAUNCH_RS4(V, X, true, 4, false); else BGS_LAUNCH_RS4(V, X, true, 1, false); } \
+        else { if (msaa4) BGS_LAUNCH_RS4(V, X, false, 4, false); else BGS_LAUNCH_RS4(V, X, false, 1, false); } \
     } while (0)
     if (fp.aabb == 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_OBB, true); else BGS_LAUNCH_RS(RV_OBB, false); }
     else if (fp.gaussian_mode != 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_AABB3D, true); else BGS_LAUNCH_RS(RV_AABB3D, false); }
     else BGS_LAUNCH_RS(RV_SURFEL, false);
 #undef BGS_LAUNCH_RS
+#undef BGS_LAUNCH_RS4
 }
 
 void launch_raster(hipStream_t stream, const FrameParams& fp, const void* records,
@@ -1271,15 +1500,20 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
     if (ntiles == 0) return;
     const float4 clear = make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]);
     const float4* rec = (const float4*)records;
-    if (fp.aabb == 0u)
-        hipLaunchKernelGGL(raster_kernel<RV_OBB>, dim3(ntiles), dim3(256), 0, stream, fp, rec, instances,
-                           ranges, framebuffer, clear, ctl);
-    else if (fp.gaussian_mode != 0u)
-        hipLaunchKernelGGL(raster_kernel<RV_AABB3D>, dim3(ntiles), dim3(256), 0, stream, fp, rec,
-                           instances, ranges, framebuffer, clear, ctl);
-    else
-        hipLaunchKernelGGL(raster_kernel<RV_SURFEL>, dim3(ntiles), dim3(256), 0, stream, fp, rec,
-                           instances, ranges, framebuffer, clear, ctl);
+    const bool msaa4 = fp.sample_count == 4u, depth = fp.depth_ptr != 0ull;
+#define BGS_LAUNCH_R(V, MS, DP)                                                                                     \
+    hipLaunchKernelGGL((raster_kernel<V, MS, DP>), dim3(ntiles), dim3(256), 0, stream, fp, rec, instances, ranges, \
+                       framebuffer, clear, ctl)
+#define BGS_LAUNCH_R2(V)                                                                          \
+    do {                                                                                          \
+        if (msaa4) { if (depth) BGS_LAUNCH_R(V, 4, true); else BGS_LAUNCH_R(V, 4, false); }       \
+        else { if (depth) BGS_LAUNCH_R(V, 1, true); else BGS_LAUNCH_R(V, 1, false); }             \
+    } while (0)
+    if (fp.aabb == 0u) BGS_LAUNCH_R2(RV_OBB);
+    else if (fp.gaussian_mode != 0u) BGS_LAUNCH_R2(RV_AABB3D);
+    else BGS_LAUNCH_R2(RV_SURFEL);
+#undef BGS_LAUNCH_R2
+#undef BGS_LAUNCH_R
 }
 
 // ---------------------------------------------------------------------------------------

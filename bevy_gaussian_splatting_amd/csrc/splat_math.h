@@ -585,6 +585,7 @@ struct Projected {
     float p[5];     // Record.p payload
     Surfel surfel;  // 2D only
     float radius;   // 2D: bb.zw
+    float ndc_z;    // the quad's depth: position.z / position.w (gaussian.wgsl:429-433), constant over the quad
     int tx0, ty0, tx1, ty1;
 };
 
@@ -638,6 +639,7 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
     }
     if (!quad_to_pixels(fp, projected, bb, o.quad)) return;
     if (!tile_rect(fp, o.quad, o.tx0, o.ty0, o.tx1, o.ty1)) return;
+    o.ndc_z = projected.z / projected.w;                           // :429-433 position = (projected.xy + bb.xy, projected.zw)
     if (!fp.aabb) {
         o.p[0] = o.quad.m00; o.p[1] = o.quad.m01; o.p[2] = o.quad.m10; o.p[3] = o.quad.m11;
     } else {

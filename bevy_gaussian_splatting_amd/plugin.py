@@ -359,6 +359,32 @@ class GaussianSplattingPlugin:
             self._check(self._lib.bgs_download(self._ctx, p, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
         return out
 
+    def device_alloc(self, nbytes: int) -> int:
+        """`bgs_device_alloc`: device memory for what the caller hands over by device pointer (a depth buffer, a packed
+        image target). Returns the address."""
+        p = ctypes.c_void_p()
+        self._check(self._lib.bgs_device_alloc(self._ctx, int(nbytes), ctypes.byref(p)))
+        return int(p.value or 0)
+
+    def device_free(self, device_ptr: int) -> None:
+        self._check(self._lib.bgs_device_free(self._ctx, ctypes.c_void_p(device_ptr)))
+
+    def upload_bytes(self, device_ptr: int, host: np.ndarray) -> None:
+        """`bgs_upload`: blocking host-to-device copy of a contiguous array."""
+        a = np.ascontiguousarray(host)
+        self._check(self._lib.bgs_upload(self._ctx, ctypes.c_void_p(device_ptr), a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+
+    def upload_depth(self, depth: np.ndarray) -> int:
+        """Put a view's scene depth on the device: `depth` is [height, width, samples] float32 (reverse-Z, what Bevy's
+        opaque passes left in the view's Depth32Float attachment; src/render/mod.rs:959-974). Returns the device
+        address for `View.depth_device_ptr`; release it with `device_free` once the frames that use it are complete."""
+        d = np.ascontiguousarray(depth, dtype=np.float32)
+        if d.ndim != 3 or d.shape[2] not in (1, 4):
+            raise ValueError("depth must be [height, width, samples] with 1 or 4 samples")
+        p = self.device_alloc(d.nbytes)
+        self.upload_bytes(p, d)
+        return p
+
     def set_tile_trace(self, device_ptr: Optional[int]) -> None:
         """`bgs_set_tile_trace`: per-tile timing / placement trace of the rasteriser into a caller-owned device buffer
         (tiles_x * tiles_y * 32 bytes); None switches it off."""

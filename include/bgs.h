@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define BGS_VERSION_MAJOR 0
-#define BGS_VERSION_MINOR 2
+#define BGS_VERSION_MINOR 3 /* 0.3: bgs_view gained sample_count + depth_device_ptr (16 bytes longer), bgs_stats is 16 bytes longer than 0.2's */
 
 typedef enum bgs_status {
     BGS_OK = 0,
@@ -68,7 +68,24 @@ typedef struct bgs_view {
      * clip_from_world (Bevy's previous_view_uniforms) and globals.delta_time in seconds */
     float previous_clip_from_world[16];
     float delta_time;
-    float reserved[3];
+    /* The camera's `Msaa` component as the pipeline is specialised on it: CloudPipelineKey.sample_count =
+     * msaa.samples() (src/render/mod.rs:357,412,422) -> MultisampleState.count (:975-979). 1 = Msaa::Off, 4 =
+     * Msaa::Sample4 — Bevy's default, i.e. what every camera of the reference's examples and tests runs with
+     * (nothing in the reference sets Msaa; src/utils.rs:34 `msaa_samples` is never read). With 4 samples coverage
+     * (and the depth test) is decided per sample at the standard sample positions, the fragment stage runs once
+     * per pixel at the pixel centre, every covered sample blends the same source colour, and the image handed
+     * back is the resolved one (mean of the samples). Anything but 1 or 4 is BGS_EINVAL (Sample2 / Sample8 are
+     * not built). bgs_view_perspective sets 4. */
+    uint32_t sample_count;
+    uint32_t reserved[2];
+    /* The view's depth attachment the draw is tested against (src/render/mod.rs:959-974: Depth32Float,
+     * CompareFunction::GreaterEqual — reverse-Z —, depth_write_enabled false): a DEVICE pointer to
+     * viewport.w * viewport.h * sample_count floats laid out [y][x][sample] (what Bevy's opaque passes left), or
+     * 0 = no scene depth (every fragment passes, as against a buffer cleared to 0.0). A quad's depth is its
+     * splat's constant NDC z (src/render/gaussian.wgsl:429-433). The memory must stay valid and unchanged until
+     * the frame has completed (bgs_device_alloc / bgs_upload below serve hosts without a HIP runtime). */
+    uint64_t depth_device_ptr;
+    uint64_t reserved_ptr;
 } bgs_view;
 
 /* gaussian_mode: src/gaussian/settings.rs:17-22 */
@@ -181,7 +198,8 @@ void bgs_settings_default(bgs_settings* out);
 
 /* Convenience: build a bgs_view the way Bevy builds its View uniform for
  * `Camera3d::default()` (infinite reverse-Z right-handed perspective) from a camera
- * world transform. Pure host arithmetic in f32. clear_color is set to opaque black. */
+ * world transform. Pure host arithmetic in f32. clear_color is set to opaque black, sample_count to 4
+ * (Msaa::default() = Sample4), depth_device_ptr to 0. */
 void bgs_view_perspective(const float world_from_view[16], float fov_y_radians,
                           float near_plane, uint32_t width, uint32_t height,
                           bgs_view* out);
@@ -254,6 +272,12 @@ int bgs_set_srgb8_target(bgs_ctx* ctx, void* device_ptr);
  * entries) to host memory, for hosts that do not link the HIP runtime themselves. Blocking. The
  * memory must belong to a COMPLETED frame: after a blocking call, bgs_pipeline_pop or bgs_synchronize. */
 int bgs_download(bgs_ctx* ctx, const void* device_ptr, void* host_out, uint64_t bytes);
+/* Device memory for what the CALLER hands to the library by device pointer (bgs_view.depth_device_ptr,
+ * bgs_set_srgb8_target), for hosts that do not link the HIP runtime themselves: allocate / free on the context's
+ * device, and a blocking host-to-device copy. bgs_device_free completes the frames in flight first. */
+int bgs_device_alloc(bgs_ctx* ctx, uint64_t bytes, void** device_ptr_out);
+int bgs_device_free(bgs_ctx* ctx, void* device_ptr);
+int bgs_upload(bgs_ctx* ctx, void* device_ptr, const void* host_in, uint64_t bytes);
 
 /* Frame pipelining. A single stream of this path's kernels is latency bound at 1M splats, so the
  * context can keep up to 8 frames in flight ("lanes", each with its own per-frame buffers, run on a

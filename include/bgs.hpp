@@ -189,6 +189,11 @@ struct View {
     void set_clear_color(float r, float g, float b, float a) {
         native.clear_color[0] = r; native.clear_color[1] = g; native.clear_color[2] = b; native.clear_color[3] = a;
     }
+    // The camera's `Msaa` component (CloudPipelineKey.sample_count = msaa.samples(), src/render/mod.rs:357-424): 1 =
+    // Msaa::Off, 4 = Msaa::Sample4 — Bevy's default, which bgs_view_perspective has already set.
+    void set_msaa_samples(uint32_t samples) { native.sample_count = samples; }
+    // The view's depth attachment as device memory ([y][x][sample] floats, reverse-Z; src/render/mod.rs:959-974), 0 = none.
+    void set_depth(const void* device_ptr) { native.depth_device_ptr = (uint64_t)(uintptr_t)device_ptr; }
 };
 
 class GaussianSplattingPlugin;

@@ -888,13 +888,44 @@ static int build_prim(prim* p, int32_t x0, int32_t y0, int32_t x1, int32_t y1, d
     return 1;
 }
 
-int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
-                  const bgs_view* view, const bgs_settings* s, int32_t x0, int32_t y0, int32_t x1,
-                  int32_t y1, float* rgba_out, float* amb_out) {
+/* Sample positions inside a pixel (origin = the pixel's top-left corner, y down) of the multisample patterns the
+ * reference can run with: MultisampleState { count: key.sample_count } (src/render/mod.rs:975-979) with
+ * sample_count = Msaa::samples() of the camera (src/render/mod.rs:357,412,422; Bevy's default is Msaa::Sample4 and
+ * nothing in the reference sets another). Third party (wgpu 29 on Vulkan / Metal / D3D12: the "standard sample
+ * locations" all three APIs prescribe for 4 samples); PARITY UNPINNED like the rest of the fixed-function stage. */
+static const double MS_POS1[1][2] = {{0.5, 0.5}};
+static const double MS_POS4[4][2] = {{0.375, 0.125}, {0.875, 0.375}, {0.125, 0.625}, {0.625, 0.875}};
+
+int oracle_sample_positions(uint32_t sample_count, float* xy_out) {
+    if (sample_count != 1 && sample_count != 4) return -1;
+    const double(*pos)[2] = sample_count == 4 ? MS_POS4 : MS_POS1;
+    for (uint32_t s = 0; s < sample_count; ++s) { xy_out[2 * s] = (float)pos[s][0]; xy_out[2 * s + 1] = (float)pos[s][1]; }
+    return 0;
+}
+
+/* The draw of src/render/mod.rs:1513-1569 into a MULTISAMPLED colour attachment, the way the fixed-function pipeline
+ * of src/render/mod.rs:925-983 defines it:
+ *   - coverage is decided per SAMPLE (is the sample position inside the quad);
+ *   - the fragment shader runs once per pixel with every interpolant evaluated at the pixel CENTRE
+ *     (`@interpolate(linear)` = linear, center: src/render/gaussian.wgsl:146-162) — extrapolated when the centre itself
+ *     lies outside the quad;
+ *   - depth test per sample against the view's depth attachment: Depth32Float, CompareFunction::GreaterEqual,
+ *     depth_write_enabled false (src/render/mod.rs:959-974); the quad's depth is the constant position.z / position.w
+ *     of src/render/gaussian.wgsl:429-433. `depth` = viewport.w * viewport.h * sample_count floats, [y][x][sample],
+ *     or NULL (no scene depth: every fragment passes, as against a buffer cleared to 0);
+ *   - every covered sample blends the SAME source colour (BlendState::PREMULTIPLIED_ALPHA_BLENDING, :946);
+ *   - the resolve is the box filter: the mean of the pixel's samples.
+ * sample_count = view->sample_count (1 or 4). */
+int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                        const bgs_view* view, const bgs_settings* s, int32_t x0, int32_t y0, int32_t x1,
+                        int32_t y1, const float* depth, float* rgba_out, float* amb_out) {
     const int32_t Wi = (int32_t)view->viewport[2], Hi = (int32_t)view->viewport[3];
     if (x0 < 0 || y0 < 0 || x1 > Wi || y1 > Hi || x0 >= x1 || y0 >= y1) return -1;
     const double W = (double)view->viewport[2], H = (double)view->viewport[3];
     const int32_t rw = x1 - x0, rh = y1 - y0;
+    const int S = (int)view->sample_count;
+    if (S != 1 && S != 4) return -5;
+    const double(*pos)[2] = S == 4 ? MS_POS4 : MS_POS1;
 
     float depth_range[2] = {0.0f, 0.0f};
     if (s->rasterize_mode == BGS_RASTERIZE_DEPTH && oracle_depth_range(cloud, entries, count, view, s, depth_range))
@@ -917,37 +948,46 @@ int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint
         if (keep[i]) { if (np != i) tmp[np] = tmp[i]; ++np; }
     free(keep);
 
-    /* clear (examples/headless.rs:70 -> view->clear_color) */
-    for (int64_t i = 0; i < (int64_t)rw * rh; ++i) {
-        for (int c = 0; c < 4; ++c) rgba_out[4 * i + c] = view->clear_color[c];
-        if (amb_out) amb_out[i] = 0.0f;
-    }
-
+    int failed = 0;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int32_t y = y0; y < y1; ++y) {
         float* row = rgba_out + (size_t)(y - y0) * rw * 4;
         float* arow = amb_out ? amb_out + (size_t)(y - y0) * rw : 0;
-        const double qy = (double)y + 0.5;
+        /* the row's samples: [x][sample][rgba], cleared (examples/headless.rs:70 -> view->clear_color) */
+        float* ms = (float*)malloc((size_t)rw * S * 4 * sizeof(float));
+        if (!ms) { failed = 1; continue; }
+        for (int64_t i = 0; i < (int64_t)rw * S; ++i)
+            for (int c = 0; c < 4; ++c) ms[4 * i + c] = view->clear_color[c];
+        if (arow) for (int32_t i = 0; i < rw; ++i) arow[i] = 0.0f;
         for (size_t pi = 0; pi < np; ++pi) {
             const prim* p = &tmp[pi];
             if (y < p->by0 || y > p->by1) continue;
             const oracle_vs_out* vs = &p->vs;
+            /* the quad's depth: constant over the quad (position.zw is the splat's, gaussian.wgsl:429-433) */
+            const float zf = vs->projected[2] / vs->projected[3];
             for (int32_t x = p->bx0; x <= p->bx1; ++x) {
-                const double qx = (double)x + 0.5;
-                const double dx = qx - p->p0x, dy = qy - p->p0y;
-                /* q - P0 = sp * Es + tp * Et */
-                const double sp = (dx * p->ety - dy * p->etx) * p->inv_det;
-                const double tp = (p->esx * dy - p->esy * dx) * p->inv_det;
-                const int inside = (sp >= 0.0 && sp <= 1.0 && tp >= 0.0 && tp <= 1.0);
-                int near_edge = 0;
-                if (arow) {
-                    const double ds = fmin(fabs(sp), fabs(sp - 1.0));
-                    const double dt = fmin(fabs(tp), fabs(tp - 1.0));
-                    const int in_band_s = sp >= -p->eps_s && sp <= 1.0 + p->eps_s;
-                    const int in_band_t = tp >= -p->eps_t && tp <= 1.0 + p->eps_t;
-                    near_edge = in_band_s && in_band_t && (ds < p->eps_s || dt < p->eps_t);
+                /* q - P0 = sp * Es + tp * Et, at the pixel centre (what the interpolants see) ... */
+                const double cdx = (double)x + 0.5 - p->p0x, cdy = (double)y + 0.5 - p->p0y;
+                const double sp = (cdx * p->ety - cdy * p->etx) * p->inv_det;
+                const double tp = (p->esx * cdy - p->esy * cdx) * p->inv_det;
+                /* ... and at every sample position (coverage) */
+                int inside[4] = {0, 0, 0, 0}, near_edge[4] = {0, 0, 0, 0}, any_inside = 0, any_near = 0;
+                for (int k = 0; k < S; ++k) {
+                    const double dx = (double)x + pos[k][0] - p->p0x, dy = (double)y + pos[k][1] - p->p0y;
+                    const double sk = (dx * p->ety - dy * p->etx) * p->inv_det;
+                    const double tk = (p->esx * dy - p->esy * dx) * p->inv_det;
+                    inside[k] = (sk >= 0.0 && sk <= 1.0 && tk >= 0.0 && tk <= 1.0);
+                    if (arow) {
+                        const double ds = fmin(fabs(sk), fabs(sk - 1.0));
+                        const double dt = fmin(fabs(tk), fabs(tk - 1.0));
+                        const int in_band_s = sk >= -p->eps_s && sk <= 1.0 + p->eps_s;
+                        const int in_band_t = tk >= -p->eps_t && tk <= 1.0 + p->eps_t;
+                        near_edge[k] = in_band_s && in_band_t && (ds < p->eps_s || dt < p->eps_t);
+                    }
+                    any_inside |= inside[k];
+                    any_near |= near_edge[k];
                 }
-                if (!inside && !near_edge) continue;
+                if (!any_inside && !any_near) continue;
                 /* linear (non-perspective) interpolation of uv and major_minor
                  * (src/render/gaussian.wgsl:148-162): vertex 0 = (-1,-1), 2 = (+1,-1), 1 = (-1,+1) */
                 v2 uv = {(float)(2.0 * sp - 1.0), (float)(2.0 * tp - 1.0)};
@@ -958,7 +998,11 @@ int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint
                 float src[4] = {0, 0, 0, 0};
                 float power = 0.0f;
                 const int drawn = fs_main(vs, uv, mm, view, s, src, &power);
-                float* dst = row + 4 * (size_t)(x - x0);
+                float* dst = ms + (size_t)(x - x0) * S * 4;
+                /* the largest magnitude any of the pixel's samples holds (for the ambiguity bounds) */
+                float dm = 0.0f;
+                if (arow)
+                    for (int k = 0; k < 4 * S; ++k) dm = fmaxf(dm, fabsf(dst[k]));
                 if (arow && s->aabb && s->gaussian_mode == BGS_GAUSSIAN_2D) {
                     /* conditioning of the surfel intersection at this pixel (see surfel_fragment_power_d) */
                     const double asp = (double)view->viewport[2] / (double)view->viewport[3];
@@ -982,35 +1026,53 @@ int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint
                     if (da > 1e-6) {
                         float cm = fmaxf(fmaxf(fabsf(vs->color[0]), fabsf(vs->color[1])),
                                          fmaxf(fabsf(vs->color[2]), 1.0f));
-                        float dm = fmaxf(fmaxf(fabsf(dst[0]), fabsf(dst[1])),
-                                         fmaxf(fabsf(dst[2]), fabsf(dst[3])));
                         arow[x - x0] += (float)(4.0 * da) * (cm + dm);
                     }
                 }
                 if (arow) {
-                    int ambiguous = near_edge;
-                    if (s->aabb && fabsf(power) < 1e-5f) ambiguous = 1;
-                    if (ambiguous) {
+                    /* a coverage decision within rounding distance of a quad edge moves ONE sample's share of the pixel;
+                     * a discard decision at the threshold (power ~ 0) moves the whole pixel */
+                    int flips = 0;
+                    for (int k = 0; k < S; ++k) flips += near_edge[k];
+                    const int whole = s->aabb && fabsf(power) < 1e-5f;
+                    if (flips || whole) {
                         float a = fminf(expf(fminf(power, 0.0f)) * fabsf(vs->color[3]), 0.999f);
                         float cm = fmaxf(fmaxf(fabsf(vs->color[0]), fabsf(vs->color[1])),
                                          fmaxf(fabsf(vs->color[2]), 1.0f));
-                        float dm = fmaxf(fmaxf(fabsf(dst[0]), fabsf(dst[1])),
-                                         fmaxf(fabsf(dst[2]), fabsf(dst[3])));
-                        arow[x - x0] += a * (cm + dm);
+                        arow[x - x0] += a * (cm + dm) * (whole ? 1.0f : (float)flips / (float)S);
                     }
                 }
-                if (!inside || !drawn) continue;
-                /* BlendState::PREMULTIPLIED_ALPHA_BLENDING (src/render/mod.rs:946) */
+                if (!drawn) continue;
+                /* BlendState::PREMULTIPLIED_ALPHA_BLENDING (src/render/mod.rs:946), per covered sample that passes
+                 * the depth test (CompareFunction::GreaterEqual against the view's depth, :959-974) */
                 const float one_minus = 1.0f - src[3];
-                dst[0] = src[0] + dst[0] * one_minus;
-                dst[1] = src[1] + dst[1] * one_minus;
-                dst[2] = src[2] + dst[2] * one_minus;
-                dst[3] = src[3] + dst[3] * one_minus;
+                for (int k = 0; k < S; ++k) {
+                    if (!inside[k]) continue;
+                    if (depth && !(zf >= depth[((size_t)y * (size_t)Wi + (size_t)x) * (size_t)S + (size_t)k])) continue;
+                    float* d = dst + 4 * k;
+                    d[0] = src[0] + d[0] * one_minus;
+                    d[1] = src[1] + d[1] * one_minus;
+                    d[2] = src[2] + d[2] * one_minus;
+                    d[3] = src[3] + d[3] * one_minus;
+                }
             }
         }
+        /* resolve: the mean of the pixel's samples */
+        for (int32_t x = 0; x < rw; ++x) {
+            const float* d = ms + (size_t)x * S * 4;
+            for (int c = 0; c < 4; ++c)
+                row[4 * x + c] = S == 4 ? ((d[c] + d[4 + c]) + (d[8 + c] + d[12 + c])) * 0.25f : d[c];
+        }
+        free(ms);
     }
     free(tmp);
-    return 0;
+    return failed ? -2 : 0;
+}
+
+int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                  const bgs_view* view, const bgs_settings* s, int32_t x0, int32_t y0, int32_t x1,
+                  int32_t y1, float* rgba_out, float* amb_out) {
+    return oracle_render_depth(cloud, entries, count, view, s, x0, y0, x1, y1, 0, rgba_out, amb_out);
 }
 
 int oracle_instance_stats(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,

@@ -138,6 +138,17 @@ int oracle_depth_range(const oracle_cloud* cloud, const bgs_sort_entry* entries,
 int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
                   const bgs_view* view, const bgs_settings* settings, int32_t x0, int32_t y0,
                   int32_t x1, int32_t y1, float* rgba_out, float* ambiguity_out);
+/* The same draw into a multisampled target with view->sample_count samples per pixel (1 or 4:
+ * MultisampleState.count = Msaa::samples(), src/render/mod.rs:357-424,975-979; coverage and depth test per sample,
+ * shading once per pixel at its centre, box resolve) and tested against a scene depth buffer (HOST memory here:
+ * viewport.w * viewport.h * sample_count floats [y][x][sample], Depth32Float / GreaterEqual / no write,
+ * src/render/mod.rs:959-974; NULL = none; bgs_view.depth_device_ptr is ignored by the oracle).
+ * oracle_render is this with depth = NULL. Returns -5 for a sample count other than 1 or 4. */
+int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                        const bgs_view* view, const bgs_settings* settings, int32_t x0, int32_t y0,
+                        int32_t x1, int32_t y1, const float* depth, float* rgba_out, float* ambiguity_out);
+/* The sample positions of a pixel (x, y pairs, origin = the pixel's top-left corner, y down). */
+int oracle_sample_positions(uint32_t sample_count, float* xy_out);
 
 /* f16 planes -> f32 planes (src/render/planar.wgsl:117-176). */
 void oracle_decode_f16(uint32_t n, const uint32_t* sh_h2 /* n*24 */,

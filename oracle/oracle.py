@@ -118,6 +118,10 @@ def lib() -> ctypes.CDLL:
         l.oracle_depth_range.restype = ctypes.c_int
         l.oracle_render.argtypes = [ctypes.POINTER(_Cloud), ep, u32, vp, sp, i32, i32, i32, i32, fp, fp]
         l.oracle_render.restype = ctypes.c_int
+        l.oracle_render_depth.argtypes = [ctypes.POINTER(_Cloud), ep, u32, vp, sp, i32, i32, i32, i32, fp, fp, fp]
+        l.oracle_render_depth.restype = ctypes.c_int
+        l.oracle_sample_positions.argtypes = [u32, fp]
+        l.oracle_sample_positions.restype = ctypes.c_int
         l.oracle_decode_f16.argtypes = [u32, up, up, fp, fp, fp]
         l.oracle_decode_f16.restype = None
         l.oracle_encode_f16.argtypes = [u32, fp, fp, fp, up, up]
@@ -244,9 +248,11 @@ def depth_range(cloud, entries: np.ndarray, view: View, settings: CloudSettings)
 
 
 def render(cloud, entries: np.ndarray, view: View, settings: CloudSettings, window=None,
-           with_ambiguity: bool = False):
-    """Draw `entries` in order. window = (x0, y0, x1, y1) or None for the full viewport.
-    Returns rgba [h, w, 4] (and the ambiguity bound [h, w] if requested)."""
+           with_ambiguity: bool = False, depth=None):
+    """Draw `entries` in order into a target with `view.msaa_samples` samples per pixel (coverage and depth test per
+    sample, shading once per pixel, box resolve). window = (x0, y0, x1, y1) or None for the full viewport.
+    depth = None or the view's scene depth as a HOST array [height, width, msaa_samples] float32 (reverse-Z; a fragment
+    passes where its depth >= the stored one). Returns rgba [h, w, 4] (and the ambiguity bound [h, w] if requested)."""
     cloud = _as_f32_cloud(cloud)
     c = _cloud_struct(cloud)
     x0, y0, x1, y1 = window if window is not None else (0, 0, view.width, view.height)
@@ -254,16 +260,30 @@ def render(cloud, entries: np.ndarray, view: View, settings: CloudSettings, wind
     out = np.empty((y1 - y0, x1 - x0, 4), np.float32)
     amb = np.empty((y1 - y0, x1 - x0), np.float32) if with_ambiguity else None
     v, s = view.to_native(), settings.to_native()
-    rc = lib().oracle_render(ctypes.byref(c), _ep(e), e.shape[0], ctypes.byref(v), ctypes.byref(s),
-                             x0, y0, x1, y1, _fp(out), _fp(amb) if amb is not None else None)
+    d = None
+    if depth is not None:
+        d = np.ascontiguousarray(depth, dtype=np.float32)
+        if d.shape != (view.height, view.width, view.msaa_samples):
+            raise ValueError(f"depth must be [height, width, samples] = {(view.height, view.width, view.msaa_samples)}, got {d.shape}")
+    rc = lib().oracle_render_depth(ctypes.byref(c), _ep(e), e.shape[0], ctypes.byref(v), ctypes.byref(s),
+                                   x0, y0, x1, y1, _fp(d) if d is not None else None, _fp(out),
+                                   _fp(amb) if amb is not None else None)
     if rc:
         raise RuntimeError(f"oracle_render failed: {rc}")
     return (out, amb) if with_ambiguity else out
 
 
-def sort_and_render(cloud, view: View, settings: CloudSettings, window=None, with_ambiguity=False):
+def sample_positions(sample_count: int) -> np.ndarray:
+    """[sample_count, 2] sample positions inside a pixel (origin = its top-left corner, y down)."""
+    out = np.empty((sample_count, 2), np.float32)
+    if lib().oracle_sample_positions(sample_count, _fp(out)):
+        raise ValueError(f"unsupported sample count {sample_count}")
+    return out
+
+
+def sort_and_render(cloud, view: View, settings: CloudSettings, window=None, with_ambiguity=False, depth=None):
     entries = sort(cloud, view, settings)
-    return entries, render(cloud, entries, view, settings, window, with_ambiguity)
+    return entries, render(cloud, entries, view, settings, window, with_ambiguity, depth)
 
 
 def instance_stats(cloud, entries, view: View, settings: CloudSettings):

@@ -6,7 +6,8 @@
    independently of the C oracle, following tests/radix.rs:96-106 literally.
 2. render_*.npz — small images produced by the oracle (oracle/bgs_oracle.c) for scenes of the
    reference's tests/tools, so a drift of the oracle itself is caught, and so GPU parity can be
-   checked against committed data. The reference cannot run here (no cargo/wgpu/GPU); these are
+   checked against committed data: `rgba` / `amb` at 4 samples per pixel (Msaa::Sample4, Bevy's default), `rgba_msaa1` /
+   `amb_msaa1` at one (Msaa::Off); amb = the oracle's per-pixel ambiguity bound. The reference cannot run here (no cargo/wgpu/GPU); these are
    oracle outputs, not reference outputs (see oracle/bgs_oracle.h "PINNING STATUS").
 """
 import json
@@ -55,10 +56,20 @@ def render_goldens():
         CloudSettings, GaussianMode, SortMode, View, random_gaussians_3d_seeded, transform_from)
 
     def save(name, cloud, view, settings):
+        # every image for both sample counts the path is built for (View.msaa_samples: 4 = Bevy's default, what the
+        # reference's cameras render with; 1 = Msaa::Off), each with the oracle's ambiguity bound, so that a consumer of
+        # the fixture can hold a renderer to the standard tolerance without re-running the oracle
         entries = oracle.sort(cloud, view, settings)
-        img = oracle.render(cloud, entries, view, settings)
-        np.savez_compressed(os.path.join(OUT, name), rgba=img, keys=entries["key"], index=entries["index"])
-        print(name, img.shape, float(np.abs(img).max()))
+        arrays = {"keys": entries["key"], "index": entries["index"]}
+        for samples, tag in ((4, ""), (1, "_msaa1")):
+            view.msaa_samples = samples
+            img, amb = oracle.render(cloud, entries, view, settings, with_ambiguity=True)
+            arrays["rgba" + tag] = img
+            arrays["amb" + tag] = amb
+        view.msaa_samples = 4
+        np.savez_compressed(os.path.join(OUT, name), **arrays)
+        print(name, arrays["rgba"].shape, float(np.abs(arrays["rgba"]).max()),
+              "max |4x - 1x|", float(np.abs(arrays["rgba"] - arrays["rgba_msaa1"]).max()))
 
     save("render_visibility_128.npz", H.visibility_test_cloud(),
          View.perspective(transform_from((0, 0, 5)), 128, 128),

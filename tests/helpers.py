@@ -46,7 +46,7 @@ class FrameParamsC(ctypes.Structure):
         ("draw_mode", ctypes.c_uint32),
         ("prev_clip_from_world", ctypes.c_float * 16), ("delta_time", ctypes.c_float),
         ("clear", ctypes.c_float * 4), ("srgb8_target", ctypes.c_uint64),
-        ("sort_path", ctypes.c_uint32), ("pad_sort", ctypes.c_uint32),
+        ("sort_path", ctypes.c_uint32), ("sample_count", ctypes.c_uint32), ("depth_ptr", ctypes.c_uint64),
     ]
 
 
@@ -62,6 +62,7 @@ class ShimOut(ctypes.Structure):
         ("T", ctypes.c_float * 9),
         ("quad_m", ctypes.c_float * 4),
         ("bounds", ctypes.c_float * 4),
+        ("ndc_z", ctypes.c_float),
     ]
 
 
@@ -177,7 +178,10 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
         count = n
     qx, qy = np.meshgrid(np.arange(W, dtype=np.float32) + np.float32(0.5),
                          np.arange(H, dtype=np.float32) + np.float32(0.5))
-    T = np.ones((H, W), np.float32)
+    # samples per pixel: offsets from the pixel centre (csrc/render_kernels.hip: MS_OX0 ... — the standard 4x pattern)
+    S = int(view.msaa_samples)
+    offs = [(0.0, 0.0)] if S == 1 else [(-0.125, -0.375), (0.375, -0.125), (-0.375, 0.125), (0.125, 0.375)]
+    T = np.ones((H, W, S), np.float32)   # per-sample transmittance
     C = np.zeros((H, W, 3), np.float32)
     out = ShimOut()
     surfel = settings.gaussian_mode == GaussianMode.Gaussian2d and settings.aabb
@@ -213,19 +217,22 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
             if not settings.aabb:
                 u = p[0] * dx + p[1] * dy
                 v = p[2] * dx + p[3] * dy
-                hit = (np.abs(u) <= 1) & (np.abs(v) <= 1)
+                cov = [(np.abs(u + (p[0] * np.float32(ox) + p[1] * np.float32(oy))) <= 1) &
+                       (np.abs(v + (p[2] * np.float32(ox) + p[3] * np.float32(oy))) <= 1) for ox, oy in offs]
+                hit = np.ones_like(u, bool)
                 sigma = np.float32(1.0) / np.float32(3.0)
                 power = (u * u + v * v) * (np.float32(-1.0) / (np.float32(2.0) * sigma * sigma))
             elif not surfel:
                 u = p[0] * dx
                 v = p[1] * dy
-                hit = (np.abs(u) <= 1) & (np.abs(v) <= 1)
+                cov = [(np.abs(u + p[0] * np.float32(ox)) <= 1) & (np.abs(v + p[1] * np.float32(oy)) <= 1) for ox, oy in offs]
                 power = np.float32(-0.5) * (p[2] * u * u + p[4] * v * v) + p[3] * u * v
-                hit &= ~(power > 0)
+                hit = ~(power > 0)
             else:
                 u = p[0] * dx
                 v = p[1] * dy
-                hit = (np.abs(u) <= 1) & (np.abs(v) <= 1)
+                cov = [(np.abs(u + p[0] * np.float32(ox)) <= 1) & (np.abs(v + p[1] * np.float32(oy)) <= 1) for ox, oy in offs]
+                hit = np.ones_like(u, bool)
                 rad = np.float32(out.radius)
                 mx, my = np.float32(out.mean[0]), np.float32(out.mean[1])
                 pcx = u * rad + mx
@@ -242,14 +249,17 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
                 power = np.float32(-0.5) * np.minimum(s3, s2)
                 hit &= ~(power > 0)
             alpha = np.minimum(np.exp(power) * col[3], np.float32(0.999)).astype(np.float32)
-        hit &= ~(T < eps)
-        w = np.where(hit, T * alpha, np.float32(0)).astype(np.float32)
+        # the fragment is shaded once (at the pixel centre); a pixel stops once its MEAN transmittance is below the cut-off
+        hit &= ~(T.mean(axis=2) < eps)
+        covered = np.stack(cov, axis=2) & hit[..., None]
+        w = (np.where(covered, T, np.float32(0)).mean(axis=2) * alpha).astype(np.float32)
         C[..., 0] += w * col[0]
         C[..., 1] += w * col[1]
         C[..., 2] += w * col[2]
-        T = np.where(hit, T * (np.float32(1) - alpha), T).astype(np.float32)
+        T = np.where(covered, T * (np.float32(1) - alpha)[..., None], T).astype(np.float32)
     clear = np.asarray(view.clear_color, np.float32)
     img = np.empty((H, W, 4), np.float32)
+    T = T.mean(axis=2).astype(np.float32)   # the resolve: mean of the samples
     img[..., :3] = C + T[..., None] * clear[:3]
     img[..., 3] = (np.float32(1) - T) + T * clear[3]
     return img

@@ -20,6 +20,7 @@ struct ShimOut {
     float T[9];
     float quad_m[4];
     float bounds[4];  // minx maxx miny maxy
+    float ndc_z;      // the quad's depth (position.z / position.w)
 };
 
 struct ShFloat {
@@ -117,6 +118,7 @@ void shim_project(const FrameParams* fp, uint32_t key, const float* pos, const f
     out->quad_m[2] = pr.quad.m10; out->quad_m[3] = pr.quad.m11;
     out->bounds[0] = pr.quad.minx; out->bounds[1] = pr.quad.maxx;
     out->bounds[2] = pr.quad.miny; out->bounds[3] = pr.quad.maxy;
+    out->ndc_z = pr.ndc_z;
 }
 
 float shim_distance_to_camera(const FrameParams* fp, const float* pos) {

@@ -27,7 +27,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert set(names) == set(_native.EXPORTED_SYMBOLS)
     for n in names:
         assert hasattr(lib, n), f"libbgs.so does not export {n}"
-    assert lib.bgs_version() == (0 << 16) | 2
+    assert lib.bgs_version() == (0 << 16) | 3
 
 
 def test_integration_doc_binds_every_exported_symbol():
@@ -41,7 +41,8 @@ def test_integration_doc_binds_every_exported_symbol():
 
 
 def test_struct_layouts_match_the_header():
-    assert ctypes.sizeof(BgsView) == (16 * 4 + 8 + 16 + 4) * 4
+    assert ctypes.sizeof(BgsView) == (16 * 4 + 8 + 16 + 4) * 4 + 16 and BgsView.depth_device_ptr.offset % 8 == 0
+    assert BgsView.sample_count.offset == (16 * 4 + 8 + 16 + 1) * 4
     assert ctypes.sizeof(BgsSettings) == (16 + 2 + 8 + 1 + 1 + 2 + 8) * 4
     assert ctypes.sizeof(_native.BgsSortEntry) == 8
     assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 4 * 4 + 8 + 8 + 8 + 8 + 8
@@ -70,6 +71,8 @@ def test_view_perspective_matches_python_mirror():
     lib.bgs_view_perspective(wfv, ctypes.c_float(np.pi / 4), ctypes.c_float(0.1), 1920, 1080, ctypes.byref(out))
     ref = v.to_native()
     assert abs(out.delta_time - 1 / 60) < 1e-7
+    # Camera3d::default() carries Bevy's default Msaa (Sample4) and no scene depth
+    assert out.sample_count == ref.sample_count == 4 and out.depth_device_ptr == 0
     for name in ("world_from_view", "view_from_world", "clip_from_view", "clip_from_world", "viewport", "clear_color",
                  "previous_clip_from_world"):
         assert np.allclose(list(getattr(out, name)), list(getattr(ref, name)), rtol=1e-5, atol=1e-6), name
