@@ -807,6 +807,13 @@ constexpr float MS_OX0 = -0.125f, MS_OY0 = -0.375f, MS_OX1 = 0.375f, MS_OY1 = -0
 __device__ __forceinline__ float ms_margin(const float a, const float b) {
     return fmaxf(fabsf(fmaf(b, MS_OY0, a * MS_OX0)), fabsf(fmaf(b, MS_OY1, a * MS_OX1)));
 }
+// 1 where |x| <= lim, 0 where |x| > lim (exactly: clamp((lim - |x|) * 2^60) — 1 from lim - |x| >= 2^-60 on, 0 from
+// lim - |x| <= 0 down; see blend_px_ms): ONE v_fma_f32 with the abs / neg input and the clamp output modifier
+__device__ __forceinline__ float ms_inside(const float x, const float big, const float limbig) {
+    float r;
+    asm("v_fma_f32 %0, -|%1|, %2, %3 clamp" : "=v"(r) : "v"(x), "v"(big), "v"(limbig));
+    return r;
+}
 template <int VARIANT, bool DEPTH>
 __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, const float qx, const float qy,
                                             const float aspect, const float t_eps, PxMs& t, v2f& crg, float& cb,
@@ -860,10 +867,19 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
             w = (t.S * t.rb) * alpha;
             t.S = fmaf(-alpha, t.S, t.S);
         } else {
-            bool c0 = fmaxf(fabsf(u + du0), fabsf(v + dv0)) <= lim, c1 = fmaxf(fabsf(u + du1), fabsf(v + dv1)) <= lim;
-            bool c2 = fmaxf(fabsf(u - du1), fabsf(v - dv1)) <= lim, c3 = fmaxf(fabsf(u - du0), fabsf(v - dv0)) <= lim;
-            if constexpr (DEPTH) { c0 = c0 && z >= dpx.x; c1 = c1 && z >= dpx.y; c2 = c2 && z >= dpx.z; c3 = c3 && z >= dpx.w; }
-            const float t0 = c0 ? t.r0 : 0.0f, t1 = c1 ? t.r1 : 0.0f, t2 = c2 ? t.r2 : 0.0f, t3 = c3 ? t.r3 : 0.0f;
+            // Coverage of a sample as a 0 / 1 factor out of multiplications, additions and the clamp output modifier:
+            // min / max, compares and selects issue at half the rate of those on this chip (wave64: 4 clocks against 2;
+            // profiles/r4_micro/valu_issue.txt). clamp((lim - |x|) * 2^60) is 1 for |x| <= lim - 2^-60, 0 for |x| >= lim —
+            // and something in between for a sample closer to the quad's edge than any rasteriser's rounding can place it.
+            const float big = 1.152921504606846976e18f, limbig = lim * 1.152921504606846976e18f;   // 2^60
+            float t0 = ms_inside(u + du0, big, limbig) * ms_inside(v + dv0, big, limbig) * t.r0;
+            float t1 = ms_inside(u + du1, big, limbig) * ms_inside(v + dv1, big, limbig) * t.r1;
+            float t2 = ms_inside(u - du1, big, limbig) * ms_inside(v - dv1, big, limbig) * t.r2;
+            float t3 = ms_inside(u - du0, big, limbig) * ms_inside(v - dv0, big, limbig) * t.r3;
+            if constexpr (DEPTH) {
+                t0 = z >= dpx.x ? t0 : 0.0f; t1 = z >= dpx.y ? t1 : 0.0f;
+                t2 = z >= dpx.z ? t2 : 0.0f; t3 = z >= dpx.w ? t3 : 0.0f;
+            }
             const float sum = (t0 + t1) + (t2 + t3), aq = 0.25f * alpha;
             w = (t.S * aq) * sum;
             t.r0 = fmaf(-alpha, t0, t.r0); t.r1 = fmaf(-alpha, t1, t.r1);

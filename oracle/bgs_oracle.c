@@ -922,7 +922,7 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
     const int32_t Wi = (int32_t)view->viewport[2], Hi = (int32_t)view->viewport[3];
     if (x0 < 0 || y0 < 0 || x1 > Wi || y1 > Hi || x0 >= x1 || y0 >= y1) return -1;
     const double W = (double)view->viewport[2], H = (double)view->viewport[3];
-    const int32_t rw = x1 - x0, rh = y1 - y0;
+    const int32_t rw = x1 - x0;
     const int S = (int)view->sample_count;
     if (S != 1 && S != 4) return -5;
     const double(*pos)[2] = S == 4 ? MS_POS4 : MS_POS1;
@@ -965,6 +965,15 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
             const oracle_vs_out* vs = &p->vs;
             /* the quad's depth: constant over the quad (position.zw is the splat's, gaussian.wgsl:429-433) */
             const float zf = vs->projected[2] / vs->projected[3];
+            /* (s, t) of sample k = (s, t) of the pixel centre + a constant of the quad (the map is affine) */
+            double dsk[4] = {0, 0, 0, 0}, dtk[4] = {0, 0, 0, 0};
+            for (int k = 0; k < S; ++k) {
+                const double ox = pos[k][0] - 0.5, oy = pos[k][1] - 0.5;
+                dsk[k] = (ox * p->ety - oy * p->etx) * p->inv_det;
+                dtk[k] = (p->esx * oy - p->esy * ox) * p->inv_det;
+            }
+            const double reach_s = 0.5 * (fabs(p->ety) + fabs(p->etx)) * fabs(p->inv_det) + p->eps_s;
+            const double reach_t = 0.5 * (fabs(p->esx) + fabs(p->esy)) * fabs(p->inv_det) + p->eps_t;
             for (int32_t x = p->bx0; x <= p->bx1; ++x) {
                 /* q - P0 = sp * Es + tp * Et, at the pixel centre (what the interpolants see) ... */
                 const double cdx = (double)x + 0.5 - p->p0x, cdy = (double)y + 0.5 - p->p0y;
@@ -972,10 +981,11 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                 const double tp = (p->esx * cdy - p->esy * cdx) * p->inv_det;
                 /* ... and at every sample position (coverage) */
                 int inside[4] = {0, 0, 0, 0}, near_edge[4] = {0, 0, 0, 0}, any_inside = 0, any_near = 0;
+                /* a pixel none of whose sample positions can be inside or within the rounding band: (s, t) moves by at
+                 * most reach_s / reach_t between the centre and a point of the pixel */
+                if (sp < -reach_s || sp > 1.0 + reach_s || tp < -reach_t || tp > 1.0 + reach_t) continue;
                 for (int k = 0; k < S; ++k) {
-                    const double dx = (double)x + pos[k][0] - p->p0x, dy = (double)y + pos[k][1] - p->p0y;
-                    const double sk = (dx * p->ety - dy * p->etx) * p->inv_det;
-                    const double tk = (p->esx * dy - p->esy * dx) * p->inv_det;
+                    const double sk = sp + dsk[k], tk = tp + dtk[k];
                     inside[k] = (sk >= 0.0 && sk <= 1.0 && tk >= 0.0 && tk <= 1.0);
                     if (arow) {
                         const double ds = fmin(fabs(sk), fabs(sk - 1.0));
@@ -999,10 +1009,10 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                 float power = 0.0f;
                 const int drawn = fs_main(vs, uv, mm, view, s, src, &power);
                 float* dst = ms + (size_t)(x - x0) * S * 4;
-                /* the largest magnitude any of the pixel's samples holds (for the ambiguity bounds) */
-                float dm = 0.0f;
-                if (arow)
-                    for (int k = 0; k < 4 * S; ++k) dm = fmaxf(dm, fabsf(dst[k]));
+                /* the largest magnitude any of the pixel's samples holds (for the ambiguity bounds; formed only where
+                 * one is charged) */
+                float dm = -1.0f;
+#define ORACLE_DM() do { if (dm < 0.0f) { dm = 0.0f; for (int k_ = 0; k_ < 4 * S; ++k_) dm = fmaxf(dm, fabsf(dst[k_])); } } while (0)
                 if (arow && s->aabb && s->gaussian_mode == BGS_GAUSSIAN_2D) {
                     /* conditioning of the surfel intersection at this pixel (see surfel_fragment_power_d) */
                     const double asp = (double)view->viewport[2] / (double)view->viewport[3];
@@ -1026,6 +1036,7 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                     if (da > 1e-6) {
                         float cm = fmaxf(fmaxf(fabsf(vs->color[0]), fabsf(vs->color[1])),
                                          fmaxf(fabsf(vs->color[2]), 1.0f));
+                        ORACLE_DM();
                         arow[x - x0] += (float)(4.0 * da) * (cm + dm);
                     }
                 }
@@ -1039,6 +1050,7 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                         float a = fminf(expf(fminf(power, 0.0f)) * fabsf(vs->color[3]), 0.999f);
                         float cm = fmaxf(fmaxf(fabsf(vs->color[0]), fabsf(vs->color[1])),
                                          fmaxf(fabsf(vs->color[2]), 1.0f));
+                        ORACLE_DM();
                         arow[x - x0] += a * (cm + dm) * (whole ? 1.0f : (float)flips / (float)S);
                     }
                 }
@@ -1046,6 +1058,11 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                 /* BlendState::PREMULTIPLIED_ALPHA_BLENDING (src/render/mod.rs:946), per covered sample that passes
                  * the depth test (CompareFunction::GreaterEqual against the view's depth, :959-974) */
                 const float one_minus = 1.0f - src[3];
+                if (!depth && S == 4 && inside[0] && inside[1] && inside[2] && inside[3]) {
+                    /* the common case, the same arithmetic as below: a straight loop the compiler can vectorise */
+                    for (int k = 0; k < 16; ++k) dst[k] = src[k & 3] + dst[k] * one_minus;
+                    continue;
+                }
                 for (int k = 0; k < S; ++k) {
                     if (!inside[k]) continue;
                     if (depth && !(zf >= depth[((size_t)y * (size_t)Wi + (size_t)x) * (size_t)S + (size_t)k])) continue;
@@ -1065,6 +1082,7 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
         }
         free(ms);
     }
+#undef ORACLE_DM
     free(tmp);
     return failed ? -2 : 0;
 }

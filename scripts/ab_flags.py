@@ -57,7 +57,8 @@ SPEC = {"dense": ("1m", CloudSettings(), 300), "scene": ("1m", CloudSettings(glo
         "2d_obb": ("2d", CloudSettings(gaussian_mode=GaussianMode.Gaussian2d), 300),
         "5m_dense": ("5m", CloudSettings(), 120), "5m_scene": ("5m", CloudSettings(global_scale=0.05), 80)}
 p = GaussianSplattingPlugin(0)
-v = View.headless(1920, 1080)
+# BGS_AB_MSAA="1,4": samples per pixel of the views (default 4 = Msaa::Sample4, Bevy's default)
+msaas = [int(x) for x in os.environ.get("BGS_AB_MSAA", "4").split(",")]
 handles = {}
 for _ in range(rounds):   # every variant is measured `rounds` times, interleaved (clock / thermal drift shows up as spread)
     for c in configs:
@@ -65,8 +66,10 @@ for _ in range(rounds):   # every variant is measured `rounds` times, interleave
         if kind not in handles:
             handles[kind] = p.upload(cloud(kind))
         for fl in flags:
+          for m in msaas:
+            v = View.headless(1920, 1080, msaa_samples=m)
             p.set_debug_flags(fl)
             p.reset_adaptive_state()
             fps, fps1, stages = run(p, handles[kind], v, s, steps)
-            print(f"{c:13s} flags {fl:#10x}: {fps:9.1f} fps (8 lanes / 4 streams)  {fps1:9.1f} single stream  {json.dumps(stages)}", flush=True)
+            print(f"{c:13s} x{m} flags {fl:#10x}: {fps:9.1f} fps (8 lanes / 4 streams)  {fps1:9.1f} single stream  {json.dumps(stages)}", flush=True)
 p.set_debug_flags(0)

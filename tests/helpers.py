@@ -168,6 +168,7 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
     formulas), without tiling. Small scenes only."""
     if entries is None:
         entries = device_sorted_entries(cloud, view, settings)
+    depth = getattr(view, "depth_host", None)   # [H, W, samples] scene depth (random_case), or None
     n = len(cloud)
     W, H = view.width, view.height
     fpc = frame_params(n, view, settings)
@@ -252,6 +253,8 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
         # the fragment is shaded once (at the pixel centre); a pixel stops once its MEAN transmittance is below the cut-off
         hit &= ~(T.mean(axis=2) < eps)
         covered = np.stack(cov, axis=2) & hit[..., None]
+        if depth is not None:   # per-sample depth test: GreaterEqual against the reverse-Z scene depth, no write
+            covered &= np.float32(out.ndc_z) >= depth
         w = (np.where(covered, T, np.float32(0)).mean(axis=2) * alpha).astype(np.float32)
         C[..., 0] += w * col[0]
         C[..., 1] += w * col[1]
@@ -369,7 +372,32 @@ def random_case(seed: int, medium: bool = False):
         sh_degree=int(rng.integers(0, 4)), rasterize_mode=mode[int(rng.integers(0, len(mode)))],
         num_classes=int(rng.integers(1, 6)), position_min=mn, position_max=mx, transform=tr,
         draw_mode=DrawMode(int(rng.choice([0, 0, 0, 1, 2]))))
+    # (a second stream, so that the configurations of the earlier rounds' sweeps keep everything above)
+    rng2 = np.random.default_rng(7_000_000 + seed)
+    v.msaa_samples = int(rng2.choice([1, 4, 4]))      # Msaa::Off or Bevy's default Sample4
+    v.depth_host = None
+    if rng2.random() < 0.35:                           # a scene depth buffer that cuts through the cloud
+        v.depth_host = random_depth_buffer(c, v, s, rng2)
     return c, v, s
+
+
+def random_depth_buffer(cloud, view, settings, rng) -> np.ndarray:
+    """[height, width, samples] float32 reverse-Z depth: a tilted plane between the 30 % and 70 % quantiles of the
+    visible splats' depths, every sample jittered on its own (so that pixels whose samples disagree exist), and a
+    corner left at 0 (no occluder: everything passes there)."""
+    w, h, S = view.width, view.height, int(view.msaa_samples)
+    pw = (np.asarray(settings.transform, np.float64) @ np.concatenate([cloud.position_visibility[:, :3].astype(np.float64),
+                                                                       np.ones((len(cloud), 1))], 1).T).T
+    clip = (np.asarray(view.clip_from_world, np.float64) @ pw.T).T
+    ok = clip[:, 3] > 1e-6
+    z = clip[ok, 2] / clip[ok, 3]
+    z = z[(z > 0) & (z < 1)]
+    lo, hi = (np.quantile(z, 0.3), np.quantile(z, 0.7)) if z.size > 10 else (0.01, 0.1)
+    yy, xx = np.mgrid[0:h, 0:w]
+    plane = lo + (hi - lo) * (0.5 * xx / max(w - 1, 1) + 0.5 * yy / max(h - 1, 1))
+    d = plane[..., None] + (hi - lo) * 0.08 * rng.uniform(-1, 1, (h, w, S))
+    d[: h // 4, : w // 4] = 0.0
+    return np.ascontiguousarray(np.clip(d, 0.0, 1.0), np.float32)
 
 
 def frustum_boundary_cloud(view, n_per_case, seed):
