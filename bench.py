@@ -10,7 +10,9 @@ radix sort -> project + ordered supertile binning -> tile raster of a 1920x1080 
 already resident in HBM (uploaded once before the timed region, like the reference's asset
 upload). Workload = BASELINE.json configs[1]: 1M random 3DGS splats (the reference's own
 `random_gaussians_3d` distributions), f32 planar cloud, SH degree 3, `CloudSettings::default()`,
-examples/headless.rs camera. With N > 1 ranks every rank renders ITS camera (camera g = the
+examples/headless.rs camera — which carries no `Msaa` component of its own, so the reference draws it with Bevy's
+default, Msaa::Sample4 (CloudPipelineKey.sample_count, src/render/mod.rs:357-424): the headline renders 4 samples per
+pixel (coverage per sample, shading per pixel, resolved frame); `msaa_off` has the single-sampled rate of rounds 1-3. With N > 1 ranks every rank renders ITS camera (camera g = the
 headless camera yawed g*45 degrees) of the replicated cloud and rank 0 gathers every rank's frames
 over RCCL, asynchronously, 8 frames per collective (weak scaling: per-GPU work fixed).
 
@@ -25,6 +27,9 @@ Prints ONE JSON line on rank 0. `value` = whole-job frames/s. Extra objects:
   stages        per-stage ms / algorithmic GB/s / %peak, V, I
   sort_msplats_per_s   "Msplats/s sorted" (keygen + depth sort only, bgs_sort)
   scene_like    the same workload with global_scale = 0.05
+  msaa_off      the same workload on a camera with Msaa::Off (one sample per pixel)
+  latency       first_frame_ms (a context that has learnt nothing yet: digit passes, first-guess capacities, the re-run
+                they may cost) and after_cut_ms (a 137-degree camera cut in a warmed-up context), blocking frames
 """
 from __future__ import annotations
 
@@ -523,24 +528,47 @@ def main():
         # transcendentals (v_exp / v_log / v_rcp / v_sqrt ...) at a quarter of that (8 clocks), fp64 at half (4) —
         # on 1024 SIMDs at the 2.4 GHz peak clock. (Round 2 priced every instruction at 4 clocks, which is the
         # ACHIEVED rate of this instruction mix — SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU — not a bound.)
-        def issue_floor_ms(k):
+        # Issue cost per wave64 instruction MEASURED on this chip (scripts/micro/valu_issue.hip, profiles/r4_micro/
+        # valu_issue.txt; 8 waves per SIMD, wall clock): v_fma / v_mul / v_add / v_mov / v_and / v_add_u32 1.06-1.28 ns
+        # (= 2 clocks at the ~1.9 GHz the chip sustains under vector load), v_max / v_min / v_cmp / v_cndmask / v_cvt /
+        # shifts / every v_pk_* 1.8-2.0 ns (4 clocks), v_exp / v_rcp / v_log / v_sqrt 3.44 ns (8 clocks). The PMC passes
+        # count the f32 FMA / ADD / MUL and the transcendental classes; what is left is a mix of both simple classes, so
+        # the floor is given as a band: `low` prices the rest at 2 clocks, `high` at 4.
+        def issue_floor_ms(k, rest_clocks=4.0):
             pk = pmc_kernels.get(k, {})
             wi = pk.get("valu_wave_instructions")
             if not wi:
                 return None, None
+            cls = pk.get("valu_classes") or {}
             trans = pk.get("valu_trans_wave_instructions") or 0.0
             f64 = pk.get("valu_f64_wave_instructions") or 0.0
-            clocks = 2.0 * (wi - trans - f64) + 8.0 * trans + 4.0 * f64
+            fast = (cls.get("fma_f32") or 0.0) + (cls.get("add_f32") or 0.0) + (cls.get("mul_f32") or 0.0)
+            rest = max(wi - trans - f64 - fast, 0.0)
+            clocks = 2.0 * fast + rest_clocks * rest + 8.0 * trans + 4.0 * f64
             return clocks / (4 * 256) / 2.4e9 * 1e3, {"wave_instructions": int(wi), "transcendental": int(trans), "fp64": int(f64),
+                                                       "fma_add_mul_f32": int(fast), "rest": int(rest),
                                                        "classes_measured": pk.get("valu_trans_wave_instructions") is not None}
         floor_ms, mix = issue_floor_ms(roofline_main["kernel"])
         if floor_ms:
+            floor_lo = issue_floor_ms(roofline_main["kernel"], 2.0)[0]
+            guide_ms = (2.0 * (mix["wave_instructions"] - mix["transcendental"] - mix["fp64"]) + 8.0 * mix["transcendental"] +
+                        4.0 * mix["fp64"]) / (4 * 256) / 2.4e9 * 1e3
             roofline_main["valu"] = {"wave_instructions_per_launch": mix["wave_instructions"],
+                                     "fma_add_mul_f32_per_launch": mix["fma_add_mul_f32"],
                                      "transcendental_per_launch": mix["transcendental"], "fp64_per_launch": mix["fp64"],
+                                     "other_per_launch": mix["rest"],
                                      "per_class_counters": mix["classes_measured"],
-                                     "clocks_per_instruction": "2 (wave64 on a SIMD-32), transcendental 8, fp64 4; 1024 SIMDs x 2.4 GHz",
-                                     "issue_floor_ms": round(floor_ms, 4),
-                                     "frac_of_issue_peak": round(floor_ms / roofline_main["launch_ms"], 3)}
+                                     "clocks_per_instruction": ("MEASURED (profiles/r4_micro/valu_issue.txt): f32 fma / add / mul 2, "
+                                                                "min / max / compare / select / convert / packed 4, transcendental 8 "
+                                                                "(fp64 priced 4); 1024 SIMDs x 2.4 GHz peak clock. The counters "
+                                                                "do not split `other` into its 2-clock (moves, logic, integer add) and "
+                                                                "4-clock members: issue_floor_ms prices it at 4, issue_floor_ms_low at 2"),
+                                     "issue_floor_ms": round(floor_ms, 4), "issue_floor_ms_low": round(floor_lo, 4),
+                                     "frac_of_issue_peak": round(floor_ms / roofline_main["launch_ms"], 3),
+                                     "frac_of_issue_peak_low": round(floor_lo / roofline_main["launch_ms"], 3),
+                                     "guide_pricing": {"note": "every non-transcendental instruction at 2 clocks (MI355X_MICROARCH.md)",
+                                                       "issue_floor_ms": round(guide_ms, 4),
+                                                       "frac_of_issue_peak": round(guide_ms / roofline_main["launch_ms"], 3)}}
             # the whole frame against the same floor: every kernel's vector instructions x its launches per
             # frame, at the frame rate of the timed region — the chip-wide VALU-issue utilisation
             per_frame = {"keygen_kernel": 1, kernel_names["depth_sort"]: table["depth_sort"]["launches"],
@@ -559,9 +587,8 @@ def main():
         valu_frac = roofline_main.get("valu", {}).get("frac_of_issue_peak")
         roofline_main["bound"] = "valu" if (valu_frac is None or valu_frac >= hbm_frac) else "hbm"
         roofline_main["bound_note"] = ("achieved / peak / frac are the HBM figures of the contract (algorithmic bytes per launch / launch "
-                                       "duration / 8 TB/s); the kernel is nearest to the vector-issue floor (`valu`), and its launch lasts "
-                                       "about twice its mean wave life (per-tile trace: profiles/r3_notes.md section 1): neither HBM nor "
-                                       "MFMA binds this algorithm")
+                                       "duration / 8 TB/s); what binds the kernel is vector-instruction issue (`valu`, priced at the "
+                                       "rates measured on this chip): neither HBM nor MFMA binds this algorithm")
         roofline_main["in_flight"] = roofline
 
         # "Msplats/s sorted": keygen + depth sort only (blocking calls, every one timed)
@@ -583,10 +610,61 @@ def main():
         plugin.set_pipeline_depth(DEPTH)
         plugin.set_pipeline_streams(max(0, min(8, args.streams)))
         s2 = CloudSettings(global_scale=0.05)
-        dt2, stage2, st2 = measure(plugin, handle, view, s2, args.steps, args.warmup, depth=DEPTH)
+        # measured like the headline: several timed regions of --steps frames, the median reported (one 20-frame region
+        # pays the fill and drain of the lanes once per region either way, but a single one is at the mercy of one late lane)
+        side_trials = max(5, min(trials, 40))
+        plugin.set_profiling(0)
+        dt2, _, _, dts2 = measure(plugin, handle, view, s2, args.steps, args.warmup, depth=DEPTH, trials=side_trials,
+                                  busy_warm_frames=400)
+        plugin.set_profiling(2)
+        _, stage2, st2 = measure(plugin, handle, view, s2, max(args.steps // 2, 4 * STRIDE), 4, depth=DEPTH)
         ms2 = sum(stage2.values())
         plugin.set_pipeline_depth(1)
-        dt2s, _, _ = measure(plugin, handle, view, s2, args.steps, args.warmup)
+        dt2s, _, _, _ = measure(plugin, handle, view, s2, args.steps, args.warmup, trials=5)
+
+        # ---- the same workload on a camera with Msaa::Off: one sample per pixel (what rounds 1-3 reported) -------
+        from bevy_gaussian_splatting_amd import View as _View
+        view_off = _View.headless(WIDTH, HEIGHT, yaw=rank * math.pi / 4.0, order=rank, msaa_samples=1)
+        plugin.set_pipeline_depth(lanes)
+        plugin.set_pipeline_streams(streams)
+        plugin.set_profiling(0)
+        dt_off, _, _, dts_off = measure(plugin, handle, view_off, settings, args.steps, args.warmup, depth=lanes,
+                                        trials=side_trials, busy_warm_frames=400)
+        dt_off2, _, _, _ = measure(plugin, handle, view_off, s2, args.steps, args.warmup, depth=lanes, trials=side_trials,
+                                   busy_warm_frames=400)
+        plugin.set_profiling(2)
+        plugin.set_pipeline_depth(1)
+        dt_off1, stage_off1, _, _ = measure(plugin, handle, view_off, settings, args.steps, args.warmup, trials=5)
+        msaa_off = {"value": round(args.steps / dt_off, 2), "unit": "frames/s", "sample_count": 1,
+                    "trials": len(dts_off), "scene_like_value": round(args.steps / dt_off2, 2),
+                    "single_stream_value": round(args.steps / dt_off1, 2),
+                    "single_stream_stage_ms": {k: round(x, 4) for k, x in stage_off1.items() if x},
+                    "note": "Camera with Msaa::Off (bgs_view.sample_count = 1): the configuration rounds 1-3 reported as the headline"}
+
+        # ---- latency of the frames that cannot lean on what completed frames taught the context -------------------
+        plugin.set_pipeline_streams(max(0, min(8, args.streams)))
+
+        def blocking_ms(v):
+            t0 = time.perf_counter()
+            plugin.render(handle, v, settings, download=False)
+            plugin.synchronize()
+            return 1e3 * (time.perf_counter() - t0)
+        plugin.set_async(False)
+        firsts, cuts, steady = [], [], []
+        cut_view = _View.headless(WIDTH, HEIGHT, yaw=rank * math.pi / 4.0 + math.radians(137.0), order=rank)
+        for _ in range(5):
+            plugin.reset_adaptive_state()
+            firsts.append(blocking_ms(view))          # nothing learnt: digit passes, first-guess capacities (+ a re-run)
+            for _ in range(6):
+                blocking_ms(view)
+            steady.append(blocking_ms(view))
+            cuts.append(blocking_ms(cut_view))        # warmed up on another view: stale splitters / hints
+        latency = {"first_frame_ms": round(statistics.median(firsts), 4), "after_cut_ms": round(statistics.median(cuts), 4),
+                   "steady_blocking_frame_ms": round(statistics.median(steady), 4),
+                   "note": "blocking frames (host wall clock incl. launch + synchronize), median of 5; first = after "
+                           "bgs_reset_adaptive_state, cut = a 137-degree yaw in a context warmed up on the headline view"}
+        plugin.set_async(True)
+        plugin.reset_adaptive_state()
 
         # ---- moving camera (the reference's use case: an interactive camera re-sorts whenever it moves,
         # src/sort/mod.rs:153-194). The static view above is the best case for everything the context learns from
@@ -629,8 +707,8 @@ def main():
         # the named instance-sort pipeline (tile-major|depth radix sort) on the same workload
         plugin.set_binning("sort")
         plugin.set_profiling_stride(1)  # blocking frames: time every one
-        dt3, stage3, st3 = measure(plugin, handle, view, settings, max(args.steps // 3, 3), 2)
-        dt4, stage4, st4 = measure(plugin, handle, view, s2, max(args.steps // 3, 3), 2)
+        dt3, stage3, st3, _ = measure(plugin, handle, view, settings, max(args.steps // 3, 3), 2, trials=3)
+        dt4, stage4, st4, _ = measure(plugin, handle, view, s2, max(args.steps // 3, 3), 2, trials=3)
         plugin.set_binning("scan")
 
         out = {
@@ -646,11 +724,15 @@ def main():
                                "pilot region precede the first one; the number of trials puts >= 0.5 s inside timed regions"},
             "config": {"workload": f"{args.splats}-splat 3DGS f32 planar cloud (seed {SEED}, reference random_gaussians_3d "
                                    "distributions), 1920x1080, SH degree 3, CloudSettings::default(), "
-                                   "examples/headless.rs camera; one camera per GPU",
+                                   "examples/headless.rs camera incl. its Msaa (Bevy's default Sample4: 4 samples per pixel, "
+                                   "resolved frame); one camera per GPU",
+                       "sample_count": view.msaa_samples,
                        "parallelism": f"views{world}", "sort": "radix32", "global_scale": 1.0,
                        "frames_in_flight": lanes, "lanes": lanes, "streams": streams},
             "build_id": plugin.build_id(),
             "single_stream": single,
+            "msaa_off": msaa_off,
+            "latency": latency,
             "orbit": orbit,
             "per_rank": per_rank,
             "roofline": roofline_main,
@@ -673,7 +755,7 @@ def main():
             "sort_msplats_per_s": round(args.splats / (sort_dev_ms * 1e-3) / 1e6, 1) if sort_dev_ms > 0 else None,
             "sort": {"device_ms": round(sort_dev_ms, 4), "wall_ms": round(sort_wall * 1e3, 4),
                      "GBps": round(sort_bytes / (sort_dev_ms * 1e-3) / 1e9, 1) if sort_dev_ms > 0 else None},
-            "scene_like": {"global_scale": 0.05, "value": round(args.steps / dt2, 2), "unit": "frames/s",
+            "scene_like": {"global_scale": 0.05, "value": round(args.steps / dt2, 2), "unit": "frames/s", "trials": len(dts2),
                            "single_stream_value": round(args.steps / dt2s, 2),
                            "device_ms": round(ms2, 4), "visible_splats": st2["visible_count"],
                            "coarse_entries": st2["instance_count"], "tile_instances": st4["instance_count"],

@@ -93,6 +93,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # V and I beside the fps numbers
     assert d["frame"]["visible_splats"] > 0 and d["frame"]["tile_instances"] > d["frame"]["coarse_entries"] > 0
     assert d["scene_like"]["tile_instances"] > 0
+    # the headline is the reference's default camera: Msaa::Sample4; the single-sampled rate rides along, and the side
+    # legs are medians of several timed regions like the headline
+    assert d["config"]["sample_count"] == 4 and "Sample4" in d["config"]["workload"]
+    assert d["msaa_off"]["sample_count"] == 1 and d["msaa_off"]["value"] > d["value"] * 0.9 and d["msaa_off"]["trials"] >= 5
+    assert d["scene_like"]["trials"] >= 5
+    assert 0.0 < d["latency"]["steady_blocking_frame_ms"] <= d["latency"]["first_frame_ms"] * 1.2
+    assert d["latency"]["after_cut_ms"] > 0.0
 
 
 @pytest.mark.gpu
