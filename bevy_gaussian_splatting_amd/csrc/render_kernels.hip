@@ -1368,10 +1368,6 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
     __shared__ float4 s_rec_all[4][STAGE * REC_V4];
     __shared__ uint32_t s_queue_all[4][64];
     __shared__ float4 s_depth_all[4][DEPTH && MSAA == 4 ? 256 : 1];   // the tile's depth samples (raster_tile)
-#ifdef BGS_EXP_LDS_PAD   // experiment: LDS the kernel does not need, to cap its occupancy (scripts/build_variant.sh)
-    __shared__ uint32_t s_pad[BGS_EXP_LDS_PAD / 4];
-    if (fpp->debug == 0xDEADBEEFu) s_pad[threadIdx.x] = 1u;
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
