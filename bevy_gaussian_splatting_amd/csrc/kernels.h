@@ -48,7 +48,7 @@ constexpr uint32_t CLOUD_F32 = 0, CLOUD_F16 = 1, CLOUD_COV3D = 2;
 struct FrameCleanup {
     uint32_t* part_status;    // keygen chain: ceil(n / KEYGEN_TILE) words used
     uint32_t* depth_status;   // depth passes: places x [pass_stride words], ceil(D / depth_tile) * 256 used each
-    uint32_t* bin_status;     // project_bin chain: ceil(D / 256) * MAX_SUPERTILES words used
+    uint32_t* bin_status;     // bin_kernel's chains: ceil(D / 1024) * MAX_SUPERTILES words used
     Control* other_ctl;       // the lane's other Control block: zeroed here
     Control* host_ctl;        // pinned host Control (device-visible)
     uint32_t pass_stride;     // words between the status arrays of consecutive depth passes
@@ -143,15 +143,15 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
                          void* records, uint2* instances, uint32_t capacity, uint32_t ticket_slot,
                          int max_blocks);
 
-// Vertex stage in front-to-back order + ORDERED coarse binning (BINNING_SCAN): every rank is
-// appended, in rank order, to the list of each supertile (sup_edge x sup_edge tiles) its
-// tile rectangle overlaps. One pass, no sort, no atomics on the data path: the <= 256 supertiles
-// are the "digits" of the same chained-scan look-back the radix sort uses.
-// d_fp: the device copy of `fp` the kernel reads (written by this frame's keygen).
+// BINNING_SCAN: the vertex stage in front-to-back order (project_kernel: rank -> record + packed tile rectangle, no
+// ordering between ranks) and the ORDERED coarse binning (bin_kernel: every rank is appended, in rank order, to the list
+// of each supertile (sup_edge x sup_edge tiles) its tile rectangle overlaps; one pass, no sort, no atomics on the data
+// path: the <= 256 supertiles are the "digits" of the same chained-scan look-back the radix sort uses), two launches.
+// d_fp: the device copy of `fp` the kernels read (written by this frame's keygen). rects: 4 bytes per rank.
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status, void* records,
-                        uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_edge,
-                        uint32_t ticket_slot, int max_blocks);
+                        uint32_t* rects, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_edge,
+                        uint32_t ticket_slot, int project_blocks, int bin_blocks);
 
 // Tile rasteriser for BINNING_SCAN: walks the supertile's ordered list, keeps the ranks whose
 // rectangle contains this tile (order-preserving ballot compaction), stages their records in LDS

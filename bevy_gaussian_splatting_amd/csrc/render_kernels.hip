@@ -373,156 +373,39 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
 }
 
 // ---------------------------------------------------------------------------------------
-// BINNING_SCAN: project + ordered coarse binning (supertile lists), one pass
+// BINNING_SCAN: the vertex stage (project_kernel) and the ordered coarse binning (bin_kernel)
+//
+// Rounds 1-3 ran both in one kernel: 256 ranks per workgroup, a ticket and a 256-wide look-back chain per workgroup
+// wrapped around a 160-190-VGPR vertex stage at 2 waves per SIMD — 470 tiles for the headline frame's 120 k ranks, the
+// last of which waited 6 us for its ticket and 10 us in the chains (profiles/r3_notes.md section 11) while holding those
+// registers. The two halves want opposite things, so they are two kernels since round 4:
+//   project_kernel   rank -> record + packed tile rectangle. No order between ranks: no ticket, no chain, a static grid.
+//   bin_kernel       reads 4 bytes per rank, 1024 ranks per workgroup (118 tiles for the headline frame, so the chains
+//                    are a quarter as long), ~30 VGPRs: its waves cost the other lanes' kernels nothing while they spin.
 // ---------------------------------------------------------------------------------------
 template <int FMT, bool SURFEL, bool ANY_MODE>
-__global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __restrict__ fpp, CloudPtrs cloud,
-                                                          const uint2* __restrict__ draw_list,
-                                                          const uint2* __restrict__ culled,
-                                                          Control* ctl, uint32_t* bin_status,
-                                                          float4* __restrict__ records,
-                                                          uint32_t* __restrict__ coarse,
-                                                          uint32_t coarse_cap, uint32_t sup_mul,
-                                                          uint32_t sup_x, uint32_t sup_y,
-                                                          uint32_t ticket_slot) {
+__global__ __launch_bounds__(256) void project_kernel(const FrameParams* __restrict__ fpp, CloudPtrs cloud,
+                                                      const uint2* __restrict__ draw_list,
+                                                      const uint2* __restrict__ culled, Control* ctl,
+                                                      float4* __restrict__ records, uint32_t* __restrict__ rects) {
     const FrameParams fp = *fpp;  // left in device memory by the frame's keygen (kernels.h, KeygenLaunch)
-    // A rank overlaps supertile (sx, sy) iff sx is in its x-range AND sy is in its y-range, so the
-    // per-supertile lane masks factor into sup_x column masks and sup_y row masks per wave:
-    // sup_x + sup_y ballots instead of sup_x * sup_y.
-    __shared__ unsigned long long s_xmask[4][32];
-    __shared__ unsigned long long s_ymask[4][32];
-    __shared__ uint32_t s_rect[256];  // packed tile rectangle of each of the block's ranks
-    __shared__ uint32_t s_excl[MAX_SUPERTILES];  // list offset of the block's first hit, per supertile
-    __shared__ unsigned long long s_m[4][MAX_SUPERTILES];  // hit mask of each rank-wave, per supertile
-    __shared__ uint32_t s_block_hits;  // list entries this block appends (picks the append strategy)
-    __shared__ uint32_t s_tile;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // a bucket sort that gave up has voided the list, whatever a later block of it wrote to draw_count (sticky)
     const uint32_t count = ctl->sort_overflow ? 0u : ctl->draw_count;
     const uint32_t num_tiles = (count + 255u) / 256u;
     if (num_tiles == 0u) return;
-    const uint32_t num_st = sup_x * sup_y;
-    const uint32_t my_sy = (uint32_t)tid / sup_x, my_sx = (uint32_t)tid - my_sy * sup_x;  // thread = supertile
     uint32_t visible_acc = 0u;
     float color_mag = 0.0f;  // max |r|, |g|, |b| of the records this thread wrote
-    const bool single_shot = gridDim.x >= num_tiles;  // one ticket per block (see keygen_kernel)
     const ColorInputs ci = ANY_MODE ? frame_color_inputs(fp, cloud, draw_list, culled, count)
                                     : ColorInputs{0.0f, 0.0f, 0.0f};
-
-    for (;;) {
-        if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
-        __syncthreads();
-        const uint32_t tile = s_tile;
-        if (tile >= num_tiles) break;
+    for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
         const uint32_t j = tile * 256u + (uint32_t)tid;  // front-to-back rank
-        uint32_t rect = RECT_EMPTY;
         if (j < count) {
             bool vis = false;
-            if (BGS_ABLATION && (fp.debug & 1u)) {  // ablation: no projection, a fixed 2x1-tile rectangle
-                rect = 0x01000000u | (j & 63u) | (((j & 63u) + 1u) << 8);
-            } else {
-                rect = project_rank<FMT, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis, color_mag);
-            }
+            // the LAST entry of the draw list is drawn on top => it is the front-most
+            rects[j] = project_rank<FMT, SURFEL, ANY_MODE>(fp, cloud, draw_list[count - 1u - j], j, records, ci, vis, color_mag);
             visible_acc += vis ? 1u : 0u;
         }
-        s_rect[tid] = rect;
-        if (tid == 0) s_block_hits = 0u;
-        if (BGS_ABLATION && (fp.debug & 2u)) {  // ablation: no coarse binning at all
-            __syncthreads();
-            continue;
-        }
-        {
-            // supertile bounds of the rectangle; an empty rect has x0 = 255 > x1 = 0, so sx0 > sx1: no column matches
-            // tile / supertile edge by reciprocal multiply (exact for tiles < 256, supertile_div)
-            const uint32_t sx0 = supertile_div(rect & 255u, sup_mul), sx1 = supertile_div((rect >> 8) & 255u, sup_mul);
-            const uint32_t sy0 = supertile_div((rect >> 16) & 255u, sup_mul), sy1 = supertile_div(rect >> 24, sup_mul);
-            for (uint32_t c = 0u; c < sup_x; ++c) {
-                const unsigned long long b = __ballot(c >= sx0 && c <= sx1);
-                if (lane == 0) s_xmask[wave][c] = b;
-            }
-            for (uint32_t r = 0u; r < sup_y; ++r) {
-                const unsigned long long b = __ballot(r >= sy0 && r <= sy1);
-                if (lane == 0) s_ymask[wave][r] = b;
-            }
-        }
-        __syncthreads();
-        if (BGS_ABLATION && (fp.debug & 4u)) {  // ablation: ballots only
-            __syncthreads();
-            continue;
-        }
-        // thread = supertile: lane masks of the 4 waves, chained scan over the blocks, then this
-        // thread appends the block's hits to ITS list in rank order (wave 0 lanes first, ...)
-        if ((uint32_t)tid < num_st) {
-            unsigned long long m[4];
-            uint32_t total = 0u;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                m[w] = s_xmask[w][my_sx] & s_ymask[w][my_sy];
-                total += (uint32_t)__popcll(m[w]);
-            }
-            uint32_t* const my_status = bin_status + (size_t)tile * MAX_SUPERTILES + tid;
-            uint32_t excl = 0u;
-            if (tile > 0u) {
-                __hip_atomic_store(my_status, STATUS_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // 4 words per hop at every size (2344 blocks of a 5 M-splat frame: 16 per hop 4 % slower, 32: 11 %)
-                excl = lookback_u32<4>(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u);
-            }
-            __hip_atomic_store(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tile == num_tiles - 1u) ctl->coarse_total[tid] = excl + total;
-            s_excl[tid] = excl;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) s_m[w][tid] = m[w];
-            if (total) atomicAdd(&s_block_hits, total);
-        }
-        __syncthreads();
-        // Append the block's hits to the supertile lists in rank order. On the dense workload the cost of
-        // this step is the stores themselves (1.78 M scattered 8-byte stores: 16 us of this kernel,
-        // whether one thread walks a supertile's up-to-256 hit bits or the walk is split four ways), so a
-        // block with many hits makes them contiguous: wave v takes supertiles v, v+4, ...; for each of the
-        // block's four rank-waves, lane l owns hit bit l and the set lanes store to consecutive list slots
-        // (11.6 us). That sweep costs ~9 us even when the lists are short, so a block with few hits (the
-        // scene-like workload: ~2 per supertile) lets one thread per supertile walk its bits (2 us).
-        // entry = (rank, its packed tile rectangle): the rasteriser's candidate scan then is one coalesced
-        // 8-byte stream instead of a rank stream plus a 64-line gather of rects[rank].
-        if (BGS_ABLATION && (fp.debug & 8u)) {
-            // ablation bit 8: chain but no list writes
-        } else if (s_block_hits >= 8u * num_st) {
-            const uint32_t r0 = s_rect[lane], r1 = s_rect[64 + lane], r2 = s_rect[128 + lane], r3 = s_rect[192 + lane];
-            const uint32_t rr[4] = {r0, r1, r2, r3};
-            for (uint32_t st = (uint32_t)wave; st < num_st; st += 4u) {
-                const unsigned long long m0 = s_m[0][st], m1 = s_m[1][st], m2 = s_m[2][st], m3 = s_m[3][st];
-                uint32_t pos = s_excl[st];
-                uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)st * coarse_cap;
-                const unsigned long long mm[4] = {m0, m1, m2, m3};
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const unsigned long long m = mm[w];
-                    const uint32_t at = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (((m >> lane) & 1ull) && at < coarse_cap)
-                        dst[at] = make_uint2(tile * 256u + (uint32_t)(w * 64 + lane), rr[w]);
-                    pos += (uint32_t)__popcll(m);
-                }
-            }
-        } else if ((uint32_t)tid < num_st) {
-            uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)tid * coarse_cap;
-            uint32_t pos = s_excl[tid];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                unsigned long long bits = s_m[w][tid];
-                const uint32_t rank0 = tile * 256u + (uint32_t)w * 64u;
-                while (bits) {
-                    const uint32_t l = (uint32_t)__builtin_ctzll(bits);
-                    bits &= bits - 1ull;
-                    if (pos < coarse_cap) dst[pos] = make_uint2(rank0 + l, s_rect[w * 64 + (int)l]);
-                    ++pos;
-                }
-            }
-        }
-        if (single_shot) break;
-        __syncthreads();
     }
     // one atomic per BLOCK: same-address atomics retire one at a time (~8 ns), and a launch's last
     // waves all arrive here together
@@ -545,22 +428,141 @@ __global__ __launch_bounds__(256) void project_bin_kernel(const FrameParams* __r
     }
 }
 
+// ORDERED coarse binning without a sort. A workgroup takes BIN_RANKS consecutive ranks as BIN_GROUPS groups of 64
+// (group q = ranks [64 q, 64 q + 64) of the tile; wave w loads groups 4 w .. 4 w + 3). A rank overlaps supertile
+// (sx, sy) iff sx is in its x-range AND sy is in its y-range, so the per-supertile lane masks factor into sup_x
+// column masks and sup_y row masks per group: sup_x + sup_y ballots instead of sup_x * sup_y. Thread = supertile then
+// counts its hits, runs the chained-scan look-back of the radix sort over the workgroups (<= 256 supertiles ride the
+// 256-wide chain) and the block appends its hits to every list in rank order: lists are front-to-back by construction.
+constexpr uint32_t BIN_GROUPS = 16u, BIN_RANKS = 64u * BIN_GROUPS;
+__global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ rects, Control* ctl, uint32_t* bin_status,
+                                                  uint32_t* __restrict__ coarse, uint32_t coarse_cap, uint32_t sup_mul,
+                                                  uint32_t sup_x, uint32_t sup_y, uint32_t ticket_slot) {
+    __shared__ unsigned long long s_xmask[BIN_GROUPS][32];
+    __shared__ unsigned long long s_ymask[BIN_GROUPS][32];
+    __shared__ uint32_t s_rect[BIN_RANKS];       // packed tile rectangle of each of the block's ranks
+    __shared__ uint32_t s_excl[MAX_SUPERTILES];  // list offset of the block's first hit, per supertile
+    __shared__ uint32_t s_block_hits;            // list entries this block appends (picks the append strategy)
+    __shared__ uint32_t s_tile;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t count = ctl->sort_overflow ? 0u : ctl->draw_count;
+    const uint32_t num_tiles = (count + BIN_RANKS - 1u) / BIN_RANKS;
+    if (num_tiles == 0u) return;
+    const uint32_t num_st = sup_x * sup_y;
+    const uint32_t my_sy = (uint32_t)tid / sup_x, my_sx = (uint32_t)tid - my_sy * sup_x;  // thread = supertile
+    const bool single_shot = gridDim.x >= num_tiles;  // one ticket per block (see keygen_kernel)
+
+    for (;;) {
+        // tiles are handed out by an atomic ticket, so a tile's predecessors have always started: nothing assumes
+        // dispatch order
+        if (tid == 0) { s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u); s_block_hits = 0u; }
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= num_tiles) break;
+        const uint32_t rank0 = tile * BIN_RANKS;
+        uint32_t rect[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t j = rank0 + (uint32_t)((wave * 4 + g) * 64 + lane);
+            rect[g] = j < count ? rects[j] : RECT_EMPTY;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int q = wave * 4 + g;
+            s_rect[q * 64 + lane] = rect[g];
+            // supertile bounds of the rectangle; an empty rect has x0 = 255 > x1 = 0, so sx0 > sx1: no column matches
+            // tile / supertile edge by reciprocal multiply (exact for tiles < 256, supertile_div)
+            const uint32_t sx0 = supertile_div(rect[g] & 255u, sup_mul), sx1 = supertile_div((rect[g] >> 8) & 255u, sup_mul);
+            const uint32_t sy0 = supertile_div((rect[g] >> 16) & 255u, sup_mul), sy1 = supertile_div(rect[g] >> 24, sup_mul);
+            for (uint32_t c = 0u; c < sup_x; ++c) {
+                const unsigned long long b = __ballot(c >= sx0 && c <= sx1);
+                if (lane == 0) s_xmask[q][c] = b;
+            }
+            for (uint32_t r = 0u; r < sup_y; ++r) {
+                const unsigned long long b = __ballot(r >= sy0 && r <= sy1);
+                if (lane == 0) s_ymask[q][r] = b;
+            }
+        }
+        __syncthreads();
+        // thread = supertile: hits of the block, chained scan over the blocks
+        if ((uint32_t)tid < num_st) {
+            uint32_t total = 0u;
+#pragma unroll
+            for (uint32_t q = 0u; q < BIN_GROUPS; ++q) total += (uint32_t)__popcll(s_xmask[q][my_sx] & s_ymask[q][my_sy]);
+            uint32_t* const my_status = bin_status + (size_t)tile * MAX_SUPERTILES + tid;
+            uint32_t excl = 0u;
+            if (tile > 0u) {
+                __hip_atomic_store(my_status, STATUS_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // 4 words per hop at every size (measured on the fused kernel of rounds 1-3: 16 per hop 4 % slower, 32: 11 %)
+                excl = lookback_u32<4>(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u);
+            }
+            __hip_atomic_store(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tile == num_tiles - 1u) ctl->coarse_total[tid] = excl + total;
+            s_excl[tid] = excl;
+            if (total) atomicAdd(&s_block_hits, total);
+        }
+        __syncthreads();
+        // Append the block's hits to the supertile lists in rank order. On the dense workload the cost of
+        // this step is the stores themselves (scattered 8-byte stores), so a block with many hits makes them
+        // contiguous: wave v takes supertiles v, v+4, ...; for each of the block's groups, lane l owns hit bit l and
+        // the set lanes store to consecutive list slots. That sweep costs a few us even when the lists are short, so
+        // a block with few hits (the scene-like workload: a handful per supertile) lets one thread per supertile
+        // walk its bits.
+        // entry = (rank, its packed tile rectangle): the rasteriser's candidate scan then is one coalesced
+        // 8-byte stream instead of a rank stream plus a 64-line gather of rects[rank].
+        if (s_block_hits >= 32u * num_st) {
+            uint32_t rr[BIN_GROUPS];
+#pragma unroll
+            for (uint32_t q = 0u; q < BIN_GROUPS; ++q) rr[q] = s_rect[q * 64u + (uint32_t)lane];
+            for (uint32_t st = (uint32_t)wave; st < num_st; st += 4u) {
+                const uint32_t sy = st / sup_x, sx = st - sy * sup_x;
+                uint32_t pos = s_excl[st];
+                uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)st * coarse_cap;
+#pragma unroll
+                for (uint32_t q = 0u; q < BIN_GROUPS; ++q) {
+                    const unsigned long long m = s_xmask[q][sx] & s_ymask[q][sy];
+                    const uint32_t at = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (((m >> lane) & 1ull) && at < coarse_cap)
+                        dst[at] = make_uint2(rank0 + q * 64u + (uint32_t)lane, rr[q]);
+                    pos += (uint32_t)__popcll(m);
+                }
+            }
+        } else if ((uint32_t)tid < num_st) {
+            uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)tid * coarse_cap;
+            uint32_t pos = s_excl[tid];
+            for (uint32_t q = 0u; q < BIN_GROUPS; ++q) {
+                unsigned long long bits = s_xmask[q][my_sx] & s_ymask[q][my_sy];
+                while (bits) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(bits);
+                    bits &= bits - 1ull;
+                    if (pos < coarse_cap) dst[pos] = make_uint2(rank0 + q * 64u + l, s_rect[q * 64u + l]);
+                    ++pos;
+                }
+            }
+        }
+        if (single_shot) break;
+        __syncthreads();
+    }
+}
+
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status,
-                        void* records, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_edge,
-                        uint32_t ticket_slot, int max_blocks) {
+                        void* records, uint32_t* rects, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_edge,
+                        uint32_t ticket_slot, int project_blocks, int bin_blocks) {
     if (fp.n == 0) return;
     uint32_t blocks = (fp.n + 255u) / 256u;
-    if (blocks > (uint32_t)max_blocks) blocks = (uint32_t)max_blocks;
+    if (blocks > (uint32_t)project_blocks) blocks = (uint32_t)project_blocks;
     const uint32_t sup = sup_edge, sup_mul = supertile_mul(sup_edge);
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup, sup_y = ((uint32_t)fp.tiles_y + sup - 1u) / sup;
     const bool surfel = fp.gaussian_mode == 0u && fp.aabb != 0u;
     float4* rec = (float4*)records;
     const bool any_mode = fp.rasterize_mode != RASTERIZE_COLOR || fp.draw_mode != 0u;
 #define BGS_LAUNCH_PB(F16, SURFEL, ANY)                                                            \
-    hipLaunchKernelGGL((project_bin_kernel<F16, SURFEL, ANY>), dim3(blocks), dim3(256), 0, stream, \
-                       d_fp, cloud, draw_list, culled, ctl, bin_status, rec, coarse,               \
-                       coarse_cap, sup_mul, sup_x, sup_y, ticket_slot)
+    hipLaunchKernelGGL((project_kernel<F16, SURFEL, ANY>), dim3(blocks), dim3(256), 0, stream,     \
+                       d_fp, cloud, draw_list, culled, ctl, rec, rects)
 #define BGS_LAUNCH_PB2(F16, SURFEL) \
     do { if (any_mode) BGS_LAUNCH_PB(F16, SURFEL, true); else BGS_LAUNCH_PB(F16, SURFEL, false); } while (0)
     if (cloud.format == CLOUD_F16) {
@@ -572,6 +574,10 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
     }
 #undef BGS_LAUNCH_PB2
 #undef BGS_LAUNCH_PB
+    uint32_t bblocks = (fp.n + BIN_RANKS - 1u) / BIN_RANKS;
+    if (bblocks > (uint32_t)bin_blocks) bblocks = (uint32_t)bin_blocks;
+    hipLaunchKernelGGL(bin_kernel, dim3(bblocks), dim3(256), 0, stream, rects, ctl, bin_status, coarse, coarse_cap,
+                       sup_mul, sup_x, sup_y, ticket_slot);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1433,7 +1439,7 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
             uint4* dst = reinterpret_cast<uint4*>(cl.depth_status);
             for (uint32_t i = g; i < cl.bucket_chain_words / 4u; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-        const uint32_t bin_v4 = ((draw_count + 255u) / 256u) * (MAX_SUPERTILES / 4u);
+        const uint32_t bin_v4 = ((draw_count + BIN_RANKS - 1u) / BIN_RANKS) * (MAX_SUPERTILES / 4u);
         uint4* bdst = reinterpret_cast<uint4*>(cl.bin_status);
         for (uint32_t i = g; i < bin_v4; i += gn) bdst[i] = make_uint4(0u, 0u, 0u, 0u);
     }
