@@ -428,29 +428,32 @@ __global__ __launch_bounds__(256) void project_kernel(const FrameParams* __restr
     }
 }
 
-// ORDERED coarse binning without a sort. A workgroup takes BIN_RANKS consecutive ranks as BIN_GROUPS groups of 64
-// (group q = ranks [64 q, 64 q + 64) of the tile; wave w loads groups 4 w .. 4 w + 3). A rank overlaps supertile
-// (sx, sy) iff sx is in its x-range AND sy is in its y-range, so the per-supertile lane masks factor into sup_x
-// column masks and sup_y row masks per group: sup_x + sup_y ballots instead of sup_x * sup_y. Thread = supertile then
-// counts its hits, runs the chained-scan look-back of the radix sort over the workgroups (<= 256 supertiles ride the
-// 256-wide chain) and the block appends its hits to every list in rank order: lists are front-to-back by construction.
-constexpr uint32_t BIN_GROUPS = 16u, BIN_RANKS = 64u * BIN_GROUPS;
-__global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ rects, Control* ctl, uint32_t* bin_status,
-                                                  uint32_t* __restrict__ coarse, uint32_t coarse_cap, uint32_t sup_mul,
-                                                  uint32_t sup_x, uint32_t sup_y, uint32_t ticket_slot) {
+// ORDERED coarse binning without a sort. A workgroup of BIN_GROUPS waves takes BIN_RANKS consecutive ranks, wave q the
+// group of 64 ranks [64 q, 64 q + 64) of the tile. A rank overlaps supertile (sx, sy) iff sx is in its x-range AND sy
+// is in its y-range, so the per-supertile lane masks factor into sup_x column masks and sup_y row masks per group:
+// sup_x + sup_y ballots instead of sup_x * sup_y. Thread = supertile (the first 256 threads) then counts its hits per
+// group, runs the chained-scan look-back of the radix sort over the workgroups (<= 256 supertiles ride the 256-wide
+// chain) and the block appends its hits to every list in rank order: lists are front-to-back by construction.
+// 1024 threads: the phases are as parallel as with one workgroup per 256 ranks, the chain is a quarter as long.
+constexpr uint32_t BIN_GROUPS = 16u, BIN_RANKS = 64u * BIN_GROUPS, BIN_THREADS = 64u * BIN_GROUPS;
+__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const uint32_t* __restrict__ rects, Control* ctl, uint32_t* bin_status,
+                                                          uint32_t* __restrict__ coarse, uint32_t coarse_cap, uint32_t sup_mul,
+                                                          uint32_t sup_x, uint32_t sup_y, uint32_t ticket_slot) {
     __shared__ unsigned long long s_xmask[BIN_GROUPS][32];
     __shared__ unsigned long long s_ymask[BIN_GROUPS][32];
     __shared__ uint32_t s_rect[BIN_RANKS];       // packed tile rectangle of each of the block's ranks
     __shared__ uint32_t s_excl[MAX_SUPERTILES];  // list offset of the block's first hit, per supertile
+    __shared__ uint16_t s_off[BIN_GROUPS][MAX_SUPERTILES];  // ... and of every group's first hit behind it
     __shared__ uint32_t s_block_hits;            // list entries this block appends (picks the append strategy)
     __shared__ uint32_t s_tile;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;   // wave = group
     const uint32_t count = ctl->sort_overflow ? 0u : ctl->draw_count;
     const uint32_t num_tiles = (count + BIN_RANKS - 1u) / BIN_RANKS;
     if (num_tiles == 0u) return;
     const uint32_t num_st = sup_x * sup_y;
-    const uint32_t my_sy = (uint32_t)tid / sup_x, my_sx = (uint32_t)tid - my_sy * sup_x;  // thread = supertile
+    const uint32_t st_of_thread = (uint32_t)tid & (MAX_SUPERTILES - 1u);
+    const uint32_t my_sy = st_of_thread / sup_x, my_sx = st_of_thread - my_sy * sup_x;
     const bool single_shot = gridDim.x >= num_tiles;  // one ticket per block (see keygen_kernel)
 
     for (;;) {
@@ -461,20 +464,14 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ r
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
         const uint32_t rank0 = tile * BIN_RANKS;
-        uint32_t rect[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint32_t j = rank0 + (uint32_t)((wave * 4 + g) * 64 + lane);
-            rect[g] = j < count ? rects[j] : RECT_EMPTY;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int q = wave * 4 + g;
-            s_rect[q * 64 + lane] = rect[g];
+        {
+            const uint32_t j = rank0 + (uint32_t)tid;
+            const uint32_t rect = j < count ? rects[j] : RECT_EMPTY;
+            s_rect[tid] = rect;
             // supertile bounds of the rectangle; an empty rect has x0 = 255 > x1 = 0, so sx0 > sx1: no column matches
             // tile / supertile edge by reciprocal multiply (exact for tiles < 256, supertile_div)
-            const uint32_t sx0 = supertile_div(rect[g] & 255u, sup_mul), sx1 = supertile_div((rect[g] >> 8) & 255u, sup_mul);
-            const uint32_t sy0 = supertile_div((rect[g] >> 16) & 255u, sup_mul), sy1 = supertile_div(rect[g] >> 24, sup_mul);
+            const uint32_t sx0 = supertile_div(rect & 255u, sup_mul), sx1 = supertile_div((rect >> 8) & 255u, sup_mul);
+            const uint32_t sy0 = supertile_div((rect >> 16) & 255u, sup_mul), sy1 = supertile_div(rect >> 24, sup_mul);
             for (uint32_t c = 0u; c < sup_x; ++c) {
                 const unsigned long long b = __ballot(c >= sx0 && c <= sx1);
                 if (lane == 0) s_xmask[q][c] = b;
@@ -485,11 +482,14 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ r
             }
         }
         __syncthreads();
-        // thread = supertile: hits of the block, chained scan over the blocks
+        // thread = supertile: hits of the block per group, chained scan over the blocks
         if ((uint32_t)tid < num_st) {
             uint32_t total = 0u;
 #pragma unroll
-            for (uint32_t q = 0u; q < BIN_GROUPS; ++q) total += (uint32_t)__popcll(s_xmask[q][my_sx] & s_ymask[q][my_sy]);
+            for (uint32_t g = 0u; g < BIN_GROUPS; ++g) {
+                s_off[g][tid] = (uint16_t)total;
+                total += (uint32_t)__popcll(s_xmask[g][my_sx] & s_ymask[g][my_sy]);
+            }
             uint32_t* const my_status = bin_status + (size_t)tile * MAX_SUPERTILES + tid;
             uint32_t excl = 0u;
             if (tile > 0u) {
@@ -504,41 +504,37 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ r
             if (total) atomicAdd(&s_block_hits, total);
         }
         __syncthreads();
-        // Append the block's hits to the supertile lists in rank order. On the dense workload the cost of
-        // this step is the stores themselves (scattered 8-byte stores), so a block with many hits makes them
-        // contiguous: wave v takes supertiles v, v+4, ...; for each of the block's groups, lane l owns hit bit l and
-        // the set lanes store to consecutive list slots. That sweep costs a few us even when the lists are short, so
-        // a block with few hits (the scene-like workload: a handful per supertile) lets one thread per supertile
-        // walk its bits.
+        // Append the block's hits to the supertile lists in rank order. On the dense workload the cost of this step is
+        // the stores themselves (scattered 8-byte stores), so a block with many hits makes them contiguous: wave v takes
+        // supertiles v, v + 16, ...; for each of the block's groups, lane l owns hit bit l and the set lanes store to
+        // consecutive list slots. A block with few hits per list (the scene-like workload) lets four threads per
+        // supertile walk the bits of four groups each.
         // entry = (rank, its packed tile rectangle): the rasteriser's candidate scan then is one coalesced
         // 8-byte stream instead of a rank stream plus a 64-line gather of rects[rank].
         if (s_block_hits >= 32u * num_st) {
-            uint32_t rr[BIN_GROUPS];
-#pragma unroll
-            for (uint32_t q = 0u; q < BIN_GROUPS; ++q) rr[q] = s_rect[q * 64u + (uint32_t)lane];
-            for (uint32_t st = (uint32_t)wave; st < num_st; st += 4u) {
+            for (uint32_t st = (uint32_t)q; st < num_st; st += BIN_GROUPS) {
                 const uint32_t sy = st / sup_x, sx = st - sy * sup_x;
                 uint32_t pos = s_excl[st];
                 uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)st * coarse_cap;
-#pragma unroll
-                for (uint32_t q = 0u; q < BIN_GROUPS; ++q) {
-                    const unsigned long long m = s_xmask[q][sx] & s_ymask[q][sy];
+                for (uint32_t g = 0u; g < BIN_GROUPS; ++g) {
+                    const unsigned long long m = s_xmask[g][sx] & s_ymask[g][sy];
                     const uint32_t at = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     if (((m >> lane) & 1ull) && at < coarse_cap)
-                        dst[at] = make_uint2(rank0 + q * 64u + (uint32_t)lane, rr[q]);
+                        dst[at] = make_uint2(rank0 + g * 64u + (uint32_t)lane, s_rect[g * 64u + (uint32_t)lane]);
                     pos += (uint32_t)__popcll(m);
                 }
             }
-        } else if ((uint32_t)tid < num_st) {
-            uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)tid * coarse_cap;
-            uint32_t pos = s_excl[tid];
-            for (uint32_t q = 0u; q < BIN_GROUPS; ++q) {
-                unsigned long long bits = s_xmask[q][my_sx] & s_ymask[q][my_sy];
+        } else if (st_of_thread < num_st) {
+            uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)st_of_thread * coarse_cap;
+            const uint32_t g0 = ((uint32_t)tid >> 8) * 4u;    // this thread's four groups
+            for (uint32_t g = g0; g < g0 + 4u; ++g) {
+                unsigned long long bits = s_xmask[g][my_sx] & s_ymask[g][my_sy];
+                uint32_t pos = s_excl[st_of_thread] + s_off[g][st_of_thread];
                 while (bits) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(bits);
                     bits &= bits - 1ull;
-                    if (pos < coarse_cap) dst[pos] = make_uint2(rank0 + q * 64u + l, s_rect[q * 64u + l]);
+                    if (pos < coarse_cap) dst[pos] = make_uint2(rank0 + g * 64u + l, s_rect[g * 64u + l]);
                     ++pos;
                 }
             }
@@ -576,7 +572,7 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
 #undef BGS_LAUNCH_PB
     uint32_t bblocks = (fp.n + BIN_RANKS - 1u) / BIN_RANKS;
     if (bblocks > (uint32_t)bin_blocks) bblocks = (uint32_t)bin_blocks;
-    hipLaunchKernelGGL(bin_kernel, dim3(bblocks), dim3(256), 0, stream, rects, ctl, bin_status, coarse, coarse_cap,
+    hipLaunchKernelGGL(bin_kernel, dim3(bblocks), dim3(BIN_THREADS), 0, stream, rects, ctl, bin_status, coarse, coarse_cap,
                        sup_mul, sup_x, sup_y, ticket_slot);
 }
 
