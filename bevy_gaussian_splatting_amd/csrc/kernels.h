@@ -148,10 +148,11 @@ void launch_project_emit(hipStream_t stream, const FrameParams& fp, const CloudP
 // of each supertile (sup_edge x sup_edge tiles) its tile rectangle overlaps; one pass, no sort, no atomics on the data
 // path: the <= 256 supertiles are the "digits" of the same chained-scan look-back the radix sort uses), two launches.
 // d_fp: the device copy of `fp` the kernels read (written by this frame's keygen). rects: 4 bytes per rank.
+// wide_bin: the frame is alone on the chip (pipeline depth 1): bin_kernel as 1024-thread workgroups (else 256).
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status, void* records,
                         uint32_t* rects, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_edge,
-                        uint32_t ticket_slot, int project_blocks, int bin_blocks);
+                        uint32_t ticket_slot, int project_blocks, int bin_blocks, bool wide_bin);
 
 // Tile rasteriser for BINNING_SCAN: walks the supertile's ordered list, keeps the ranks whose
 // rectangle contains this tile (order-preserving ballot compaction), stages their records in LDS

@@ -434,11 +434,21 @@ __global__ __launch_bounds__(256) void project_kernel(const FrameParams* __restr
 // sup_x + sup_y ballots instead of sup_x * sup_y. Thread = supertile (the first 256 threads) then counts its hits per
 // group, runs the chained-scan look-back of the radix sort over the workgroups (<= 256 supertiles ride the 256-wide
 // chain) and the block appends its hits to every list in rank order: lists are front-to-back by construction.
-// 1024 threads: the phases are as parallel as with one workgroup per 256 ranks, the chain is a quarter as long.
-constexpr uint32_t BIN_GROUPS = 16u, BIN_RANKS = 64u * BIN_GROUPS, BIN_THREADS = 64u * BIN_GROUPS;
-__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const uint32_t* __restrict__ rects, Control* ctl, uint32_t* bin_status,
+// WAVES = 16 (a 1024-thread workgroup, one wave per group): the phases are as parallel as with one workgroup per 256
+// ranks and the chain is a quarter as long — the fastest shape for a frame that is alone on the chip (project + bin
+// 27.6 us against the fused kernel's 29.2 on the headline frame, 78 against 90 on the 5 M-splat scene-like frame). But a
+// 16-wave workgroup needs a whole CU's worth of wave slots at once, and with the frames of eight lanes in flight that
+// costs throughput (like the wide keygen and bucket sort, kernels.h): WAVES = 4 (256 threads, four groups per wave:
+// slower alone — 31 / 130 us on those two frames — and +15 % / +11 % frames per second in flight on the 5 M-splat
+// frames, +1-2 % at 1 M) is what pipelined frames run. Same-box A/B: profiles/r4_experiments/project_bin_split.txt.
+constexpr uint32_t BIN_GROUPS = 16u, BIN_RANKS = 64u * BIN_GROUPS;
+template <uint32_t WAVES>
+__global__ __launch_bounds__(64u * WAVES) void bin_kernel(const uint32_t* __restrict__ rects, Control* ctl, uint32_t* bin_status,
                                                           uint32_t* __restrict__ coarse, uint32_t coarse_cap, uint32_t sup_mul,
                                                           uint32_t sup_x, uint32_t sup_y, uint32_t ticket_slot) {
+    constexpr uint32_t GPW = BIN_GROUPS / WAVES;          // groups per wave
+    constexpr uint32_t TPS = 64u * WAVES / MAX_SUPERTILES; // threads per supertile in the sparse append (1 or 4)
+    static_assert(WAVES == 4u || WAVES == 16u, "256 or 1024 threads");
     __shared__ unsigned long long s_xmask[BIN_GROUPS][32];
     __shared__ unsigned long long s_ymask[BIN_GROUPS][32];
     __shared__ uint32_t s_rect[BIN_RANKS];       // packed tile rectangle of each of the block's ranks
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const uint32_t* __rest
     __shared__ uint32_t s_block_hits;            // list entries this block appends (picks the append strategy)
     __shared__ uint32_t s_tile;
 
-    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;   // wave = group
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t count = ctl->sort_overflow ? 0u : ctl->draw_count;
     const uint32_t num_tiles = (count + BIN_RANKS - 1u) / BIN_RANKS;
     if (num_tiles == 0u) return;
@@ -464,10 +474,16 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const uint32_t* __rest
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
         const uint32_t rank0 = tile * BIN_RANKS;
-        {
-            const uint32_t j = rank0 + (uint32_t)tid;
-            const uint32_t rect = j < count ? rects[j] : RECT_EMPTY;
-            s_rect[tid] = rect;
+        uint32_t rect_g[GPW];
+#pragma unroll
+        for (uint32_t g = 0u; g < GPW; ++g) {   // the wave's loads first, all in flight together
+            const uint32_t j = rank0 + ((uint32_t)wave * GPW + g) * 64u + (uint32_t)lane;
+            rect_g[g] = j < count ? rects[j] : RECT_EMPTY;
+        }
+#pragma unroll
+        for (uint32_t g = 0u; g < GPW; ++g) {
+            const uint32_t q = (uint32_t)wave * GPW + g, rect = rect_g[g];
+            s_rect[q * 64u + (uint32_t)lane] = rect;
             // supertile bounds of the rectangle; an empty rect has x0 = 255 > x1 = 0, so sx0 > sx1: no column matches
             // tile / supertile edge by reciprocal multiply (exact for tiles < 256, supertile_div)
             const uint32_t sx0 = supertile_div(rect & 255u, sup_mul), sx1 = supertile_div((rect >> 8) & 255u, sup_mul);
@@ -485,7 +501,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const uint32_t* __rest
         // thread = supertile: hits of the block per group, chained scan over the blocks
         if ((uint32_t)tid < num_st) {
             uint32_t total = 0u;
-#pragma unroll
+#pragma unroll 4
             for (uint32_t g = 0u; g < BIN_GROUPS; ++g) {
                 s_off[g][tid] = (uint16_t)total;
                 total += (uint32_t)__popcll(s_xmask[g][my_sx] & s_ymask[g][my_sy]);
@@ -506,13 +522,13 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const uint32_t* __rest
         __syncthreads();
         // Append the block's hits to the supertile lists in rank order. On the dense workload the cost of this step is
         // the stores themselves (scattered 8-byte stores), so a block with many hits makes them contiguous: wave v takes
-        // supertiles v, v + 16, ...; for each of the block's groups, lane l owns hit bit l and the set lanes store to
-        // consecutive list slots. A block with few hits per list (the scene-like workload) lets four threads per
-        // supertile walk the bits of four groups each.
+        // supertiles v, v + WAVES, ...; for each of the block's groups, lane l owns hit bit l and the set lanes store to
+        // consecutive list slots. A block with few hits per list (the scene-like workload) lets the threads of a
+        // supertile (one, or four with four groups each) walk the bits.
         // entry = (rank, its packed tile rectangle): the rasteriser's candidate scan then is one coalesced
         // 8-byte stream instead of a rank stream plus a 64-line gather of rects[rank].
         if (s_block_hits >= 32u * num_st) {
-            for (uint32_t st = (uint32_t)q; st < num_st; st += BIN_GROUPS) {
+            for (uint32_t st = (uint32_t)wave; st < num_st; st += WAVES) {
                 const uint32_t sy = st / sup_x, sx = st - sy * sup_x;
                 uint32_t pos = s_excl[st];
                 uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)st * coarse_cap;
@@ -527,8 +543,8 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const uint32_t* __rest
             }
         } else if (st_of_thread < num_st) {
             uint2* __restrict__ dst = reinterpret_cast<uint2*>(coarse) + (size_t)st_of_thread * coarse_cap;
-            const uint32_t g0 = ((uint32_t)tid >> 8) * 4u;    // this thread's four groups
-            for (uint32_t g = g0; g < g0 + 4u; ++g) {
+            const uint32_t g0 = ((uint32_t)tid >> 8) * (BIN_GROUPS / TPS);    // this thread's groups
+            for (uint32_t g = g0; g < g0 + BIN_GROUPS / TPS; ++g) {
                 unsigned long long bits = s_xmask[g][my_sx] & s_ymask[g][my_sy];
                 uint32_t pos = s_excl[st_of_thread] + s_off[g][st_of_thread];
                 while (bits) {
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const uint32_t* __rest
 void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const CloudPtrs& cloud,
                         const uint2* draw_list, const uint2* culled, Control* ctl, uint32_t* bin_status,
                         void* records, uint32_t* rects, uint32_t* coarse, uint32_t coarse_cap, uint32_t sup_edge,
-                        uint32_t ticket_slot, int project_blocks, int bin_blocks) {
+                        uint32_t ticket_slot, int project_blocks, int bin_blocks, bool wide_bin) {
     if (fp.n == 0) return;
     uint32_t blocks = (fp.n + 255u) / 256u;
     if (blocks > (uint32_t)project_blocks) blocks = (uint32_t)project_blocks;
@@ -572,8 +588,12 @@ void launch_project_bin(hipStream_t stream, const FrameParams& fp, const FramePa
 #undef BGS_LAUNCH_PB
     uint32_t bblocks = (fp.n + BIN_RANKS - 1u) / BIN_RANKS;
     if (bblocks > (uint32_t)bin_blocks) bblocks = (uint32_t)bin_blocks;
-    hipLaunchKernelGGL(bin_kernel, dim3(bblocks), dim3(BIN_THREADS), 0, stream, rects, ctl, bin_status, coarse, coarse_cap,
-                       sup_mul, sup_x, sup_y, ticket_slot);
+    if (wide_bin)
+        hipLaunchKernelGGL(bin_kernel<16u>, dim3(bblocks), dim3(1024), 0, stream, rects, ctl, bin_status, coarse, coarse_cap,
+                           sup_mul, sup_x, sup_y, ticket_slot);
+    else
+        hipLaunchKernelGGL(bin_kernel<4u>, dim3(bblocks), dim3(256), 0, stream, rects, ctl, bin_status, coarse, coarse_cap,
+                           sup_mul, sup_x, sup_y, ticket_slot);
 }
 
 // ---------------------------------------------------------------------------------------
