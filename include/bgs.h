@@ -27,6 +27,11 @@
  *     (matches Bevy: one render thread); distinct contexts are independent.
  *   - there is NO CPU fallback: without a usable HIP device bgs_create fails with
  *     BGS_EHIP.
+ *
+ * This header is the seam and nothing else: context, cloud upload, sort, render, the frame's targets and
+ * the frame pipeline. Diagnostics, test hooks and experiment switches (per-tile trace, counters of the
+ * adaptive machinery, the HBM probe, the radix kernel on caller keys, the ln self-test, debug flags, the
+ * queue-holder switch) are declared in bgs_diag.h; libbgs.so exports both sets.
  */
 #ifndef BGS_H
 #define BGS_H
@@ -319,28 +324,11 @@ int bgs_stream(bgs_ctx* ctx, void** hip_stream);
 #define BGS_BINNING_SORT 1u
 int bgs_set_binning(bgs_ctx* ctx, uint32_t mode);
 
-/* Kernel-ablation switches for performance experiments (scripts/ablate.py). Bits 1..64 switch parts
- * of kernels off and produce WRONG images; 0x1000 (per-frame memset + Control copy instead of the
- * rasteriser's in-kernel clean-up), 0x2000 (no draw-count hint for the sort grids), 0x4000 (no
- * hipGraph replay even when bgs_set_graphs is on), 0x10000 / 0x8000 / 0x400000 / 0x800000 (force supertile
- * level 0 / 1 / 2 / 3 instead of choosing by the completed frames' list statistics), 0x40000 (sRGB8 image from the
- * separate encode pass instead of the rasteriser's fused output), 0x80000 (depth sort always by the
- * onesweep digit passes, never the bucket sort), 0x200000 (bucket sort even before a completed frame has
- * told the key range: full 32-bit range guessed), 0x100000 (supertile lists start at 64 entries, to
- * exercise the overflow -> re-run path) keep images correct and exist for A/B timing and tests.
- * Production code leaves this at 0. */
-int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags);
 /* Forget what completed frames taught the context: draw-count hint (grid sizes), drawable key range and
  * the bucket-sort back-off, supertile rule, list-capacity hint. Buffers stay allocated. The next frames
  * behave like the first frames of a fresh context (onesweep passes, default capacities, re-run on
  * overflow). Completes the frames in flight. */
 int bgs_reset_adaptive_state(bgs_ctx* ctx);
-/* What the adaptive machinery has done since bgs_create: out[0] frames enqueued on the bucket sort path,
- * [1] on the onesweep passes (both counts include re-runs), [2] frames re-run because the bucket sort gave
- * up, [3] because a supertile list overflowed, [4] because the tile-instance buffer was too small,
- * [5] supertile level changes, [6] the current level, [7] the current list-capacity hint (entries). */
-int bgs_adaptive_counters(bgs_ctx* ctx, uint64_t out[8]);
-
 /* HIP-event timing level: 0 = none, 1 = frame start/end only (total_ms), 2 = every stage
  * (default). Each recorded event costs a few microseconds of GPU timeline. */
 int bgs_set_profiling(bgs_ctx* ctx, int enabled);
@@ -349,28 +337,6 @@ int bgs_set_profiling(bgs_ctx* ctx, int enabled);
 int bgs_set_profiling_stride(bgs_ctx* ctx, uint32_t every_nth_frame);
 /* Stats of the most recent bgs_sort / bgs_render. Synchronises the stream. */
 int bgs_get_stats(bgs_ctx* ctx, bgs_stats* out);
-
-/* ---- building blocks exported for tests and reuse -------------------------------- */
-/* Stable LSD radix sort of n (key,index) pairs on the device, `passes` 8-bit digit
- * places starting at bit 0 (the Onesweep kernel used for both the depth and the tile
- * sort). entries_inout is a HOST buffer; used by the parity tests to exercise the sort
- * kernel on arbitrary keys (ties, all-equal, ragged sizes). */
-int bgs_radix_sort_pairs(bgs_ctx* ctx, bgs_sort_entry* entries_inout, uint32_t n,
-                         uint32_t passes);
-
-/* Measured HBM ceiling of this device, for the roofline ("state both" the nominal and
- * the measured peak): `bytes` per buffer (rounded down to 16), `iters` timed repetitions.
- * copy_gbs = hipMemcpyDtoD rate counting read + write; triad_gbs = a[i] = b[i] + s * c[i] with
- * float4 accesses, counting 2 reads + 1 write. Allocates 3 * bytes for the call. */
-int bgs_hbm_probe(bgs_ctx* ctx, uint64_t bytes, uint32_t iters, float* copy_gbs, float* triad_gbs);
-
-/* Device self-test of the correctly rounded natural logarithm behind the adaptive cutoff
- * (src/render/gaussian.wgsl:229-235; csrc/exact_log.h: the one transcendental that reaches a cull decision).
- * Evaluates it ON THE DEVICE for the `count` binary32 bit patterns first_bits, first_bits + 1, ...:
- * host_out (may be NULL) receives the results; checksum_out (may be NULL) the wrap-around sum over the inputs of
- * mix((in_bits << 32 | out_bits)) with mix(v) = (v * 0x9E3779B97F4A7C15, v ^= v >> 29, v * 0xBF58476D1CE4E5B9),
- * so that a caller can compare 2^31 results with its own without moving them. */
-int bgs_selftest_ln_f32(bgs_ctx* ctx, uint32_t first_bits, uint32_t count, float* host_out, uint64_t* checksum_out);
 
 /* Streams the lanes run on: lane i uses stream i % min(streams, depth); 0 = one stream per lane.
  * Default 4: the HIP runtime multiplexes a process's streams onto 4 hardware queues (per priority), and only
@@ -382,21 +348,6 @@ int bgs_selftest_ln_f32(bgs_ctx* ctx, uint32_t first_bits, uint32_t count, float
  * 5 on 5 15.6 k). BGS_QUEUE_HOLDERS=0 in the environment keeps the library from parking its idle streams: for
  * processes whose other streams (RCCL's) already hold the queues. */
 int bgs_set_pipeline_streams(bgs_ctx* ctx, uint32_t streams);
-/* The library parks three idle "queue holder" streams per DEVICE (process-global, created once, however many
- * contexts the process has) before a context creates its own streams, so that the HIP runtime deals those out one per
- * hardware queue (see above). 0 switches that off for contexts that have not created their streams yet — for a
- * process whose other streams already hold the queues (e.g. RCCL's after a process group was initialised); 1 forces
- * it on; -1 (default) follows the environment variable BGS_QUEUE_HOLDERS (unset or non-zero: on). Never fails. */
-int bgs_set_queue_holders(int enabled);
-
-/* Diagnostics: per-tile trace of the default (BGS_BINNING_SCAN) rasteriser. With a non-NULL device buffer of
- * tiles_x * tiles_y * 32 bytes, every following frame runs the rasteriser's instrumented instantiation, in which each
- * tile's wave writes 8 uint32: s_memtime at its start (lo, hi) and end (lo, hi), the HW_ID and XCC_ID registers (which
- * XCD / SE / CU / SIMD / wave slot it ran on), the list candidates it scanned, and records blended | staged << 16.
- * scripts/tile_trace.py turns that into the launch's per-SIMD occupancy picture (the "tail"). NULL switches it off.
- * Completes the frames in flight; the buffer stays the caller's. Costs ~10 % of the rasteriser's time while on. */
-int bgs_set_tile_trace(bgs_ctx* ctx, void* device_ptr);
-
 /* Frame graphs (opt-in, default off). An asynchronous BINNING_SCAN frame (bgs_set_async) in the
  * steady state is replayed from a hipGraph captured once per (lane, parity): the frame's first kernel
  * receives the new view/settings as its arguments (one graph-node update) and leaves them in device
@@ -406,9 +357,6 @@ int bgs_set_tile_trace(bgs_ctx* ctx, void* device_ptr);
  * changes (cloud, buffers, viewport size, pipeline variant, grid sizes, debug flags); frames whose
  * stages are timed with events (bgs_set_profiling) are always launched directly. */
 int bgs_set_graphs(bgs_ctx* ctx, int enabled);
-/* How many frames were captured into a graph / replayed from one since bgs_create. */
-int bgs_graph_counters(bgs_ctx* ctx, uint64_t* captures, uint64_t* replays);
-
 #ifdef __cplusplus
 }
 #endif

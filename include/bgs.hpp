@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "bgs.h"
+#include "bgs_diag.h"  // adaptive_counters()
 
 namespace bgs {
 

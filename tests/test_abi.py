@@ -14,10 +14,25 @@ from bevy_gaussian_splatting_amd.settings import BgsSettings
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "bgs.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(bgs_[a-z0-9_]+)\s*\(", text)))
+def _declared(headers=("bgs.h", "bgs_diag.h")):
+    """Entry points declared by the seam (include/bgs.h) and the diagnostics header (include/bgs_diag.h)."""
+    names = set()
+    for hname in headers:
+        text = open(os.path.join(ROOT, "include", hname)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(bgs_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_the_seam_header_carries_no_diagnostics():
+    """include/bgs.h is the drop-in boundary: context, upload, sort, render, targets, frame pipeline. Test hooks,
+    counters and experiment switches live in include/bgs_diag.h."""
+    seam, diag = set(_declared(("bgs.h",))), set(_declared(("bgs_diag.h",)))
+    assert not seam & diag
+    assert {"bgs_create", "bgs_cloud_upload_f32", "bgs_sort", "bgs_render", "bgs_pipeline_pop"} <= seam
+    assert {"bgs_set_debug_flags", "bgs_set_tile_trace", "bgs_selftest_ln_f32", "bgs_hbm_probe", "bgs_radix_sort_pairs",
+            "bgs_set_queue_holders", "bgs_adaptive_counters", "bgs_graph_counters"} == diag
+    assert len(seam) <= 40
 
 
 def test_library_is_built_and_exports_every_declared_symbol():
@@ -109,7 +124,7 @@ def test_header_is_plain_c_and_the_cpp_layer_is_standard_cpp17(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     c = tmp_path / "abi.c"
-    c.write_text('#include "bgs.h"\nint main(void) { bgs_settings s; bgs_settings_default(&s); '
+    c.write_text('#include "bgs.h"\n#include "bgs_diag.h"\nint main(void) { bgs_settings s; bgs_settings_default(&s); '
                  "return (int)sizeof(bgs_view) == 0; }\n")
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
                     "-c", str(c), "-o", str(tmp_path / "abi.o")], check=True)
