@@ -764,3 +764,163 @@ def test_random_scene_against_an_independent_float64_renderer(oracle, aabb, samp
     assert err[ok].max() < 2e-5, (err[ok].max(), np.abs(ref).max())   # measured: 1e-6 (f32 oracle vs float64 geometry)
     # and the scene is not trivial: most pixels see several splats
     assert (np.abs(ref[..., :3] - np.asarray(view.clear_color)[:3]).sum(-1) > 1e-3).mean() > 0.5
+
+
+# ---------------------------------------------------------------------------------------------------
+# The independent renderer, widened (round 4): the f16 storage, the precomputed-covariance plane and a whole scene of
+# 2DGS surfels go through an independent float64 derivation as well.
+# ---------------------------------------------------------------------------------------------------
+def _scene_cloud(n, seed):
+    rng = np.random.default_rng(seed)
+    c = random_gaussians_3d_seeded(n, 77)
+    c.position_visibility[:, :3] = (rng.uniform(-1, 1, (n, 3)) * [2.6, 1.6, 2.5] + [0.0, 1.5, 0.5]).astype(np.float32)
+    c.scale_opacity[:, :3] = rng.uniform(0.05, 0.45, (n, 3)).astype(np.float32)
+    c.scale_opacity[:, 3] = rng.uniform(0.05, 0.9, n).astype(np.float32)
+    c.spherical_harmonic[:] = rng.uniform(-0.6, 0.6, c.spherical_harmonic.shape).astype(np.float32)
+    return c
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_f16_cloud_scene_against_the_independent_renderer(oracle, samples):
+    """The f16 planar storage (src/gaussian/f16.rs:29-55, src/render/planar.wgsl:117-176): the oracle draws the PACKED
+    cloud (its own unpack: which half holds which value, coefficient pairing); the independent renderer draws the cloud
+    whose attributes were rounded to binary16 by numpy — another implementation of round-to-nearest-even, and no
+    packing at all. Same image => the pack / unpack conventions and the rounding are what the format says."""
+    c = _scene_cloud(120, 2025)
+    packed = c.to_f16()
+    h = lambda a: a.astype(np.float16).astype(np.float32)
+    rounded = PlanarGaussian3d(c.position_visibility, h(c.spherical_harmonic), h(c.rotation), h(c.scale_opacity))
+    view = View.headless(96, 64, msaa_samples=samples)
+    st = CloudSettings()
+    e = oracle.sort(packed, view, st)
+    img = oracle.render(packed, e, view, st).astype(np.float64)
+    ref, edge, drawn = _independent_scene(view, rounded, st)
+    assert 40 < drawn < len(c)
+    err = np.abs(img - ref)
+    assert err[~edge].max() < 2e-5, err[~edge].max()
+    # ... and it is not the f32 cloud's image: the rounding is visible
+    img32 = oracle.render(c, oracle.sort(c, view, st), view, st)
+    assert np.abs(img32 - img).max() > 1e-3
+
+
+def test_covariance_3d_plane_against_float64():
+    """`precompute_covariance_3d` (src/gaussian/covariance.rs:4-41, f32.rs:218-251): the six entries (xx, xy, xz, yy, yz,
+    zz) of M^T M with M = S R, R the reference's rotation polynomial of the (unnormalised) quaternion — against
+    R_std S^2 R_std^T in float64, R_std = the textbook rotation of that quaternion evaluated without normalising."""
+    from bevy_gaussian_splatting_amd.gaussian import covariance_3d_opacity
+    c = random_gaussians_3d_seeded(500, 9)
+    got = covariance_3d_opacity(c).astype(np.float64)
+    for i in range(len(c)):
+        S = _sigma_world(c.scale_opacity[i, :3], c.rotation[i], unit=False)
+        want = [S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]]
+        assert np.allclose(got[i, :6], want, rtol=2e-5, atol=1e-6), i
+        assert got[i, 6] == c.scale_opacity[i, 3]
+
+
+def _internal_frame_many(view, pw):
+    """_internal_frame for an [n, 3] array of world points."""
+    Rc, tc, fx, fy = _cam(view)
+    t = (np.asarray(pw, np.float64) - tc) @ Rc
+    ndc = np.stack([fx * t[:, 0] / -t[:, 2], fy * t[:, 1] / -t[:, 2]], 1)
+    return np.stack([ndc[:, 0] * fx * view.width / 2 + (view.width - 1) / 2,
+                     ndc[:, 1] * fy * view.height / 2 + (view.height - 1) / 2], 1)
+
+
+def _independent_surfel_scene(view, cloud, settings):
+    """[H, W, 4] float64 image of a scene of 2DGS surfels (GaussianMode::Gaussian2d, aabb) + the mask of pixels with a
+    sample position within 0.02 px of a quad edge. Per surfel, from the geometry only: tangent vectors t_u, t_v = the
+    first two columns of the rotation times the scales; the quad = the square of half-size radius / 2 framebuffer pixels
+    about the projected centre, radius = the larger half-side of the bounding box of the projected cutoff ellipse in the
+    surfel code's own frame (sampled; at least cutoff * 0.707106); alpha at a pixel = opacity exp(-1/2 min(u^2 + v^2,
+    2 |mean_2d - pc|^2)) with (u, v) from the float64 ray-plane intersection at the coordinate pc the fragment stage
+    derives for the pixel (see test_surfel_image_follows_the_intersection for the reference's two frames)."""
+    W_, H_ = view.width, view.height
+    Rc, tc, fx, fy = _cam(view)
+    P = np.asarray(view.clip_from_view, np.float64)
+    V = np.linalg.inv(np.asarray(view.world_from_view, np.float64))
+    ys, xs = np.mgrid[0:H_, 0:W_]
+    samples = SAMPLE_POS[view.msaa_samples]
+    img = np.zeros((len(samples), H_, W_, 4))
+    img[..., :] = np.asarray(view.clear_color, np.float64)
+    edge_mask = np.zeros((H_, W_), bool)
+    pos = cloud.position_visibility[:, :3].astype(np.float64)
+    order = np.argsort(-((pos - tc) ** 2).sum(1), kind="stable")
+    ang = np.linspace(0, 2 * np.pi, 4001)
+    drawn = 0
+    for i in order:
+        clip = P @ V @ np.append(pos[i], 1.0)
+        ndc = clip / (clip[3] + 1e-9)
+        if not (abs(ndc[0]) < 1.1 and abs(ndc[1]) < 1.1 and abs(ndc[2] - 0.5) < 0.5):
+            continue
+        w, x, y, z = (float(v) for v in cloud.rotation[i])
+        R = Rotation.from_quat([x, y, z, w]).as_matrix()
+        sc = cloud.scale_opacity[i, :3].astype(np.float64) * settings.global_scale
+        opacity = float(cloud.scale_opacity[i, 3])
+        k = math.sqrt(max(9 + 2 * math.log(opacity), 1e-6)) if settings.opacity_adaptive_radius else 3.0
+        tu, tv = R[:, 0] * sc[0], R[:, 1] * sc[1]
+        pts = _internal_frame_many(view, pos[i] + k * np.cos(ang)[:, None] * tu + k * np.sin(ang)[:, None] * tv)
+        mn, mx = pts.min(0), pts.max(0)
+        mean, half = (mn + mx) / 2, (mx - mn) / 2
+        radius = max(half[0], half[1], k * 0.707106)
+        c = _pixel_of(view, pos[i])
+
+        def quad_uv(ox, oy):
+            return (xs + ox - c[0]) / (radius / 2), -(ys + oy - c[1]) / (radius / 2)
+
+        uq, vq = quad_uv(0.5, 0.5)                          # shaded once per pixel, at its centre
+        pcx, pcy = uq * radius + mean[0], vq * radius * W_ / H_ + mean[1]
+        nx, ny = (pcx - (W_ - 1) / 2) / (fx * W_ / 2), (pcy - (H_ - 1) / 2) / (fy * H_ / 2)
+        dw = np.einsum("ij,...j->...i", Rc, np.stack([nx / fx, ny / fy, -np.ones_like(nx)], -1))
+        # camera centre + t dw = p + u t_u + v t_v  ->  [t_u t_v -dw] (u, v, t)^T = camera centre - p  (Cramer)
+        b = tc - pos[i]
+        det = np.einsum("i,...i->...", np.cross(tu, tv), -dw)
+        u = np.einsum("i,...i->...", np.cross(b, tv), -dw) / det
+        v = np.einsum("i,...i->...", np.cross(tu, b), -dw) / det
+        power = -0.5 * np.minimum(u * u + v * v, 2 * ((mean[0] - pcx) ** 2 + (mean[1] - pcy) ** 2))
+        alpha = np.minimum(opacity * settings.global_opacity * np.exp(power), 0.999)
+        dirv = pos[i] - tc
+        B = _real_sh_basis(dirv / np.linalg.norm(dirv))
+        rgb = 0.5 + B @ cloud.spherical_harmonic[i].astype(np.float64).reshape(16, 3)
+        if settings.color_space != GaussianColorSpace.LinRec709Display:
+            rgb = _srgb_to_linear64(rgb)
+        for si, (ox, oy) in enumerate(samples):
+            us, vs = quad_uv(ox, oy)
+            g = np.maximum(np.abs(us), np.abs(vs))
+            edge_mask |= np.abs(g - 1) * (radius / 2) < 0.02
+            a = np.where(g <= 1, alpha, 0.0)[..., None]
+            img[si] = np.concatenate([rgb[None, None, :] * a, a], -1) + img[si] * (1.0 - a)
+        drawn += 1
+    return img.mean(0), edge_mask, drawn
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_surfel_scene_against_an_independent_float64_renderer(oracle, samples):
+    """100 overlapping 2DGS surfels (unit quaternions within ~50 degrees of facing the camera, SH degree 3, sRGB colour
+    space, adaptive radius) at 128x80, GaussianMode::Gaussian2d + aabb (the true surfel fragment path): the oracle's
+    whole image against the independent surfel renderer above. Covers what the single-surfel pins cannot: order, blending
+    and clipping of many surfels, each with its own two frames."""
+    rng = np.random.default_rng(11)
+    n = 100
+    c = random_gaussians_3d_seeded(n, 5)
+    c.position_visibility[:, :3] = (rng.uniform(-1, 1, (n, 3)) * [2.4, 1.4, 1.5] + [0.0, 1.5, 0.0]).astype(np.float32)
+    q = Rotation.from_euler("xyz", rng.uniform(-0.8, 0.8, (n, 3))).as_quat()      # x, y, z, w
+    c.rotation[:] = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], 1).astype(np.float32)
+    c.scale_opacity[:, :3] = rng.uniform(0.08, 0.35, (n, 3)).astype(np.float32)
+    c.scale_opacity[:, 3] = rng.uniform(0.2, 0.9, n).astype(np.float32)
+    c.spherical_harmonic[:] = rng.uniform(-0.6, 0.6, c.spherical_harmonic.shape).astype(np.float32)
+    view = View.headless(128, 80, msaa_samples=samples)
+    st = CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, aabb=True)
+    e = oracle.sort(c, view, st)
+    # none of the reference's degeneracy branches is taken in this scene (they are pinned by their own tests)
+    live = [oracle.vs(c, ent, view, st) for ent in e if ent["key"] != 0xFFFFFFFF]
+    assert all(v.discard == 0 and v.radius[0] > 0 for v in live)
+    img = oracle.render(c, e, view, st).astype(np.float64)
+    ref, edge, drawn = _independent_surfel_scene(view, c, st)
+    assert drawn == len(live) and 60 < drawn <= n
+    ok = ~edge
+    assert ok.mean() > 0.6
+    err = np.abs(img - ref)
+    # (f32 ray-plane intersection against float64 geometry; the bound of the single-surfel pin, relative to the colour range)
+    assert err[ok].max() < 4e-3 * max(1.0, np.abs(ref).max()), (err[ok].max(), np.abs(ref).max())
+    assert np.quantile(err[ok], 0.99) < 2e-4
+    assert (np.abs(ref[..., :3] - np.asarray(view.clear_color)[:3]).sum(-1) > 1e-3).mean() > 0.4
