@@ -52,6 +52,12 @@ struct FrameParams {
     // the view's depth attachment (Depth32Float, reverse-Z, [y][x][sample] floats) the quads are tested against with
     // GreaterEqual (src/render/mod.rs:959-974), as a device address; 0 = none
     uint64_t depth_ptr;
+    // Per-frame constants the vertex stage used to re-derive per splat (each a few correctly rounded divisions / square
+    // roots of uniform data: ~130 instructions per thread). Formed by fill_frame_params on the host with the same IEEE
+    // operations in the same order, so every bit downstream is what it was:
+    float basis[9];            // normalize(transform[0].xyz), [1].xyz, [2].xyz  (gaussian.wgsl:166-176)
+    float inv_viewport_w, inv_viewport_h;   // 1.0 / viewport.zw                (helpers.wgsl:116-117)
+    float pad_uniform;
 };
 static_assert(sizeof(FrameParams) % 8 == 0 && sizeof(FrameParams) / 4 <= 256, "keygen copies it with one block");
 

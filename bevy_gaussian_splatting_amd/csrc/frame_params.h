@@ -51,6 +51,18 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     fp.sort_path = 0;  // chosen per frame by the host (bgs_api.hip)
     fp.sample_count = view->sample_count;
     fp.depth_ptr = view->depth_device_ptr;
+    // uniform parts of world_to_local_direction (gaussian.wgsl:166-176: normalize(basis[k]) = v / length(v),
+    // length = sqrt(dot)) and of the bounding boxes (1.0 / viewport): IEEE binary32, the order of splat_math.h
+    for (int k = 0; k < 3; ++k) {
+        const float x = s->transform[4 * k], y = s->transform[4 * k + 1], z = s->transform[4 * k + 2];
+        const float len = __builtin_sqrtf((x * x + y * y) + z * z);
+        fp.basis[3 * k] = x / len;
+        fp.basis[3 * k + 1] = y / len;
+        fp.basis[3 * k + 2] = z / len;
+    }
+    fp.inv_viewport_w = 1.0f / view->viewport[2];
+    fp.inv_viewport_h = 1.0f / view->viewport[3];
+    fp.pad_uniform = 0.0f;
     for (int i = 0; i < 3; ++i) {
         fp.pos_min[i] = s->position_min[i];
         fp.pos_max[i] = s->position_max[i];

@@ -388,7 +388,10 @@ __global__ __launch_bounds__(256) void project_kernel(const FrameParams* __restr
                                                       const uint2* __restrict__ draw_list,
                                                       const uint2* __restrict__ culled, Control* ctl,
                                                       float4* __restrict__ records, uint32_t* __restrict__ rects) {
-    const FrameParams fp = *fpp;  // left in device memory by the frame's keygen (kernels.h, KeygenLaunch)
+    // left in device memory by the frame's keygen (kernels.h, KeygenLaunch). Read THROUGH the pointer, where it is used:
+    // a by-value copy parks ~110 dwords in scalar registers and the compiler spills them to vector lanes
+    // (v_writelane / v_readlane: 220 of the kernel's 1700 vector instructions)
+    const FrameParams& fp = *fpp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // a bucket sort that gave up has voided the list, whatever a later block of it wrote to draw_count (sticky)
     const uint32_t count = ctl->sort_overflow ? 0u : ctl->draw_count;

@@ -233,32 +233,69 @@ BGS_HD M3 scale_matrix(const float* scale, float gs) {
 // the six covariance entries come from the cloud (Covariance3dOpacity, src/gaussian/f32.rs:218-251) and
 // compute_cov3d is skipped — with it the model transform's linear part and global_scale, which the
 // reference applies inside compute_cov3d only.
+// The matrix products are written out with their STRUCTURE used: S is diagonal, J has a zero column and two zero
+// entries, Sigma and T Sigma T^T are symmetric, and only the upper-left 2x2 block of the projected covariance is read.
+// Every term that is kept is the reference's term in the reference's order ((a0 b0 + a1 b1) + a2 b2); what is dropped
+// is a multiplication by a structural zero and the addition of its product, which in IEEE arithmetic change nothing but
+// the sign of a zero result (x + (+-0) = x, and y * 0 = +-0 for every finite y) — and NaN propagation for non-finite
+// scales, where the reference's 0 * inf poisons entries this form leaves finite. A symmetric entry [i][j] is the same
+// three products added in the same order as [j][i] (IEEE multiplication commutes), so it is formed once.
 BGS_HD void cov2d_3dgs(const FrameParams& fp, V3 position, const float* scale, const float* rot,
                        const float* cov3d_pre, float out[3]) {
     float c0, c1, c2, c3, c4, c5;
     if (cov3d_pre) {
         c0 = cov3d_pre[0]; c1 = cov3d_pre[1]; c2 = cov3d_pre[2]; c3 = cov3d_pre[3]; c4 = cov3d_pre[4]; c5 = cov3d_pre[5];
     } else {
-        M3 S = scale_matrix(scale, fp.global_scale);
-        M3 T = m3_from_m4(fp.transform);
-        M3 R = rotation_matrix(rot);
-        M3 M = m3_mul(S, R);
-        M3 Sigma = m3_mul(m3_transpose(M), M);
-        M3 TS = m3_mul(m3_mul(T, Sigma), m3_transpose(T));
-        c0 = TS.m[0]; c1 = TS.m[1]; c2 = TS.m[2]; c3 = TS.m[4]; c4 = TS.m[5]; c5 = TS.m[8];
+        const M3 R = rotation_matrix(rot);
+        const float s0 = scale[0] * fp.global_scale, s1 = scale[1] * fp.global_scale, s2 = scale[2] * fp.global_scale;
+        // M = S R (helpers.wgsl:12): row r of R scaled by s_r. Column-major m[3 c + r].
+        float M[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { M[3 * c] = s0 * R.m[3 * c]; M[3 * c + 1] = s1 * R.m[3 * c + 1]; M[3 * c + 2] = s2 * R.m[3 * c + 2]; }
+        // Sigma = M^T M: Sigma[c][r] = dot(column r of M, column c of M), summed left to right over the ROWS of M
+        auto sig = [&](int r, int c) { return (M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1]) + M[3 * r + 2] * M[3 * c + 2]; };
+        const float g00 = sig(0, 0), g01 = sig(0, 1), g02 = sig(0, 2), g11 = sig(1, 1), g12 = sig(1, 2), g22 = sig(2, 2);
+        const float G[9] = {g00, g01, g02, g01, g11, g12, g02, g12, g22};   // symmetric, column-major
+        const float* tm = fp.transform;   // T = mat3(transform[0].xyz, [1].xyz, [2].xyz): T[c][r] = tm[4 c + r]
+        // A = T Sigma: A[c][r] = (T[0][r] G[c][0] + T[1][r] G[c][1]) + T[2][r] G[c][2]
+        float A[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                A[3 * c + r] = (tm[r] * G[3 * c] + tm[4 + r] * G[3 * c + 1]) + tm[8 + r] * G[3 * c + 2];
+        // TS = A T^T: TS[c][r] = (A[0][r] T^T[c][0] + A[1][r] T^T[c][1]) + A[2][r] T^T[c][2], T^T[c][k] = T[k][c] = tm[4 k + c]
+        auto ts = [&](int r, int c) { return (A[r] * tm[c] + A[3 + r] * tm[4 + c]) + A[6 + r] * tm[8 + c]; };
+        c0 = ts(0, 0); c1 = ts(1, 0); c2 = ts(2, 0); c3 = ts(1, 1); c4 = ts(2, 1); c5 = ts(2, 2);
     }
-    M3 Vrk = m3_cols(V3{c0, c1, c2}, V3{c1, c3, c4}, V3{c2, c4, c5});
+    // Vrk = (c0 c1 c2 / c1 c3 c4 / c2 c4 c5), symmetric: transpose(Vrk) = Vrk
+    const float Vrk[9] = {c0, c1, c2, c1, c3, c4, c2, c4, c5};
 
     V4 t = m4_mul_point(fp.view_from_world, position);
     float sI = 1.0f / (t.z * t.z);
-    M3 J = m3_cols(V3{fp.focal_x / t.z, 0.0f, -(fp.focal_x * t.x) * sI},
-                   V3{0.0f, -fp.focal_y / t.z, (fp.focal_y * t.y) * sI}, V3{0.0f, 0.0f, 0.0f});
-    M3 W = m3_transpose(m3_from_m4(fp.view_from_world));
-    M3 Tm = m3_mul(W, J);
-    M3 cov = m3_mul(m3_mul(m3_transpose(Tm), m3_transpose(Vrk)), Tm);
-    out[0] = cov.m[0] + 0.3f;
-    out[1] = cov.m[1];
-    out[2] = cov.m[4] + 0.3f;
+    // J = cols (fx / tz, 0, -(fx tx) sI), (0, -fy / tz, (fy ty) sI), (0, 0, 0)      (helpers.wgsl:20-33)
+    const float j00 = fp.focal_x / t.z, j02 = -(fp.focal_x * t.x) * sI;
+    const float j11 = -fp.focal_y / t.z, j12 = (fp.focal_y * t.y) * sI;
+    // W = transpose(mat3(view_from_world)): W[k][r] = vfw[4 r + k]. Tm = W J; its third column is zero.
+    // Tm[0][r] = (W[0][r] j00 + W[1][r] 0) + W[2][r] j02,  Tm[1][r] = (W[0][r] 0 + W[1][r] j11) + W[2][r] j12
+    const float* vw = fp.view_from_world;
+    float t0[3], t1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        t0[r] = vw[4 * r] * j00 + vw[4 * r + 2] * j02;
+        t1[r] = vw[4 * r + 1] * j11 + vw[4 * r + 2] * j12;
+    }
+    // B = Tm^T Vrk^T, rows 0 and 1: B[c][r] = (Tm[r][0] Vrk[c][0] + Tm[r][1] Vrk[c][1]) + Tm[r][2] Vrk[c][2]
+    float b0[3], b1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        b0[c] = (t0[0] * Vrk[3 * c] + t0[1] * Vrk[3 * c + 1]) + t0[2] * Vrk[3 * c + 2];
+        b1[c] = (t1[0] * Vrk[3 * c] + t1[1] * Vrk[3 * c + 1]) + t1[2] * Vrk[3 * c + 2];
+    }
+    // cov = B Tm: cov[c][r] = (B[0][r] Tm[c][0] + B[1][r] Tm[c][1]) + B[2][r] Tm[c][2]; entries [0][0], [0][1], [1][1]
+    out[0] = ((b0[0] * t0[0] + b0[1] * t0[1]) + b0[2] * t0[2]) + 0.3f;
+    out[1] = (b1[0] * t0[0] + b1[1] * t0[1]) + b1[2] * t0[2];
+    out[2] = ((b1[0] * t1[0] + b1[1] * t1[1]) + b1[2] * t1[2]) + 0.3f;
 }
 
 // src/render/helpers.wgsl:49-120: bb.xy (NDC offset) and bb.zw for one quad corner.
@@ -292,8 +329,8 @@ BGS_HD void bounding_box_clip(const FrameParams& fp, const float c2d[3], V2 dir,
     V2 e2{e1.y, -e1.x};
     V2 sv{dir.x * bounds.x, dir.y * bounds.y};
     V2 rv{dot2(sv, V2{e1.x, e2.x}), dot2(sv, V2{e1.y, e2.y})};
-    out[0] = rv.x * (1.0f / fp.viewport_w);
-    out[1] = rv.y * (1.0f / fp.viewport_h);
+    out[0] = rv.x * fp.inv_viewport_w;   // rv * (1.0 / viewport): the reciprocal is a constant of the frame
+    out[1] = rv.y * fp.inv_viewport_h;
     out[2] = rv.x;
     out[3] = rv.y;
 }
@@ -375,17 +412,24 @@ BGS_HD void cov2d_surfel(const FrameParams& fp, V3 gp, const float* rot, const f
 }
 
 // src/material/spherical_harmonics.wgsl:22-32
+// (colour only, no decision downstream: the two divisions by constants are multiplications by the rounded reciprocals,
+// within an ulp of the quotient; the power is hardware exp2 / log2 as before)
 BGS_HD float srgb_to_linear1(float c) {
-    if (c <= 0.04045f) return c / 12.92f;
-    return BGS_FAST_POW((c + 0.055f) / 1.055f, 2.4f);
+    if (c <= 0.04045f) return c * (1.0f / 12.92f);
+    return BGS_FAST_POW((c + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
 
 // src/render/gaussian.wgsl:166-183
-BGS_HD V3 world_to_local_direction(V3 dir, const float* tr) {
-    V3 bx = normalize3(V3{tr[0], tr[1], tr[2]});
-    V3 by = normalize3(V3{tr[4], tr[5], tr[6]});
-    V3 bz = normalize3(V3{tr[8], tr[9], tr[10]});
-    return normalize3(V3{dot3(bx, dir), dot3(by, dir), dot3(bz, dir)});
+// normalize(v) as ONE reciprocal of the length and three multiplications (the view direction feeds the colour only)
+BGS_HD V3 normalize3_rcp(V3 a) {
+    const float inv = 1.0f / sqrtf(dot3(a, a));
+    return V3{a.x * inv, a.y * inv, a.z * inv};
+}
+// The normalised basis vectors of the model transform are constants of the frame (FrameParams::basis, formed on the
+// host by the reference's operations).
+BGS_HD V3 world_to_local_direction(V3 dir, const float* basis) {
+    V3 bx{basis[0], basis[1], basis[2]}, by{basis[3], basis[4], basis[5]}, bz{basis[6], basis[7], basis[8]};
+    return normalize3_rcp(V3{dot3(bx, dir), dot3(by, dir), dot3(bz, dir)});
 }
 
 // SH basis constants, src/material/spherical_harmonics.wgsl:3-20
@@ -433,8 +477,8 @@ BGS_HD void sh_weights(V3 d, uint32_t degree, float w[16]) {
 // View-dependent direction used for the colour (src/render/gaussian.wgsl:408-412).
 BGS_HD V3 sh_direction(const FrameParams& fp, V3 transformed_position) {
     V3 cam{fp.cam[0], fp.cam[1], fp.cam[2]};
-    V3 rdw = normalize3(sub3(transformed_position, cam));
-    return world_to_local_direction(rdw, fp.transform);
+    V3 rdw = normalize3_rcp(sub3(transformed_position, cam));
+    return world_to_local_direction(rdw, fp.basis);
 }
 
 // ---- colour variants other than RASTERIZE_COLOR (src/render/gaussian.wgsl:312-405) -------------
@@ -526,10 +570,13 @@ struct QuadPx {
 
 BGS_HD bool quad_to_pixels(const FrameParams& fp, V4 projected, const float bb[4][4], QuadPx& q) {
     float X[4], Y[4];
+    // the perspective divide of the four corners shares its divisor: one correctly rounded reciprocal, eight products
+    // (within 1.5 ulp of the quotients; positions feed no decision finer than the tile rectangle's guard band)
+    const float inv_w = 1.0f / projected.w;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float nx = (projected.x + bb[k][0]) / projected.w;
-        float ny = (projected.y + bb[k][1]) / projected.w;
+        float nx = (projected.x + bb[k][0]) * inv_w;
+        float ny = (projected.y + bb[k][1]) * inv_w;
         X[k] = (nx + 1.0f) * 0.5f * fp.viewport_w;
         Y[k] = (1.0f - ny) * 0.5f * fp.viewport_h;
     }
@@ -661,15 +708,20 @@ BGS_HD void project_splat(const FrameParams& fp, uint32_t key, V3 pos, const flo
         float w[16];
         sh_weights(dir, fp.sh_degree, w);
         r = 0.5f; g = 0.5f; b = 0.5f;
-        const int ncoef = fp.sh_degree == 0 ? 1 : (fp.sh_degree == 1 ? 4 : (fp.sh_degree == 2 ? 9 : 16));
+        // coefficients past the requested degree are never touched (may be garbage). The degree is a constant of the
+        // frame: a scalar branch per band (same sums in the same order as one loop with a per-coefficient test)
+        auto band = [&](const int k0, const int k1) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k < ncoef) {  // coefficients past the requested degree are never touched (may be garbage)
+            for (int k = k0; k < k1; ++k) {
                 r += w[k] * shc[3 * k];
                 g += w[k] * shc[3 * k + 1];
                 b += w[k] * shc[3 * k + 2];
             }
-        }
+        };
+        band(0, 1);
+        if (fp.sh_degree > 0) band(1, 4);
+        if (fp.sh_degree > 1) band(4, 9);
+        if (fp.sh_degree > 2) band(9, 16);
         if (fp.color_space != 1u) {                                // planar.wgsl:91-106
             r = srgb_to_linear1(r);
             g = srgb_to_linear1(g);

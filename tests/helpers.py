@@ -47,6 +47,8 @@ class FrameParamsC(ctypes.Structure):
         ("prev_clip_from_world", ctypes.c_float * 16), ("delta_time", ctypes.c_float),
         ("clear", ctypes.c_float * 4), ("srgb8_target", ctypes.c_uint64),
         ("sort_path", ctypes.c_uint32), ("sample_count", ctypes.c_uint32), ("depth_ptr", ctypes.c_uint64),
+        ("basis", ctypes.c_float * 9), ("inv_viewport_w", ctypes.c_float), ("inv_viewport_h", ctypes.c_float),
+        ("pad_uniform", ctypes.c_float),
     ]
 
 
