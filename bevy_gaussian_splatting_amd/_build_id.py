@@ -1,4 +1,5 @@
-"""Identity of the kernel sources: SHA-256 over every HIP source and header of libbgs (csrc/*.hip, csrc/*.h).
+"""Identity of the kernel sources: SHA-256 over every HIP source and header of libbgs (csrc/*.hip, csrc/*.h) and the
+Makefile that holds the compiler flags they are built with.
 
 The Makefile compiles it into libbgs.so (`bgs_build_id()`, and as the byte string `BGS_BUILD_ID=<hex>` so that it can
 be read without loading the library); `_native.load()` refuses a library built from other sources and rebuilds it
@@ -19,7 +20,7 @@ MARKER = b"BGS_BUILD_ID="
 def kernel_source_sha256() -> str:
     h = hashlib.sha256()
     for name in sorted(os.listdir(CSRC)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h")) or name == "Makefile":   # (build_id.inc is generated FROM this hash: not a source)
             h.update(name.encode())
             with open(os.path.join(CSRC, name), "rb") as f:
                 h.update(f.read())
