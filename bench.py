@@ -110,13 +110,15 @@ def stage_table(stats: dict, cloud_bytes_per_splat: int, rec_bytes: int = 48) ->
     # index-ordered list), ONE launch reads them and writes the sorted list (16 B per pair)
     sort_stage = {"bytes": D * 16, "launches": 1} if bucket else {"bytes": k * D * 16, "launches": max(k, 1)}
     if stats.get("binning") == "scan":
-        # I = coarse (supertile) list entries (rank + tile rect, 8 B): written once by project_bin, read
+        # I = coarse (supertile) list entries (rank + tile rect, 8 B): written once by bin_kernel, read
         # once by the rasteriser, which also reads each visible record at least once
         return {
             # keygen reads N positions and writes the D drawable pairs (the culled tail has no reader in a Color frame)
             "keygen": {"bytes": N * 16 + D * 8, "launches": 1},
             "depth_sort": sort_stage,
-            "project": {"bytes": V * 8 + V * (B - 16) + V * rec_bytes + I * 8, "launches": 1},
+            # two launches: project_kernel (entry + cloud record in, projected record + 4-byte rect out) and bin_kernel
+            # (rects in, list entries out); timed together between two HIP events
+            "project": {"bytes": V * 8 + V * (B - 16) + V * rec_bytes + V * 8 + I * 8, "launches": 2},
             "raster": {"bytes": I * 8 + V * rec_bytes + P * 16, "launches": 1},
         }
     return {
@@ -475,7 +477,7 @@ def main():
         scan_mode = st.get("binning") == "scan"
         kernel_names = {"keygen": "keygen_kernel",
                         "depth_sort": "bucket_sort_kernel" if st.get("sort_path") == "bucket" else "onesweep_kernel",
-                        "project": "project_bin_kernel" if scan_mode else "project_emit_kernel",
+                        "project": "project_kernel" if scan_mode else "project_emit_kernel",
                         "tile_sort": "onesweep_kernel", "ranges": "tile_ranges_kernel",
                         "raster": "raster_scan_kernel" if scan_mode else "raster_kernel"}
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
@@ -572,7 +574,7 @@ def main():
             # the whole frame against the same floor: every kernel's vector instructions x its launches per
             # frame, at the frame rate of the timed region — the chip-wide VALU-issue utilisation
             per_frame = {"keygen_kernel": 1, kernel_names["depth_sort"]: table["depth_sort"]["launches"],
-                         "project_bin_kernel": 1, "raster_scan_kernel": 1}
+                         "project_kernel": 1, "bin_kernel": 1, "raster_scan_kernel": 1}
             floors = {k: issue_floor_ms(k)[0] for k in per_frame}
             if scan_mode and all(floors.values()):
                 frame_issue_ms = sum(floors[k] * m for k, m in per_frame.items())
