@@ -1024,8 +1024,10 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                     const double a64 = pd > 0.0 ? 0.0 : fmin(exp(pd) * op, 0.999);
                     double da = fabs(a32 - a64);
                     /* ... and its sensitivity to a 2-ulp change of the pixel coordinate, which is what one
-                     * rounding of pcx * T2 amounts to in any f32 evaluation order */
-                    for (int k = 0; k < 4; ++k) {
+                     * rounding of pcx * T2 amounts to in any f32 evaluation order. (Not where the surfel is invisible
+                     * in both evaluations: 2^-22 of relative change in the coordinate cannot lift an alpha below 1e-8
+                     * past the 1e-6 threshold below — the exponent would have to move by 4.6.) */
+                    for (int k = 0; k < 4 && (a32 > 1e-8 || a64 > 1e-8); ++k) {
                         const double ex = (k & 1) ? 1.0 + 0x1p-22 : 1.0 - 0x1p-22;
                         const double ey = (k & 2) ? 1.0 + 0x1p-22 : 1.0 - 0x1p-22;
                         const double pk = surfel_fragment_power_d(vs->local_to_pixel, pcx * ex, pcy * ey, vs->mean_2d[0],
