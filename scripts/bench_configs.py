@@ -34,16 +34,21 @@ def run(p, h, v, s, steps=60, warm=30, depth=8):
 
 out = {}
 p = GaussianSplattingPlugin(0)
+SAMPLES = ((4, ""), (1, "_msaa_off"))
 c = random_gaussians_3d_seeded(10_000, 1); h = p.upload(c)
-out["cfg0_10k_256x256"] = run(p, h, View.headless(256, 256), CloudSettings()); h.free()
+for m, tag in SAMPLES:
+    out["cfg0_10k_256x256" + tag] = run(p, h, View.headless(256, 256, msaa_samples=m), CloudSettings())
+h.free()
 c = random_gaussians_3d_seeded(5_000_000, 3).to_f16(); h = p.upload(c)
 for gs in (1.0, 0.05):
-    out[f"cfg2_5M_f16_1080p_gs{gs}"] = run(p, h, View.headless(1920, 1080), CloudSettings(global_scale=gs), steps=40)
+    for m, tag in SAMPLES:
+        out[f"cfg2_5M_f16_1080p_gs{gs}{tag}"] = run(p, h, View.headless(1920, 1080, msaa_samples=m), CloudSettings(global_scale=gs), steps=40)
 h.free()
 c = random_gaussians_3d_seeded(1_000_000, 4); h = p.upload(c)
 for name, kw in (("surfel_aabb", {"aabb": True}), ("obb", {})):
     for gs in (1.0, 0.05):
         s = CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, global_scale=gs, **kw)
-        out[f"cfg3_1M_2dgs_{name}_gs{gs}"] = run(p, h, View.headless(1920, 1080), s, steps=40)
+        for m, tag in SAMPLES:
+            out[f"cfg3_1M_2dgs_{name}_gs{gs}{tag}"] = run(p, h, View.headless(1920, 1080, msaa_samples=m), s, steps=40)
 h.free()
 print(json.dumps(out, indent=1))

@@ -463,7 +463,7 @@ def test_full_size_f16_5m_sort_and_crop(plugin, oracle):
     ref, amb = oracle.render(dec, e, v, s, window=win, with_ambiguity=True)
     _assert_image(ref, got[516:564, 936:984], amb, frac_slack=0.01, what="5M f16 crop")
 
-    # Liveness with many frames in flight: 6 lanes x (1221-tile keygen, 512-block project_bin looping over
+    # Liveness with many frames in flight: 6 lanes x (1221-tile keygen, 512-block project + bin looping over
     # ~2900 tiles) oversubscribe the chip and thousands of threads wait in look-back at once. Without a
     # spin back-off the polling loads starved the blocks everybody waited for and the device watchdog
     # tripped (seen at depth 3); the pipelined frames must complete and equal the blocking one.
