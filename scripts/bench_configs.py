@@ -10,10 +10,13 @@ def run(p, h, v, s, steps=60, warm=30, depth=8):
     p.set_async(True); p.set_pipeline_depth(depth); p.set_profiling(0)
     for _ in range(warm): p.render(h, v, s, download=False)
     p.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps): p.render(h, v, s, download=False)
-    p.synchronize()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(5):   # five timed regions, the median reported (like bench.py's legs)
+        t0 = time.perf_counter()
+        for _ in range(steps): p.render(h, v, s, download=False)
+        p.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[2]
     p.set_profiling(2); p.set_profiling_stride(4)
     for _ in range(8): p.render(h, v, s, download=False)
     p.synchronize()
@@ -21,10 +24,13 @@ def run(p, h, v, s, steps=60, warm=30, depth=8):
     p.set_pipeline_depth(1)
     for _ in range(warm): p.render(h, v, s, download=False)
     p.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps): p.render(h, v, s, download=False)
-    p.synchronize()
-    dt1 = time.perf_counter() - t0
+    dts1 = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps): p.render(h, v, s, download=False)
+        p.synchronize()
+        dts1.append(time.perf_counter() - t0)
+    dt1 = sorted(dts1)[1]
     st1 = p.stats()
     p.set_async(False)
     return {"frames_per_s": round(steps / dt, 1), "single_stream_frames_per_s": round(steps / dt1, 1),
