@@ -1792,6 +1792,28 @@ def _nccl_gather_worker(rank, world, port, outdir):
 
 
 @pytest.mark.timeout(600)
+def test_nccl_frame_gather_worker_with_one_rank(tmp_path):
+    """The worker of the two-device test below on the ONE device every box has (a process group of one rank on RCCL,
+    the same zero-copy staged batches, pops and flush): everything but the second rank, so that the two-rank test
+    cannot fail on a multi-GPU box for a reason a one-GPU box could have found."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_gather_worker, args=(0, 1, port, str(tmp_path)))
+    p.start()
+    p.join(500)
+    assert p.exitcode == 0
+    assert int(np.load(tmp_path / "received.npy")[0]) == 11
+    own, seq = np.load(tmp_path / "own_0.npy"), np.load(tmp_path / "gathered_0.npy")
+    assert seq.shape == (11, 360, 640, 4) and own.any()
+    for f in seq:
+        assert np.array_equal(f, own)
+
+
+@pytest.mark.timeout(600)
 def test_two_rank_nccl_frame_gather_end_to_end(tmp_path):
     """The N > 1 path of bench.py on real devices (needs two): two processes, one GPU and one camera each, RCCL gather of
     the Rgba8UnormSrgb frames through BatchedFrameGather (zero-copy: every frame rendered into its slot of the staging
