@@ -1042,6 +1042,35 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                         arow[x - x0] += (float)(4.0 * da) * (cm + dm);
                     }
                 }
+                if (arow && s->aabb && s->gaussian_mode != BGS_GAUSSIAN_2D) {
+                    /* conditioning of the AABB conic at this pixel: power = -1/2 (A dx^2 + C dy^2) + B dx dy cancels for a
+                     * very elongated splat seen along its long axis (terms of 1e4 for a power of -1: found by the round-4
+                     * sweep, seed 40411), and then ANY f32 evaluation of the reference's expression — its own WGSL under the
+                     * compiler's contraction rules included — scatters by the rounding of the terms. Same treatment as the
+                     * surfel intersection above: the expression in double at the pixel and at +-2 ulp of the interpolated
+                     * offsets; four times the largest alpha difference goes into the pixel's bound. */
+                    const double ddx = -(double)mm.x, ddy = -(double)mm.y, op = fabs((double)vs->color[3]);
+                    const double cA = vs->conic[0], cB = vs->conic[1], cC = vs->conic[2];
+                    const double pd = -0.5 * (cA * ddx * ddx + cC * ddy * ddy) + cB * ddx * ddy;
+                    const double a32 = power > 0.0f ? 0.0 : fmin(exp((double)power) * op, 0.999);
+                    const double a64 = pd > 0.0 ? 0.0 : fmin(exp(pd) * op, 0.999);
+                    double da = fabs(a32 - a64);
+                    for (int k = 0; k < 4 && (a32 > 1e-8 || a64 > 1e-8); ++k) {
+                        const double ex = ddx * ((k & 1) ? 1.0 + 0x1p-22 : 1.0 - 0x1p-22);
+                        const double ey = ddy * ((k & 2) ? 1.0 + 0x1p-22 : 1.0 - 0x1p-22);
+                        const double pk = -0.5 * (cA * ex * ex + cC * ey * ey) + cB * ex * ey;
+                        const double ak = pk > 0.0 ? 0.0 : fmin(exp(pk) * op, 0.999);
+                        if (fabs(ak - a64) > da) da = fabs(ak - a64);
+                    }
+                    /* (from 1e-5 up only: a conic whose terms are ~35 times its power or more; below that the scatter
+                     * is a few 1e-6 of alpha and stays inside the tolerance) */
+                    if (da > 1e-5) {
+                        float cm = fmaxf(fmaxf(fabsf(vs->color[0]), fabsf(vs->color[1])),
+                                         fmaxf(fabsf(vs->color[2]), 1.0f));
+                        ORACLE_DM();
+                        arow[x - x0] += (float)(4.0 * da) * (cm + dm);
+                    }
+                }
                 if (arow) {
                     /* a coverage decision within rounding distance of a quad edge moves ONE sample's share of the pixel;
                      * a discard decision at the threshold (power ~ 0) moves the whole pixel */
