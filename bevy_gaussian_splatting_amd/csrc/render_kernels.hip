@@ -1110,6 +1110,16 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 #ifndef BGS_MIDROUND_PERIOD
 #define BGS_MIDROUND_PERIOD 4u
 #endif
+// What a tile cost its wave, in eighths of a blended record (kernels.h TileCost): a record that went through the four
+// rows' blend, a record staged (and possibly skipped), a staging round (one dependent gather nothing hides, ~5 records'
+// worth), a group of 64 candidates scanned. Scalar additions on wave-uniform counts; the same frame gives the same
+// numbers whatever else runs on the chip, which a wave's lifetime does not.
+constexpr uint32_t WORK_BLENDED = 8u, WORK_STAGED = 1u, WORK_ROUND = 40u, WORK_GROUP = 3u;
+// Which group of four tiles workgroup b of n draws when nothing is known about the frame (RUNS: see raster_scan_kernel)
+template <uint32_t RUNS>
+__device__ __forceinline__ uint32_t raster_block_item(const uint32_t b, const uint32_t n) {
+    return RUNS == 1u ? xcd_remap(b, n) : xcd_remap_runs(b, n, RUNS);
+}
 // One tile — or, with ROWS == 1, one 16 x 4 ROW STRIP of a tile (rows row0 .. row0 + 3, one pixel per lane) — by one wave.
 // A wave that owns a whole tile has four pixels per lane (rows row0 + (lane >> 4) + {0, 4, 8, 12}, row0 = 0) and runs
 // the four strips' chains one after the other, ~950 clocks per record whether it shares its SIMD or not; a strip wave
@@ -1142,7 +1152,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                                                const uint32_t want_srgb8, const float t_eps, const float surfel_limit,
                                                float4* const s_rec, uint32_t* const s_queue, float4* const s_depth, const int lane,
                                                const uint32_t tile, const int row0, uint32_t& trace_scanned,
-                                               uint32_t& trace_blended, uint32_t& trace_staged) {
+                                               uint32_t& trace_blended, uint32_t& trace_staged, uint32_t& work) {
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     constexpr uint32_t STAGE = 64u;
     constexpr bool ABLATE = BGS_ABLATION != 0;
@@ -1232,6 +1242,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                 s_queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = rank_cur;
             qn += hits;
             if constexpr (TRACE) trace_scanned += min(64u, total - base);
+            work += WORK_GROUP;
             rank_cur = rank_nxt; rect_cur = rect_nxt;
             rank_nxt = rank_nn; rect_nxt = rect_nn;
             base += 64u;
@@ -1243,6 +1254,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             bool saturated = false;
             for (uint32_t c0 = 0u; c0 < cnt && !saturated; c0 += STAGE) {
             const uint32_t ccnt = min(STAGE, cnt - c0);
+            work += WORK_ROUND + ccnt * WORK_STAGED;
             __builtin_amdgcn_wave_barrier();
             if ((uint32_t)lane < ccnt) {
                 const float4* src = records + (size_t)s_queue[c0 + (uint32_t)lane] * REC_V4;
@@ -1305,6 +1317,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                 const float zr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(keepz)));
                 if (!keepz_keeps(zr)) continue;
                 if constexpr (TRACE) trace_blended += 1u;
+                work += WORK_BLENDED;
                 const bool zmixed = DEPTH && zr < tile_dmax;
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r) {
@@ -1373,6 +1386,10 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
 constexpr int raster_waves_per_simd(const int variant, const int msaa, const bool depth) {
     return msaa == 4 ? (variant == 2 ? (depth ? 3 : 4) : 5) : (variant == 2 ? (depth ? 5 : 6) : (depth ? 7 : 8));
 }
+int raster_scan_waves_per_simd(const FrameParams& fp) {
+    const int variant = fp.aabb == 0u ? RV_OBB : (fp.gaussian_mode != 0u ? RV_AABB3D : RV_SURFEL);
+    return raster_waves_per_simd(variant, fp.sample_count == 4u ? 4 : 1, fp.depth_ptr != 0ull);
+}
 template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false, int MSAA = 1, bool DEPTH = false>
 __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
@@ -1381,9 +1398,10 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
                                                           float4* __restrict__ fb,
                                                           uint32_t* __restrict__ fb8_default, uint32_t want_srgb8,
                                                           FrameCleanup cl, uint4* __restrict__ trace,
-                                                          const uint8_t* __restrict__ heavy_in, uint8_t* __restrict__ heavy_out) {
+                                                          const uint8_t* __restrict__ heavy_in, uint8_t* __restrict__ heavy_out,
+                                                          const uint16_t* __restrict__ order, uint16_t* __restrict__ cost_out) {
     unsigned long long trace_t0 = 0ull;
-    uint32_t trace_scanned = 0u, trace_blended = 0u, trace_staged = 0u;
+    uint32_t trace_scanned = 0u, trace_blended = 0u, trace_staged = 0u, work = 0u;
     if constexpr (TRACE) trace_t0 = __builtin_amdgcn_s_memtime();
     const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
@@ -1406,7 +1424,10 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
     // dense 1 M surfel frame 544 -> 492 us (runs 2 / 4 / 8: 520 / 492 / 508). The ellipse variants keep one band per XCD:
     // their tiles share lists and records with their neighbours and the split only costs (scene-like 61.5 -> 63.6 us).
     constexpr uint32_t RUNS = VARIANT == RV_SURFEL ? 4u : 1u;
-    uint32_t tile = strip_block ? 0xFFFFFFFFu : (RUNS == 1u ? xcd_remap(blockIdx.x, nblocks) : xcd_remap_runs(blockIdx.x, nblocks, RUNS)) * 4u + (uint32_t)wave;
+    // `order` (tile_order_kernel): this frame's workgroups in the order of the work a completed frame found in them,
+    // heaviest first inside every XCD's share — the same share xcd_remap / xcd_remap_runs deal out
+    uint32_t tile = strip_block ? 0xFFFFFFFFu
+                  : (order ? (uint32_t)order[blockIdx.x] : raster_block_item<RUNS>(blockIdx.x, nblocks)) * 4u + (uint32_t)wave;
     if constexpr (MIDROUND_EXIT) {
         if (strip_block) {
             const uint32_t have = heavy_in ? min(*reinterpret_cast<const uint32_t*>(heavy_in), HEAVY_CAP) : 0u;
@@ -1469,14 +1490,19 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
         if (MIDROUND_EXIT && strip_block) {
             rounds = raster_tile<VARIANT, false, MIDROUND_EXIT, 1, MSAA, DEPTH>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
                                                                    t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 4 * wave,
-                                                                   trace_scanned, trace_blended, trace_staged);
+                                                                   trace_scanned, trace_blended, trace_staged, work);
             reports = wave == 0;
         } else {
             rounds = raster_tile<VARIANT, TRACE, MIDROUND_EXIT, 4, MSAA, DEPTH>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
                                                                    t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 0,
-                                                                   trace_scanned, trace_blended, trace_staged);
+                                                                   trace_scanned, trace_blended, trace_staged, work);
             tile_done = tile;
         }
+        // what the tile cost, for the order of the frames behind this one (kernels.h TileCost): whoever drew it says so —
+        // its regular wave, or the first strip's wave for all four (it scanned and staged what the tile's wave would
+        // have; a regular wave that stepped aside writes nothing, so the tile keeps a cost worth its place in the order
+        // should the next frame draw it whole again)
+        if (cost_out && reports && lane == 0) cost_out[tile] = (uint16_t)min(0xFFFFu, work);
         if constexpr (MIDROUND_EXIT) {
             // feedback for the frames behind this one: a tile that did not saturate inside its first staging round is
             // heavy (parameter-free: the median tile of a dense frame saturates after ~35 of the round's <= 64 records)
@@ -1503,11 +1529,60 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
     }
 }
 
+// TileCost -> the order of a frame's raster workgroups (kernels.h). Workgroup b of the raster grid runs on XCD b % 8 and
+// draws the b / 8-th group of four tiles of that XCD's share (xcd_remap / xcd_remap_runs). Block x of this kernel sorts
+// XCD x's share by what a completed frame's waves measured — the group's longest wave, descending, ties in the share's
+// own order — and writes order[8 i + x] = the group the XCD's i-th workgroup draws. The hardware hands workgroups out
+// in grid order as wave slots free up, so every XCD starts its longest chains first and fills up behind them with short
+// ones (longest-processing-time list scheduling) instead of ending on whatever its share's last rows hold. Whatever the
+// cost words hold (zeros, another view's frame), `order` is a permutation of the groups: the costs only decide balance.
+// Bitonic sort of (0xFFFF - cost) << 16 | i in LDS, up to 2048 groups per XCD (65 535 tiles).
+constexpr uint32_t ORDER_MAX_SHARE = 2048u;
+template <uint32_t RUNS>
+__global__ __launch_bounds__(256) void tile_order_kernel(const uint16_t* __restrict__ cost, uint16_t* __restrict__ order,
+                                                         const uint32_t nblocks, const uint32_t ntiles) {
+    __shared__ uint32_t s_key[ORDER_MAX_SHARE];
+    const uint32_t x = blockIdx.x, tid = threadIdx.x;
+    const uint32_t len = nblocks > x ? (nblocks - x + 7u) / 8u : 0u;
+    uint32_t n2 = 2u;
+    while (n2 < len) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += 256u) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (i < len) {
+            const uint32_t t0 = raster_block_item<RUNS>(8u * i + x, nblocks) * 4u;
+            uint32_t c = 0u;
+            for (uint32_t k = 0u; k < 4u; ++k) if (t0 + k < ntiles) c = max(c, (uint32_t)cost[t0 + k]);
+            key = ((0xFFFFu - c) << 16) | i;
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    for (uint32_t k = 2u; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+            for (uint32_t p = tid; p < n2 / 2u; p += 256u) {
+                const uint32_t a = 2u * j * (p / j) + (p % j), b = a + j;
+                const uint32_t ka = s_key[a], kb = s_key[b];
+                const bool up = (a & k) == 0u;
+                if ((ka > kb) == up) { s_key[a] = kb; s_key[b] = ka; }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = tid; i < len; i += 256u)
+        order[8u * i + x] = (uint16_t)raster_block_item<RUNS>(8u * (s_key[i] & 0xFFFFu) + x, nblocks);
+}
+
+void launch_tile_order(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, bool surfel) {
+    const uint32_t nblocks = (ntiles + 3u) / 4u;
+    if (nblocks == 0u || nblocks > 8u * ORDER_MAX_SHARE) return;
+    if (surfel) hipLaunchKernelGGL((tile_order_kernel<4u>), dim3(8), dim3(256), 0, stream, cost, order, nblocks, ntiles);
+    else hipLaunchKernelGGL((tile_order_kernel<1u>), dim3(8), dim3(256), 0, stream, cost, order, nblocks, ntiles);
+}
+
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
                         uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace, bool midround_exit,
-                        const uint8_t* heavy_in, uint8_t* heavy_out) {
+                        const uint8_t* heavy_in, uint8_t* heavy_out, const uint16_t* order, uint16_t* cost_out) {
     if (!midround_exit) { heavy_in = nullptr; heavy_out = nullptr; }
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
@@ -1519,7 +1594,7 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
     const bool msaa4 = fp.sample_count == 4u, depth = fp.depth_ptr != 0ull;
 #define BGS_LAUNCH_RS4(V, X, TR, MS, DP)                                                          \
     hipLaunchKernelGGL((raster_scan_kernel<V, TR, X, MS, DP>), dim3(grid), dim3(256), 0, stream, d_fp, rec, coarse,      \
-                       coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (TR) ? tile_trace : (uint4*)nullptr, heavy_in, heavy_out)
+                       coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (TR) ? tile_trace : (uint4*)nullptr, heavy_in, heavy_out, order, cost_out)
 #define BGS_LAUNCH_RS(V, X)                                                                       \
     do {                                                                                          \
         const uint32_t grid = (ntiles + 3u) / 4u + ((X) && heavy_in ? HEAVY_CAP : 0u);            \

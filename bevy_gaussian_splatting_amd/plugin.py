@@ -280,6 +280,13 @@ class GaussianSplattingPlugin:
         self._check(self._lib.bgs_graph_counters(self._ctx, ctypes.byref(c), ctypes.byref(r)))
         return int(c.value), int(r.value)
 
+    def tile_order_counters(self) -> tuple:
+        """(frames that left per-tile costs, frames whose raster workgroups ran in cost order, times that order was made
+        anew) since the plugin was created."""
+        c, r, n = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._lib.bgs_tile_order_counters(self._ctx, ctypes.byref(c), ctypes.byref(r), ctypes.byref(n)))
+        return int(c.value), int(r.value), int(n.value)
+
     # -- interop / introspection -----------------------------------------------------
     def synchronize(self) -> None:
         self._check(self._lib.bgs_synchronize(self._ctx))

@@ -1371,7 +1371,7 @@ def test_heavy_tiles_drawn_by_strip_waves_give_the_same_bits(plugin, oracle, clo
     h = plugin.upload(cloud_1m)
     plugin.reset_adaptive_state()
     try:
-        plugin.set_debug_flags(0x1000000 | 0x2000000)
+        plugin.set_debug_flags(0x1000000 | 0x2000000 | 0x10000000)   # (and no cost-ordered workgroups: the test below)
         for _ in range(4):
             plain = plugin.render(h, v, s)
         assert plugin.stats()["strip_tiles"] == 0
@@ -1435,6 +1435,86 @@ def test_heavy_tiles_drawn_by_strip_waves_give_the_same_bits(plugin, oracle, clo
         _assert_image(ref, plain[y0:y0 + 48, x0:x0 + 48], amb, frac_slack=0.01, what=f"heavy corner {what} {win}")
     h.free()
     plugin.reset_adaptive_state()
+
+@pytest.mark.parametrize("what", ["dense", "scene_like", "surfel", "aabb3d_depth"])
+def test_cost_ordered_raster_workgroups_give_the_same_bits(plugin, cloud_1m, what):
+    """A frame with more tile waves than the chip holds at once (4 samples per pixel: 5 waves per SIMD, 5120 of a 1080p
+    frame's 8160 tiles) draws its raster workgroups in the order made of the per-tile costs a completed frame left
+    (tile_order_kernel: heaviest first inside every XCD's share; pipeline depth 1). The order is a permutation of the
+    workgroups whatever the costs hold, and which workgroup draws a tile changes no arithmetic: every frame of a
+    sequence — first frame (no costs yet), ordered frames, frames of a moving camera (another view's costs), a re-run
+    frame, frames in flight with the order forced on — is bit-identical to the frame with the
+    feedback switched off (debug flag 0x10000000). A viewport whose workgroup count is no multiple of 8 and the
+    instantiations with their own XCD shares (surfels: four runs per XCD) are covered."""
+    from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
+    kw = {"dense": {}, "scene_like": {"global_scale": 0.05},
+          "surfel": {"gaussian_mode": GaussianMode.Gaussian2d, "aabb": True, "global_scale": 0.3},
+          "aabb3d_depth": {"aabb": True}}[what]
+    W, Hh = (1336, 1000) if what == "scene_like" else (1920, 1080)   # 84 x 63 tiles: 1323 workgroups = 8 * 165 + 3
+    s = CloudSettings(**kw)
+    v = View.headless(W, Hh)
+    views = [View.headless(W, Hh, yaw=0.03 * (k + 1)) for k in range(3)]
+    depth_dev = None
+    if what == "aabb3d_depth":
+        d = np.full((Hh, W, 4), 0.02, np.float32)
+        d[:, W // 2:, :] = 0.2
+        depth_dev = plugin.upload_depth(d)
+        for vk in [v] + views:
+            vk.depth_device_ptr = depth_dev
+    h = plugin.upload(cloud_1m)
+    plugin.reset_adaptive_state()
+    try:
+        base = plugin.tile_order_counters()
+        plugin.set_debug_flags(0x10000000)
+        for _ in range(4):
+            plain = plugin.render(h, v, s)
+        refs = [plugin.render(h, vk, s) for vk in views]
+        assert plugin.tile_order_counters() == base
+        plugin.set_debug_flags(0)
+        plugin.reset_adaptive_state()
+        for k in range(6):
+            img = plugin.render(h, v, s)
+            assert np.array_equal(img, plain), (what, k)
+        cost, ordered, made = (a - b for a, b in zip(plugin.tile_order_counters(), base))
+        assert cost >= 6 and 1 <= ordered <= cost - 1, (what, cost, ordered)   # every frame but the first (and re-runs without a completed predecessor)
+        assert 1 <= made < ordered, (what, made, ordered)                      # made once, then kept (refreshed every 8th frame)
+        for k in range(10):                                                    # ... across a refresh
+            assert np.array_equal(plugin.render(h, v, s), plain), (what, "kept order", k)
+        assert plugin.tile_order_counters()[2] - base[2] >= made + 1, (what, made)
+        for k, vk in enumerate(views):                                         # another view's costs: balance, never pixels
+            assert np.array_equal(plugin.render(h, vk, s), refs[k]), (what, "moving", k)
+        plugin.render(h, v, s)
+        plugin.set_debug_flags(0x8000000)                                      # forced re-run: writes its own buffer again, reads its predecessor's
+        for k in range(2):
+            a = plugin.render(h, v, s)
+            assert plugin.stats()["regrow_count"] >= 1
+            assert np.array_equal(a, plain), (what, "re-run", k)
+        plugin.set_debug_flags(0x40000000)                                     # the order made anew with every frame
+        made = plugin.tile_order_counters()[2]
+        for k in range(3):
+            assert np.array_equal(plugin.render(h, v, s), plain), (what, "refreshed every frame", k)
+        assert plugin.tile_order_counters()[2] - made == 3, what
+        before = plugin.tile_order_counters()[1]
+        plugin.set_async(True)
+        plugin.set_pipeline_depth(8)
+        for flags, want in ((0, False), (0x20000000, True), (0x20000000 | 0x4000000, True)):
+            plugin.set_debug_flags(flags)
+            for _ in range(40):
+                plugin.render(h, v, s, download=False)
+            plugin.synchronize()
+            now = plugin.tile_order_counters()[1]
+            assert (now > before) == want, (what, flags, before, now)
+            before = now
+            assert np.array_equal(framebuffer_as_tensor(plugin, Hh, W).cpu().numpy(), plain), (what, "in flight", flags)
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        h.free()
+        if depth_dev is not None:
+            plugin.device_free(depth_dev)
+        plugin.reset_adaptive_state()
+
 
 def test_rerun_keeps_the_output_state_the_frame_was_enqueued_with(plugin):
     """A frame whose supertile lists overflow is re-run when its lane completes. If the caller changed the packed
