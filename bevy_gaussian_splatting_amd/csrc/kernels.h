@@ -171,15 +171,17 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
 // Work counts, not the waves' lifetimes: the same frame leaves the same costs whatever else runs on the chip, and the
 // order made of lifetimes was the worse one (a wave of the launch's first round shares its SIMD with four others and
 // looks heavier than it is). Frames with more tile waves than the chip holds at once (4x multisampling) end earlier
-// for it when they are alone on the chip: the rasteriser of the dense / scene-like 1 M frame 69.6 -> 62.3 / 129.6 ->
-// 117.3 us, of the 1 M-surfel frame 674 -> 528 us, of the scene-like 5 M frame 540 -> 504 us
-// (profiles/r4_experiments/tile_order.txt). `surfel` picks the share each XCD has in that variant (raster_scan_kernel:
-// RUNS). An order stays valid — a permutation of the workgroups — for as long as the tile grid does, so it is made
-// anew every TILE_ORDER_REFRESH-th frame only (the kernel is a chain of ~40 barriers, ~7 us).
+// for it when they are alone on the chip: the rasteriser of the dense / scene-like 1 M frame 68.4 -> 61.0 / 128 ->
+// 116 us, of the 1 M-surfel frame 662 -> 522 us, of the scene-like 5 M frame 538 -> 504 us
+// (profiles/r4_experiments/tile_order.txt); with frames in flight it is worth under 1 %. `fp` and `midround_exit`
+// pick the share each XCD has in the frame's instantiation (raster_scan_kernel: RUNS). An order stays valid — a
+// permutation of the workgroups — for as long as the tile grid does, so it is made anew every TILE_ORDER_REFRESH-th
+// frame only (the kernel is a chain of ~40 barriers, ~7 us).
 constexpr uint32_t TILE_ORDER_REFRESH = 8u;
 inline size_t tile_cost_bytes(uint32_t tiles) { return ((size_t)tiles + 4u) * 2u; }
 inline size_t tile_order_bytes(uint32_t tiles) { return (((size_t)tiles + 3u) / 4u + 8u) * 2u; }
-void launch_tile_order(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, bool surfel);
+void launch_tile_order(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, const FrameParams& fp,
+                       bool midround_exit);
 // tile waves of raster_scan_kernel a SIMD holds at once for this frame's instantiation (its __launch_bounds__)
 int raster_scan_waves_per_simd(const FrameParams& fp);
 // HeavyFeedback: what the rasteriser of a dense frame (midround_exit) leaves for the frames behind it — the tiles that

@@ -1115,6 +1115,16 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 // worth), a group of 64 candidates scanned. Scalar additions on wave-uniform counts; the same frame gives the same
 // numbers whatever else runs on the chip, which a wave's lifetime does not.
 constexpr uint32_t WORK_BLENDED = 8u, WORK_STAGED = 1u, WORK_ROUND = 40u, WORK_GROUP = 3u;
+#ifndef BGS_DENSE_RUNS_MS
+#define BGS_DENSE_RUNS_MS 2u
+#endif
+#ifndef BGS_DENSE_RUNS
+#define BGS_DENSE_RUNS 1u
+#endif
+// contiguous runs of workgroups per XCD (raster_scan_kernel: RUNS)
+constexpr uint32_t raster_runs(const int variant, const int msaa, const bool midround_exit) {
+    return variant == RV_SURFEL ? 4u : (midround_exit ? (msaa == 4 ? BGS_DENSE_RUNS_MS : BGS_DENSE_RUNS) : 1u);
+}
 // Which group of four tiles workgroup b of n draws when nothing is known about the frame (RUNS: see raster_scan_kernel)
 template <uint32_t RUNS>
 __device__ __forceinline__ uint32_t raster_block_item(const uint32_t b, const uint32_t n) {
@@ -1421,9 +1431,14 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
     const bool strip_block = MIDROUND_EXIT && blockIdx.x >= nblocks;
     // Surfel frames: four runs per XCD. A surfel tile is ~10x the work of an ellipse tile and only 5120 of the 8160 tile
     // waves are resident at once, so an XCD whose band is the image's (heavier) top or bottom edge ends the launch:
-    // dense 1 M surfel frame 544 -> 492 us (runs 2 / 4 / 8: 520 / 492 / 508). The ellipse variants keep one band per XCD:
-    // their tiles share lists and records with their neighbours and the split only costs (scene-like 61.5 -> 63.6 us).
-    constexpr uint32_t RUNS = VARIANT == RV_SURFEL ? 4u : 1u;
+    // dense 1 M surfel frame 544 -> 492 us (runs 2 / 4 / 8: 520 / 492 / 508). The ellipse variants keep one band per XCD
+    // — their tiles share lists and records with their neighbours and the split only costs (scene-like 61.5 -> 63.6 us) —
+    // except the multisampled dense (mid-round-exit) frames, two runs: the bottom band of the dense 1 M frame holds 13 %
+    // more work than the mean band (tile trace), and with 5 waves per SIMD that XCD ends the launch. Same-box A/B, runs
+    // 1 / 2 / 4: rasteriser alone 61.3 / 57.8 / 58.0 us, frames in flight 15.9 / 16.3 / 16.1 k frames/s (5 M dense: 49.8 /
+    // 47.2 / 47.6 us, in flight the same); single-sampled 45.2 / 44.4 / 46.4 us and no change in flight: one band kept
+    // (profiles/r4_experiments/tile_order.txt).
+    constexpr uint32_t RUNS = raster_runs(VARIANT, MSAA, MIDROUND_EXIT);
     // `order` (tile_order_kernel): this frame's workgroups in the order of the work a completed frame found in them,
     // heaviest first inside every XCD's share — the same share xcd_remap / xcd_remap_runs deal out
     uint32_t tile = strip_block ? 0xFFFFFFFFu
@@ -1571,10 +1586,14 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint16_t* __restr
         order[8u * i + x] = (uint16_t)raster_block_item<RUNS>(8u * (s_key[i] & 0xFFFFu) + x, nblocks);
 }
 
-void launch_tile_order(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, bool surfel) {
+void launch_tile_order(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, const FrameParams& fp,
+                       bool midround_exit) {
     const uint32_t nblocks = (ntiles + 3u) / 4u;
     if (nblocks == 0u || nblocks > 8u * ORDER_MAX_SHARE) return;
-    if (surfel) hipLaunchKernelGGL((tile_order_kernel<4u>), dim3(8), dim3(256), 0, stream, cost, order, nblocks, ntiles);
+    const int variant = fp.aabb == 0u ? RV_OBB : (fp.gaussian_mode != 0u ? RV_AABB3D : RV_SURFEL);
+    const uint32_t runs = raster_runs(variant, fp.sample_count == 4u ? 4 : 1, midround_exit);
+    if (runs == 4u) hipLaunchKernelGGL((tile_order_kernel<4u>), dim3(8), dim3(256), 0, stream, cost, order, nblocks, ntiles);
+    else if (runs == 2u) hipLaunchKernelGGL((tile_order_kernel<2u>), dim3(8), dim3(256), 0, stream, cost, order, nblocks, ntiles);
     else hipLaunchKernelGGL((tile_order_kernel<1u>), dim3(8), dim3(256), 0, stream, cost, order, nblocks, ntiles);
 }
 

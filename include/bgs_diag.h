@@ -25,8 +25,8 @@ extern "C" {
  * told the key range: full 32-bit range guessed), 0x100000 (supertile lists start at 64 entries, to
  * exercise the overflow -> re-run path) keep images correct and exist for A/B timing and tests.
  * 0x8000000: every BINNING_SCAN frame is run twice, as if a data-dependent capacity had been too small (exercises the
- * re-run path). 0x10000000: no tile-cost feedback / cost-ordered raster workgroups; 0x20000000: both at any pipeline
- * depth (default: depth 1 only); 0x40000000: the order is made anew with every frame (default: every 8th).
+ * re-run path). 0x10000000: no tile-cost feedback / cost-ordered raster workgroups; 0x20000000: none at pipeline
+ * depths > 1; 0x40000000: the order is made anew with every frame (default: every 8th).
  * Bits 1..64 exist only in libraries built with -DBGS_ABLATION=1 (scripts/build_variant.sh); the production library
  * ignores them. Production code leaves this at 0. */
 int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags);
@@ -77,7 +77,7 @@ int bgs_set_tile_trace(bgs_ctx* ctx, void* device_ptr);
 int bgs_graph_counters(bgs_ctx* ctx, uint64_t* captures, uint64_t* replays);
 
 /* How many frames (re-runs included) left per-tile costs for the frames behind them / drew their raster workgroups in the
- * order made of a completed frame's costs (pipeline depth 1, frames with more tile waves than the chip holds at once) /
+ * order made of a completed frame's costs (frames with more tile waves than the chip holds at once) /
  * made that order anew (tile_order_kernel launches). */
 int bgs_tile_order_counters(bgs_ctx* ctx, uint64_t* cost_frames, uint64_t* ordered_frames, uint64_t* refreshes);
 
