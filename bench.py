@@ -505,9 +505,14 @@ def main():
 
         # the same frames on ONE stream (pipeline depth 1): per-kernel times without overlap
         plugin.set_pipeline_depth(1)
+        toc0 = plugin.tile_order_counters()
         dt1, stage1, st1 = measure(plugin, handle, view, settings, args.steps, args.warmup)
+        toc1 = plugin.tile_order_counters()
         single = {"value": round(args.steps / dt1, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt1 / args.steps, 4),
-                  "stage_ms": {k: round(v, 4) for k, v in stage1.items() if v}}
+                  "stage_ms": {k: round(v, 4) for k, v in stage1.items() if v},
+                  # raster workgroups drawn in the order of a completed frame's per-tile work (kernels.h TileCost)
+                  "tile_order": dict(zip(("frames_leaving_costs", "frames_in_cost_order", "orders_made"),
+                                         (b - a for a, b in zip(toc0, toc1))))}
         dom1 = max(stage1, key=lambda k: stage1[k] / table[k]["launches"] if k in table else 0.0)
         b1 = table[dom1]["bytes"] / table[dom1]["launches"]
         t1 = max(stage1[dom1] * 1e-3 / table[dom1]["launches"], 1e-12)
