@@ -67,6 +67,7 @@ EXPORTED_SYMBOLS = (
     "bgs_set_graphs",
     "bgs_graph_counters",
     "bgs_tile_order_counters",
+    "bgs_selftest_tile_order",
     "bgs_reset_adaptive_state",
     "bgs_cloud_upload_cov3d_f32",
     "bgs_adaptive_counters",
@@ -272,6 +273,8 @@ def load() -> ctypes.CDLL:
     lib.bgs_graph_counters.restype = ctypes.c_int
     lib.bgs_tile_order_counters.argtypes = [vp] + [ctypes.POINTER(ctypes.c_uint64)] * 3
     lib.bgs_tile_order_counters.restype = ctypes.c_int
+    lib.bgs_selftest_tile_order.argtypes = [vp, vp, u32, u32, vp]
+    lib.bgs_selftest_tile_order.restype = ctypes.c_int
     lib.bgs_cloud_upload_cov3d_f32.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                                ctypes.POINTER(ctypes.c_float), ctypes.POINTER(vp)]
     lib.bgs_cloud_upload_cov3d_f32.restype = ctypes.c_int

@@ -182,6 +182,8 @@ inline size_t tile_cost_bytes(uint32_t tiles) { return ((size_t)tiles + 4u) * 2u
 inline size_t tile_order_bytes(uint32_t tiles) { return (((size_t)tiles + 3u) / 4u + 8u) * 2u; }
 void launch_tile_order(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, const FrameParams& fp,
                        bool midround_exit);
+// the same with the runs per XCD given (1, 2 or 4; bgs_selftest_tile_order)
+void launch_tile_order_runs(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, uint32_t runs);
 // tile waves of raster_scan_kernel a SIMD holds at once for this frame's instantiation (its __launch_bounds__)
 int raster_scan_waves_per_simd(const FrameParams& fp);
 // HeavyFeedback: what the rasteriser of a dense frame (midround_exit) leaves for the frames behind it — the tiles that

@@ -1588,10 +1588,13 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint16_t* __restr
 
 void launch_tile_order(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, const FrameParams& fp,
                        bool midround_exit) {
+    const int variant = fp.aabb == 0u ? RV_OBB : (fp.gaussian_mode != 0u ? RV_AABB3D : RV_SURFEL);
+    launch_tile_order_runs(stream, cost, order, ntiles, raster_runs(variant, fp.sample_count == 4u ? 4 : 1, midround_exit));
+}
+
+void launch_tile_order_runs(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, uint32_t runs) {
     const uint32_t nblocks = (ntiles + 3u) / 4u;
     if (nblocks == 0u || nblocks > 8u * ORDER_MAX_SHARE) return;
-    const int variant = fp.aabb == 0u ? RV_OBB : (fp.gaussian_mode != 0u ? RV_AABB3D : RV_SURFEL);
-    const uint32_t runs = raster_runs(variant, fp.sample_count == 4u ? 4 : 1, midround_exit);
     if (runs == 4u) hipLaunchKernelGGL((tile_order_kernel<4u>), dim3(8), dim3(256), 0, stream, cost, order, nblocks, ntiles);
     else if (runs == 2u) hipLaunchKernelGGL((tile_order_kernel<2u>), dim3(8), dim3(256), 0, stream, cost, order, nblocks, ntiles);
     else hipLaunchKernelGGL((tile_order_kernel<1u>), dim3(8), dim3(256), 0, stream, cost, order, nblocks, ntiles);

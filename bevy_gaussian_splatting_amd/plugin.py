@@ -287,6 +287,15 @@ class GaussianSplattingPlugin:
         self._check(self._lib.bgs_tile_order_counters(self._ctx, ctypes.byref(c), ctypes.byref(r), ctypes.byref(n)))
         return int(c.value), int(r.value), int(n.value)
 
+    def selftest_tile_order(self, cost: np.ndarray, runs: int = 1) -> np.ndarray:
+        """`bgs_selftest_tile_order`: the raster workgroups' order tile_order_kernel makes of per-tile costs (uint16,
+        one per tile): uint16[(tiles + 3) // 4]."""
+        c = np.ascontiguousarray(cost, dtype=np.uint16)
+        out = np.empty((c.size + 3) // 4, np.uint16)
+        self._check(self._lib.bgs_selftest_tile_order(self._ctx, c.ctypes.data_as(ctypes.c_void_p), c.size, runs,
+                                                      out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     # -- interop / introspection -----------------------------------------------------
     def synchronize(self) -> None:
         self._check(self._lib.bgs_synchronize(self._ctx))

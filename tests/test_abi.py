@@ -32,7 +32,7 @@ def test_the_seam_header_carries_no_diagnostics():
     assert {"bgs_create", "bgs_cloud_upload_f32", "bgs_sort", "bgs_render", "bgs_pipeline_pop"} <= seam
     assert {"bgs_set_debug_flags", "bgs_set_tile_trace", "bgs_selftest_ln_f32", "bgs_hbm_probe", "bgs_radix_sort_pairs",
             "bgs_set_queue_holders", "bgs_adaptive_counters", "bgs_graph_counters",
-            "bgs_tile_order_counters"} == diag
+            "bgs_tile_order_counters", "bgs_selftest_tile_order"} == diag
     assert len(seam) <= 40
 
 

@@ -1436,6 +1436,43 @@ def test_heavy_tiles_drawn_by_strip_waves_give_the_same_bits(plugin, oracle, clo
     h.free()
     plugin.reset_adaptive_state()
 
+@pytest.mark.parametrize("runs", [1, 2, 4])
+def test_tile_order_is_a_permutation_whatever_the_costs_hold(plugin, runs):
+    """tile_order_kernel on arbitrary per-tile costs (bgs_selftest_tile_order): for every grid size — fewer workgroups
+    than XCDs, counts that are no multiple of 8 or 4, the largest grid — and whatever the cost words hold (zeros, all
+    equal, all 0xFFFF, random, a completed frame's shape) the order is a permutation of the workgroups (a workgroup
+    nobody draws would be a hole in the image, one drawn twice a race), XCD b % 8 keeps exactly the workgroups the
+    static order gives it (splat_math.h xcd_runs_item, the host build of the same function), and inside a share the
+    workgroups' heaviest tiles are non-increasing with ties in the share's own order."""
+    import ctypes
+    l = H.shim()
+    rng = np.random.default_rng(1234 + runs)
+    for ntiles in [1, 3, 4, 5, 29, 32, 33, 61, 255, 1021, 1024, 5292, 8160, 8161, 14400, 65535]:
+        nb = (ntiles + 3) // 4
+        static = np.empty(nb, np.uint32)
+        l.shim_xcd_runs_items(nb, runs, static.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+        for kind in ("zeros", "equal", "max", "random", "few_levels", "ramp"):
+            cost = {"zeros": np.zeros(ntiles, np.uint16), "equal": np.full(ntiles, 777, np.uint16),
+                    "max": np.full(ntiles, 0xFFFF, np.uint16),
+                    "random": rng.integers(0, 65536, ntiles).astype(np.uint16),
+                    "few_levels": (rng.integers(0, 4, ntiles) * 100).astype(np.uint16),
+                    "ramp": (np.arange(ntiles) % 65536).astype(np.uint16)}[kind]
+            order = plugin.selftest_tile_order(cost, runs).astype(np.int64)
+            assert np.array_equal(np.sort(order), np.arange(nb)), (ntiles, runs, kind)
+            group = np.zeros(nb * 4, np.int64)
+            group[:ntiles] = cost
+            group = group.reshape(nb, 4).max(axis=1)                  # a workgroup costs what its heaviest tile costs
+            for x in range(min(8, nb)):
+                mine, share = order[x::8], static[x::8].astype(np.int64)
+                assert np.array_equal(np.sort(mine), np.sort(share)), (ntiles, runs, kind, x)
+                c = group[mine]
+                assert np.all(np.diff(c) <= 0), (ntiles, runs, kind, x)
+                pos = {g: i for i, g in enumerate(share)}              # ties: the share's own (spatial) order
+                p = np.array([pos[g] for g in mine])
+                same = np.diff(c) == 0
+                assert np.all(np.diff(p)[same] > 0), (ntiles, runs, kind, x)
+
+
 @pytest.mark.parametrize("what", ["dense", "scene_like", "surfel", "aabb3d_depth"])
 def test_cost_ordered_raster_workgroups_give_the_same_bits(plugin, cloud_1m, what):
     """A frame with more tile waves than the chip holds at once (4 samples per pixel: 5 waves per SIMD, 5120 of a 1080p

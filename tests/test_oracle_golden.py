@@ -671,9 +671,12 @@ def _srgb_to_linear64(c):
     return np.where(c <= 0.04045, c / 12.92, np.power(np.maximum((c + 0.055) / 1.055, 0.0), 2.4))
 
 
-def _independent_scene(view, cloud, settings):
+def _independent_scene(view, cloud, settings, depth=None):
     """[H, W, 4] float64 image of the scene + a mask of pixels within 0.02 px of some quad edge (their coverage
-    decision cannot be pinned tighter than the rasteriser's rounding)."""
+    decision cannot be pinned tighter than the rasteriser's rounding). depth: None or [H, W, samples] scene depth
+    (reverse-Z): a quad — one depth for all its fragments, the centre's clip z / w, the vertex stage offsets xy only
+    (gaussian.wgsl:395-417) — is drawn at a sample where its depth >= the stored one (CompareFunction::GreaterEqual,
+    no depth write; src/render/mod.rs:959-974)."""
     W_, H_ = view.width, view.height
     Rc, tc, fx, fy = _cam(view)
     P = np.asarray(view.clip_from_view, np.float64)
@@ -728,6 +731,8 @@ def _independent_scene(view, cloud, settings):
         for si, (ox, oy) in enumerate(samples):         # coverage per sample, the same source colour for all of them
             inside, on_edge, _ = at(ox, oy)
             edge_mask |= on_edge
+            if depth is not None:
+                inside = inside & (clip[2] / clip[3] >= depth[..., si].astype(np.float64))
             a = np.where(inside, alpha, 0.0)[..., None]
             src = np.concatenate([rgb[None, None, :] * a, a], -1)
             img[si] = src + img[si] * (1.0 - a)
@@ -764,6 +769,52 @@ def test_random_scene_against_an_independent_float64_renderer(oracle, aabb, samp
     assert err[ok].max() < 2e-5, (err[ok].max(), np.abs(ref).max())   # measured: 1e-6 (f32 oracle vs float64 geometry)
     # and the scene is not trivial: most pixels see several splats
     assert (np.abs(ref[..., :3] - np.asarray(view.clear_color)[:3]).sum(-1) > 1e-3).mean() > 0.5
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("aabb", [False, True])
+def test_random_scene_with_a_depth_buffer_against_an_independent_float64_renderer(oracle, aabb, samples):
+    """The same 120-splat scene drawn against a scene depth buffer that differs from SAMPLE to sample: every stored depth
+    is 0 (nothing in front), 1 (everything in front) or the midpoint between two neighbouring quad depths, drawn at
+    random per pixel and sample — so every quad is cut at some samples of some pixels and none of the comparisons is
+    within rounding of a tie. The oracle's depth test (per sample, GreaterEqual on the quad's one depth, no write)
+    against the independent renderer's."""
+    rng = np.random.default_rng(2024)
+    n = 120
+    c = random_gaussians_3d_seeded(n, 77)
+    c.position_visibility[:, :3] = (rng.uniform(-1, 1, (n, 3)) * [2.6, 1.6, 2.5] + [0.0, 1.5, 0.5]).astype(np.float32)
+    c.scale_opacity[:, :3] = rng.uniform(0.05, 0.45, (n, 3)).astype(np.float32)
+    c.scale_opacity[:, 3] = rng.uniform(0.05, 0.9, n).astype(np.float32)
+    c.spherical_harmonic[:] = rng.uniform(-0.6, 0.6, c.spherical_harmonic.shape).astype(np.float32)
+    view = View.headless(96, 64, msaa_samples=samples)
+    st = CloudSettings(aabb=aabb)
+    P = np.asarray(view.clip_from_view, np.float64)
+    V = np.linalg.inv(np.asarray(view.world_from_view, np.float64))
+    clip = (P @ V @ np.concatenate([c.position_visibility[:, :3].astype(np.float64), np.ones((n, 1))], 1).T).T
+    z = np.sort(clip[clip[:, 3] > 0.05, 2] / clip[clip[:, 3] > 0.05, 3])
+    gaps = np.diff(z)
+    mids = (z[:-1] + 0.5 * gaps)[gaps > 1e-4 * z[1:]]           # clear of every quad's depth by far more than f32 rounding
+    assert len(mids) > 40
+    levels = np.concatenate([[0.0, 1.0], mids]).astype(np.float32)
+    depth = levels[rng.integers(0, len(levels), (view.height, view.width, samples))]
+    e = oracle.sort(c, view, st)
+    img = oracle.render(c, e, view, st, depth=depth).astype(np.float64)
+    ref, edge, drawn = _independent_scene(view, c, st, depth=depth)
+    open_ref, _, _ = _independent_scene(view, c, st)
+    ok = ~edge
+    err = np.abs(img - ref)
+    assert err[ok].max() < 2e-5, (err[ok].max(), np.abs(ref).max())
+    # the depth buffer matters: most pixels differ from the undepthed scene, and (4x) by amounts no whole-pixel test gives
+    changed = np.abs(ref - open_ref).max(-1) > 1e-3
+    assert changed.mean() > 0.5
+    # a buffer that is the same at every sample of a pixel gives the per-pixel test: the two sample counts' oracles agree
+    # with their own independent renderers there too (plane through the middle of the cloud)
+    plane = np.full((view.height, view.width, samples), np.float32(np.median(mids)))
+    plane[:, : view.width // 2] = 0.0
+    img2 = oracle.render(c, e, view, st, depth=plane).astype(np.float64)
+    ref2, edge2, _ = _independent_scene(view, c, st, depth=plane)
+    assert np.abs(img2 - ref2)[~edge2].max() < 2e-5
+    assert np.array_equal(img2[:, : view.width // 2 - 8], oracle.render(c, e, view, st)[:, : view.width // 2 - 8].astype(np.float64))
 
 
 # ---------------------------------------------------------------------------------------------------
