@@ -1553,8 +1553,46 @@ def test_cost_ordered_raster_workgroups_give_the_same_bits(plugin, cloud_1m, wha
         plugin.reset_adaptive_state()
 
 
+def test_first_frames_of_a_context_learn_one_by_one(plugin):
+    """A context that has learnt nothing (list capacity, supertile level) used to send pipeline-depth async frames out on
+    first guesses and re-run every one of them ("reruns: 8" in every first use). Now its async frames are completed one by
+    one until a frame has run with everything it needed: a couple of re-runs instead of one per lane, and the frames
+    completed early are handed out by bgs_pipeline_pop in order like any other."""
+    from bevy_gaussian_splatting_amd.multiview import device_ptr_as_tensor
+    c = random_gaussians_3d_seeded(200_000, 9)
+    views = [View.headless(1280, 720, yaw=0.01 * k) for k in range(8)]
+    s = CloudSettings()
+    h = plugin.upload(c)
+    refs = [plugin.render(h, v, s) for v in views]
+    assert not np.array_equal(refs[0], refs[1])
+    try:
+        for depth in (8, 3):
+            plugin.reset_adaptive_state()
+            before = plugin.adaptive_counters()
+            plugin.set_async(True)
+            plugin.set_pipeline_depth(depth)
+            for rnd in range(2):                                   # round 0 learns, round 1 runs on what it learnt
+                for k in range(depth):
+                    plugin.render(h, views[k], s, download=False)
+                    assert plugin.frames_in_flight() == k + 1
+                for k in range(depth):
+                    f32, _ = plugin.pipeline_pop()
+                    got = device_ptr_as_tensor(f32, (720, 1280, 4), "<f4", "cuda:0").cpu().numpy()
+                    assert np.array_equal(got, refs[k]), (depth, rnd, k)
+                    assert plugin.frames_in_flight() == depth - 1 - k
+                after = plugin.adaptive_counters()
+                reruns = sum(after[n] - before[n] for n in ("reruns_sort", "reruns_lists", "reruns_instances"))
+                assert reruns <= 3, (depth, rnd, reruns, before, after)
+            plugin.set_async(False)
+    finally:
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.reset_adaptive_state()
+    h.free()
+
+
 def test_rerun_keeps_the_output_state_the_frame_was_enqueued_with(plugin):
-    """A frame whose supertile lists overflow is re-run when its lane completes. If the caller changed the packed
+    """A frame whose supertile lists overflow is re-run when its lane completes (here: forced). If the caller changed the packed
     output format in between (bgs_set_output_rgba16f / _srgb8 / _packed_only complete nothing), the re-run must still
     produce what the frame was ENQUEUED for: an Rgba8UnormSrgb image of w*h*4 bytes in the caller's target — not
     8 B per pixel of Rgba16Float written past its end."""
@@ -1571,9 +1609,11 @@ def test_rerun_keeps_the_output_state_the_frame_was_enqueued_with(plugin):
     want8 = device_ptr_as_tensor(p8, (360, 640, 4), "|u1", "cuda:0").cpu().numpy().copy()
     assert want8.any()
     plugin.reset_adaptive_state()
+    for _ in range(3):                            # (a context that has learnt nothing completes its async frames at once)
+        plugin.render(h, v, s)
     target = torch.zeros((2, 360, 640, 4), dtype=torch.uint8, device="cuda:0")   # second half = guard zone
     try:
-        plugin.set_debug_flags(0x100000)          # lists start at 64 entries: this frame WILL overflow and be re-run
+        plugin.set_debug_flags(0x8000000)         # this frame WILL be re-run when its lane is completed
         plugin.set_async(True)
         plugin.set_pipeline_depth(2)
         plugin.set_srgb8_target(target[0].data_ptr())
