@@ -1584,6 +1584,21 @@ def test_first_frames_of_a_context_learn_one_by_one(plugin):
                 reruns = sum(after[n] - before[n] for n in ("reruns_sort", "reruns_lists", "reruns_instances"))
                 assert reruns <= 3, (depth, rnd, reruns, before, after)
             plugin.set_async(False)
+        # ANOTHER kind of frame in the same context (here: splats twenty times smaller, then the first kind again, then a
+        # larger viewport): what the previous kind left may not fit — found out by ONE frame, not by every lane in flight
+        plugin.set_async(True)
+        plugin.set_pipeline_depth(8)
+        small = CloudSettings(global_scale=0.05)
+        big_views = [View.headless(1920, 1080, yaw=0.01 * k) for k in range(8)]
+        for kind, (vs, st_) in enumerate(((views, small), (views, s), (big_views, s), (views, small))):
+            before = plugin.adaptive_counters()
+            for rnd in range(2):
+                for k in range(8):
+                    plugin.render(h, vs[k], st_, download=False)
+                plugin.synchronize()
+            after = plugin.adaptive_counters()
+            reruns = sum(after[n] - before[n] for n in ("reruns_sort", "reruns_lists", "reruns_instances"))
+            assert reruns <= 3, (kind, reruns, before, after)
     finally:
         plugin.set_async(False)
         plugin.set_pipeline_depth(1)
