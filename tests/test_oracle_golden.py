@@ -877,7 +877,7 @@ def _internal_frame_many(view, pw):
                      ndc[:, 1] * fy * view.height / 2 + (view.height - 1) / 2], 1)
 
 
-def _independent_surfel_scene(view, cloud, settings):
+def _independent_surfel_scene(view, cloud, settings, depth=None):
     """[H, W, 4] float64 image of a scene of 2DGS surfels (GaussianMode::Gaussian2d, aabb) + the mask of pixels with a
     sample position within 0.02 px of a quad edge. Per surfel, from the geometry only: tangent vectors t_u, t_v = the
     first two columns of the rotation times the scales; the quad = the square of half-size radius / 2 framebuffer pixels
@@ -938,7 +938,10 @@ def _independent_surfel_scene(view, cloud, settings):
             us, vs = quad_uv(ox, oy)
             g = np.maximum(np.abs(us), np.abs(vs))
             edge_mask |= np.abs(g - 1) * (radius / 2) < 0.02
-            a = np.where(g <= 1, alpha, 0.0)[..., None]
+            inside = g <= 1
+            if depth is not None:                           # the quad's one depth (the centre's), per sample, GreaterEqual
+                inside = inside & (clip[2] / clip[3] >= depth[..., si].astype(np.float64))
+            a = np.where(inside, alpha, 0.0)[..., None]
             img[si] = np.concatenate([rgb[None, None, :] * a, a], -1) + img[si] * (1.0 - a)
         drawn += 1
     return img.mean(0), edge_mask, drawn
@@ -975,3 +978,18 @@ def test_surfel_scene_against_an_independent_float64_renderer(oracle, samples):
     assert err[ok].max() < 4e-3 * max(1.0, np.abs(ref).max()), (err[ok].max(), np.abs(ref).max())
     assert np.quantile(err[ok], 0.99) < 2e-4
     assert (np.abs(ref[..., :3] - np.asarray(view.clear_color)[:3]).sum(-1) > 1e-3).mean() > 0.4
+    # and against a depth buffer that differs from sample to sample (levels clear of every surfel's depth, as in
+    # test_random_scene_with_a_depth_buffer_against_an_independent_float64_renderer)
+    P = np.asarray(view.clip_from_view, np.float64)
+    V = np.linalg.inv(np.asarray(view.world_from_view, np.float64))
+    clip = (P @ V @ np.concatenate([c.position_visibility[:, :3].astype(np.float64), np.ones((n, 1))], 1).T).T
+    z = np.sort(clip[clip[:, 3] > 0.05, 2] / clip[clip[:, 3] > 0.05, 3])
+    gaps = np.diff(z)
+    mids = (z[:-1] + 0.5 * gaps)[gaps > 1e-4 * z[1:]]
+    levels = np.concatenate([[0.0, 1.0], mids]).astype(np.float32)
+    depth = levels[rng.integers(0, len(levels), (view.height, view.width, samples))]
+    img_d = oracle.render(c, e, view, st, depth=depth).astype(np.float64)
+    ref_d, edge_d, _ = _independent_surfel_scene(view, c, st, depth=depth)
+    err_d = np.abs(img_d - ref_d)[~edge_d]
+    assert err_d.max() < 4e-3 * max(1.0, np.abs(ref_d).max()) and np.quantile(err_d, 0.99) < 2e-4
+    assert (np.abs(ref_d - ref).max(-1) > 1e-3).mean() > 0.3     # the buffer cuts the scene
