@@ -383,13 +383,37 @@ def main():
     gather_ms = [0.0]
     gather = None
     batcher = None
+    native_gather, native_err = False, None
     if dist is not None:
         # the gathered frame is the reference's colour-attachment format (Rgba8UnormSrgb, 8.3 MB at
         # 1080p); the f32 target stays on its GPU. One collective per GATHER_BATCH frames, asynchronous
         # and double-buffered (BatchedFrameGather): a per-frame gather would be bound by the collective's
         # latency at these frame rates.
-        from bevy_gaussian_splatting_amd.multiview import BatchedFrameGather, device_ptr_as_tensor
-        batcher = BatchedFrameGather((HEIGHT, WIDTH, 4), torch.uint8, f"cuda:{local_rank}", batch=GATHER_BATCH)
+        # The gather itself runs behind the C ABI (bgs_comm_*: RCCL's ncclGather on the communicator's own stream,
+        # multiview.NativeFrameGather) — what a host without torch would run; torch.distributed is the launcher's
+        # rendezvous here (rank / world size, the barrier, shipping rank 0's 128-byte unique id) and the fallback
+        # (BGS_BENCH_GATHER=torch, or a box whose librccl cannot be opened: said in the line, "gather_backend").
+        from bevy_gaussian_splatting_amd.multiview import BatchedFrameGather, NativeFrameGather, device_ptr_as_tensor
+        frame_bytes8 = WIDTH * HEIGHT * 4
+        native_err = None
+        if os.environ.get("BGS_BENCH_GATHER", "native") != "torch":
+            try:
+                uid = plugin.comm_unique_id()        # every rank: proves librccl opens here (only rank 0's id is used)
+            except Exception as e:  # noqa: BLE001
+                uid, native_err = None, str(e)
+            flag = torch.tensor([0 if uid is None else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                box = [uid if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                batcher = NativeFrameGather(plugin, frame_bytes8, world, rank, box[0], batch=GATHER_BATCH)
+            elif native_err is None:
+                native_err = "another rank could not open librccl"
+        else:
+            native_err = "BGS_BENCH_GATHER=torch"
+        native_gather = batcher is not None
+        if batcher is None:
+            batcher = BatchedFrameGather((HEIGHT, WIDTH, 4), torch.uint8, f"cuda:{local_rank}", batch=GATHER_BATCH)
 
         def gather(f32_ptr, srgb8_ptr):
             # the frame was rendered straight into its slot of the staging batch (bgs_set_srgb8_target)
@@ -398,7 +422,8 @@ def main():
             gather_ms[0] += (time.perf_counter() - t0) * 1e3
 
         gather.flush = batcher.flush
-        gather.before_render = lambda: plugin.set_srgb8_target(batcher.next_target().data_ptr())
+        gather.before_render = ((lambda: plugin.set_srgb8_target(batcher.next_target())) if native_gather else
+                                (lambda: plugin.set_srgb8_target(batcher.next_target().data_ptr())))
         # the gathered frame IS the product on this path (the reference's Rgba8UnormSrgb colour attachment):
         # the rasteriser writes it straight into the staging batch and skips the f32 target nobody reads
         # (33 MB of writes per frame); the N = 1 headline keeps the f32 target
@@ -454,6 +479,22 @@ def main():
             if batcher.frames_received != want:
                 raise SystemExit(f"gather check failed: rank 0 received {batcher.frames_received} frames, "
                                  f"{world} ranks issued {want}")
+    gather_selfcheck = None
+    if dist is not None and batcher is not None and native_gather:
+        # outside the timed region: one more native gather of a known pattern — rank r's batch holds the byte r + 1 —
+        # checked on rank 0 block by block (the frame COUNT above says every collective completed, this says the bytes
+        # landed where bgs.h says they land)
+        nb = GATHER_BATCH * frame_bytes8
+        import numpy as _np
+        plugin.upload_bytes(batcher.stage[0], _np.full(nb, rank + 1, dtype=_np.uint8))
+        tk = plugin.comm_gather(batcher.comm, 0, batcher.stage[0], nb, batcher.recv[0])
+        plugin.comm_wait(batcher.comm, tk)
+        if rank == 0:
+            got = device_ptr_as_tensor(batcher.recv[0], (world, nb), "|u1", f"cuda:{local_rank}")
+            want = torch.arange(1, world + 1, dtype=torch.uint8, device=got.device)[:, None]
+            gather_selfcheck = bool((got == want).all().item())
+            if not gather_selfcheck:
+                raise SystemExit("native gather self-check failed: a rank's block does not hold that rank's bytes")
     dt = statistics.median(dts)
     fps = world * args.steps / dt
 
@@ -756,6 +797,9 @@ def main():
                       "gather_ms_per_step": round(gather_ms[0] / max(args.steps + args.warmup, 1), 4),
                       "gathered_format": "Rgba8UnormSrgb (packed-only frames: no f32 target)" if dist is not None else None,
                       "gather_batch_frames": GATHER_BATCH if dist is not None else None,
+                      "gather_backend": (None if dist is None else ("bgs_comm_gather (RCCL ncclGather behind the C ABI)" if native_gather
+                                                                    else f"torch.distributed.gather (fallback: {native_err})")),
+                      "gather_selfcheck": gather_selfcheck,
                       "frames_gathered_on_rank0": batcher.frames_received if batcher is not None else None,
                       "frames_issued_per_rank": issued_main},
             "stages": stages,

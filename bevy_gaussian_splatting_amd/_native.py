@@ -77,7 +77,20 @@ EXPORTED_SYMBOLS = (
     "bgs_device_alloc",
     "bgs_device_free",
     "bgs_upload",
+    "bgs_abi_check",
+    "bgs_learning_counters",
+    "bgs_comm_unique_id",
+    "bgs_comm_create",
+    "bgs_comm_gather",
+    "bgs_comm_wait",
+    "bgs_comm_stream",
+    "bgs_comm_destroy",
 )
+
+COMM_ID_BYTES = 128
+# what this binding was written against (include/bgs.h BGS_VERSION_*): load() hands it to bgs_abi_check together with
+# the sizes of its ctypes structs
+ABI_VERSION = (0 << 16) | 4
 
 
 class BgsSortEntry(ctypes.Structure):
@@ -294,6 +307,26 @@ def load() -> ctypes.CDLL:
     lib.bgs_adaptive_counters.restype = ctypes.c_int
     lib.bgs_reset_adaptive_state.argtypes = [vp]
     lib.bgs_reset_adaptive_state.restype = ctypes.c_int
+    lib.bgs_learning_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.bgs_learning_counters.restype = ctypes.c_int
+    lib.bgs_abi_check.argtypes = [u32, u32, u32, u32]
+    lib.bgs_abi_check.restype = ctypes.c_int
+    lib.bgs_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.bgs_comm_unique_id.restype = ctypes.c_int
+    lib.bgs_comm_create.argtypes = [vp, ctypes.c_char_p, u32, u32, ctypes.POINTER(vp)]
+    lib.bgs_comm_create.restype = ctypes.c_int
+    lib.bgs_comm_gather.argtypes = [vp, vp, u32, vp, ctypes.c_uint64, vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.bgs_comm_gather.restype = ctypes.c_int
+    lib.bgs_comm_wait.argtypes = [vp, vp, ctypes.c_uint64]
+    lib.bgs_comm_wait.restype = ctypes.c_int
+    lib.bgs_comm_stream.argtypes = [vp, vp, ctypes.POINTER(vp)]
+    lib.bgs_comm_stream.restype = ctypes.c_int
+    lib.bgs_comm_destroy.argtypes = [vp, vp]
+    lib.bgs_comm_destroy.restype = None
+    # the handshake a binding owes the library (a stale struct layout is refused here, not read past)
+    rc = lib.bgs_abi_check(ABI_VERSION, ctypes.sizeof(BgsView), ctypes.sizeof(BgsSettings), ctypes.sizeof(BgsStats))
+    if rc != BGS_OK:
+        raise ImportError("libbgs.so refuses this binding: " + (lib.bgs_last_error(None) or b"").decode("utf-8", "replace"))
     _lib = lib
     return lib
 

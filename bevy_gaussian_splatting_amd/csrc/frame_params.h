@@ -49,7 +49,7 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     memcpy(fp.clear, view->clear_color, sizeof fp.clear);
     fp.srgb8_target = 0;
     fp.sort_path = 0;  // chosen per frame by the host (bgs_api.hip)
-    fp.sample_count = view->sample_count;
+    fp.sample_count = view->sample_count ? view->sample_count : 4u;   // 0 = not set = Msaa::default() = Sample4
     fp.depth_ptr = view->depth_device_ptr;
     // uniform parts of world_to_local_direction (gaussian.wgsl:166-176: normalize(basis[k]) = v / length(v),
     // length = sqrt(dot)) and of the bounding boxes (1.0 / viewport): IEEE binary32, the order of splat_math.h

@@ -172,3 +172,81 @@ def framebuffer_as_tensor(plugin, height: int, width: int, device: Optional[str]
     ptr, nbytes = plugin.framebuffer_device_ptr()
     assert nbytes == height * width * 16
     return torch.as_tensor(_DeviceArray(ptr, (height, width, 4)), device=device or f"cuda:{plugin.device}")
+
+
+class NativeFrameGather:
+    """`BatchedFrameGather` without torch: the same double-buffered, batched gather of packed frames to rank `dst`,
+    through the C ABI (`bgs_comm_*`: RCCL's ncclGather on a stream the communicator owns) — what a Rust host binding
+    include/bgs.h runs for BASELINE configs[4]. `unique_id` = `GaussianSplattingPlugin.comm_unique_id()` of rank 0,
+    shipped to every rank by the launcher (bench.py: one torch.distributed broadcast at start-up; the tests: a file).
+    The producer writes each frame straight into its slot: `next_target()` is the device pointer for the NEXT frame to
+    be enqueued (`plugin.set_srgb8_target`), `frame_completed()` says the oldest outstanding frame is complete in its
+    slot (after `plugin.pipeline_pop()`), `flush()` sends a partial batch and waits for everything. On `dst`,
+    `on_batch(recv_ptr, count)` is called for every completed batch: rank r's frames are at
+    recv_ptr + (r * batch + k) * frame_bytes, k < count."""
+
+    def __init__(self, plugin, frame_bytes: int, world: int, rank: int, unique_id: bytes, batch: int = 8, dst: int = 0,
+                 on_batch=None):
+        self.plugin, self.frame_bytes, self.world, self.rank, self.dst = plugin, int(frame_bytes), int(world), int(rank), int(dst)
+        self.batch = max(1, int(batch))
+        self.comm = plugin.comm_create(unique_id, world, rank)
+        self.stage = [plugin.device_alloc(self.batch * self.frame_bytes) for _ in range(2)]
+        self.recv = [plugin.device_alloc(self.world * self.batch * self.frame_bytes) if rank == dst else None for _ in range(2)]
+        self.ticket = [0, 0]
+        self.count_in_flight = [0, 0]
+        self.pushed = 0
+        self.issued = 0
+        self.frames_received = 0
+        self.gathers = 0
+        self.on_batch = on_batch
+
+    def _complete(self, s: int) -> None:
+        if not self.ticket[s]:
+            return
+        self.plugin.comm_wait(self.comm, self.ticket[s])
+        self.ticket[s] = 0
+        if self.rank == self.dst:
+            k = self.count_in_flight[s]
+            self.frames_received += k * self.world
+            if self.on_batch is not None:
+                self.on_batch(self.recv[s], k)
+
+    def _send(self, s: int, count: int) -> None:
+        # every rank sends the whole staging batch (a partial batch only at the very end): one message size per
+        # collective on every rank, whatever `count` is
+        self.count_in_flight[s] = count
+        self.ticket[s] = self.plugin.comm_gather(self.comm, self.dst, self.stage[s], self.batch * self.frame_bytes, self.recv[s])
+        self.gathers += 1
+
+    def next_target(self) -> int:
+        s, slot = (self.issued // self.batch) % 2, self.issued % self.batch
+        if slot == 0:
+            self._complete(s)  # the previous gather out of this staging buffer must have finished
+        self.issued += 1
+        return self.stage[s] + slot * self.frame_bytes
+
+    def frame_completed(self) -> None:
+        self.pushed += 1
+        if self.pushed % self.batch == 0:
+            self._send((self.pushed // self.batch - 1) % 2, self.batch)
+
+    def flush(self) -> None:
+        s, slot = (self.pushed // self.batch) % 2, self.pushed % self.batch
+        if slot:
+            self._send(s, slot)
+            self.pushed += self.batch - slot  # keep the batch phase of every rank aligned
+            self.issued = self.pushed
+            self._complete(1 - s)
+            self._complete(s)
+        else:
+            self._complete(s)
+            self._complete(1 - s)
+
+    def close(self) -> None:
+        if self.comm is None:
+            return
+        self.plugin.comm_wait(self.comm, 0)
+        self.plugin.comm_destroy(self.comm)
+        self.comm = None
+        for p in self.stage + [r for r in self.recv if r]:
+            self.plugin.device_free(p)

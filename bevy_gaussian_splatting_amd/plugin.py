@@ -390,6 +390,14 @@ class GaussianSplattingPlugin:
         a = np.ascontiguousarray(host)
         self._check(self._lib.bgs_upload(self._ctx, ctypes.c_void_p(device_ptr), a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
 
+    def download(self, device_ptr: int, host_out: np.ndarray) -> np.ndarray:
+        """`bgs_download`: blocking device-to-host copy into a contiguous array (of a COMPLETED frame's memory)."""
+        if not host_out.flags["C_CONTIGUOUS"] or not host_out.flags["WRITEABLE"]:
+            raise ValueError("host_out must be a writeable C-contiguous array")
+        self._check(self._lib.bgs_download(self._ctx, ctypes.c_void_p(device_ptr), host_out.ctypes.data_as(ctypes.c_void_p),
+                                           host_out.nbytes))
+        return host_out
+
     def upload_depth(self, depth: np.ndarray) -> int:
         """Put a view's scene depth on the device: `depth` is [height, width, samples] float32 (reverse-Z, what Bevy's
         opaque passes left in the view's Depth32Float attachment; src/render/mod.rs:959-974). Returns the device
@@ -417,6 +425,44 @@ class GaussianSplattingPlugin:
         names = ("bucket_frames", "onesweep_frames", "reruns_sort", "reruns_lists", "reruns_instances",
                  "level_changes", "supertile_level", "list_capacity_hint")
         return {k: int(v) for k, v in zip(names, out)}
+
+    def learning_counters(self) -> dict:
+        """Async frames completed inside their render call because their kind of frame was new to the context, and the
+        kinds it has settled on (bgs_learning_counters)."""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._lib.bgs_learning_counters(self._ctx, ctypes.byref(a), ctypes.byref(b)))
+        return {"early_frames": a.value, "kinds_settled": b.value}
+
+    # -- the multi-GPU frame gather (bgs_comm_*: RCCL behind the C ABI) ---------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 bytes rank 0 ships to every rank (by any means) before `comm_create`."""
+        buf = ctypes.create_string_buffer(_native.COMM_ID_BYTES)
+        lib = _native.load()
+        _native.check(lib, None, lib.bgs_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_create(self, unique_id: bytes, world_size: int, rank: int) -> int:
+        """Collective: returns the communicator handle once every rank has called it."""
+        if len(unique_id) != _native.COMM_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        out = ctypes.c_void_p()
+        self._check(self._lib.bgs_comm_create(self._ctx, unique_id, int(world_size), int(rank), ctypes.byref(out)))
+        return out.value
+
+    def comm_gather(self, comm: int, root: int, send_ptr: int, nbytes: int, recv_ptr: Optional[int]) -> int:
+        """Enqueue one gather of `nbytes` per rank (device pointers; `recv_ptr` on the root only). Returns its ticket."""
+        ticket = ctypes.c_uint64()
+        self._check(self._lib.bgs_comm_gather(self._ctx, comm, int(root), ctypes.c_void_p(send_ptr), int(nbytes),
+                                              ctypes.c_void_p(recv_ptr or 0), ctypes.byref(ticket)))
+        return ticket.value
+
+    def comm_wait(self, comm: int, ticket: int = 0) -> None:
+        """Block until the gather with `ticket` (and every earlier one) has completed; 0 = all of them."""
+        self._check(self._lib.bgs_comm_wait(self._ctx, comm, int(ticket)))
+
+    def comm_destroy(self, comm: int) -> None:
+        self._lib.bgs_comm_destroy(self._ctx, comm)
 
     def reset_adaptive_state(self) -> None:
         """Forget the hints completed frames left in the context (draw count, key range, list capacity,

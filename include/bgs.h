@@ -43,7 +43,8 @@ extern "C" {
 #endif
 
 #define BGS_VERSION_MAJOR 0
-#define BGS_VERSION_MINOR 3 /* 0.3: bgs_view gained sample_count + depth_device_ptr (16 bytes longer), bgs_stats is 16 bytes longer than 0.2's */
+#define BGS_VERSION_MINOR 4 /* 0.4: bgs_abi_check, bgs_comm_* (the multi-GPU frame gather), sample_count 0 = default; struct layouts as 0.3
+                               (0.3: bgs_view gained sample_count + depth_device_ptr, 16 bytes longer; bgs_stats 16 bytes longer than 0.2's) */
 
 typedef enum bgs_status {
     BGS_OK = 0,
@@ -79,8 +80,9 @@ typedef struct bgs_view {
      * (nothing in the reference sets Msaa; src/utils.rs:34 `msaa_samples` is never read). With 4 samples coverage
      * (and the depth test) is decided per sample at the standard sample positions, the fragment stage runs once
      * per pixel at the pixel centre, every covered sample blends the same source colour, and the image handed
-     * back is the resolved one (mean of the samples). Anything but 1 or 4 is BGS_EINVAL (Sample2 / Sample8 are
-     * not built). bgs_view_perspective sets 4. */
+     * back is the resolved one (mean of the samples). 0 (a zero-initialised bgs_view) means "not set" and renders
+     * with Msaa::default() = 4; anything else but 1 or 4 is BGS_EINVAL (Sample2 / Sample8 are not built).
+     * bgs_view_perspective sets 4. */
     uint32_t sample_count;
     uint32_t reserved[2];
     /* The view's depth attachment the draw is tested against (src/render/mod.rs:959-974: Depth32Float,
@@ -192,6 +194,12 @@ int bgs_create(int hip_device, bgs_ctx** out);
 void bgs_destroy(bgs_ctx* ctx);
 const char* bgs_last_error(const bgs_ctx* ctx); /* ctx may be NULL: global message   */
 uint32_t bgs_version(void);                     /* (major << 16) | minor             */
+/* A binding's handshake, once at start-up: the version and the struct sizes IT was built with. BGS_EINVAL (message via
+ * bgs_last_error(NULL)) unless they are this library's — the structs are passed by pointer, so a binding built
+ * against another layout (0.2's bgs_view was 16 bytes shorter) would otherwise have the library read past its
+ * struct. C callers: bgs_abi_check(BGS_ABI_VERSION, sizeof(bgs_view), sizeof(bgs_settings), sizeof(bgs_stats)). */
+#define BGS_ABI_VERSION ((BGS_VERSION_MAJOR << 16) | BGS_VERSION_MINOR)
+int bgs_abi_check(uint32_t version, uint32_t sizeof_view, uint32_t sizeof_settings, uint32_t sizeof_stats);
 /* Identity of the kernel sources the library was compiled from: the SHA-256 (64 hex digits) over the HIP
  * sources and headers of libbgs (csrc/ .hip and .h files). The Python binding, the tests and bench.py refuse a library whose id is not the
  * tree's (and rebuild it); counter files under profiles/ carry the same stamp. */
@@ -357,6 +365,34 @@ int bgs_set_pipeline_streams(bgs_ctx* ctx, uint32_t streams);
  * changes (cloud, buffers, viewport size, pipeline variant, grid sizes, debug flags); frames whose
  * stages are timed with events (bgs_set_profiling) are always launched directly. */
 int bgs_set_graphs(bgs_ctx* ctx, int enabled);
+
+/* ---- multi-GPU: the gather of finished frames ------------------------------------------------------------------
+ * Views are independent units (the reference keys its sort state and entry offsets by camera: src/sort/mod.rs:143-150,
+ * src/render/mod.rs:1548-1554): one process per GPU, camera g on rank g, a replica of the cloud on every GPU, no
+ * exchange during sort / rasterise. The ONE collective is the gather of finished frames to a root rank: RCCL
+ * ncclGather (grouped send / receive over xGMI, every non-root rank on its own link), enqueued on a stream the
+ * communicator owns. librccl is opened when the first bgs_comm_* call needs it (hosts that never gather do not need
+ * it installed).
+ *   rank 0:      bgs_comm_unique_id(id)   -> ship the 128 bytes to every rank by the host's own means (a file, MPI,
+ *                                            the launcher's rendezvous)
+ *   every rank:  bgs_comm_create(ctx, id, world_size, rank, &comm)      (collective: returns once all ranks called it)
+ *   per batch:   bgs_comm_gather(ctx, comm, root, send, bytes, recv, &ticket)   asynchronous; `send` (device memory
+ *                holding COMPLETED frames: after bgs_pipeline_pop / bgs_synchronize — e.g. the batch buffer the frames
+ *                were written to through bgs_set_srgb8_target) and `recv` (root only: world_size * bytes, rank r's
+ *                block at r * bytes) must stay untouched until that gather has completed
+ *                bgs_comm_wait(ctx, comm, ticket)  blocks until the gather with that ticket (and every earlier one) has
+ *                completed on this rank; ticket 0 = every gather enqueued so far. Double buffering: gather batch k,
+ *                render batch k + 1 into the other buffer, wait for ticket k - 1 before reusing its buffer.
+ * A communicator belongs to the context's device and, like the context, is driven by one thread. */
+#define BGS_COMM_ID_BYTES 128
+typedef struct bgs_comm bgs_comm;
+int bgs_comm_unique_id(uint8_t id_out[BGS_COMM_ID_BYTES]);
+int bgs_comm_create(bgs_ctx* ctx, const uint8_t id[BGS_COMM_ID_BYTES], uint32_t world_size, uint32_t rank, bgs_comm** out);
+int bgs_comm_gather(bgs_ctx* ctx, bgs_comm* comm, uint32_t root, const void* send_device_ptr, uint64_t bytes_per_rank,
+                    void* recv_device_ptr_root_only, uint64_t* ticket_out_or_null);
+int bgs_comm_wait(bgs_ctx* ctx, bgs_comm* comm, uint64_t ticket);
+int bgs_comm_stream(bgs_ctx* ctx, bgs_comm* comm, void** hip_stream); /* the stream the gathers run on */
+void bgs_comm_destroy(bgs_ctx* ctx, bgs_comm* comm);
 #ifdef __cplusplus
 }
 #endif

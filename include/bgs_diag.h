@@ -37,6 +37,11 @@ int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags);
  * [5] supertile level changes, [6] the current level, [7] the current list-capacity hint (entries). */
 int bgs_adaptive_counters(bgs_ctx* ctx, uint64_t out[8]);
 
+/* The learning phase (bgs.h "Async frames"): how many async frames were completed inside their bgs_render
+ * call because the context had not settled on their kind of frame yet, and how many kinds it has settled on. A host
+ * whose frames/s fall to the blocking rate sees it here: early_frames grows with every frame. */
+int bgs_learning_counters(bgs_ctx* ctx, uint64_t* early_frames, uint64_t* kinds_settled);
+
 /* Stable LSD radix sort of n (key,index) pairs on the device, `passes` 8-bit digit
  * places starting at bit 0 (the Onesweep kernel used for both the depth and the tile
  * sort). entries_inout is a HOST buffer; used by the parity tests to exercise the sort
@@ -70,7 +75,9 @@ int bgs_set_queue_holders(int enabled);
  * tile's wave writes 8 uint32: s_memtime at its start (lo, hi) and end (lo, hi), the HW_ID and XCC_ID registers (which
  * XCD / SE / CU / SIMD / wave slot it ran on), the list candidates it scanned, and records blended | staged << 16.
  * scripts/tile_trace.py turns that into the launch's per-SIMD occupancy picture (the "tail"). NULL switches it off.
- * Completes the frames in flight; the buffer stays the caller's. Costs ~10 % of the rasteriser's time while on. */
+ * Completes the frames in flight; the buffer stays the caller's. Costs ~10 % of the rasteriser's time while on.
+ * There is no traced instantiation with a depth buffer: bgs_render with bgs_view.depth_device_ptr set while a trace
+ * buffer is set fails with BGS_EINVAL (it used to run untraced and leave the buffer's old contents). */
 int bgs_set_tile_trace(bgs_ctx* ctx, void* device_ptr);
 
 /* How many frames were captured into a graph / replayed from one since bgs_create. */

@@ -31,9 +31,12 @@ def test_the_seam_header_carries_no_diagnostics():
     assert not seam & diag
     assert {"bgs_create", "bgs_cloud_upload_f32", "bgs_sort", "bgs_render", "bgs_pipeline_pop"} <= seam
     assert {"bgs_set_debug_flags", "bgs_set_tile_trace", "bgs_selftest_ln_f32", "bgs_hbm_probe", "bgs_radix_sort_pairs",
-            "bgs_set_queue_holders", "bgs_adaptive_counters", "bgs_graph_counters",
+            "bgs_set_queue_holders", "bgs_adaptive_counters", "bgs_graph_counters", "bgs_learning_counters",
             "bgs_tile_order_counters", "bgs_selftest_tile_order"} == diag
-    assert len(seam) <= 40
+    # the seam proper, plus the multi-GPU frame gather ("ncclGather ... behind the boundary")
+    assert {n for n in seam if n.startswith("bgs_comm_")} == {"bgs_comm_unique_id", "bgs_comm_create", "bgs_comm_gather",
+                                                               "bgs_comm_wait", "bgs_comm_stream", "bgs_comm_destroy"}
+    assert len(seam) <= 48
 
 
 def test_library_is_built_and_exports_every_declared_symbol():
@@ -43,7 +46,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert set(names) == set(_native.EXPORTED_SYMBOLS)
     for n in names:
         assert hasattr(lib, n), f"libbgs.so does not export {n}"
-    assert lib.bgs_version() == (0 << 16) | 3
+    assert lib.bgs_version() == (0 << 16) | 4 == _native.ABI_VERSION
 
 
 def test_integration_doc_binds_every_exported_symbol():
@@ -64,6 +67,20 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_native.BgsStats) == 6 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 4 * 4 + 8 + 8 + 8 + 8 + 8
     # the ctypes images include natural padding exactly like the C structs
     assert _native.BgsStats.instance_count.offset % 8 == 0
+
+
+def test_abi_check_refuses_a_stale_binding():
+    """bgs_abi_check is the binding's handshake (bgs_view grew by 16 bytes between 0.2 and 0.3 and
+    nothing noticed a caller with the short struct): the right version and sizes pass, anything else is BGS_EINVAL
+    with a message, and _native.load() performs it."""
+    lib = _native.load()
+    sizes = (ctypes.sizeof(BgsView), ctypes.sizeof(BgsSettings), ctypes.sizeof(_native.BgsStats))
+    assert lib.bgs_abi_check(_native.ABI_VERSION, *sizes) == _native.BGS_OK
+    assert lib.bgs_abi_check((0 << 16) | 2, *sizes) == _native.BGS_EINVAL
+    assert b"built against 0.2" in lib.bgs_last_error(None)
+    assert lib.bgs_abi_check(_native.ABI_VERSION, sizes[0] - 16, sizes[1], sizes[2]) == _native.BGS_EINVAL   # 0.2's bgs_view
+    assert b"stale binding" in lib.bgs_last_error(None)
+    assert lib.bgs_abi_check(_native.ABI_VERSION, sizes[0], sizes[1], sizes[2] + 8) == _native.BGS_EINVAL
 
 
 def test_settings_default_equals_cloud_settings_default():
