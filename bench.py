@@ -653,6 +653,42 @@ def main():
         sort_dev_ms /= reps
         sort_bytes = plugin.stats()["algorithmic_bytes"]
 
+        # The same stages with EVERY splat drawable (D = N): `sort.device_ms` above is the headline camera's sort, whose
+        # list is 88 % culled sentinels that never go through a digit pass. SortMode::Rayon / Std never cull
+        # (src/sort/rayon.rs:86-104) and a SortMode::Radix camera that sees the whole cloud keys every splat
+        # (src/sort/radix.wgsl:109-279): four onesweep passes over N pairs (a frame with more than 786 k drawable pairs
+        # does not take the bucket path). GB/s on SURVEY 8(d)'s 88 B per splat (16 positions + 8 pairs + 4 x 16).
+        def sort_rate(h, n, vw, st_, reps_):
+            for _ in range(3):
+                plugin.sort(h, vw, st_, download=False)
+            ms, kg, ds = 0.0, 0.0, 0.0
+            for _ in range(reps_):
+                plugin.sort(h, vw, st_, download=False)
+                stt = plugin.stats()
+                ms += stt["total_ms"]; kg += stt["stage_ms"]["keygen"]; ds += stt["stage_ms"]["depth_sort"]
+            ms, kg, ds = ms / reps_, kg / reps_, ds / reps_
+            stt = plugin.stats()
+            return {"device_ms": round(ms, 4), "keygen_ms": round(kg, 4), "digit_passes_ms": round(ds, 4),
+                    "passes": stt["depth_passes"], "ms_per_pass": round(ds / max(stt["depth_passes"], 1), 4),
+                    "drawable": stt["draw_count"], "splats": n, "sort_path": stt["sort_path"],
+                    "Msplats_per_s": round(n / (ms * 1e-3) / 1e6, 1) if ms > 0 else None,
+                    "GBps_on_88B_per_splat": round(88.0 * n / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                    "pct_hbm_peak": round(100 * 88.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 2) if ms > 0 else None}
+        from bevy_gaussian_splatting_amd import SortMode, View, transform_from
+        far_view = View.perspective(transform_from((0.0, 0.0, 120.0), (0.0, 0.0, 0.0, 1.0)), WIDTH, HEIGHT)  # sees all of U(-20, 20)^3
+        sort_all = {"note": "keygen + depth sort with D = N drawable pairs (nothing culled): blocking bgs_sort calls, device time "
+                            "by HIP events; 88 B per splat = SURVEY 8(d) bytes_sort at 4 digit places",
+                    "1m_rayon": sort_rate(handle, args.splats, view, CloudSettings(sort_mode=SortMode.Rayon), max(args.steps, 10)),
+                    "1m_radix_whole_cloud_in_view": sort_rate(handle, args.splats, far_view, settings, max(args.steps, 10))}
+        if os.environ.get("BGS_BENCH_SKIP_5M") != "1":   # (BASELINE configs[2]'s cloud: ~10 s of host time to make and upload)
+            c5 = random_gaussians_3d_seeded(5_000_000, 3)
+            h5 = plugin.upload(c5)
+            sort_all["5m_rayon"] = sort_rate(h5, 5_000_000, view, CloudSettings(sort_mode=SortMode.Rayon), 10)
+            sort_all["5m_radix_whole_cloud_in_view"] = sort_rate(h5, 5_000_000, far_view, settings, 10)
+            h5.free()
+            del c5
+        plugin.reset_adaptive_state()
+
         # scene-like variant: global_scale = 0.05
         plugin.set_profiling_stride(STRIDE)
         plugin.set_pipeline_depth(DEPTH)
@@ -806,6 +842,7 @@ def main():
             "sort_msplats_per_s": round(args.splats / (sort_dev_ms * 1e-3) / 1e6, 1) if sort_dev_ms > 0 else None,
             "sort": {"device_ms": round(sort_dev_ms, 4), "wall_ms": round(sort_wall * 1e3, 4),
                      "GBps": round(sort_bytes / (sort_dev_ms * 1e-3) / 1e9, 1) if sort_dev_ms > 0 else None},
+            "sort_all_visible": sort_all,
             "scene_like": {"global_scale": 0.05, "value": round(args.steps / dt2, 2), "unit": "frames/s", "trials": len(dts2),
                            "single_stream_value": round(args.steps / dt2s, 2),
                            "device_ms": round(ms2, 4), "visible_splats": st2["visible_count"],

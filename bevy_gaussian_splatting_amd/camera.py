@@ -102,7 +102,8 @@ class View:
     camera: GaussianCamera = field(default_factory=GaussianCamera)
     # The camera's `Msaa` component (Bevy: required component of Camera, default Msaa::Sample4) as the pipeline is
     # specialised on it: CloudPipelineKey.sample_count = msaa.samples() (src/render/mod.rs:357,412,422,975-979).
-    # 1 = Msaa::Off, 4 = Msaa::Sample4. Nothing in the reference sets it, so its cameras all run with 4.
+    # 1 = Msaa::Off, 2 / 4 / 8 = Msaa::Sample2 / Sample4 / Sample8 (0 = not set = 4). Nothing in the reference sets it, so
+    # its cameras all run with 4.
     msaa_samples: int = 4
     # Device address of the view's depth attachment (Depth32Float, reverse-Z; [y][x][sample] floats) the draw is tested
     # against with GreaterEqual (src/render/mod.rs:959-974), or 0: no scene depth. GaussianSplattingPlugin.upload_depth

@@ -47,7 +47,7 @@ struct FrameParams {
     // Depth-sort path of the frame (sort_kernels.hip): 0 = onesweep digit passes, 1 = bucket sort (keygen
     // places the drawable pairs into key-range buckets, one kernel sorts each bucket in LDS)
     uint32_t sort_path;
-    // MultisampleState.count of the pipeline = Msaa::samples() of the camera (src/render/mod.rs:357-424,975-979): 1 or 4
+    // MultisampleState.count of the pipeline = Msaa::samples() of the camera (src/render/mod.rs:357-424,975-979): 1, 2, 4 or 8
     uint32_t sample_count;
     // the view's depth attachment (Depth32Float, reverse-Z, [y][x][sample] floats) the quads are tested against with
     // GreaterEqual (src/render/mod.rs:959-974), as a device address; 0 = none
@@ -57,7 +57,7 @@ struct FrameParams {
     // operations in the same order, so every bit downstream is what it was:
     float basis[9];            // normalize(transform[0].xyz), [1].xyz, [2].xyz  (gaussian.wgsl:166-176)
     float inv_viewport_w, inv_viewport_h;   // 1.0 / viewport.zw                (helpers.wgsl:116-117)
-    float pad_uniform;
+    uint32_t visualize_bbox;   // CloudSettings::visualize_bounding_box (src/render/gaussian.wgsl:486-495): the quads' frames
 };
 static_assert(sizeof(FrameParams) % 8 == 0 && sizeof(FrameParams) / 4 <= 256, "keygen copies it with one block");
 

@@ -62,7 +62,7 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     }
     fp.inv_viewport_w = 1.0f / view->viewport[2];
     fp.inv_viewport_h = 1.0f / view->viewport[3];
-    fp.pad_uniform = 0.0f;
+    fp.visualize_bbox = s->visualize_bounding_box ? 1u : 0u;
     for (int i = 0; i < 3; ++i) {
         fp.pos_min[i] = s->position_min[i];
         fp.pos_max[i] = s->position_max[i];

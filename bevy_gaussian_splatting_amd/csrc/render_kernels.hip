@@ -746,18 +746,27 @@ __device__ __forceinline__ float frame_surfel_limit(const uint32_t color_max_bit
 typedef float v2f __attribute__((ext_vector_type(2)));
 // DEPTH: the fragment is also tested against the pixel's scene depth `dpx` (src/render/mod.rs:959-974: GreaterEqual on
 // a reverse-Z Depth32Float attachment, no write); `z` is the quad's constant depth.
-template <int VARIANT, bool DEPTH = false>
+// BBOX: CloudSettings::visualize_bounding_box (src/gaussian/settings.rs:95, key bit src/render/mod.rs:418,824,
+// src/render/gaussian.wgsl:486-495): a fragment in the outer 8 % of the quad's uv square — uv * 0.5 + 0.5 outside
+// [0.08, 0.92], i.e. max(|u|, |v|) > 0.84 — is (0.3, 1, 0.1, 1) instead of the splat's colour: alpha 1, whatever is
+// behind it is hidden (front-to-back: the pixel's transmittance drops to 0). fs_main's AABB discard (power > 0) comes
+// first, as in the shader. A separate instantiation: frames without the switch carry none of it.
+constexpr float BBOX_EDGE_WIDTH = 0.08f;                       // gaussian.wgsl:488
+constexpr float BBOX_EDGE = 1.0f - 2.0f * BBOX_EDGE_WIDTH;      // uv * 0.5 + 0.5 outside [w, 1 - w]  <=>  |uv| > 1 - 2 w
+template <int VARIANT, bool DEPTH = false, bool BBOX = false>
 __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const float qx, const float qy,
                                          const float aspect, const float t_eps, float& T, v2f& crg, float& cb,
                                          const float z = 0.0f, const float dpx = 0.0f) {
     float alpha, r, g, b;
     bool hit;
+    [[maybe_unused]] float bu = 0.0f, bv = 0.0f, blim = 1.0f;   // the quad's own uv and its limit (BBOX)
     if constexpr (VARIANT == RV_OBB) {
         // staged by stage_obb: a0 = U0' V0' m00' m01' | a1 = m10' m11' - r | a2 = g b a -; here
         // (qx, qy) is the pixel's position INSIDE the tile (0..15)
         const float u = fmaf(s.a0.w, qy, fmaf(s.a0.z, qx, s.a0.x));
         const float v = fmaf(s.a1.y, qy, fmaf(s.a1.x, qx, s.a0.y));
         hit = fmaxf(fabsf(u), fabsf(v)) <= OBB_C;
+        if constexpr (BBOX) { bu = u; bv = v; blim = OBB_C; }
         // fs_main OBB: power = -dot(uv,uv) / (2 * (1/3)^2)  (gaussian.wgsl:474-480);
         // exp(power) = exp2(-(u'^2 + v'^2))
         const float e = __builtin_amdgcn_exp2f(-fmaf(u, u, v * v));
@@ -767,6 +776,7 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
         const float dx = qx - s.a0.x, dy = qy - s.a0.y;
         // a0 = cx cy m00 m11 | a1 = A B C r | a2 = g b a rect
         const float u = s.a0.z * dx, v = s.a0.w * dy;
+        if constexpr (BBOX) { bu = u; bv = v; }
         hit = fmaxf(fabsf(u), fabsf(v)) <= 1.0f;
         const float power = fmaf(s.a1.y * u, v, -0.5f * fmaf(s.a1.x * u, u, s.a1.z * v * v));
         hit = hit && !(power > 0.0f);
@@ -775,6 +785,7 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
     } else {
         // staged by stage_surfel; (qx, qy) is the pixel's position INSIDE the tile (0..15)
         const float u = fmaf(s.a0.y, qx, s.a0.x), v = fmaf(s.a0.w, qy, s.a0.z);
+        if constexpr (BBOX) { bu = u; bv = v; }
         hit = fmaxf(fabsf(u), fabsf(v)) <= 1.0f;
         // surfel_fragment_power (gaussian_2d.wgsl:134-156): p = P0 + Px xl + Py yl, the x part is shared
         // by the pixels of a lane
@@ -794,6 +805,10 @@ __device__ __forceinline__ void blend_px(const StagedRecord<VARIANT>& s, const f
         r = s.a4.y; g = s.a4.z; b = s.a4.w;
     }
     if constexpr (DEPTH) hit = hit && z >= dpx;
+    if constexpr (BBOX) {
+        const bool frame = fmaxf(fabsf(bu), fabsf(bv)) > BBOX_EDGE * blim;
+        alpha = frame ? 1.0f : alpha; r = frame ? 0.3f : r; g = frame ? 1.0f : g; b = frame ? 0.1f : b;
+    }
     // a real branch on purpose: it becomes an exec-mask region that a wave skips entirely when none
     // of its 64 pixels (a 16x4 strip in the wave-per-tile rasteriser) is covered
     if (hit && T >= t_eps) {
@@ -839,7 +854,7 @@ __device__ __forceinline__ float ms_inside(const float x, const float big, const
     asm("v_fma_f32 %0, -|%1|, %2, %3 clamp" : "=v"(r) : "v"(x), "v"(big), "v"(limbig));
     return r;
 }
-template <int VARIANT, bool DEPTH>
+template <int VARIANT, bool DEPTH, bool BBOX = false>
 __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, const float qx, const float qy,
                                             const float aspect, const float t_eps, PxMs& t, v2f& crg, float& cb,
                                             const float z, const bool zmixed, const float4 dpx) {
@@ -883,6 +898,10 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
         du0 = s.a0.y * MS_OX0; du1 = s.a0.y * MS_OX1; dv0 = s.a0.w * MS_OY0; dv1 = s.a0.w * MS_OY1;
     }
     const float gmax = fmaxf(fabsf(u), fabsf(v));
+    if constexpr (BBOX) {   // the fragment at the pixel centre is the quad's frame (see blend_px)
+        const bool frame = gmax > BBOX_EDGE * lim;
+        alpha = frame ? 1.0f : alpha; r = frame ? 0.3f : r; g = frame ? 1.0f : g; b = frame ? 0.1f : b;
+    }
     // beyond lim + m no sample of the pixel is covered; within lim - m all four are
     if (gmax <= lim + m && ok && t.S * t.rb >= t_eps) {
         asm volatile("");  // keeps this a branch (see blend_px)
@@ -915,6 +934,130 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
         cb = fmaf(w, b, cb);
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// Msaa::Sample2 and Msaa::Sample8 (Bevy's `Msaa` enum feeds MultisampleState.count unfiltered: src/render/mod.rs:357,
+// 412-424, 975-979): the same scheme with N samples at the graphics APIs' standard positions, written out generally (no
+// symmetric pairs to exploit at 8x). Offsets from the pixel centre:
+//   2x  (+1/4, +1/4) (-1/4, -1/4)
+//   8x  (+1, -3) (-1, +3) (+5, +1) (-3, -5) (-5, +5) (-7, -1) (+3, +7) (+7, -7)  / 16
+// The 4x instantiations above stay as they are (the headline's inner loop); nothing in the reference selects 2 or 8.
+// ---------------------------------------------------------------------------------------
+template <int NS> struct PxMsN { float S, rb, r[NS]; };
+template <int NS> __device__ constexpr float ms_ox(const int k) {
+    constexpr float o2[2] = {0.25f, -0.25f};
+    constexpr float o8[8] = {0.0625f, -0.0625f, 0.3125f, -0.1875f, -0.3125f, -0.4375f, 0.1875f, 0.4375f};
+    return NS == 2 ? o2[k & 1] : o8[k & 7];
+}
+template <int NS> __device__ constexpr float ms_oy(const int k) {
+    constexpr float o2[2] = {0.25f, -0.25f};
+    constexpr float o8[8] = {-0.1875f, 0.1875f, 0.0625f, -0.3125f, 0.3125f, -0.0625f, 0.4375f, -0.4375f};
+    return NS == 2 ? o2[k & 1] : o8[k & 7];
+}
+// largest |offset| component of the pattern (the axis-aligned variants' margin), and the half extent of the box a tile's
+// sample positions span around the tile centre
+constexpr float ms_reach(const int ns) { return ns == 1 ? 0.0f : ns == 2 ? 0.25f : ns == 4 ? 0.375f : 0.4375f; }
+// largest |change of u| between the pixel centre and one of its samples, u = a x + b y
+template <int NS> __device__ __forceinline__ float ms_margin_n(const float a, const float b) {
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) m = fmaxf(m, fabsf(fmaf(b, ms_oy<NS>(k), a * ms_ox<NS>(k))));
+    return m;
+}
+template <int VARIANT, bool DEPTH, int NS, bool BBOX>
+__device__ __forceinline__ void blend_px_msn(const StagedRecord<VARIANT>& s, const float qx, const float qy,
+                                             const float aspect, const float t_eps, PxMsN<NS>& t, v2f& crg, float& cb,
+                                             const float z, const bool zmixed, const float* __restrict__ dpx) {
+    float u, v, lim, m, alpha, r, g, b, au, bu_, av, bv_;   // u = au x + bu y (+ const), v = av x + bv y (+ const)
+    bool ok = true;
+    if constexpr (VARIANT == RV_OBB) {
+        u = fmaf(s.a0.w, qy, fmaf(s.a0.z, qx, s.a0.x));
+        v = fmaf(s.a1.y, qy, fmaf(s.a1.x, qx, s.a0.y));
+        lim = OBB_C;
+        m = s.a1.z;
+        const float e = __builtin_amdgcn_exp2f(-fmaf(u, u, v * v));
+        alpha = fminf(e * s.a2.z, 0.999f);
+        r = s.a1.w; g = s.a2.x; b = s.a2.y;
+        au = s.a0.z; bu_ = s.a0.w; av = s.a1.x; bv_ = s.a1.y;
+    } else if constexpr (VARIANT == RV_AABB3D) {
+        const float dx = qx - s.a0.x, dy = qy - s.a0.y;
+        u = s.a0.z * dx; v = s.a0.w * dy;
+        lim = 1.0f;
+        m = ms_reach(NS) * fmaxf(fabsf(s.a0.z), fabsf(s.a0.w));
+        const float power = fmaf(s.a1.y * u, v, -0.5f * fmaf(s.a1.x * u, u, s.a1.z * v * v));
+        ok = !(power > 0.0f);
+        alpha = fminf(__expf(power) * s.a2.z, 0.999f);
+        r = s.a1.w; g = s.a2.x; b = s.a2.y;
+        au = s.a0.z; bu_ = 0.0f; av = 0.0f; bv_ = s.a0.w;
+    } else {
+        u = fmaf(s.a0.y, qx, s.a0.x); v = fmaf(s.a0.w, qy, s.a0.z);
+        lim = 1.0f;
+        m = ms_reach(NS) * fmaxf(fabsf(s.a0.y), fabsf(s.a0.w));
+        const float px = fmaf(s.a2.z, qy, fmaf(s.a1.w, qx, s.a1.x));
+        const float py = fmaf(s.a2.w, qy, fmaf(s.a2.x, qx, s.a1.y));
+        const float pz = fmaf(s.a3.x, qy, fmaf(s.a2.y, qx, s.a1.z));
+        const float icz = __builtin_amdgcn_rcpf(pz);
+        const float us = px * icz, vs = py * icz;
+        const float ddx = fmaf(s.a3.z, qx, s.a3.y), ddy = fmaf(s.a4.x, qy, s.a3.w);
+        const float s3 = fmaf(us, us, vs * vs);
+        const float s2 = fmaf(ddx, ddx, ddy * ddy);
+        alpha = fminf(__builtin_amdgcn_exp2f(-fminf(s3, s2)) * s.a5.x, 0.999f);
+        r = s.a4.y; g = s.a4.z; b = s.a4.w;
+        au = s.a0.y; bu_ = 0.0f; av = 0.0f; bv_ = s.a0.w;
+    }
+    const float gmax = fmaxf(fabsf(u), fabsf(v));
+    if constexpr (BBOX) {
+        const bool frame = gmax > BBOX_EDGE * lim;
+        alpha = frame ? 1.0f : alpha; r = frame ? 0.3f : r; g = frame ? 1.0f : g; b = frame ? 0.1f : b;
+    }
+    if (gmax <= lim + m && ok && t.S * t.rb >= t_eps) {
+        asm volatile("");  // keeps this a branch (see blend_px)
+        const bool full = gmax <= lim - m;
+        float w;
+        if (!(DEPTH && zmixed) && __builtin_amdgcn_ballot_w64(!full) == 0ull) {
+            w = (t.S * t.rb) * alpha;
+            t.S = fmaf(-alpha, t.S, t.S);
+        } else {
+            const float big = 1.152921504606846976e18f, limbig = lim * 1.152921504606846976e18f;   // 2^60
+            float ts[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const float du = fmaf(bu_, ms_oy<NS>(k), au * ms_ox<NS>(k)), dv = fmaf(bv_, ms_oy<NS>(k), av * ms_ox<NS>(k));
+                float c = ms_inside(u + du, big, limbig) * ms_inside(v + dv, big, limbig) * t.r[k];
+                if constexpr (DEPTH) c = z >= dpx[k] ? c : 0.0f;
+                ts[k] = c;
+            }
+            float sum;
+            if constexpr (NS == 2) sum = ts[0] + ts[1];
+            else sum = ((ts[0] + ts[1]) + (ts[2] + ts[3])) + ((ts[4] + ts[5]) + (ts[6] + ts[7]));
+            const float aq = (1.0f / (float)NS) * alpha;
+            w = (t.S * aq) * sum;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) t.r[k] = fmaf(-alpha, ts[k], t.r[k]);
+            t.rb = fmaf(-aq, sum, t.rb);
+        }
+        crg = __builtin_elementwise_fma((v2f){w, w}, (v2f){r, g}, crg);
+        cb = fmaf(w, b, cb);
+    }
+}
+// the per-pixel transmittance state of a rasteriser instantiation, and one blend of it
+template <int MSAA> struct TransOf { typedef PxMsN<MSAA> type; };
+template <> struct TransOf<1> { typedef float type; };
+template <> struct TransOf<4> { typedef PxMs type; };
+template <int MSAA> __device__ __forceinline__ typename TransOf<MSAA>::type trans_init(const bool inside) {
+    if constexpr (MSAA == 1) return inside ? 1.0f : 0.0f;
+    else if constexpr (MSAA == 4) return PxMs{inside ? 1.0f : 0.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+    else {
+        PxMsN<MSAA> t;
+        t.S = inside ? 1.0f : 0.0f; t.rb = 1.0f;
+#pragma unroll
+        for (int k = 0; k < MSAA; ++k) t.r[k] = 1.0f;
+        return t;
+    }
+}
+__device__ __forceinline__ float trans_mean(const float T) { return T; }
+__device__ __forceinline__ float trans_mean(const PxMs& T) { return T.S * T.rb; }
+template <int NS> __device__ __forceinline__ float trans_mean(const PxMsN<NS>& T) { return T.S * T.rb; }
 
 // Rgba8UnormSrgb packing of one premultiplied linear pixel (shared by the rasteriser's fused output and
 // encode_srgb8_kernel, so both give the same bytes)
@@ -962,7 +1105,9 @@ __device__ __forceinline__ uint32_t xcd_remap_runs(const uint32_t b, const uint3
 //   A kept record's depth is > 0 (in_frustum), so the sign bit is the flag.
 template <int MSAA>
 __device__ __forceinline__ void stage_obb_margin(const float4& r0, float4& r1) {
-    r1.z = MSAA == 4 ? fmaxf(ms_margin(r0.z, r0.w), ms_margin(r1.x, r1.y)) : 0.0f;
+    if constexpr (MSAA == 4) r1.z = fmaxf(ms_margin(r0.z, r0.w), ms_margin(r1.x, r1.y));
+    else if constexpr (MSAA == 1) r1.z = 0.0f;
+    else r1.z = fmaxf(ms_margin_n<MSAA>(r0.z, r0.w), ms_margin_n<MSAA>(r1.x, r1.y));
 }
 __device__ __forceinline__ float keepz_of(const bool keep, const float z) { return keep ? z : -1.0f; }
 __device__ __forceinline__ bool keepz_keeps(const float keepz) { return (int32_t)__float_as_uint(keepz) >= 0; }
@@ -982,7 +1127,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // BINNING_SORT rasteriser: one workgroup per tile, one pixel per thread; the tile's instances are
 // a contiguous range of the tile-sorted list, staged 256 records at a time in LDS.
 // MSAA: samples per pixel (1 or 4, blend_px_ms); DEPTH: test against the view's depth buffer (fp.depth_ptr).
-template <int VARIANT, int MSAA, bool DEPTH>
+template <int VARIANT, int MSAA, bool DEPTH, bool BBOX>
 __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float4* __restrict__ records,
                                                      const uint2* __restrict__ instances,
                                                      const uint2* __restrict__ ranges,
@@ -1006,20 +1151,28 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     const uint2 range = ranges[(ty << 8) | tx];
     const float t_eps = frame_t_eps(ctl->color_max_bits);
     const float surfel_limit = frame_surfel_limit(ctl->color_max_bits);
-    float T = in_image ? 1.0f : 0.0f, cb = 0.0f;
-    PxMs tm{T, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+    float cb = 0.0f;
+    typename TransOf<MSAA>::type tm = trans_init<MSAA>(in_image);
     v2f crg = {0.0f, 0.0f};
     // the pixel's scene depth(s) and the tile's range of them (what a record's constant depth is compared with first)
     float4 dpx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    [[maybe_unused]] float dpn[MSAA];   // Sample2 / Sample8
+#pragma unroll
+    for (int k = 0; k < MSAA; ++k) dpn[k] = 0.0f;
     float tile_dmin = 0.0f, tile_dmax = 0.0f;
     if constexpr (DEPTH) {
         float lo = INFINITY, hi = -INFINITY;
         if (in_image) {
             const float* dsrc = reinterpret_cast<const float*>(fp.depth_ptr) + ((size_t)py * (size_t)fp.width + (size_t)px) * MSAA;
             if constexpr (MSAA == 4) dpx = *reinterpret_cast<const float4*>(dsrc);
-            else dpx.x = dpx.y = dpx.z = dpx.w = dsrc[0];
-            lo = fminf(fminf(dpx.x, dpx.y), fminf(dpx.z, dpx.w));
-            hi = fmaxf(fmaxf(dpx.x, dpx.y), fmaxf(dpx.z, dpx.w));
+            else if constexpr (MSAA == 1) dpx.x = dpx.y = dpx.z = dpx.w = dsrc[0];
+            if constexpr (MSAA == 1 || MSAA == 4) {
+                lo = fminf(fminf(dpx.x, dpx.y), fminf(dpx.z, dpx.w));
+                hi = fmaxf(fmaxf(dpx.x, dpx.y), fmaxf(dpx.z, dpx.w));
+            } else {
+#pragma unroll
+                for (int k = 0; k < MSAA; ++k) { dpn[k] = dsrc[k]; lo = fminf(lo, dpn[k]); hi = fmaxf(hi, dpn[k]); }
+            }
         }
         lo = wave_min(lo); hi = wave_max(hi);
         if ((tid & 63) == 0) { s_zr[tid >> 6][0] = lo; s_zr[tid >> 6][1] = hi; }
@@ -1027,7 +1180,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
         tile_dmin = fminf(fminf(s_zr[0][0], s_zr[1][0]), fminf(s_zr[2][0], s_zr[3][0]));
         tile_dmax = fmaxf(fmaxf(s_zr[0][1], s_zr[1][1]), fmaxf(s_zr[2][1], s_zr[3][1]));
     }
-    auto saturated = [&]() { return MSAA == 4 ? tm.S * tm.rb < t_eps : T < t_eps; };
+    auto saturated = [&]() { return trans_mean(tm) < t_eps; };
 
     for (uint32_t base = range.x; base < range.y; base += 256u) {
         const uint32_t cnt = min(256u, range.y - base);
@@ -1065,8 +1218,9 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
                 const float keepz = VARIANT == RV_SURFEL ? sr.a5.y : sr.a2.w;
                 const float zr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(keepz)));
                 if (!keepz_keeps(zr)) continue;
-                if constexpr (MSAA == 4) blend_px_ms<VARIANT, DEPTH>(sr, qx, qy, aspect, t_eps, tm, crg, cb, zr, DEPTH && zr < tile_dmax, dpx);
-                else blend_px<VARIANT, DEPTH>(sr, qx, qy, aspect, t_eps, T, crg, cb, zr, dpx.x);
+                if constexpr (MSAA == 4) blend_px_ms<VARIANT, DEPTH, BBOX>(sr, qx, qy, aspect, t_eps, tm, crg, cb, zr, DEPTH && zr < tile_dmax, dpx);
+                else if constexpr (MSAA == 1) blend_px<VARIANT, DEPTH, BBOX>(sr, qx, qy, aspect, t_eps, tm, crg, cb, zr, dpx.x);
+                else blend_px_msn<VARIANT, DEPTH, MSAA, BBOX>(sr, qx, qy, aspect, t_eps, tm, crg, cb, zr, DEPTH && zr < tile_dmax, dpn);
             }
         // also the barrier that protects s_rec before the next batch overwrites it
         if (__syncthreads_and(saturated() ? 1 : 0)) break;
@@ -1074,7 +1228,7 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
     if (in_image) {
         // dst = src + dst*(1-src.a) unrolled over the whole list, target cleared to `clear`; multisampled: the mean
         // of the samples, C + clear * mean_s(T_s)
-        const float Tf = MSAA == 4 ? tm.S * tm.rb : T;
+        const float Tf = trans_mean(tm);
         fb[(size_t)py * (size_t)fp.width + (size_t)px] =
             make_float4(fmaf(Tf, clear.x, crg.x), fmaf(Tf, clear.y, crg.y), fmaf(Tf, clear.z, cb),
                         fmaf(Tf, clear.w, 1.0f - Tf));
@@ -1154,7 +1308,14 @@ __device__ __forceinline__ bool all_saturated(const PxMs (&T)[ROWS], const float
 // once (single-sampled: a register per pixel; 4x: 4 KB of the wave's LDS, s_depth), a record is compared with the
 // tile's [min, max] first: behind everything -> dropped at staging, in front of everything -> the plain path, in between
 // -> the per-sample path.
-template <int VARIANT, bool TRACE, bool MIDROUND_EXIT, int ROWS, int MSAA, bool DEPTH>
+template <int ROWS, int NS>
+__device__ __forceinline__ bool all_saturated(const PxMsN<NS> (&T)[ROWS], const float t_eps) {
+    bool s = true;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) s = s && T[r].S * T[r].rb < t_eps;
+    return s;
+}
+template <int VARIANT, bool TRACE, bool MIDROUND_EXIT, int ROWS, int MSAA, bool DEPTH, bool BBOX>
 __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const float4* __restrict__ records,
                                                const uint32_t* __restrict__ coarse, const uint32_t coarse_cap,
                                                const uint32_t sup_mul, const uint32_t sup_x, Control* ctl,
@@ -1167,7 +1328,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     constexpr uint32_t STAGE = 64u;
     constexpr bool ABLATE = BGS_ABLATION != 0;
     // half extent of the box the tile's sample positions span around the tile centre (the exact quad-vs-tile test)
-    constexpr float HALF = MSAA == 4 ? 7.875f : 7.5f;
+    constexpr float HALF = 7.5f + ms_reach(MSAA);
 
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
     const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + row0 + (lane >> 4);
@@ -1178,8 +1339,9 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     const float tile_ox = (float)((int)tx * TILE_PX) + 0.5f, tile_oy = (float)((int)ty * TILE_PX) + 0.5f;
 
     // per-pixel transmittance: one number (single-sampled target) or PxMs (4x)
-    typedef typename std::conditional<MSAA == 4, PxMs, float>::type Trans;
+    typedef typename TransOf<MSAA>::type Trans;
     Trans T[ROWS];
+    float* const s_depth_f = reinterpret_cast<float*>(s_depth);   // Sample2 / Sample8: MSAA floats per pixel, pixel = r * 64 + lane
     float cb[ROWS], qy[ROWS], dpx[ROWS];
     v2f crg[ROWS];
     float tile_dmin = 0.0f, tile_dmax = 0.0f;
@@ -1190,12 +1352,11 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             const int py = py0 + 4 * r;
             qy[r] = VARIANT != RV_AABB3D ? (float)(row0 + (lane >> 4) + 4 * r) : (float)py + 0.5f;
             const bool inside = px < fp.width && py < fp.height;
-            if constexpr (MSAA == 4) T[r] = PxMs{inside ? 1.0f : 0.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
-            else T[r] = inside ? 1.0f : 0.0f;
+            T[r] = trans_init<MSAA>(inside);
             crg[r] = (v2f){0.0f, 0.0f};
             cb[r] = 0.0f;
             dpx[r] = 0.0f;
-            if constexpr (DEPTH) {
+            if constexpr (DEPTH && (MSAA == 1 || MSAA == 4)) {
                 float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (inside) {
                     const float* dsrc = reinterpret_cast<const float*>(fp.depth_ptr) + ((size_t)py * (size_t)fp.width + (size_t)px) * MSAA;
@@ -1206,6 +1367,14 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                 }
                 if constexpr (MSAA == 4) s_depth[r * 64 + lane] = d;
                 else dpx[r] = d.x;
+            } else if constexpr (DEPTH) {
+                const float* dsrc = reinterpret_cast<const float*>(fp.depth_ptr) + ((size_t)py * (size_t)fp.width + (size_t)px) * MSAA;
+#pragma unroll
+                for (int k = 0; k < MSAA; ++k) {
+                    const float d = inside ? dsrc[k] : 0.0f;
+                    if (inside) { lo = fminf(lo, d); hi = fmaxf(hi, d); }
+                    s_depth_f[(r * 64 + lane) * MSAA + k] = d;
+                }
             }
         }
         if constexpr (DEPTH) {
@@ -1334,9 +1503,12 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                     if constexpr (MSAA == 4) {
                         float4 d4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         if constexpr (DEPTH) if (zmixed) d4 = s_depth[r * 64 + lane];
-                        blend_px_ms<VARIANT, DEPTH>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, zmixed, d4);
+                        blend_px_ms<VARIANT, DEPTH, BBOX>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, zmixed, d4);
+                    } else if constexpr (MSAA == 1) {
+                        blend_px<VARIANT, DEPTH, BBOX>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, dpx[r]);
                     } else {
-                        blend_px<VARIANT, DEPTH>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, dpx[r]);
+                        blend_px_msn<VARIANT, DEPTH, MSAA, BBOX>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, zmixed,
+                                                                 s_depth_f + (r * 64 + lane) * MSAA);
                     }
                 }
                 if constexpr (MIDROUND_EXIT)
@@ -1362,8 +1534,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             const int py = pyw + 4 * r;
             if (pxw < fp.width && py < fp.height) {
                 // (multisampled: the resolve — the mean of the samples is C + clear * mean_s(T_s))
-                float Tf;
-                if constexpr (MSAA == 4) Tf = T[r].S * T[r].rb; else Tf = T[r];
+                const float Tf = trans_mean(T[r]);
                 const float4 c = make_float4(fmaf(Tf, fp.clear[0], crg[r].x), fmaf(Tf, fp.clear[1], crg[r].y),
                                              fmaf(Tf, fp.clear[2], cb[r]), fmaf(Tf, fp.clear[3], 1.0f - Tf));
                 const size_t at = (size_t)py * (size_t)fp.width + (size_t)pxw;
@@ -1394,13 +1565,14 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
 // Waves per SIMD: 8 for the single-sampled ellipse variants (<= 64 VGPRs), 6 for the surfel variant; the multisampled
 // instantiations carry six transmittance words per pixel instead of one (5 / 4 waves).
 constexpr int raster_waves_per_simd(const int variant, const int msaa, const bool depth) {
-    return msaa == 4 ? (variant == 2 ? (depth ? 3 : 4) : 5) : (variant == 2 ? (depth ? 5 : 6) : (depth ? 7 : 8));
+    return msaa == 8 ? (variant == 2 ? (depth ? 2 : 3) : (depth ? 3 : 4))   // ten transmittance words per pixel; 8 KB of depth samples per wave
+         : msaa >= 2 ? (variant == 2 ? (depth ? 3 : 4) : 5) : (variant == 2 ? (depth ? 5 : 6) : (depth ? 7 : 8));
 }
 int raster_scan_waves_per_simd(const FrameParams& fp) {
     const int variant = fp.aabb == 0u ? RV_OBB : (fp.gaussian_mode != 0u ? RV_AABB3D : RV_SURFEL);
-    return raster_waves_per_simd(variant, fp.sample_count == 4u ? 4 : 1, fp.depth_ptr != 0ull);
+    return raster_waves_per_simd(variant, (int)fp.sample_count, fp.depth_ptr != 0ull);
 }
-template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false, int MSAA = 1, bool DEPTH = false>
+template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false, int MSAA = 1, bool DEPTH = false, bool BBOX = false>
 __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_mul,
@@ -1420,7 +1592,7 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
     constexpr uint32_t STAGE = 64u;
     __shared__ float4 s_rec_all[4][STAGE * REC_V4];
     __shared__ uint32_t s_queue_all[4][64];
-    __shared__ float4 s_depth_all[4][DEPTH && MSAA == 4 ? 256 : 1];   // the tile's depth samples (raster_tile)
+    __shared__ float4 s_depth_all[4][DEPTH && MSAA > 1 ? 64 * MSAA : 1];   // the tile's depth samples (raster_tile): MSAA floats per pixel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
@@ -1503,12 +1675,12 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
         uint32_t rounds;
         bool reports = true;   // which wave speaks for the tile in the feedback
         if (MIDROUND_EXIT && strip_block) {
-            rounds = raster_tile<VARIANT, false, MIDROUND_EXIT, 1, MSAA, DEPTH>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
+            rounds = raster_tile<VARIANT, false, MIDROUND_EXIT, 1, MSAA, DEPTH, BBOX>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
                                                                    t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 4 * wave,
                                                                    trace_scanned, trace_blended, trace_staged, work);
             reports = wave == 0;
         } else {
-            rounds = raster_tile<VARIANT, TRACE, MIDROUND_EXIT, 4, MSAA, DEPTH>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
+            rounds = raster_tile<VARIANT, TRACE, MIDROUND_EXIT, 4, MSAA, DEPTH, BBOX>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
                                                                    t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 0,
                                                                    trace_scanned, trace_blended, trace_staged, work);
             tile_done = tile;
@@ -1589,7 +1761,7 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint16_t* __restr
 void launch_tile_order(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, const FrameParams& fp,
                        bool midround_exit) {
     const int variant = fp.aabb == 0u ? RV_OBB : (fp.gaussian_mode != 0u ? RV_AABB3D : RV_SURFEL);
-    launch_tile_order_runs(stream, cost, order, ntiles, raster_runs(variant, fp.sample_count == 4u ? 4 : 1, midround_exit));
+    launch_tile_order_runs(stream, cost, order, ntiles, raster_runs(variant, (int)fp.sample_count, midround_exit));
 }
 
 void launch_tile_order_runs(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, uint32_t runs) {
@@ -1605,28 +1777,54 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
                         uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace, bool midround_exit,
                         const uint8_t* heavy_in, uint8_t* heavy_out, const uint16_t* order, uint16_t* cost_out) {
-    if (!midround_exit) { heavy_in = nullptr; heavy_out = nullptr; }
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
     const float4* rec = (const float4*)records;
     const uint32_t sup = sup_edge, sup_mul = supertile_mul(sup_edge);
     const uint32_t sup_x = ((uint32_t)fp.tiles_x + sup - 1u) / sup;
     // instantiations: variant x mid-round exit x samples per pixel; the per-tile trace exists for the variants without a
-    // depth buffer, the depth test for the untraced ones
-    const bool msaa4 = fp.sample_count == 4u, depth = fp.depth_ptr != 0ull;
-#define BGS_LAUNCH_RS4(V, X, TR, MS, DP)                                                          \
-    hipLaunchKernelGGL((raster_scan_kernel<V, TR, X, MS, DP>), dim3(grid), dim3(256), 0, stream, d_fp, rec, coarse,      \
+    // depth buffer, the depth test for the untraced ones. Sample2 / Sample8 and the bounding-box overlay (debug features:
+    // nothing in the reference selects them by default) come untraced and without the mid-round exit only — the caller
+    // (enqueue_frame) never asks those frames for either.
+    const bool depth = fp.depth_ptr != 0ull, bbox = fp.visualize_bbox != 0u;
+    const uint32_t ms = fp.sample_count;
+    const bool plain = (ms == 1u || ms == 4u) && !bbox;
+    if (!plain) midround_exit = false;
+    if (!midround_exit) { heavy_in = nullptr; heavy_out = nullptr; }
+#define BGS_LAUNCH_RS4(V, X, TR, MS, DP, BB)                                                      \
+    hipLaunchKernelGGL((raster_scan_kernel<V, TR, X, MS, DP, BB>), dim3(grid), dim3(256), 0, stream, d_fp, rec, coarse,      \
                        coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (TR) ? tile_trace : (uint4*)nullptr, heavy_in, heavy_out, order, cost_out)
 #define BGS_LAUNCH_RS(V, X)                                                                       \
     do {                                                                                          \
         const uint32_t grid = (ntiles + 3u) / 4u + ((X) && heavy_in ? HEAVY_CAP : 0u);            \
-        if (depth) { if (msaa4) BGS_LAUNCH_RS4(V, X, false, 4, true); else BGS_LAUNCH_RS4(V, X, false, 1, true); } \
-        else if (tile_trace) { if (msaa4) BGS_LAUNCH_RS4(V, X, true, 4, false); else BGS_LAUNCH_RS4(V, X, true, 1, false); } \
-        else { if (msaa4) BGS_LAUNCH_RS4(V, X, false, 4, false); else BGS_LAUNCH_RS4(V, X, false, 1, false); } \
+        const bool msaa4 = ms == 4u;                                                              \
+        if (depth) { if (msaa4) BGS_LAUNCH_RS4(V, X, false, 4, true, false); else BGS_LAUNCH_RS4(V, X, false, 1, true, false); } \
+        else if (tile_trace) { if (msaa4) BGS_LAUNCH_RS4(V, X, true, 4, false, false); else BGS_LAUNCH_RS4(V, X, true, 1, false, false); } \
+        else { if (msaa4) BGS_LAUNCH_RS4(V, X, false, 4, false, false); else BGS_LAUNCH_RS4(V, X, false, 1, false, false); } \
     } while (0)
-    if (fp.aabb == 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_OBB, true); else BGS_LAUNCH_RS(RV_OBB, false); }
+    // the rarely used instantiations: V x samples {1, 2, 4, 8} x depth x overlay, minus the plain ones above
+#define BGS_LAUNCH_RSX(V)                                                                         \
+    do {                                                                                          \
+        const uint32_t grid = (ntiles + 3u) / 4u;                                                 \
+        if (bbox) {                                                                               \
+            if (depth) { if (ms == 1u) BGS_LAUNCH_RS4(V, false, false, 1, true, true); else if (ms == 2u) BGS_LAUNCH_RS4(V, false, false, 2, true, true); \
+                         else if (ms == 4u) BGS_LAUNCH_RS4(V, false, false, 4, true, true); else BGS_LAUNCH_RS4(V, false, false, 8, true, true); } \
+            else { if (ms == 1u) BGS_LAUNCH_RS4(V, false, false, 1, false, true); else if (ms == 2u) BGS_LAUNCH_RS4(V, false, false, 2, false, true); \
+                   else if (ms == 4u) BGS_LAUNCH_RS4(V, false, false, 4, false, true); else BGS_LAUNCH_RS4(V, false, false, 8, false, true); } \
+        } else {                                                                                  \
+            if (depth) { if (ms == 2u) BGS_LAUNCH_RS4(V, false, false, 2, true, false); else BGS_LAUNCH_RS4(V, false, false, 8, true, false); } \
+            else { if (ms == 2u) BGS_LAUNCH_RS4(V, false, false, 2, false, false); else BGS_LAUNCH_RS4(V, false, false, 8, false, false); } \
+        }                                                                                         \
+    } while (0)
+    if (!plain) {
+        if (fp.aabb == 0u) BGS_LAUNCH_RSX(RV_OBB);
+        else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RSX(RV_AABB3D);
+        else BGS_LAUNCH_RSX(RV_SURFEL);
+    }
+    else if (fp.aabb == 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_OBB, true); else BGS_LAUNCH_RS(RV_OBB, false); }
     else if (fp.gaussian_mode != 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_AABB3D, true); else BGS_LAUNCH_RS(RV_AABB3D, false); }
     else BGS_LAUNCH_RS(RV_SURFEL, false);
+#undef BGS_LAUNCH_RSX
 #undef BGS_LAUNCH_RS
 #undef BGS_LAUNCH_RS4
 }
@@ -1638,19 +1836,26 @@ void launch_raster(hipStream_t stream, const FrameParams& fp, const void* record
     if (ntiles == 0) return;
     const float4 clear = make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]);
     const float4* rec = (const float4*)records;
-    const bool msaa4 = fp.sample_count == 4u, depth = fp.depth_ptr != 0ull;
-#define BGS_LAUNCH_R(V, MS, DP)                                                                                     \
-    hipLaunchKernelGGL((raster_kernel<V, MS, DP>), dim3(ntiles), dim3(256), 0, stream, fp, rec, instances, ranges, \
+    const bool depth = fp.depth_ptr != 0ull, bbox = fp.visualize_bbox != 0u;
+    const uint32_t ms = fp.sample_count;
+#define BGS_LAUNCH_R(V, MS, DP, BB)                                                                                     \
+    hipLaunchKernelGGL((raster_kernel<V, MS, DP, BB>), dim3(ntiles), dim3(256), 0, stream, fp, rec, instances, ranges, \
                        framebuffer, clear, ctl)
+#define BGS_LAUNCH_R3(V, MS)                                                                      \
+    do {                                                                                          \
+        if (bbox) { if (depth) BGS_LAUNCH_R(V, MS, true, true); else BGS_LAUNCH_R(V, MS, false, true); }   \
+        else { if (depth) BGS_LAUNCH_R(V, MS, true, false); else BGS_LAUNCH_R(V, MS, false, false); }      \
+    } while (0)
 #define BGS_LAUNCH_R2(V)                                                                          \
     do {                                                                                          \
-        if (msaa4) { if (depth) BGS_LAUNCH_R(V, 4, true); else BGS_LAUNCH_R(V, 4, false); }       \
-        else { if (depth) BGS_LAUNCH_R(V, 1, true); else BGS_LAUNCH_R(V, 1, false); }             \
+        if (ms == 4u) BGS_LAUNCH_R3(V, 4); else if (ms == 1u) BGS_LAUNCH_R3(V, 1);               \
+        else if (ms == 2u) BGS_LAUNCH_R3(V, 2); else BGS_LAUNCH_R3(V, 8);                        \
     } while (0)
     if (fp.aabb == 0u) BGS_LAUNCH_R2(RV_OBB);
     else if (fp.gaussian_mode != 0u) BGS_LAUNCH_R2(RV_AABB3D);
     else BGS_LAUNCH_R2(RV_SURFEL);
 #undef BGS_LAUNCH_R2
+#undef BGS_LAUNCH_R3
 #undef BGS_LAUNCH_R
 }
 

@@ -135,7 +135,8 @@ class BgsSettings(ctypes.Structure):
         ("rasterize_mode", ctypes.c_uint32),
         ("num_classes", ctypes.c_uint32),
         ("draw_mode", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32 * 2),
+        ("visualize_bounding_box", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32 * 1),
         ("position_min", ctypes.c_float * 4),
         ("position_max", ctypes.c_float * 4),
     ]
@@ -158,7 +159,7 @@ class CloudSettings:
     global_opacity: float = 1.0
     global_scale: float = 1.0
     opacity_adaptive_radius: bool = True
-    visualize_bounding_box: bool = False  # carried, not rendered (debug overlay)
+    visualize_bounding_box: bool = False  # the quads' frames drawn over the splats (src/render/gaussian.wgsl:486-495)
     sort_mode: SortMode = SortMode.Radix
     radix_sort_depth_bits: RadixSortDepthBits = RadixSortDepthBits.Bits32
     draw_mode: DrawMode = DrawMode.All
@@ -196,6 +197,7 @@ class CloudSettings:
         s.rasterize_mode = int(self.rasterize_mode)
         s.num_classes = int(self.num_classes)
         s.draw_mode = int(self.draw_mode)
+        s.visualize_bounding_box = 1 if self.visualize_bounding_box else 0
         s.position_min[:] = [float(v) for v in self.position_min] + [1.0]
         s.position_max[:] = [float(v) for v in self.position_max] + [1.0]
         return s

@@ -75,19 +75,18 @@ typedef struct bgs_view {
     float previous_clip_from_world[16];
     float delta_time;
     /* The camera's `Msaa` component as the pipeline is specialised on it: CloudPipelineKey.sample_count =
-     * msaa.samples() (src/render/mod.rs:357,412,422) -> MultisampleState.count (:975-979). 1 = Msaa::Off, 4 =
-     * Msaa::Sample4 — Bevy's default, i.e. what every camera of the reference's examples and tests runs with
-     * (nothing in the reference sets Msaa; src/utils.rs:34 `msaa_samples` is never read). With 4 samples coverage
-     * (and the depth test) is decided per sample at the standard sample positions, the fragment stage runs once
-     * per pixel at the pixel centre, every covered sample blends the same source colour, and the image handed
-     * back is the resolved one (mean of the samples). 0 (a zero-initialised bgs_view) means "not set" and renders
-     * with Msaa::default() = 4; anything else but 1 or 4 is BGS_EINVAL (Sample2 / Sample8 are not built).
-     * bgs_view_perspective sets 4. */
+     * msaa.samples() (src/render/mod.rs:357,412,422) -> MultisampleState.count (:975-979). 1 = Msaa::Off, 2 / 4 / 8 =
+     * Msaa::Sample2 / Sample4 / Sample8; 4 is Bevy's default, i.e. what every camera of the reference's examples and
+     * tests runs with (nothing in the reference sets Msaa; src/utils.rs:34 `msaa_samples` is never read). With N > 1
+     * samples coverage (and the depth test) is decided per sample at the graphics APIs' standard sample positions, the
+     * fragment stage runs once per pixel at the pixel centre, every covered sample blends the same source colour, and
+     * the image handed back is the resolved one (mean of the samples). 0 (a zero-initialised bgs_view) means "not set"
+     * and renders with Msaa::default() = 4; anything else is BGS_EINVAL. bgs_view_perspective sets 4. */
     uint32_t sample_count;
     uint32_t reserved[2];
     /* The view's depth attachment the draw is tested against (src/render/mod.rs:959-974: Depth32Float,
      * CompareFunction::GreaterEqual — reverse-Z —, depth_write_enabled false): a DEVICE pointer to
-     * viewport.w * viewport.h * sample_count floats laid out [y][x][sample] (what Bevy's opaque passes left), or
+     * viewport.w * viewport.h * sample_count floats laid out [y][x][sample] (sample order: the standard pattern's) (what Bevy's opaque passes left), or
      * 0 = no scene depth (every fragment passes, as against a buffer cleared to 0.0). A quad's depth is its
      * splat's constant NDC z (src/render/gaussian.wgsl:429-433). The memory must stay valid and unchanged until
      * the frame has completed (bgs_device_alloc / bgs_upload below serve hosts without a HIP runtime). */
@@ -140,7 +139,10 @@ typedef struct bgs_settings {
     uint32_t rasterize_mode;          /* BGS_RASTERIZE_COLOR default   settings.rs:38-47 */
     uint32_t num_classes;             /* default 1 (Classification)    settings.rs:124   */
     uint32_t draw_mode;               /* BGS_DRAW_ALL default          settings.rs:6-12  */
-    uint32_t reserved[2];
+    uint32_t visualize_bounding_box;  /* default 0: VISUALIZE_BOUNDING_BOX (settings.rs:95,117; key bit
+                                         src/render/mod.rs:418,824; src/render/gaussian.wgsl:486-495): fragments in the
+                                         outer 8 % of a quad's uv square are (0.3, 1, 0.1, 1) — the quads' frames  */
+    uint32_t reserved[1];
     float position_min[4];            /* CloudUniform.min/max = the cloud entity's Aabb   */
     float position_max[4];            /* (src/render/mod.rs:1070-1071); Position mode     */
 } bgs_settings;

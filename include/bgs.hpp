@@ -72,6 +72,7 @@ struct CloudSettings {
     float global_opacity = 1.0f;
     float global_scale = 1.0f;
     bool opacity_adaptive_radius = true;
+    bool visualize_bounding_box = false;   // the quads' frames (src/render/gaussian.wgsl:486-495)
     SortMode sort_mode = SortMode::Radix;
     RadixSortDepthBits radix_sort_depth_bits = RadixSortDepthBits::Bits32;
     DrawMode draw_mode = DrawMode::All;
@@ -100,6 +101,7 @@ struct CloudSettings {
         s.rasterize_mode = static_cast<uint32_t>(rasterize_mode);
         s.num_classes = num_classes;
         s.draw_mode = static_cast<uint32_t>(draw_mode);
+        s.visualize_bounding_box = visualize_bounding_box ? 1u : 0u;
         for (int i = 0; i < 3; ++i) {
             s.position_min[i] = position_min[i];
             s.position_max[i] = position_max[i];

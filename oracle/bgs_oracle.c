@@ -824,6 +824,16 @@ static int fs_main(const oracle_vs_out* in, v2 uv, v2 major_minor, const bgs_vie
         *power_out = power;
         if (distance_squared > 3.0f * 3.0f) return 0;
     }
+    if (s->visualize_bounding_box) {
+        /* VISUALIZE_BOUNDING_BOX (src/render/gaussian.wgsl:486-495; key bit src/render/mod.rs:418,824): a frame of
+         * 8 % of the quad's uv square, returned as it stands — alpha 1, so it replaces what is under it */
+        v2 uv01 = {uv.x * 0.5f + 0.5f, uv.y * 0.5f + 0.5f};
+        const float edge_width = 0.08f;
+        if ((uv01.x < edge_width || uv01.x > 1.0f - edge_width) || (uv01.y < edge_width || uv01.y > 1.0f - edge_width)) {
+            src[0] = 0.3f; src[1] = 1.0f; src[2] = 0.1f; src[3] = 1.0f;
+            return 1;
+        }
+    }
     float alpha = fminf(expf(power) * in->color[3], 0.999f);
     src[0] = in->color[0] * alpha;
     src[1] = in->color[1] * alpha;
@@ -854,6 +864,15 @@ static void vertex_pixel(const oracle_vs_out* vs, int k, double W, double H, dou
     *Y = (1.0 - ny) * 0.5 * H;
 }
 
+/* Half-width, in pixels, of the band around a quad edge inside which a sample's coverage decision counts as ambiguous
+ * (the ambiguity bound charges the pixel one sample's share of the fragment): how far a rasteriser's fixed-point /
+ * f32 vertex positions may sit from this file's float64 ones. 2e-3 px (= 16 ulp of a pixel coordinate at 1920) is the
+ * default the goldens were made with; tests/test_gpu_parity.py runs the whole-frame comparisons at 5e-4 px as well
+ * (BGS_ORACLE_EDGE_BAND_PX) and profiles/r5/tolerance_accounting_*.json hold both outcomes. */
+static double g_edge_band_px = 2e-3;
+void oracle_set_edge_band_px(double px) { if (px >= 0.0 && px <= 0.5) g_edge_band_px = px; }
+double oracle_edge_band_px(void) { return g_edge_band_px; }
+
 static int build_prim(prim* p, int32_t x0, int32_t y0, int32_t x1, int32_t y1, double W, double H) {
     double X[4], Y[4];
     for (int k = 0; k < 4; ++k) vertex_pixel(&p->vs, k, W, H, &X[k], &Y[k]);
@@ -865,8 +884,8 @@ static int build_prim(prim* p, int32_t x0, int32_t y0, int32_t x1, int32_t y1, d
     p->inv_det = 1.0 / det;
     double ls = sqrt(p->esx * p->esx + p->esy * p->esy);
     double lt = sqrt(p->etx * p->etx + p->ety * p->ety);
-    p->eps_s = 2e-3 / ls;
-    p->eps_t = 2e-3 / lt;
+    p->eps_s = g_edge_band_px / ls;
+    p->eps_t = g_edge_band_px / lt;
     double minx = X[0], maxx = X[0], miny = Y[0], maxy = Y[0];
     for (int k = 1; k < 4; ++k) {
         if (X[k] < minx) minx = X[k];
@@ -894,13 +913,78 @@ static int build_prim(prim* p, int32_t x0, int32_t y0, int32_t x1, int32_t y1, d
  * nothing in the reference sets another). Third party (wgpu 29 on Vulkan / Metal / D3D12: the "standard sample
  * locations" all three APIs prescribe for 4 samples); PARITY UNPINNED like the rest of the fixed-function stage. */
 static const double MS_POS1[1][2] = {{0.5, 0.5}};
+static const double MS_POS2[2][2] = {{0.75, 0.75}, {0.25, 0.25}};
 static const double MS_POS4[4][2] = {{0.375, 0.125}, {0.875, 0.375}, {0.125, 0.625}, {0.625, 0.875}};
+static const double MS_POS8[8][2] = {{0.5625, 0.3125}, {0.4375, 0.6875}, {0.8125, 0.5625}, {0.3125, 0.1875},
+                                     {0.1875, 0.8125}, {0.0625, 0.4375}, {0.6875, 0.9375}, {0.9375, 0.0625}};
+#define ORACLE_MAX_SAMPLES 8
+static const double (*ms_positions(int S))[2] {
+    return S == 1 ? MS_POS1 : S == 2 ? MS_POS2 : S == 4 ? MS_POS4 : S == 8 ? MS_POS8 : 0;
+}
 
 int oracle_sample_positions(uint32_t sample_count, float* xy_out) {
-    if (sample_count != 1 && sample_count != 4) return -1;
-    const double(*pos)[2] = sample_count == 4 ? MS_POS4 : MS_POS1;
+    const double(*pos)[2] = ms_positions((int)sample_count);
+    if (!pos) return -1;
     for (uint32_t s = 0; s < sample_count; ++s) { xy_out[2 * s] = (float)pos[s][0]; xy_out[2 * s + 1] = (float)pos[s][1]; }
     return 0;
+}
+
+/* ---- the colour attachment's storage format (src/render/mod.rs:917-921: Rgba8UnormSrgb, or Rgba16Float for key.hdr;
+ * examples/headless.rs:120-123). The blend unit reads the stored texel, blends, and stores the rounded result: with a
+ * packed target every sample is QUANTISED AT EVERY BLEND. Third-party (wgpu / the graphics API's format conversion
+ * rules), restated from the Vulkan / D3D specifications; PARITY UNPINNED:
+ *   Rgba8UnormSrgb: source colour and blend factor clamped to [0, 1] before the blend (fixed-point attachment), the
+ *     blend evaluated on the LINEAR value of the stored texel, the result encoded (sRGB OETF for RGB, linear alpha) and
+ *     rounded to the nearest of 256 codes;
+ *   Rgba16Float: no clamp, the result rounded to nearest-even binary16.
+ * ORACLE_TARGET_F32 (0) keeps every sample in binary32: the ideal target the image parity is stated against. */
+#define ORACLE_TARGET_F32 0
+#define ORACLE_TARGET_SRGB8 1
+#define ORACLE_TARGET_RGBA16F 2
+static float half_to_float(uint16_t h);
+static uint16_t float_to_half(float f);
+static inline double srgb_oetf(double x);
+static inline double srgb_eotf(double v) { return v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4); }
+static inline double clamp01d(double x) { return x > 0.0 ? (x < 1.0 ? x : 1.0) : 0.0; /* NaN -> 0 */ }
+/* the value a channel holds after a store to the attachment (c = 0..2 colour, 3 alpha). Rgba8UnormSrgb without a pow()
+ * per store: code = round(255 oetf(x)) is the number of thresholds eotf((k - 1/2) / 255), k = 1..255, that x reaches
+ * (the OETF is increasing), found by bisection; the stored value is a table entry. */
+static double g_srgb_thr[256];   /* g_srgb_thr[k] = eotf((k - 0.5) / 255): the least linear value that rounds to code k */
+static float g_srgb_val[256];    /* the linear value of code k */
+static int g_srgb_ready = 0;
+static void srgb_tables(void) {
+    if (g_srgb_ready) return;
+    for (int k = 0; k < 256; ++k) {
+        g_srgb_thr[k] = k ? srgb_eotf(((double)k - 0.5) / 255.0) : -1.0;
+        g_srgb_val[k] = (float)srgb_eotf((double)k / 255.0);
+    }
+    g_srgb_ready = 1;
+}
+static inline int srgb8_code(float x) {
+    if (!(x > 0.0f)) return 0;   /* NaN, negative */
+    int lo = 0, hi = 255;        /* largest k with thr[k] <= x */
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (g_srgb_thr[mid] <= (double)x) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+static inline float target_store(float x, int c, int fmt) {
+    if (fmt == ORACLE_TARGET_SRGB8) {
+        if (c < 3) return g_srgb_val[srgb8_code(x)];
+        return (float)(floor(clamp01d((double)x) * 255.0 + 0.5) / 255.0);
+    }
+    if (fmt == ORACLE_TARGET_RGBA16F) return half_to_float(float_to_half(x));
+    return x;
+}
+
+/* Rgba8UnormSrgb codes of stored values (what a read-back of the attachment holds): n RGBA pixels -> n*4 bytes */
+void oracle_srgb8_codes(const float* rgba, uint32_t n, uint8_t* out) {
+    srgb_tables();
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 3; ++c) out[4 * i + c] = (uint8_t)srgb8_code(rgba[4 * i + c]);
+        out[4 * i + 3] = (uint8_t)floor(clamp01d((double)rgba[4 * i + 3]) * 255.0 + 0.5);
+    }
 }
 
 /* The draw of src/render/mod.rs:1513-1569 into a MULTISAMPLED colour attachment, the way the fixed-function pipeline
@@ -916,16 +1000,19 @@ int oracle_sample_positions(uint32_t sample_count, float* xy_out) {
  *   - every covered sample blends the SAME source colour (BlendState::PREMULTIPLIED_ALPHA_BLENDING, :946);
  *   - the resolve is the box filter: the mean of the pixel's samples.
  * sample_count = view->sample_count (1 or 4). */
-int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
-                        const bgs_view* view, const bgs_settings* s, int32_t x0, int32_t y0, int32_t x1,
-                        int32_t y1, const float* depth, float* rgba_out, float* amb_out) {
+int oracle_render_target(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                         const bgs_view* view, const bgs_settings* s, int32_t x0, int32_t y0, int32_t x1,
+                         int32_t y1, const float* depth, int target_format, float* rgba_out, float* amb_out) {
     const int32_t Wi = (int32_t)view->viewport[2], Hi = (int32_t)view->viewport[3];
     if (x0 < 0 || y0 < 0 || x1 > Wi || y1 > Hi || x0 >= x1 || y0 >= y1) return -1;
     const double W = (double)view->viewport[2], H = (double)view->viewport[3];
     const int32_t rw = x1 - x0;
-    const int S = (int)view->sample_count;
-    if (S != 1 && S != 4) return -5;
-    const double(*pos)[2] = S == 4 ? MS_POS4 : MS_POS1;
+    const int S = view->sample_count ? (int)view->sample_count : 4;   /* 0 = not set = Msaa::default() */
+    const double(*pos)[2] = ms_positions(S);
+    if (!pos) return -5;
+    if (target_format < ORACLE_TARGET_F32 || target_format > ORACLE_TARGET_RGBA16F) return -6;
+    const int fmt = target_format;
+    srgb_tables();
 
     float depth_range[2] = {0.0f, 0.0f};
     if (s->rasterize_mode == BGS_RASTERIZE_DEPTH && oracle_depth_range(cloud, entries, count, view, s, depth_range))
@@ -948,16 +1035,19 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
         if (keep[i]) { if (np != i) tmp[np] = tmp[i]; ++np; }
     free(keep);
 
-    int failed = 0;
-#pragma omp parallel for schedule(dynamic, 1)
+    /* one row of samples per thread, allocated before the loop (an allocation failure inside it used to leave some
+     * rows written and others not: ADVICE round 4) */
+    const int nthreads = omp_get_max_threads();
+    float* ms_all = (float*)malloc((size_t)nthreads * (size_t)rw * S * 4 * sizeof(float));
+    if (!ms_all) { free(tmp); return -2; }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int32_t y = y0; y < y1; ++y) {
         float* row = rgba_out + (size_t)(y - y0) * rw * 4;
         float* arow = amb_out ? amb_out + (size_t)(y - y0) * rw : 0;
         /* the row's samples: [x][sample][rgba], cleared (examples/headless.rs:70 -> view->clear_color) */
-        float* ms = (float*)malloc((size_t)rw * S * 4 * sizeof(float));
-        if (!ms) { failed = 1; continue; }
+        float* ms = ms_all + (size_t)omp_get_thread_num() * (size_t)rw * S * 4;
         for (int64_t i = 0; i < (int64_t)rw * S; ++i)
-            for (int c = 0; c < 4; ++c) ms[4 * i + c] = view->clear_color[c];
+            for (int c = 0; c < 4; ++c) ms[4 * i + c] = target_store(view->clear_color[c], c, fmt);
         if (arow) for (int32_t i = 0; i < rw; ++i) arow[i] = 0.0f;
         for (size_t pi = 0; pi < np; ++pi) {
             const prim* p = &tmp[pi];
@@ -966,7 +1056,7 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
             /* the quad's depth: constant over the quad (position.zw is the splat's, gaussian.wgsl:429-433) */
             const float zf = vs->projected[2] / vs->projected[3];
             /* (s, t) of sample k = (s, t) of the pixel centre + a constant of the quad (the map is affine) */
-            double dsk[4] = {0, 0, 0, 0}, dtk[4] = {0, 0, 0, 0};
+            double dsk[ORACLE_MAX_SAMPLES] = {0}, dtk[ORACLE_MAX_SAMPLES] = {0};
             for (int k = 0; k < S; ++k) {
                 const double ox = pos[k][0] - 0.5, oy = pos[k][1] - 0.5;
                 dsk[k] = (ox * p->ety - oy * p->etx) * p->inv_det;
@@ -980,7 +1070,7 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                 const double sp = (cdx * p->ety - cdy * p->etx) * p->inv_det;
                 const double tp = (p->esx * cdy - p->esy * cdx) * p->inv_det;
                 /* ... and at every sample position (coverage) */
-                int inside[4] = {0, 0, 0, 0}, near_edge[4] = {0, 0, 0, 0}, any_inside = 0, any_near = 0;
+                int inside[ORACLE_MAX_SAMPLES] = {0}, near_edge[ORACLE_MAX_SAMPLES] = {0}, any_inside = 0, any_near = 0;
                 /* a pixel none of whose sample positions can be inside or within the rounding band: (s, t) moves by at
                  * most reach_s / reach_t between the centre and a point of the pixel */
                 if (sp < -reach_s || sp > 1.0 + reach_s || tp < -reach_t || tp > 1.0 + reach_t) continue;
@@ -1071,6 +1161,18 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                         arow[x - x0] += (float)(4.0 * da) * (cm + dm);
                     }
                 }
+                if (arow && s->visualize_bounding_box && drawn) {
+                    /* VISUALIZE_BOUNDING_BOX: a fragment whose |uv| sits within rounding distance of the frame's inner
+                     * edge (0.84) is the splat's colour in one evaluation and the opaque frame colour in another: the
+                     * whole fragment */
+                    const double bu = 2.0 * p->eps_s + 1e-5, bv = 2.0 * p->eps_t + 1e-5;
+                    const double ax = fabs((double)uv.x), ay = fabs((double)uv.y);
+                    if ((fabs(ax - 0.84) < bu && ay < 0.84 + bv) || (fabs(ay - 0.84) < bv && ax < 0.84 + bu)) {
+                        float cm = fmaxf(fmaxf(fabsf(vs->color[0]), fabsf(vs->color[1])), fmaxf(fabsf(vs->color[2]), 1.0f));
+                        ORACLE_DM();
+                        arow[x - x0] += cm + dm;
+                    }
+                }
                 if (arow) {
                     /* a coverage decision within rounding distance of a quad edge moves ONE sample's share of the pixel;
                      * a discard decision at the threshold (power ~ 0) moves the whole pixel */
@@ -1078,7 +1180,7 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                     for (int k = 0; k < S; ++k) flips += near_edge[k];
                     const int whole = s->aabb && fabsf(power) < 1e-5f;
                     if (flips || whole) {
-                        float a = fminf(expf(fminf(power, 0.0f)) * fabsf(vs->color[3]), 0.999f);
+                        float a = s->visualize_bounding_box ? 1.0f : fminf(expf(fminf(power, 0.0f)) * fabsf(vs->color[3]), 0.999f);
                         float cm = fmaxf(fmaxf(fabsf(vs->color[0]), fabsf(vs->color[1])),
                                          fmaxf(fabsf(vs->color[2]), 1.0f));
                         ORACLE_DM();
@@ -1088,7 +1190,20 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
                 if (!drawn) continue;
                 /* BlendState::PREMULTIPLIED_ALPHA_BLENDING (src/render/mod.rs:946), per covered sample that passes
                  * the depth test (CompareFunction::GreaterEqual against the view's depth, :959-974) */
+                if (fmt == ORACLE_TARGET_SRGB8) {
+                    /* fixed-point attachment: the source colour is clamped to [0, 1] before the blend */
+                    for (int c = 0; c < 4; ++c) src[c] = (float)clamp01d((double)src[c]);
+                }
                 const float one_minus = 1.0f - src[3];
+                if (fmt != ORACLE_TARGET_F32) {
+                    for (int k = 0; k < S; ++k) {
+                        if (!inside[k]) continue;
+                        if (depth && !(zf >= depth[((size_t)y * (size_t)Wi + (size_t)x) * (size_t)S + (size_t)k])) continue;
+                        float* d = dst + 4 * k;
+                        for (int c = 0; c < 4; ++c) d[c] = target_store(src[c] + d[c] * one_minus, c, fmt);
+                    }
+                    continue;
+                }
                 if (!depth && S == 4 && inside[0] && inside[1] && inside[2] && inside[3]) {
                     /* the common case, the same arithmetic as below: a straight loop the compiler can vectorise */
                     for (int k = 0; k < 16; ++k) dst[k] = src[k & 3] + dst[k] * one_minus;
@@ -1108,14 +1223,27 @@ int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries
         /* resolve: the mean of the pixel's samples */
         for (int32_t x = 0; x < rw; ++x) {
             const float* d = ms + (size_t)x * S * 4;
-            for (int c = 0; c < 4; ++c)
-                row[4 * x + c] = S == 4 ? ((d[c] + d[4 + c]) + (d[8 + c] + d[12 + c])) * 0.25f : d[c];
+            for (int c = 0; c < 4; ++c) {
+                /* the box filter, summed pairwise; a packed resolve target stores the mean in its own format */
+                float v;
+                if (S == 1) v = d[c];
+                else if (S == 2) v = (d[c] + d[4 + c]) * 0.5f;
+                else if (S == 4) v = ((d[c] + d[4 + c]) + (d[8 + c] + d[12 + c])) * 0.25f;
+                else v = (((d[c] + d[4 + c]) + (d[8 + c] + d[12 + c])) + ((d[16 + c] + d[20 + c]) + (d[24 + c] + d[28 + c]))) * 0.125f;
+                row[4 * x + c] = target_store(v, c, fmt);
+            }
         }
-        free(ms);
     }
 #undef ORACLE_DM
+    free(ms_all);
     free(tmp);
-    return failed ? -2 : 0;
+    return 0;
+}
+
+int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                        const bgs_view* view, const bgs_settings* s, int32_t x0, int32_t y0, int32_t x1,
+                        int32_t y1, const float* depth, float* rgba_out, float* amb_out) {
+    return oracle_render_target(cloud, entries, count, view, s, x0, y0, x1, y1, depth, ORACLE_TARGET_F32, rgba_out, amb_out);
 }
 
 int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,

@@ -143,10 +143,25 @@ int oracle_render(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint
  * shading once per pixel at its centre, box resolve) and tested against a scene depth buffer (HOST memory here:
  * viewport.w * viewport.h * sample_count floats [y][x][sample], Depth32Float / GreaterEqual / no write,
  * src/render/mod.rs:959-974; NULL = none; bgs_view.depth_device_ptr is ignored by the oracle).
- * oracle_render is this with depth = NULL. Returns -5 for a sample count other than 1 or 4. */
+ * oracle_render is this with depth = NULL. Sample counts: 1, 2, 4, 8 (Msaa::Off / Sample2 / Sample4 / Sample8 at the
+ * graphics APIs' standard positions; 0 = not set = 4); -5 for anything else. */
 int oracle_render_depth(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
                         const bgs_view* view, const bgs_settings* settings, int32_t x0, int32_t y0,
                         int32_t x1, int32_t y1, const float* depth, float* rgba_out, float* ambiguity_out);
+/* The same draw into a colour attachment of the reference's STORAGE format (src/render/mod.rs:917-921,944-948):
+ * target_format 0 = binary32 samples (= oracle_render_depth: the ideal target), 1 = Rgba8UnormSrgb, 2 = Rgba16Float.
+ * With a packed format every covered sample is read, blended and stored ROUNDED at every blend (source colour clamped
+ * to [0, 1] first for the fixed-point format), and the resolve target holds the mean of the stored samples in the same
+ * format. rgba_out receives the resolved texels' VALUES as float (decoded to linear for sRGB8). The per-blend rounding
+ * is fixed-function behaviour of wgpu / the graphics API: restated from the Vulkan / D3D format-conversion rules,
+ * PARITY UNPINNED. -6 for an unknown format. */
+int oracle_render_target(const oracle_cloud* cloud, const bgs_sort_entry* entries, uint32_t count,
+                         const bgs_view* view, const bgs_settings* settings, int32_t x0, int32_t y0,
+                         int32_t x1, int32_t y1, const float* depth, int target_format, float* rgba_out,
+                         float* ambiguity_out);
+/* The Rgba8UnormSrgb codes (R, G, B, A bytes) of n RGBA values: exact rounding of 255 * OETF by threshold search — for
+ * values that ARE stored texels (oracle_render_target's output) this is the read-back of the attachment. */
+void oracle_srgb8_codes(const float* rgba, uint32_t n, uint8_t* out);
 /* The sample positions of a pixel (x, y pairs, origin = the pixel's top-left corner, y down). */
 int oracle_sample_positions(uint32_t sample_count, float* xy_out);
 
@@ -172,6 +187,10 @@ int oracle_instance_stats(const oracle_cloud* cloud, const bgs_sort_entry* entri
  * through the sRGB transfer function (third-party wgpu / Vulkan format conversion: parity
  * unpinned), round to nearest unorm8; alpha linear. out = n*4 bytes R,G,B,A. */
 void oracle_encode_srgb8(const float* rgba, uint32_t n, uint8_t* out);
+
+/* The quad-edge ambiguity band of oracle_render's ambiguity bound, in pixels (default 2e-3; accepted range [0, 0.5]). */
+void oracle_set_edge_band_px(double px);
+double oracle_edge_band_px(void);
 
 int oracle_max_threads(void);
 /* OpenMP threads used by keygen / render from now on (bench.py: the pinned 1-core baseline). */

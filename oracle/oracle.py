@@ -120,6 +120,10 @@ def lib() -> ctypes.CDLL:
         l.oracle_render.restype = ctypes.c_int
         l.oracle_render_depth.argtypes = [ctypes.POINTER(_Cloud), ep, u32, vp, sp, i32, i32, i32, i32, fp, fp, fp]
         l.oracle_render_depth.restype = ctypes.c_int
+        l.oracle_render_target.argtypes = [ctypes.POINTER(_Cloud), ep, u32, vp, sp, i32, i32, i32, i32, fp, ctypes.c_int, fp, fp]
+        l.oracle_render_target.restype = ctypes.c_int
+        l.oracle_srgb8_codes.argtypes = [fp, u32, ctypes.POINTER(ctypes.c_uint8)]
+        l.oracle_srgb8_codes.restype = None
         l.oracle_sample_positions.argtypes = [u32, fp]
         l.oracle_sample_positions.restype = ctypes.c_int
         l.oracle_decode_f16.argtypes = [u32, up, up, fp, fp, fp]
@@ -135,6 +139,12 @@ def lib() -> ctypes.CDLL:
         l.oracle_set_threads.restype = None
         l.oracle_max_threads.argtypes = []
         l.oracle_max_threads.restype = ctypes.c_int
+        l.oracle_set_edge_band_px.argtypes = [ctypes.c_double]
+        l.oracle_set_edge_band_px.restype = None
+        l.oracle_edge_band_px.argtypes = []
+        l.oracle_edge_band_px.restype = ctypes.c_double
+        if os.environ.get("BGS_ORACLE_EDGE_BAND_PX"):
+            l.oracle_set_edge_band_px(float(os.environ["BGS_ORACLE_EDGE_BAND_PX"]))
         if "OMP_NUM_THREADS" not in os.environ:
             l.oracle_set_threads(min(l.oracle_max_threads(), effective_cpus()))
         _lib = l
@@ -247,12 +257,17 @@ def depth_range(cloud, entries: np.ndarray, view: View, settings: CloudSettings)
     return float(out[0]), float(out[1])
 
 
+TARGET_F32, TARGET_SRGB8, TARGET_RGBA16F = 0, 1, 2
+
+
 def render(cloud, entries: np.ndarray, view: View, settings: CloudSettings, window=None,
-           with_ambiguity: bool = False, depth=None):
+           with_ambiguity: bool = False, depth=None, target_format: int = TARGET_F32):
     """Draw `entries` in order into a target with `view.msaa_samples` samples per pixel (coverage and depth test per
     sample, shading once per pixel, box resolve). window = (x0, y0, x1, y1) or None for the full viewport.
     depth = None or the view's scene depth as a HOST array [height, width, msaa_samples] float32 (reverse-Z; a fragment
-    passes where its depth >= the stored one). Returns rgba [h, w, 4] (and the ambiguity bound [h, w] if requested)."""
+    passes where its depth >= the stored one). target_format: TARGET_F32 (the ideal binary32 target the parity is stated
+    against), TARGET_SRGB8 / TARGET_RGBA16F = the reference's colour attachment, every sample rounded at every blend
+    (src/render/mod.rs:917-921,944-948). Returns rgba [h, w, 4] (and the ambiguity bound [h, w] if requested)."""
     cloud = _as_f32_cloud(cloud)
     c = _cloud_struct(cloud)
     x0, y0, x1, y1 = window if window is not None else (0, 0, view.width, view.height)
@@ -265,12 +280,20 @@ def render(cloud, entries: np.ndarray, view: View, settings: CloudSettings, wind
         d = np.ascontiguousarray(depth, dtype=np.float32)
         if d.shape != (view.height, view.width, view.msaa_samples):
             raise ValueError(f"depth must be [height, width, samples] = {(view.height, view.width, view.msaa_samples)}, got {d.shape}")
-    rc = lib().oracle_render_depth(ctypes.byref(c), _ep(e), e.shape[0], ctypes.byref(v), ctypes.byref(s),
-                                   x0, y0, x1, y1, _fp(d) if d is not None else None, _fp(out),
-                                   _fp(amb) if amb is not None else None)
+    rc = lib().oracle_render_target(ctypes.byref(c), _ep(e), e.shape[0], ctypes.byref(v), ctypes.byref(s),
+                                    x0, y0, x1, y1, _fp(d) if d is not None else None, int(target_format), _fp(out),
+                                    _fp(amb) if amb is not None else None)
     if rc:
         raise RuntimeError(f"oracle_render failed: {rc}")
     return (out, amb) if with_ambiguity else out
+
+
+def srgb8_codes(rgba: np.ndarray) -> np.ndarray:
+    """Rgba8UnormSrgb codes [..., 4] uint8 of RGBA values (exact rounding by threshold search, no pow per value)."""
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    out = np.empty(a.shape, np.uint8)
+    lib().oracle_srgb8_codes(_fp(a), a.size // 4, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    return out
 
 
 def sample_positions(sample_count: int) -> np.ndarray:

@@ -43,3 +43,29 @@ def plugin():
     p = GaussianSplattingPlugin(0)
     yield p
     p.close()
+
+
+def pytest_collection_modifyitems(config, items):
+    """The tolerance-accounting test closes the run: it asserts on what EVERY oracle comparison before it recorded."""
+    last = [it for it in items if it.name.startswith("test_zz_")]
+    if last:
+        items[:] = [it for it in items if not it.name.startswith("test_zz_")] + last
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Leave the run's tolerance accounting next to the other evidence (gpurun_out/ on the GPU box)."""
+    try:
+        import json
+        import helpers as H
+        t = H.TOLERANCE
+        if not t["checked"]:
+            return
+        band = os.environ.get("BGS_ORACLE_EDGE_BAND_PX", "2e-3")
+        outdir = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(outdir, exist_ok=True)
+        with open(os.path.join(outdir, f"tolerance_accounting_band_{band}.json"), "w") as f:
+            json.dump({"edge_band_px": float(band), "values_compared": t["checked"], "beyond_strict_tolerance": t["values"],
+                       "max_excess_over_strict": t["max_excess"], "exit_status": int(exitstatus),
+                       "comparisons": sorted(t["comparisons"], key=lambda r: -r["max_excess"])}, f, indent=1)
+    except Exception:  # noqa: BLE001 - reporting must never turn a green run red
+        pass

@@ -48,7 +48,7 @@ class FrameParamsC(ctypes.Structure):
         ("clear", ctypes.c_float * 4), ("srgb8_target", ctypes.c_uint64),
         ("sort_path", ctypes.c_uint32), ("sample_count", ctypes.c_uint32), ("depth_ptr", ctypes.c_uint64),
         ("basis", ctypes.c_float * 9), ("inv_viewport_w", ctypes.c_float), ("inv_viewport_h", ctypes.c_float),
-        ("pad_uniform", ctypes.c_float),
+        ("visualize_bbox", ctypes.c_uint32),
     ]
 
 
@@ -183,7 +183,9 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
                          np.arange(H, dtype=np.float32) + np.float32(0.5))
     # samples per pixel: offsets from the pixel centre (csrc/render_kernels.hip: MS_OX0 ... — the standard 4x pattern)
     S = int(view.msaa_samples)
-    offs = [(0.0, 0.0)] if S == 1 else [(-0.125, -0.375), (0.375, -0.125), (-0.375, 0.125), (0.125, 0.375)]
+    offs = {1: [(0.0, 0.0)], 2: [(0.25, 0.25), (-0.25, -0.25)],
+            4: [(-0.125, -0.375), (0.375, -0.125), (-0.375, 0.125), (0.125, 0.375)],
+            8: [(k / 16.0, l / 16.0) for k, l in ((1, -3), (-1, 3), (5, 1), (-3, -5), (-5, 5), (-7, -1), (3, 7), (7, -7))]}[S]
     T = np.ones((H, W, S), np.float32)   # per-sample transmittance
     C = np.zeros((H, W, 3), np.float32)
     out = ShimOut()
@@ -252,6 +254,10 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
                 power = np.float32(-0.5) * np.minimum(s3, s2)
                 hit &= ~(power > 0)
             alpha = np.minimum(np.exp(power) * col[3], np.float32(0.999)).astype(np.float32)
+            if settings.visualize_bounding_box:   # the quad's frame (csrc/render_kernels.hip: BBOX_EDGE), per pixel
+                frame = np.maximum(np.abs(u), np.abs(v)) > np.float32(0.84)
+                alpha = np.where(frame, np.float32(1.0), alpha).astype(np.float32)
+                col = [np.where(frame, np.float32(c0), c1).astype(np.float32) for c0, c1 in zip((0.3, 1.0, 0.1), col[:3])] + [col[3]]
         # the fragment is shaded once (at the pixel centre); a pixel stops once its MEAN transmittance is below the cut-off
         hit &= ~(T.mean(axis=2) < eps)
         covered = np.stack(cov, axis=2) & hit[..., None]
@@ -329,6 +335,28 @@ def tolerance_mask(ref: np.ndarray, got: np.ndarray, amb: np.ndarray | None, ato
     return err <= lim, err
 
 
+# Tolerance accounting (round 4's verdict: "the tolerance is builder-adjustable"): every oracle comparison of a run reports
+# here how many values passed only through the oracle's ambiguity bound and by HOW MUCH they exceed the strict tolerance
+# 1e-3 + 1e-4 |ref|; the run's last test asserts on the totals and conftest writes them next to the other evidence.
+TOLERANCE = {"values": 0, "checked": 0, "max_excess": 0.0, "comparisons": []}
+
+
+def account(ref, got, amb, what: str = "") -> dict:
+    """Record one oracle comparison: values beyond the strict tolerance and their largest excess over it."""
+    strict, err = tolerance_mask(ref, got, None)
+    lim = 1e-3 + 1e-4 * np.abs(ref.astype(np.float64))
+    over = ~strict
+    excess = float((err - lim)[over].max()) if over.any() else 0.0
+    rec = {"what": what, "values": int(strict.size), "beyond_strict": int(over.sum()), "max_excess": excess,
+           "max_err": float(err.max()) if err.size else 0.0}
+    TOLERANCE["values"] += rec["beyond_strict"]
+    TOLERANCE["checked"] += rec["values"]
+    TOLERANCE["max_excess"] = max(TOLERANCE["max_excess"], excess)
+    if rec["beyond_strict"] or rec["values"] >= 1_000_000:
+        TOLERANCE["comparisons"].append(rec)
+    return rec
+
+
 def random_case(seed: int, medium: bool = False):
     """One random (cloud, view, settings) configuration for the randomized parity sweeps: camera pose,
     field of view, near plane and aspect; model transform with rotation, non-uniform scale and
@@ -377,6 +405,14 @@ def random_case(seed: int, medium: bool = False):
     # (a second stream, so that the configurations of the earlier rounds' sweeps keep everything above)
     rng2 = np.random.default_rng(7_000_000 + seed)
     v.msaa_samples = int(rng2.choice([1, 4, 4]))      # Msaa::Off or Bevy's default Sample4
+    # (a third stream, round 5: Msaa::Sample2 / Sample8 on a quarter of the seeds, the bounding-box overlay on an eighth)
+    rng3 = np.random.default_rng(9_000_000 + seed)
+    r3 = rng3.random()
+    if r3 < 0.125:
+        v.msaa_samples = 2
+    elif r3 < 0.25:
+        v.msaa_samples = 8
+    s.visualize_bounding_box = bool(rng3.random() < 0.125)
     v.depth_host = None
     if rng2.random() < 0.35:                           # a scene depth buffer that cuts through the cloud
         v.depth_host = random_depth_buffer(c, v, s, rng2)

@@ -49,10 +49,13 @@ def _assert_image(ref, got, amb, frac_slack=0.002, what=""):
     assert got.shape == ref.shape and np.isfinite(got).all()
     ok, err = H.tolerance_mask(ref, got, amb)
     assert ok.all(), f"{what}: {(~ok).sum()} values out of tolerance, max err {err.max():.3e}"
-    strict, _ = H.tolerance_mask(ref, got, None)
-    SLACK_USED["values"] += int((~strict).sum())
-    SLACK_USED["checked"] += int(strict.size)
-    assert (~strict).sum() <= frac_slack * strict.size, f"{what}: ambiguity slack used by too many pixels"
+    rec = H.account(ref, got, amb, what)
+    SLACK_USED["values"] += rec["beyond_strict"]
+    SLACK_USED["checked"] += rec["values"]
+    if rec["beyond_strict"]:
+        print(f"[tolerance: {what}] {rec['beyond_strict']} of {rec['values']} values beyond 1e-3 + 1e-4 |ref| "
+              f"(accepted through the oracle's ambiguity bound), largest excess {rec['max_excess']:.2e}")
+    assert rec["beyond_strict"] <= frac_slack * rec["values"], f"{what}: ambiguity slack used by too many pixels"
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1606,6 +1609,99 @@ def test_first_frames_of_a_context_learn_one_by_one(plugin):
     h.free()
 
 
+def test_forty_kinds_of_frame_stay_pipelined_after_their_first_visit(plugin):
+    """Round 4 remembered the last 16 kinds of frame (FIFO) and hashed the cloud's address and the raw global_scale bits into
+    the kind: a host cycling through more than 16 (cloud, viewport, mode) combinations, uploading a cloud per frame or
+    animating the scale completed EVERY async frame inside its render call — correct images at the blocking rate, silently
+    (ADVICE round 4, medium). Now: the set never forgets, the cloud counts by size and format, the scale by half octaves,
+    and bgs_learning_counters shows the phase. 40 kinds, three cycles: only the first visit of a kind completes frames
+    early; every frame is bit-identical to the blocking frame of the same inputs."""
+    from bevy_gaussian_splatting_amd.multiview import device_ptr_as_tensor
+    clouds = [random_gaussians_3d_seeded(n, 70 + i) for i, n in enumerate((30_000, 45_000))]
+    handles = [plugin.upload(c) for c in clouds]
+    sizes = [(320, 192), (400, 240), (480, 272), (352, 208), (448, 256)]
+    kinds = []
+    for ci in range(2):
+        for (w, hh) in sizes:
+            for aabb in (False, True):
+                for gs in (1.0, 0.2):
+                    kinds.append((ci, View.headless(w, hh, yaw=0.02 * len(kinds)), CloudSettings(aabb=aabb, global_scale=gs), (hh, w)))
+    assert len(kinds) == 40
+    refs = [plugin.render(handles[ci], v, s) for ci, v, s, _ in kinds]
+    try:
+        plugin.reset_adaptive_state()
+        assert plugin.learning_counters()["kinds_settled"] == 0
+        plugin.set_async(True)
+        plugin.set_pipeline_depth(4)
+        early = []
+        for cycle in range(3):
+            for k, (ci, v, s, shape) in enumerate(kinds):
+                for rep in range(3):
+                    plugin.render(handles[ci], v, s, download=False)
+                # pop the three frames of this kind and compare the last one
+                while plugin.frames_in_flight() > 1:
+                    plugin.pipeline_pop()
+                f32, _ = plugin.pipeline_pop()
+                got = device_ptr_as_tensor(f32, (*shape, 4), "<f4", "cuda:0").cpu().numpy()
+                assert np.array_equal(got, refs[k]), (cycle, k)
+            early.append(plugin.learning_counters()["early_frames"])
+        lc = plugin.learning_counters()
+        assert lc["kinds_settled"] == 40
+        assert 40 <= early[0] <= 40 * 3, early            # the first visit of a kind: one to three frames completed early
+        assert early[1] == early[0] and early[2] == early[0], early   # ... and never again: pipelined from then on
+
+        # a NEW cloud handle of a known size for every frame, and an animated global_scale: still pipelined
+        before = plugin.learning_counters()["early_frames"]
+        ci, v, s, shape = kinds[0]
+        for i in range(12):
+            hx = plugin.upload(clouds[0])
+            plugin.render(hx, v, s, download=False)
+            plugin.synchronize()
+            hx.free()
+        for i in range(64):
+            plugin.render(handles[0], v, CloudSettings(global_scale=1.0 + 0.004 * i), download=False)
+            if plugin.frames_in_flight() >= 4:
+                plugin.pipeline_pop()
+        plugin.synchronize()
+        after = plugin.learning_counters()["early_frames"]
+        assert after - before <= 3, (before, after)     # (1.0 -> 1.25 crosses at most one half-octave step)
+    finally:
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.reset_adaptive_state()
+    for h in handles:
+        h.free()
+
+
+def test_a_kind_that_never_runs_clean_is_settled_on_anyway(plugin):
+    """Debug flag 0x8000000 re-runs every frame: no frame of the kind ever completes "with everything it needed". The learning
+    phase is bounded all the same (LEARN_MAX frames in a row of one kind), after which the kind's frames are pipelined."""
+    c = random_gaussians_3d_seeded(40_000, 75)
+    h = plugin.upload(c)
+    v, s = View.headless(416, 240), CloudSettings()
+    ref = plugin.render(h, v, s)
+    from bevy_gaussian_splatting_amd.multiview import device_ptr_as_tensor
+    try:
+        plugin.reset_adaptive_state()
+        plugin.set_debug_flags(0x8000000)
+        plugin.set_async(True)
+        plugin.set_pipeline_depth(4)
+        e0 = plugin.learning_counters()["early_frames"]
+        for i in range(16):
+            plugin.render(h, v, s, download=False)
+            if plugin.frames_in_flight() >= 4:
+                f32, _ = plugin.pipeline_pop()
+                assert np.array_equal(device_ptr_as_tensor(f32, (240, 416, 4), "<f4", "cuda:0").cpu().numpy(), ref)
+        plugin.synchronize()
+        assert plugin.learning_counters()["early_frames"] - e0 == 3
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.reset_adaptive_state()
+    h.free()
+
+
 def test_rerun_keeps_the_output_state_the_frame_was_enqueued_with(plugin):
     """A frame whose supertile lists overflow is re-run when its lane completes (here: forced). If the caller changed the packed
     output format in between (bgs_set_output_rgba16f / _srgb8 / _packed_only complete nothing), the re-run must still
@@ -1753,13 +1849,22 @@ def test_draw_modes(plugin, oracle, binning):
                 h.free()
 
 
-def test_zz_report_ambiguity_slack_use():
-    """Last test of the file (run with -s to see it): over every oracle comparison of this run, how many
-    values were accepted only thanks to the oracle's per-pixel ambiguity bound (quad-edge coverage flips,
-    ill-conditioned surfel intersections) rather than the plain 1e-3 + 1e-4 |ref| tolerance."""
-    v, n = SLACK_USED["values"], SLACK_USED["checked"]
-    print(f"[ambiguity slack] used by {v} of {n} compared values ({100.0 * v / max(n, 1):.5f} %)")
-    assert v <= 2e-3 * max(n, 1)
+def test_zz_report_ambiguity_slack_use(oracle):
+    """LAST test of the run (tests/conftest.py moves it behind every other collected test; run with -s to see it). Over
+    every oracle comparison of this run: how many values were accepted only through the oracle's per-pixel ambiguity bound
+    (quad-edge coverage flips, ill-conditioned surfel intersections / AABB conics) rather than the plain
+    1e-3 + 1e-4 |ref| tolerance, and by how much the worst of them exceeds that tolerance. Teeth (from the runs under
+    profiles/r5/tolerance_accounting_*.json, at both edge bands): at most 2e-5 of the values, none more than 0.05 beyond —
+    one sample's share (a quarter) of a fragment of alpha exp(-4.5) * 0.8 and a colour of magnitude 15, the brightest the
+    synthetic clouds hold, is 0.033."""
+    t = H.TOLERANCE
+    v, n = t["values"], t["checked"]
+    print(f"[tolerance accounting] edge band {oracle.lib().oracle_edge_band_px():g} px: {v} of {n} compared values "
+          f"({100.0 * v / max(n, 1):.5f} %) beyond 1e-3 + 1e-4 |ref|, largest excess {t['max_excess']:.3e}")
+    for rec in sorted(t["comparisons"], key=lambda r: -r["max_excess"])[:12]:
+        print(f"    {rec['what']}: {rec['beyond_strict']} of {rec['values']}, excess {rec['max_excess']:.2e}, max |err| {rec['max_err']:.2e}")
+    assert v <= 2e-5 * max(n, 1) + 50
+    assert t["max_excess"] <= 0.05
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1781,7 +1886,7 @@ def test_multisampled_target_matches_the_oracle(plugin, oracle, binning, variant
     s = CloudSettings(global_scale=global_scale, **_MS_VARIANTS[variant])
     h = plugin.upload(c)
     imgs = {}
-    for samples in (4, 1):
+    for samples in (4, 1, 2, 8):     # Msaa::Sample4 (Bevy's default), Off, Sample2, Sample8
         v = View.headless(640, 360, msaa_samples=samples)
         got = plugin.render(h, v, s)
         e = oracle.sort(c, v, s)
@@ -1791,6 +1896,8 @@ def test_multisampled_target_matches_the_oracle(plugin, oracle, binning, variant
     d = np.abs(imgs[4] - imgs[1])
     # (a dense frame saturates within a few large splats: its quad edges are worth ~1e-3; small splats show them)
     assert d.max() > (2e-3 if global_scale < 1.0 else 2e-4), "4x and 1x must differ at quad edges"
+    for a, b in ((2, 1), (2, 4), (8, 4)):
+        assert np.abs(imgs[a] - imgs[b]).max() > (1e-3 if global_scale < 1.0 else 1e-4), f"{a}x and {b}x must differ at quad edges"
     print(f"[msaa {variant} gs={global_scale} {binning}] |4x - 1x|: mean {d.mean():.2e} max {d.max():.2e}, "
           f"values apart by more than 1e-3: {(d > 1e-3).mean():.2%}")
     h.free()
@@ -1799,10 +1906,27 @@ def test_multisampled_target_matches_the_oracle(plugin, oracle, binning, variant
 def test_sample_count_and_depth_pointer_are_validated(plugin):
     c = random_gaussians_3d_seeded(100, 1)
     h = plugin.upload(c)
-    for bad in (0, 2, 3, 8, 16):
+    for bad in (3, 5, 16, 64):
         with pytest.raises(Exception) as ei:
             plugin.render(h, View.headless(64, 64, msaa_samples=bad), CloudSettings())
         assert "sample_count" in str(ei.value)
+    # 0 = "not set" (a zero-initialised bgs_view): Msaa::default() = Sample4, bit for bit
+    assert np.array_equal(plugin.render(h, View.headless(64, 64, msaa_samples=0), CloudSettings()),
+                          plugin.render(h, View.headless(64, 64, msaa_samples=4), CloudSettings()))
+    # the per-tile trace has no instantiation with a depth buffer: refused, not silently untraced
+    vz = View.headless(64, 64, msaa_samples=4)
+    pz = plugin.device_alloc(64 * 64 * 16)
+    tr = plugin.device_alloc(4 * 4 * 32)
+    vz.depth_device_ptr = pz
+    plugin.set_tile_trace(tr)
+    try:
+        with pytest.raises(Exception) as ei:
+            plugin.render(h, vz, CloudSettings())
+        assert "trace" in str(ei.value)
+    finally:
+        plugin.set_tile_trace(None)
+    plugin.device_free(tr)
+    plugin.device_free(pz)
     v = View.headless(64, 64, msaa_samples=4)
     p = plugin.device_alloc(64 * 64 * 16 + 64)
     v.depth_device_ptr = p + 4                      # not aligned to one pixel's four samples
@@ -1810,12 +1934,48 @@ def test_sample_count_and_depth_pointer_are_validated(plugin):
         plugin.render(h, v, CloudSettings())
     assert "depth_device_ptr" in str(ei.value)
     plugin.device_free(p)
-    plugin.sort(h, View.headless(64, 64, msaa_samples=2), CloudSettings())   # the sort does not look at the samples
+    plugin.sort(h, View.headless(64, 64, msaa_samples=3), CloudSettings())   # the sort does not look at the samples
     h.free()
 
 
 @pytest.mark.parametrize("variant", sorted(_MS_VARIANTS))
-@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("samples", [1, 4, 8])
+@pytest.mark.parametrize("depth", [False, True])
+def test_bounding_box_overlay_matches_the_oracle(plugin, oracle, binning, variant, samples, depth):
+    """CloudSettings::visualize_bounding_box (src/gaussian/settings.rs:95,117; pipeline key bit src/render/mod.rs:418,824;
+    src/render/gaussian.wgsl:486-495): a fragment in the outer 8 % of its quad's uv square is (0.3, 1, 0.1, 1) — the
+    quads' frames, opaque, over the splats. Every rasteriser variant, both binnings, 1 / 4 / 8 samples per pixel, with
+    and without a scene depth buffer, against the oracle on every pixel; the overlay changes the image."""
+    c = random_gaussians_3d_seeded(30_000, 41)
+    v = View.headless(480, 270, msaa_samples=samples)
+    v.clear_color = (0.05, 0.1, 0.2, 1.0)
+    kw = dict(global_scale=0.25, **_MS_VARIANTS[variant])
+    s = CloudSettings(visualize_bounding_box=True, **kw)
+    h = plugin.upload(c)
+    dhost, dptr = None, None
+    if depth:
+        dhost = H.random_depth_buffer(c, v, s, np.random.default_rng(5))
+        dptr = plugin.upload_depth(dhost)
+        v.depth_device_ptr = dptr
+    try:
+        got = plugin.render(h, v, s)
+        plain = plugin.render(h, v, CloudSettings(**kw))
+    finally:
+        if dptr is not None:
+            plugin.device_free(dptr)
+            v.depth_device_ptr = 0
+    e = oracle.sort(c, v, s)
+    ref, amb = oracle.render(c, e, v, s, with_ambiguity=True, depth=dhost)
+    _assert_image(ref, got, amb, frac_slack=0.02, what=f"bbox {variant} x{samples} depth={depth} {binning}")
+    assert np.abs(got - plain).max() > 0.2
+    # the frame colour really is there: pixels that are (nearly) pure (0.3, 1, 0.1) with alpha 1
+    frame_px = (np.abs(got[..., :3] - np.array([0.3, 1.0, 0.1], np.float32)).max(axis=2) < 1e-3) & (np.abs(got[..., 3] - 1.0) < 1e-3)
+    assert frame_px.sum() > 50
+    h.free()
+
+
+@pytest.mark.parametrize("variant", sorted(_MS_VARIANTS))
+@pytest.mark.parametrize("samples", [1, 2, 4, 8])
 def test_depth_buffer_occludes_splats(plugin, oracle, binning, variant, samples):
     """The view's depth attachment (Depth32Float, reverse-Z, GreaterEqual, no write: src/render/mod.rs:959-974) as a device
     buffer: a tilted, per-sample jittered plane through the middle of the cloud — tiles wholly in front of it, wholly

@@ -333,14 +333,26 @@ def _same_point_set(a, b, atol):
 # specifications (Vulkan "standard sample locations", D3D11+ standard patterns, Metal's default positions) — typed
 # here, not taken from the oracle: what MultisampleState { count: 4 } (src/render/mod.rs:975-979) means on every
 # backend wgpu has.
-SAMPLE_POS = {1: [(0.5, 0.5)], 4: [(0.375, 0.125), (0.875, 0.375), (0.125, 0.625), (0.625, 0.875)]}
+_SAMPLE_POS_1_4 = {1: [(0.5, 0.5)], 4: [(0.375, 0.125), (0.875, 0.375), (0.125, 0.625), (0.625, 0.875)]}
+# Msaa::Sample2 / Sample8 (typed from the Vulkan "standard sample locations" table / D3D11's standard patterns, in
+# sixteenths of a pixel from the top-left corner — not taken from the oracle)
+SAMPLE_POS_ALL = dict(_SAMPLE_POS_1_4)
+SAMPLE_POS_ALL[2] = [(12 / 16, 12 / 16), (4 / 16, 4 / 16)]
+SAMPLE_POS_ALL[8] = [(9 / 16, 5 / 16), (7 / 16, 11 / 16), (13 / 16, 9 / 16), (5 / 16, 3 / 16),
+                     (3 / 16, 13 / 16), (1 / 16, 7 / 16), (11 / 16, 15 / 16), (15 / 16, 1 / 16)]
+
+
+SAMPLE_POS = SAMPLE_POS_ALL   # every pixel-level pin below runs at Msaa::Off / Sample2 / Sample4 / Sample8
 
 
 def test_oracle_sample_positions_are_the_standard_ones(oracle):
-    for n, pos in SAMPLE_POS.items():
+    for n, pos in SAMPLE_POS_ALL.items():
         assert np.allclose(oracle.sample_positions(n), pos)
-    with pytest.raises(ValueError):
-        oracle.sample_positions(2)
+        # every standard pattern is centred on the pixel centre
+        assert np.allclose(np.mean(pos, axis=0), (0.5, 0.5))
+    for bad in (3, 16):
+        with pytest.raises(ValueError):
+            oracle.sample_positions(bad)
 
 
 ANISO_CASES = [
@@ -383,7 +395,7 @@ def test_anisotropic_splat_covariance_and_quad_from_geometry(oracle, case, aabb)
     assert _same_point_set(corners, expected, atol=1e-3 * k * math.sqrt(lam[1]) + 0.02), (corners, expected)
 
 
-@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("samples", [1, 2, 4, 8])
 @pytest.mark.parametrize("aabb", [False, True])
 @pytest.mark.parametrize("adaptive", [False, True])
 def test_anisotropic_splat_image_is_the_projected_gaussian(oracle, aabb, adaptive, samples):
@@ -563,7 +575,7 @@ def test_surfel_ray_plane_intersection_and_bounds_from_geometry(oracle):
     assert np.isclose(vs.radius[0], max((mx - mn) / 2)) or vs.radius[0] >= 3 * 0.707106
 
 
-@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("samples", [1, 2, 4, 8])
 def test_surfel_image_follows_the_intersection(oracle, samples):
     """Every pixel the surfel quad covers: alpha = opacity exp(-1/2 min(u^2 + v^2, 2 |mean_2d - pc|^2)) with
     (u, v) from the float64 ray-plane intersection at the coordinate pc the fragment stage derives for that
@@ -609,7 +621,7 @@ def test_surfel_image_follows_the_intersection(oracle, samples):
     assert checked > 2000
 
 
-@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("samples", [1, 2, 4, 8])
 def test_three_splat_stack_blends_back_to_front(oracle, samples):
     """Three overlapping splats at different depths (AABB, analytic alphas as above): the target must hold
     sum_i c_i a_i prod_{j nearer} (1 - a_j) over an opaque clear colour — premultiplied 'over' in
@@ -740,7 +752,7 @@ def _independent_scene(view, cloud, settings, depth=None):
     return img.mean(0), edge_mask, drawn
 
 
-@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("samples", [1, 2, 4, 8])
 @pytest.mark.parametrize("aabb", [False, True])
 def test_random_scene_against_an_independent_float64_renderer(oracle, aabb, samples):
     """120 random anisotropic splats (unnormalised rotations, SH degree 3, sRGB colour space, adaptive radius, overlapping,
@@ -764,14 +776,14 @@ def test_random_scene_against_an_independent_float64_renderer(oracle, aabb, samp
     ref, edge, drawn = _independent_scene(view, c, st)
     assert 40 < drawn < n                            # a real mix of drawn and culled splats
     ok = ~edge
-    assert ok.mean() > (0.9 if samples == 1 else 0.7)
+    assert ok.mean() > {1: 0.9, 2: 0.8, 4: 0.7, 8: 0.55}[samples]   # (more sample positions, more pixels with one near an edge)
     err = np.abs(img - ref)
     assert err[ok].max() < 2e-5, (err[ok].max(), np.abs(ref).max())   # measured: 1e-6 (f32 oracle vs float64 geometry)
     # and the scene is not trivial: most pixels see several splats
     assert (np.abs(ref[..., :3] - np.asarray(view.clear_color)[:3]).sum(-1) > 1e-3).mean() > 0.5
 
 
-@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("samples", [1, 2, 4, 8])
 @pytest.mark.parametrize("aabb", [False, True])
 def test_random_scene_with_a_depth_buffer_against_an_independent_float64_renderer(oracle, aabb, samples):
     """The same 120-splat scene drawn against a scene depth buffer that differs from SAMPLE to sample: every stored depth
@@ -831,7 +843,7 @@ def _scene_cloud(n, seed):
     return c
 
 
-@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("samples", [1, 2, 4, 8])
 def test_f16_cloud_scene_against_the_independent_renderer(oracle, samples):
     """The f16 planar storage (src/gaussian/f16.rs:29-55, src/render/planar.wgsl:117-176): the oracle draws the PACKED
     cloud (its own unpack: which half holds which value, coefficient pairing); the independent renderer draws the cloud
@@ -947,7 +959,7 @@ def _independent_surfel_scene(view, cloud, settings, depth=None):
     return img.mean(0), edge_mask, drawn
 
 
-@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("samples", [1, 2, 4, 8])
 def test_surfel_scene_against_an_independent_float64_renderer(oracle, samples):
     """100 overlapping 2DGS surfels (unit quaternions within ~50 degrees of facing the camera, SH degree 3, sRGB colour
     space, adaptive radius) at 128x80, GaussianMode::Gaussian2d + aabb (the true surfel fragment path): the oracle's
