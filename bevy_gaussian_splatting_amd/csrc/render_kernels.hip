@@ -1199,7 +1199,8 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
                 float4 st[6];
                 stage_surfel(src, tile_ox, tile_oy, aspect, st);
                 const float z = src[5].x;
-                st[5].y = keepz_of(!surfel_negligible_in_tile(st, surfel_limit) && (!DEPTH || z >= tile_dmin), z);  // as raster_scan_kernel decides
+                // (the bounding-box overlay draws a quad's frame whatever its Gaussian is worth there: nothing is negligible)
+                st[5].y = keepz_of((BBOX || !surfel_negligible_in_tile(st, surfel_limit)) && (!DEPTH || z >= tile_dmin), z);  // as raster_scan_kernel decides
 #pragma unroll
                 for (int v = 0; v < 6; ++v) s_rec[tid * REC_V4 + v] = st[v];
             } else {
@@ -1475,7 +1476,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                 } else {
                     float4 st[6];
                     stage_surfel(src, tile_ox, tile_oy, aspect, st);
-                    keep = keep && !(surfel_negligible_in_tile(st, surfel_limit) && !(ABLATE && (fp.debug & 64u)));
+                    if constexpr (!BBOX) keep = keep && !(surfel_negligible_in_tile(st, surfel_limit) && !(ABLATE && (fp.debug & 64u)));
                     const float z = src[5].x;
                     st[5].y = keepz_of(keep && (!DEPTH || z >= tile_dmin), z);
 #pragma unroll

@@ -403,8 +403,8 @@ class GaussianSplattingPlugin:
         opaque passes left in the view's Depth32Float attachment; src/render/mod.rs:959-974). Returns the device
         address for `View.depth_device_ptr`; release it with `device_free` once the frames that use it are complete."""
         d = np.ascontiguousarray(depth, dtype=np.float32)
-        if d.ndim != 3 or d.shape[2] not in (1, 4):
-            raise ValueError("depth must be [height, width, samples] with 1 or 4 samples")
+        if d.ndim != 3 or d.shape[2] not in (1, 2, 4, 8):
+            raise ValueError("depth must be [height, width, samples] with 1, 2, 4 or 8 samples")
         p = self.device_alloc(d.nbytes)
         self.upload_bytes(p, d)
         return p

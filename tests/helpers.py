@@ -338,11 +338,13 @@ def tolerance_mask(ref: np.ndarray, got: np.ndarray, amb: np.ndarray | None, ato
 # Tolerance accounting (round 4's verdict: "the tolerance is builder-adjustable"): every oracle comparison of a run reports
 # here how many values passed only through the oracle's ambiguity bound and by HOW MUCH they exceed the strict tolerance
 # 1e-3 + 1e-4 |ref|; the run's last test asserts on the totals and conftest writes them next to the other evidence.
-TOLERANCE = {"values": 0, "checked": 0, "max_excess": 0.0, "comparisons": []}
+TOLERANCE = {"values": 0, "checked": 0, "max_excess": 0.0, "max_excess_overlay": 0.0, "comparisons": []}
 
 
-def account(ref, got, amb, what: str = "") -> dict:
-    """Record one oracle comparison: values beyond the strict tolerance and their largest excess over it."""
+def account(ref, got, amb, what: str = "", overlay: bool = False) -> dict:
+    """Record one oracle comparison: values beyond the strict tolerance and their largest excess over it. `overlay`: a
+    frame with the bounding-box overlay — an ambiguous decision there swaps a splat's fragment for the opaque frame colour
+    (the whole fragment, colour magnitude 1), so its excess is reported apart from the splat images'."""
     strict, err = tolerance_mask(ref, got, None)
     lim = 1e-3 + 1e-4 * np.abs(ref.astype(np.float64))
     over = ~strict
@@ -351,7 +353,9 @@ def account(ref, got, amb, what: str = "") -> dict:
            "max_err": float(err.max()) if err.size else 0.0}
     TOLERANCE["values"] += rec["beyond_strict"]
     TOLERANCE["checked"] += rec["values"]
-    TOLERANCE["max_excess"] = max(TOLERANCE["max_excess"], excess)
+    key = "max_excess_overlay" if overlay else "max_excess"
+    TOLERANCE[key] = max(TOLERANCE[key], excess)
+    rec["overlay"] = bool(overlay)
     if rec["beyond_strict"] or rec["values"] >= 1_000_000:
         TOLERANCE["comparisons"].append(rec)
     return rec
