@@ -108,11 +108,24 @@ static_assert(sizeof(RecordSurfel) == 96, "RecordSurfel must be 96 bytes");
 // LDS of one workgroup. bucket(key) = number of splitters <= key, the splitters being the 255 keys at
 // the 1/256-quantiles of a recently completed frame's sorted list: balanced by construction while the
 // view changes slowly, and monotone in the key whatever the table holds (order never depends on it).
-constexpr uint32_t BUCKET_COUNT = 256;       // = the 256 chains of the look-back (thread = bucket)
+constexpr uint32_t BUCKET_COUNT = 256;       // key ranges the splitters define
 constexpr uint32_t BUCKET_CAP = 4096;        // pairs per bucket: 32 KB of LDS
 constexpr uint32_t BUCKET_FINE = 2048;       // fine key ranges inside a bucket (counting sort + rank among equals)
 constexpr uint32_t BUCKET_FINE_MAX = 1024;   // more pairs than this in one fine range: give up (ties), onesweep re-run
-struct SplitterTable { uint32_t key[BUCKET_COUNT]; };  // key[0..254] ascending; key[255] unused
+// Draw lists longer than 256 buckets hold (round 5: a camera that sees the whole cloud, SortMode::Rayon / Std — D = N):
+// 256 * sub buckets, sub <= BUCKET_SUB_MAX, with the 256 * sub - 1 keys at the 1 / (256 sub)-quantiles of a completed
+// frame's list as splitters — exact quantiles, so the buckets stay balanced whatever the key distribution is (equal KEY
+// intervals inside a 1/256-quantile range were tried first: the first and the last range of a distance-keyed list
+// span many binades and nearly all of their pairs fall into one interval). sub <= 3 is what fits the table into a
+// kernel's 4 KB of arguments: 768 buckets, 2.36 M drawable pairs; longer lists take the digit passes.
+constexpr uint32_t BUCKET_SUB_MAX = 3;
+constexpr uint32_t BUCKET_MAX = BUCKET_COUNT * BUCKET_SUB_MAX;
+constexpr uint32_t BUCKET_TARGET = 2048;     // pairs per bucket the host aims at when it picks `sub`
+struct SplitterTable {
+    uint32_t key[BUCKET_MAX];     // key[0 .. 256 * sub - 2] ascending quantile keys (the rest unused)
+    uint32_t sub;                 // 1 .. BUCKET_SUB_MAX: the table defines 256 * sub buckets
+    uint32_t pad[3];
+};
 
 // Device-resident control block, zeroed at the start of every frame by one memset.
 struct Control {
@@ -139,9 +152,9 @@ struct Control {
     uint32_t hist_depth[4][RADIX_BASE];  // global digit histograms of the depth keys
     uint32_t hist_tile[2][RADIX_BASE];   // digit 0 = tile x, digit 1 = tile y
     uint32_t coarse_total[RADIX_BASE];   // scan binning: entries in each supertile's ordered list
-    uint32_t bucket_count[BUCKET_COUNT]; // bucket sort: pairs in each key-range bucket (written by keygen's last tile)
-    uint32_t splitters[BUCKET_COUNT];    // quantile keys of THIS frame's sorted list (keygen key space): the
-                                         // host hands them to later frames' keygen (SplitterTable)
+    uint32_t splitters[BUCKET_MAX];      // the 256 * sub - 1 quantile keys of THIS frame's sorted list (keygen key space; sub =
+                                         // FrameCleanup::split_sub): the host hands them to later frames' keygen (SplitterTable)
+    uint32_t bucket_count[BUCKET_MAX];   // bucket sort: pairs in each bucket (keygen's returning atomics); the frame's 256 * sub first
 };
 constexpr uint32_t CONTROL_HEADER_WORDS = 11;  // draw_count .. strip_tiles: what a frame reports to the host
 

@@ -54,10 +54,10 @@ struct FrameCleanup {
     uint32_t pass_stride;     // words between the status arrays of consecutive depth passes
     uint32_t places;
     uint32_t depth_tile;      // keys per onesweep tile of the depth passes
-    uint32_t bucket_chain_words;  // bucket sort frames: look-back words keygen used at depth_status (else 0)
     // quantile keys of this frame's sorted list -> host_ctl->splitters (keygen key space = key ^ key_xor)
     const uint2* sorted;
     uint32_t key_xor;
+    uint32_t split_sub;       // the table this frame leaves has 256 * split_sub - 1 quantile keys (1 .. BUCKET_SUB_MAX)
 };
 
 // Onesweep geometry: 256 threads x KPT keys per tile.
@@ -82,15 +82,16 @@ struct KeygenLaunch {
     uint32_t places;
     uint32_t ticket_slot;
     FrameParams* fp_out;
-    uint2* bucket_slots;  // fp.sort_path == 1: [BUCKET_COUNT][BUCKET_CAP] slot regions
-    uint32_t* bucket_status;  // fp.sort_path == 1: zeroed look-back words [keygen tiles][BUCKET_COUNT]
-    SplitterTable split;      // fp.sort_path == 1: bucket = number of entries <= key
+    uint2* bucket_slots;  // fp.sort_path == 1: [BUCKET_COUNT * split.sub][BUCKET_CAP] slot regions
+    uint32_t* bucket_status;  // (unused since round 5: bucket placement needs no chains)
+    SplitterTable split;      // fp.sort_path == 1: bucket = number of key[0 .. 256 * sub - 2] <= key
     uint32_t* zero_word;      // a word the frame needs zeroed before its later kernels run (the rasteriser's heavy-tile count), or null
     bool wide = false;        // the frame is alone on the chip (pipeline depth 1): chainless tiles as 1024-thread workgroups
     // filled by prepare(): the launch geometry and the argument vector (points into this object)
     const void* func;
     uint32_t blocks, threads;
     void* argv[13];
+    uint32_t lds_bytes;   // dynamic LDS of the launch (the per-bucket counters of a bucket frame)
     bool prepare(int max_blocks);  // false: nothing to launch (n == 0)
     hipError_t launch(hipStream_t stream);
     hipError_t update_node(hipGraphExec_t exec, hipGraphNode_t node);  // same launch, as a graph node update
@@ -132,9 +133,10 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
 // to out[] at its offset; out[0 .. draw_count) is then bit-identical to what the stable LSD passes
 // produce. Sets ctl->sort_overflow instead when a bucket holds more than BUCKET_CAP pairs or one key value
 // repeats more than BUCKET_FINE_MAX times (the host re-runs the frame with the onesweep passes).
-void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor);
+void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor,
+                        uint32_t buckets = BUCKET_COUNT /* 256 * sub */);
 // ctl->splitters = the 255 quantile keys of the sorted draw list (for frames without a cleaning rasteriser).
-void launch_splitters(hipStream_t stream, const uint2* sorted, Control* ctl, uint32_t key_xor);
+void launch_splitters(hipStream_t stream, const uint2* sorted, Control* ctl, uint32_t key_xor, uint32_t sub = 1u);
 
 // Vertex stage in front-to-back order + ordered tile-instance emission
 // (vs_points once per splat, src/render/gaussian.wgsl:184-436).

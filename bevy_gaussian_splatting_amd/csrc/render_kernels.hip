@@ -1650,11 +1650,12 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
                 host[tid] = strips;
             }
             host[COARSE_OFF + (uint32_t)tid] = src[COARSE_OFF + (uint32_t)tid];
-            // the 1/256-quantile keys of this frame's sorted list: later frames' bucket splitters
-            host[SPLIT_OFF + (uint32_t)tid] =
-                (draw_count != 0u && (uint32_t)tid < BUCKET_COUNT - 1u)
-                    ? (cl.sorted[(uint32_t)(((unsigned long long)((uint32_t)tid + 1u) * draw_count) >> 8)].x ^ cl.key_xor)
-                    : 0xFFFFFFFFu;
+            // the 1 / (256 sub)-quantile keys of this frame's sorted list: later frames' bucket splitters
+            const uint32_t nbk = BUCKET_COUNT * min(max(cl.split_sub, 1u), BUCKET_SUB_MAX);
+            for (uint32_t t = (uint32_t)tid; t < BUCKET_MAX; t += 256u)
+                host[SPLIT_OFF + t] = (draw_count != 0u && t < nbk - 1u)
+                                          ? (cl.sorted[(uint32_t)(((unsigned long long)(t + 1u) * draw_count) / nbk)].x ^ cl.key_xor)
+                                          : 0xFFFFFFFFu;
         }
         const uint32_t part_words = (fp.n + KEYGEN_TILE - 1u) / KEYGEN_TILE;
         for (uint32_t i = g; i < part_words; i += gn) cl.part_status[i] = 0u;
@@ -1662,10 +1663,6 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
         for (uint32_t p = 0u; p < cl.places; ++p) {
             uint4* dst = reinterpret_cast<uint4*>(cl.depth_status + (size_t)p * cl.pass_stride);
             for (uint32_t i = g; i < depth_v4; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        {   // bucket-sort frames: keygen's per-bucket chains live at the start of the depth status words
-            uint4* dst = reinterpret_cast<uint4*>(cl.depth_status);
-            for (uint32_t i = g; i < cl.bucket_chain_words / 4u; i += gn) dst[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         const uint32_t bin_v4 = ((draw_count + BIN_RANKS - 1u) / BIN_RANKS) * (MAX_SUPERTILES / 4u);
         uint4* bdst = reinterpret_cast<uint4*>(cl.bin_status);

@@ -111,12 +111,12 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     __shared__ uint32_t s_off[ROWS];   // ... and of the rows before it
     __shared__ uint32_t s_keys[THREADS * KG_ITEMS];  // the tile's drawable keys, compacted (for the histograms / the buckets)
     __shared__ uint32_t s_idx[BUCKET ? THREADS * KG_ITEMS : 1];  // their splat indices (BUCKET)
-    __shared__ uint32_t s_split[BUCKET ? BUCKET_COUNT : 1];
-    __shared__ uint32_t s_bcnt[BUCKET ? BUCKET_COUNT : 1];   // pairs of this tile per bucket
-    __shared__ uint32_t s_bexcl[BUCKET ? BUCKET_COUNT : 1];  // pairs of earlier tiles per bucket
+    __shared__ uint32_t s_split[BUCKET ? 1024 : 1];           // the nb - 1 splitters, then ~0 up to the next power of two
+    extern __shared__ uint32_t s_dyn[];                       // BUCKET: 2 x nb words (nb = 256 * split.sub buckets)
+    uint32_t* const s_bcnt = s_dyn;                           // pairs of this tile per bucket
+    uint32_t* const s_bexcl = s_dyn + (BUCKET ? BUCKET_COUNT * split.sub : 0u);   // pairs of earlier tiles per bucket
     __shared__ uint16_t s_at[BUCKET ? THREADS * KG_ITEMS : 1];  // arrival slot of compacted pair j inside its bucket (this tile)
-    __shared__ uint8_t s_bk[BUCKET ? THREADS * KG_ITEMS : 1];   // its bucket
-    __shared__ uint32_t s_tot[4];
+    __shared__ uint16_t s_bk[BUCKET ? THREADS * KG_ITEMS : 1];  // its bucket
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_tile;
@@ -127,13 +127,13 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     if (fp_out && blockIdx.x == 0 && (uint32_t)tid < (uint32_t)(sizeof(FrameParams) / 4u))
         reinterpret_cast<uint32_t*>(fp_out)[tid] = reinterpret_cast<const uint32_t*>(&fp)[tid];
     if (zero_word && blockIdx.x == 0 && tid == 0) *zero_word = 0u;
-    if (tid < 256) {
-        if constexpr (BUCKET) {
-            s_split[tid] = tid < (int)BUCKET_COUNT - 1 ? split.key[tid] : 0xFFFFFFFFu;
-        } else {
+    const uint32_t nsub = BUCKET ? split.sub : 1u, nb = BUCKET_COUNT * nsub;   // buckets of the frame
+    if constexpr (BUCKET) {
+        for (uint32_t t = (uint32_t)tid; t < (nsub == 1u ? 256u : 1024u); t += (uint32_t)THREADS)
+            s_split[t] = t < nb - 1u ? split.key[t] : 0xFFFFFFFFu;
+    } else if (tid < 256) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
-        }
+        for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
     }
     const uint32_t sentinel = KEY_CULLED >> fp.key_shift;
     constexpr uint32_t per_tile = (uint32_t)(THREADS * KG_ITEMS);
@@ -145,10 +145,25 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     // after its tile instead of queueing for a second ticket only to be told there is nothing left.
     const bool single_shot = gridDim.x >= num_tiles;
 
+    // bucket of a key = the number of splitters <= key (the entries behind the table's end are ~0: never counted unless the
+    // key is ~0 itself, hence the min): 8 steps over the 255 splitters of the usual frame, 10 over up to 767
+    auto bucket_of = [&](const uint32_t kk) -> uint32_t {
+        uint32_t lo = 0u;
+        if (nsub == 1u) {
+#pragma unroll
+            for (uint32_t step = 128u; step > 0u; step >>= 1)
+                if (s_split[lo + step - 1u] <= kk) lo += step;
+        } else {
+#pragma unroll
+            for (uint32_t step = 512u; step > 0u; step >>= 1)
+                if (s_split[lo + step - 1u] <= kk) lo += step;
+        }
+        return min(lo, nb - 1u);
+    };
     if constexpr (BUCKET && !ORDERED) {
         if (blockIdx.x == 0 && tid == 0) ctl->splat_count = fp.n;
         for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-            if (tid < (int)BUCKET_COUNT) s_bcnt[tid] = 0u;
+            for (uint32_t f = (uint32_t)tid; f < nb; f += (uint32_t)THREADS) s_bcnt[f] = 0u;
             if (tid == 0) s_total = 0u;
             __syncthreads();   // (first tile: s_split is in place as well)
             const uint32_t base = tile * per_tile;
@@ -209,21 +224,16 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
             for (int r = 0; r < KG_ITEMS; ++r) {
                 const uint32_t j = (uint32_t)(r * THREADS) + (uint32_t)tid;
                 if (j < total) {
-                    const uint32_t kk = s_keys[j];
-                    uint32_t lo = 0u;  // number of splitters <= kk (s_split[255] = ~0: never counted unless kk = ~0)
-#pragma unroll
-                    for (uint32_t step = BUCKET_COUNT / 2u; step > 0u; step >>= 1)
-                        if (s_split[lo + step - 1u] <= kk) lo += step;
-                    const uint32_t bkt = min(lo, BUCKET_COUNT - 1u);
-                    s_bk[j] = (uint8_t)bkt;
+                    const uint32_t bkt = bucket_of(s_keys[j]);
+                    s_bk[j] = (uint16_t)bkt;
                     s_at[j] = (uint16_t)min(atomicAdd(&s_bcnt[bkt], 1u), 0xFFFFu);
                 }
             }
             __syncthreads();
             // thread = bucket: the tile's pairs of a bucket take the next `mine` slots of the bucket, whoever comes first
-            if (tid < (int)BUCKET_COUNT) {
-                const uint32_t mine = s_bcnt[tid];
-                s_bexcl[tid] = mine ? atomicAdd(&ctl->bucket_count[tid], mine) : 0u;
+            for (uint32_t f = (uint32_t)tid; f < nb; f += (uint32_t)THREADS) {
+                const uint32_t mine = s_bcnt[f];
+                s_bexcl[f] = mine ? atomicAdd(&ctl->bucket_count[f], mine) : 0u;
             }
             __syncthreads();
 #pragma unroll
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
 
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&ctl->ticket[ticket_slot][0], 1u);
-        if constexpr (BUCKET) { if (tid < (int)BUCKET_COUNT) s_bcnt[tid] = 0u; }
+        if constexpr (BUCKET) { for (uint32_t f = (uint32_t)tid; f < nb; f += (uint32_t)THREADS) s_bcnt[f] = 0u; }
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                 s_keys[off[k] + below[k]] = key[k];
                 if constexpr (BUCKET) s_idx[off[k] + below[k]] = base + (uint32_t)(k * THREADS) + (uint32_t)tid;
             }
-        if constexpr (!BUCKET) {
+        {
             if (wave == 0) {  // one chain per block: the whole wave walks it, 64 predecessors per hop
                 uint32_t* const my_status = part_status + tile;
                 uint32_t excl = 0u;
@@ -328,61 +338,31 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                 }
             }
             __syncthreads();
-            for (uint32_t j = (uint32_t)tid; j < total; j += (uint32_t)THREADS) {
-                const uint32_t kk = s_keys[j];
-                for (uint32_t pl = 0; pl < places; ++pl)
-                    atomicAdd(&s_hist[pl][(kk >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
-            }
+            if constexpr (!BUCKET)
+                for (uint32_t j = (uint32_t)tid; j < total; j += (uint32_t)THREADS) {
+                    const uint32_t kk = s_keys[j];
+                    for (uint32_t pl = 0; pl < places; ++pl)
+                        atomicAdd(&s_hist[pl][(kk >> (RADIX_BITS * pl)) & (RADIX_BASE - 1u)], 1u);
+                }
         }
         if constexpr (BUCKET) {
-            __syncthreads();
+            // Bucket placement as in the chainless tiles above: a returning atomic per (tile, bucket). The tile's place
+            // in the index order — what the culled tail needs — comes from the block's ONE chain above (round 4 walked
+            // 256 per-bucket chains here and took their sum).
 #pragma unroll
             for (int r = 0; r < KG_ITEMS; ++r) {
                 const uint32_t j = (uint32_t)(r * THREADS) + (uint32_t)tid;
                 if (j < total) {
-                    const uint32_t kk = s_keys[j];
-                    uint32_t lo = 0u;  // number of splitters <= kk (s_split[255] = ~0: never counted unless kk = ~0)
-#pragma unroll
-                    for (uint32_t step = BUCKET_COUNT / 2u; step > 0u; step >>= 1)
-                        if (s_split[lo + step - 1u] <= kk) lo += step;
-                    // bucket and arrival slot wait in LDS for the chain (16 + 16 registers per thread otherwise: typically
-                    // only the first two of the 16 rounds hold pairs, but the registers are reserved for all)
-                    const uint32_t bkt = min(lo, BUCKET_COUNT - 1u);
-                    s_bk[j] = (uint8_t)bkt;
+                    const uint32_t bkt = bucket_of(s_keys[j]);
+                    s_bk[j] = (uint16_t)bkt;
                     s_at[j] = (uint16_t)min(atomicAdd(&s_bcnt[bkt], 1u), 0xFFFFu);
                 }
             }
             __syncthreads();
-            // thread = bucket (the first 256 threads): chained scan over the tiles, one chain per bucket
-            uint32_t excl = 0u, mine = 0u;
-            if (tid < (int)BUCKET_COUNT) {
-                mine = s_bcnt[tid];
-                uint32_t* const my_status = bucket_status + (size_t)tile * BUCKET_COUNT + tid;
-                if (tile > 0u) {
-                    st_agent(my_status, STATUS_AGGREGATE | mine);
-                    // 4 words per hop at every size: on a 5 M-splat cloud (1221 tiles) 16 per hop were 5 % slower
-                    excl = lookback_u32<4>(bucket_status + tid, tile, BUCKET_COUNT, &ctl->error, 8u);
-                }
-                st_agent(my_status, STATUS_PREFIX | ((excl + mine) & STATUS_VALUE_MASK));
-                s_bexcl[tid] = excl;
+            for (uint32_t f = (uint32_t)tid; f < nb; f += (uint32_t)THREADS) {
+                const uint32_t mine = s_bcnt[f];
+                s_bexcl[f] = mine ? atomicAdd(&ctl->bucket_count[f], mine) : 0u;
             }
-            // the sum of the 256 exclusive prefixes = the drawable entries of the earlier tiles
-            uint32_t before_tile = tid < (int)BUCKET_COUNT ? excl : 0u;
-            if (wave < 4) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) before_tile += (uint32_t)__shfl_xor((int)before_tile, o, 64);
-                if (lane == 0) s_tot[wave] = before_tile;
-            }
-            __syncthreads();
-            before_tile = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-            if (tile == num_tiles - 1u && tid < (int)BUCKET_COUNT) {
-                ctl->bucket_count[tid] = excl + mine;
-                if (tid == 0) {
-                    ctl->draw_count = before_tile + total;
-                    ctl->splat_count = fp.n;
-                }
-            }
-            if (tid == 0) s_base = before_tile;
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < KG_ITEMS; ++r) {
@@ -462,11 +442,13 @@ bool KeygenLaunch::prepare(int max_blocks) {
     argv[0] = &fp; argv[1] = &pos; argv[2] = &entries; argv[3] = &culled; argv[4] = &ctl;
     argv[5] = &part_status; argv[6] = &places; argv[7] = &ticket_slot; argv[8] = &fp_out; argv[9] = &bucket_slots;
     argv[10] = &bucket_status; argv[11] = &split; argv[12] = &zero_word;
+    if (split.sub < 1u || split.sub > BUCKET_SUB_MAX) split.sub = 1u;
+    lds_bytes = bucket ? 2u * BUCKET_COUNT * split.sub * (uint32_t)sizeof(uint32_t) : 0u;   // s_bcnt + s_bexcl
     return true;
 }
 
 hipError_t KeygenLaunch::launch(hipStream_t stream) {
-    return hipLaunchKernel(func, dim3(blocks), dim3(threads), argv, 0, stream);
+    return hipLaunchKernel(func, dim3(blocks), dim3(threads), argv, lds_bytes, stream);
 }
 
 hipError_t KeygenLaunch::update_node(hipGraphExec_t exec, hipGraphNode_t node) {
@@ -474,7 +456,7 @@ hipError_t KeygenLaunch::update_node(hipGraphExec_t exec, hipGraphNode_t node) {
     np.func = const_cast<void*>(func);
     np.gridDim = dim3(blocks);
     np.blockDim = dim3(threads);
-    np.sharedMemBytes = 0;
+    np.sharedMemBytes = lds_bytes;
     np.kernelParams = argv;
     np.extra = nullptr;
     return hipGraphExecKernelNodeSetParams(exec, node, &np);
@@ -687,7 +669,7 @@ constexpr uint32_t BUCKET_SORT_THREADS = BGS_BUCKET_SORT_THREADS;
 template <uint32_t THREADS>  // 256 or 1024
 __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __restrict__ slots,
                                                               uint2* __restrict__ out, Control* ctl,
-                                                              uint32_t key_xor) {
+                                                              uint32_t key_xor, uint32_t nb /* buckets of the frame: 256 * sub */) {
     constexpr uint32_t WAVES = THREADS / 64u;
     constexpr uint32_t EPT = BUCKET_CAP / THREADS;              // pairs per thread (strided)
     constexpr uint32_t NF = BUCKET_FINE, FPT = NF / THREADS;    // fine ranges per thread (contiguous)
@@ -699,9 +681,14 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
-    // offset of this bucket in the sorted list, its own count, the fullest bucket (threads 0..255 = buckets)
-    const uint32_t cnt = tid < (int)BUCKET_COUNT ? ctl->bucket_count[tid] : 0u;
-    uint32_t before = tid < (int)b ? cnt : 0u, mine = tid == (int)b ? cnt : 0u, mx = cnt;
+    // offset of this bucket in the sorted list, its own count, the fullest bucket (every thread takes a stride of the counts)
+    uint32_t before = 0u, mine = 0u, mx = 0u;
+    for (uint32_t i = (uint32_t)tid; i < nb; i += THREADS) {
+        const uint32_t cnt = ctl->bucket_count[i];
+        before += i < b ? cnt : 0u;
+        mine += i == b ? cnt : 0u;
+        mx = max(mx, cnt);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         before += (uint32_t)__shfl_xor((int)before, off, 64);
@@ -712,9 +699,10 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
 #pragma unroll
     for (uint32_t j = 0; j < FPT; ++j) s_f[j * THREADS + (uint32_t)tid] = 0u;
     __syncthreads();
-    const uint32_t base = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-    const uint32_t m = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
-    mx = max(max(s_tot[0], s_tot[1]), max(s_tot[2], s_tot[3]));
+    uint32_t base = 0u, m = 0u;
+    mx = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; ++w) { base += s_red[w][0]; m += s_red[w][1]; mx = max(mx, s_tot[w]); }
     if (b == 0u && tid == 0) {
         ctl->bucket_max = mx;
         if (mx > BUCKET_CAP) {
@@ -726,7 +714,7 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     }
     // the length of the list: the last bucket's offset + its pairs (a keygen without chains leaves only the per-bucket
     // counts; one with chains has written the same number already)
-    if (b == BUCKET_COUNT - 1u && tid == 0 && mx <= BUCKET_CAP) ctl->draw_count = base + m;
+    if (b == nb - 1u && tid == 0 && mx <= BUCKET_CAP) ctl->draw_count = base + m;
     if (m == 0u || mx > BUCKET_CAP) return;
     __syncthreads();  // s_red / s_tot are reused below
 
@@ -820,22 +808,22 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     }
 }
 
-void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor) {
-    hipLaunchKernelGGL(bucket_sort_kernel<BUCKET_SORT_THREADS>, dim3(BUCKET_COUNT), dim3(BUCKET_SORT_THREADS), 0, stream,
-                       bucket_slots, out, ctl, key_xor);
+void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor, uint32_t buckets) {
+    hipLaunchKernelGGL(bucket_sort_kernel<BUCKET_SORT_THREADS>, dim3(buckets), dim3(BUCKET_SORT_THREADS), 0, stream,
+                       bucket_slots, out, ctl, key_xor, buckets);
 }
 
 // The 255 keys at the 1/256-quantiles of a sorted draw list, in keygen's key space (key ^ key_xor): the
 // SplitterTable of later frames. Frames whose rasteriser does the clean-up (BINNING_SCAN) get them from
 // there; this one-block kernel serves the others (bgs_sort, BINNING_SORT).
-__global__ __launch_bounds__(256) void splitter_kernel(const uint2* __restrict__ sorted, Control* ctl, uint32_t key_xor) {
-    const uint32_t d = ctl->draw_count, t = threadIdx.x;
-    ctl->splitters[t] = (d != 0u && t < BUCKET_COUNT - 1u)
-                            ? (sorted[(uint32_t)(((unsigned long long)(t + 1u) * d) >> 8)].x ^ key_xor) : 0xFFFFFFFFu;
+__global__ __launch_bounds__(256) void splitter_kernel(const uint2* __restrict__ sorted, Control* ctl, uint32_t key_xor, uint32_t sub) {
+    const uint32_t d = ctl->draw_count, nbk = BUCKET_COUNT * min(max(sub, 1u), BUCKET_SUB_MAX);
+    for (uint32_t t = threadIdx.x; t < BUCKET_MAX; t += 256u)
+        ctl->splitters[t] = (d != 0u && t < nbk - 1u) ? (sorted[(uint32_t)(((unsigned long long)(t + 1u) * d) / nbk)].x ^ key_xor) : 0xFFFFFFFFu;
 }
 
-void launch_splitters(hipStream_t stream, const uint2* sorted, Control* ctl, uint32_t key_xor) {
-    hipLaunchKernelGGL(splitter_kernel, dim3(1), dim3(256), 0, stream, sorted, ctl, key_xor);
+void launch_splitters(hipStream_t stream, const uint2* sorted, Control* ctl, uint32_t key_xor, uint32_t sub) {
+    hipLaunchKernelGGL(splitter_kernel, dim3(1), dim3(256), 0, stream, sorted, ctl, key_xor, sub);
 }
 
 // ---------------------------------------------------------------------------------------
