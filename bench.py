@@ -687,6 +687,21 @@ def main():
             sort_all["5m_radix_whole_cloud_in_view"] = sort_rate(h5, 5_000_000, far_view, settings, 10)
             h5.free()
             del c5
+        # ... and whole FRAMES of such a view (the camera outside the cloud, every splat keyed, projected and drawn: what an
+        # object-centric scene is; small on screen, so the quads are small): the frame rate that the 768-bucket sort serves
+        plugin.reset_adaptive_state()
+        plugin.set_profiling(0)
+        plugin.set_pipeline_depth(lanes)
+        plugin.set_pipeline_streams(streams)
+        _, _, st_far, dts_far = measure(plugin, handle, far_view, settings, args.steps, args.warmup, depth=lanes, trials=5)
+        plugin.set_pipeline_depth(1)
+        _, _, _, dts_far1 = measure(plugin, handle, far_view, settings, args.steps, args.warmup, depth=1, trials=3)
+        plugin.set_profiling(2)
+        sort_all["frames_1m_whole_cloud_in_view"] = {
+            "value": round(args.steps / statistics.median(dts_far), 2), "unit": "frames/s",
+            "single_stream_value": round(args.steps / statistics.median(dts_far1), 2),
+            "visible_splats": st_far["visible_count"], "drawable": st_far["draw_count"], "sort_path": st_far.get("sort_path"),
+            "camera": "(0, 0, 120) looking at the cloud, fov pi/4: all 1 M splats inside the frustum"}
         plugin.reset_adaptive_state()
 
         # scene-like variant: global_scale = 0.05

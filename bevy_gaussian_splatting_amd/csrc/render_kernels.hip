@@ -1565,9 +1565,12 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
 
 // Waves per SIMD: 8 for the single-sampled ellipse variants (<= 64 VGPRs), 6 for the surfel variant; the multisampled
 // instantiations carry six transmittance words per pixel instead of one (5 / 4 waves).
+#ifndef BGS_MS_WAVES
+#define BGS_MS_WAVES 5   // multisampled ellipse variants: 92-96 VGPRs; 6 (<= 80) spills (profiles/r5_experiments/occupancy_ms.txt)
+#endif
 constexpr int raster_waves_per_simd(const int variant, const int msaa, const bool depth) {
     return msaa == 8 ? (variant == 2 ? (depth ? 2 : 3) : (depth ? 3 : 4))   // ten transmittance words per pixel; 8 KB of depth samples per wave
-         : msaa >= 2 ? (variant == 2 ? (depth ? 3 : 4) : 5) : (variant == 2 ? (depth ? 5 : 6) : (depth ? 7 : 8));
+         : msaa >= 2 ? (variant == 2 ? (depth ? 3 : 4) : (depth ? 5 : BGS_MS_WAVES)) : (variant == 2 ? (depth ? 5 : 6) : (depth ? 7 : 8));
 }
 int raster_scan_waves_per_simd(const FrameParams& fp) {
     const int variant = fp.aabb == 0u ? RV_OBB : (fp.gaussian_mode != 0u ? RV_AABB3D : RV_SURFEL);

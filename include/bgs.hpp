@@ -193,7 +193,7 @@ struct View {
         native.clear_color[0] = r; native.clear_color[1] = g; native.clear_color[2] = b; native.clear_color[3] = a;
     }
     // The camera's `Msaa` component (CloudPipelineKey.sample_count = msaa.samples(), src/render/mod.rs:357-424): 1 =
-    // Msaa::Off, 4 = Msaa::Sample4 — Bevy's default, which bgs_view_perspective has already set.
+    // Msaa::Off, 2 / 4 / 8 = Msaa::Sample2 / Sample4 / Sample8; 4 is Bevy's default, which bgs_view_perspective has already set.
     void set_msaa_samples(uint32_t samples) { native.sample_count = samples; }
     // The view's depth attachment as device memory ([y][x][sample] floats, reverse-Z; src/render/mod.rs:959-974), 0 = none.
     void set_depth(const void* device_ptr) { native.depth_device_ptr = (uint64_t)(uintptr_t)device_ptr; }
@@ -237,6 +237,9 @@ class PlanarGaussian3dHandle {
 class GaussianSplattingPlugin {
   public:
     explicit GaussianSplattingPlugin(int hip_device = 0) {
+        // the binding's handshake: this header's structs are the library's (a stale libbgs.so is refused, not misread)
+        if (bgs_abi_check(BGS_ABI_VERSION, sizeof(bgs_view), sizeof(bgs_settings), sizeof(bgs_stats)) != BGS_OK)
+            throw Error(BGS_EINVAL, std::string("bgs_abi_check: ") + bgs_last_error(nullptr));
         const int rc = bgs_create(hip_device, &ctx_);
         if (rc != BGS_OK) throw Error(rc, std::string("bgs_create: ") + bgs_last_error(nullptr));
     }
@@ -296,6 +299,39 @@ class GaussianSplattingPlugin {
         check(bgs_adaptive_counters(ctx_, out.data()), "bgs_adaptive_counters");
         return out;
     }
+    // async frames completed inside their render call (a kind of frame new to the context), kinds settled on
+    std::pair<uint64_t, uint64_t> learning_counters() {
+        uint64_t early = 0, kinds = 0;
+        check(bgs_learning_counters(ctx_, &early, &kinds), "bgs_learning_counters");
+        return {early, kinds};
+    }
+    // ---- the multi-GPU frame gather (bgs_comm_*: RCCL's ncclGather behind the C ABI; one process per GPU) ----
+    static std::array<uint8_t, BGS_COMM_ID_BYTES> comm_unique_id() {   // rank 0; ship the 128 bytes to every rank
+        std::array<uint8_t, BGS_COMM_ID_BYTES> id{};
+        const int rc = bgs_comm_unique_id(id.data());
+        if (rc != BGS_OK) throw Error(rc, std::string("bgs_comm_unique_id: ") + bgs_last_error(nullptr));
+        return id;
+    }
+    bgs_comm* comm_create(const std::array<uint8_t, BGS_COMM_ID_BYTES>& id, uint32_t world_size, uint32_t rank) {   // collective
+        bgs_comm* c = nullptr;
+        check(bgs_comm_create(ctx_, id.data(), world_size, rank, &c), "bgs_comm_create");
+        return c;
+    }
+    // enqueue one gather of `bytes` per rank (device memory of COMPLETED frames; recv on the root only); returns its ticket
+    uint64_t comm_gather(bgs_comm* c, uint32_t root, const void* send, uint64_t bytes, void* recv) {
+        uint64_t ticket = 0;
+        check(bgs_comm_gather(ctx_, c, root, send, bytes, recv, &ticket), "bgs_comm_gather");
+        return ticket;
+    }
+    void comm_wait(bgs_comm* c, uint64_t ticket = 0) { check(bgs_comm_wait(ctx_, c, ticket), "bgs_comm_wait"); }
+    void comm_destroy(bgs_comm* c) { bgs_comm_destroy(ctx_, c); }
+    void* device_alloc(uint64_t bytes) {
+        void* p = nullptr;
+        check(bgs_device_alloc(ctx_, bytes, &p), "bgs_device_alloc");
+        return p;
+    }
+    void device_free(void* p) { check(bgs_device_free(ctx_, p), "bgs_device_free"); }
+    void set_srgb8_target(void* device_ptr) { check(bgs_set_srgb8_target(ctx_, device_ptr), "bgs_set_srgb8_target"); }
     void set_profiling(int level) { check(bgs_set_profiling(ctx_, level), "bgs_set_profiling"); }
     void synchronize() { check(bgs_synchronize(ctx_), "bgs_synchronize"); }
     uint32_t frames_in_flight() {

@@ -1,10 +1,11 @@
 """Per-kernel register / LDS / occupancy table of the HIP sources (hipcc -Rpass-analysis=kernel-resource-usage).
-python scripts/kernel_resources.py [file.hip ...]   (default: every csrc/*.hip)"""
+python scripts/kernel_resources.py [-Dflag ...] [file.hip ...]   (default: every csrc/*.hip; the Makefile's flags)"""
 import os, re, subprocess, sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bevy_gaussian_splatting_amd", "csrc")
-files = [os.path.abspath(a) for a in sys.argv[1:]] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+extra = [a for a in sys.argv[1:] if a.startswith("-")]
+files = [os.path.abspath(a) for a in sys.argv[1:] if not a.startswith("-")] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
 for f in files:
-    p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", f,
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", *extra, "-c", f,
                         "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=CSRC)
     cur = None
     rows = []

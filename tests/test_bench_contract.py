@@ -98,6 +98,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["config"]["sample_count"] == 4 and "Sample4" in d["config"]["workload"]
     assert d["msaa_off"]["sample_count"] == 1 and d["msaa_off"]["value"] > d["value"] * 0.9 and d["msaa_off"]["trials"] >= 5
     assert d["scene_like"]["trials"] >= 5
+    # "Msplats/s sorted" with EVERY splat drawable (round 4's verdict: the headline camera's list is 88 % culled sentinels):
+    # SortMode::Rayon and a SortMode::Radix camera that sees the whole cloud, 1 M and 5 M, on SURVEY 8(d)'s 88 B per splat
+    sa = d["sort_all_visible"]
+    for k in ("1m_rayon", "1m_radix_whole_cloud_in_view", "5m_rayon", "5m_radix_whole_cloud_in_view"):
+        assert sa[k]["drawable"] == sa[k]["splats"] and sa[k]["Msplats_per_s"] > 1000.0 and sa[k]["GBps_on_88B_per_splat"] > 88.0, k
+    assert sa["1m_rayon"]["sort_path"] == "bucket" and sa["1m_rayon"]["Msplats_per_s"] > 10_000.0      # one launch of 512 buckets
+    assert sa["frames_1m_whole_cloud_in_view"]["drawable"] == 1_000_000 and sa["frames_1m_whole_cloud_in_view"]["value"] > 100.0
     assert 0.0 < d["latency"]["steady_blocking_frame_ms"] <= d["latency"]["first_frame_ms"] * 1.2
     assert d["latency"]["after_cut_ms"] > 0.0
 
