@@ -868,6 +868,10 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
         m = s.a1.z;
         const float e = __builtin_amdgcn_exp2f(-fmaf(u, u, v * v));
         alpha = fminf(e * s.a2.z, 0.999f);
+        // fs_main's OBB discard (dot(uv, uv) > 9, gaussian.wgsl:481-483) can only fire for a fragment shaded at a pixel centre
+        // OUTSIDE a small quad (a sample is covered, the centre extrapolates); its alpha is < e^-40 there, so dropping it
+        // or not is the same image — except under the overlay, which would paint it opaque
+        if constexpr (BBOX) ok = !(fmaf(u, u, v * v) > 9.0f * OBB_C * OBB_C);
         r = s.a1.w; g = s.a2.x; b = s.a2.y;
         du0 = fmaf(s.a0.w, MS_OY0, s.a0.z * MS_OX0); du1 = fmaf(s.a0.w, MS_OY1, s.a0.z * MS_OX1);
         dv0 = fmaf(s.a1.y, MS_OY0, s.a1.x * MS_OX0); dv1 = fmaf(s.a1.y, MS_OY1, s.a1.x * MS_OX1);
@@ -977,6 +981,7 @@ __device__ __forceinline__ void blend_px_msn(const StagedRecord<VARIANT>& s, con
         m = s.a1.z;
         const float e = __builtin_amdgcn_exp2f(-fmaf(u, u, v * v));
         alpha = fminf(e * s.a2.z, 0.999f);
+        if constexpr (BBOX) ok = !(fmaf(u, u, v * v) > 9.0f * OBB_C * OBB_C);   // fs_main's OBB discard (see blend_px_ms)
         r = s.a1.w; g = s.a2.x; b = s.a2.y;
         au = s.a0.z; bu_ = s.a0.w; av = s.a1.x; bv_ = s.a1.y;
     } else if constexpr (VARIANT == RV_AABB3D) {

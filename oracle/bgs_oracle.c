@@ -1161,6 +1161,11 @@ int oracle_render_target(const oracle_cloud* cloud, const bgs_sort_entry* entrie
                         arow[x - x0] += (float)(4.0 * da) * (cm + dm);
                     }
                 }
+                if (arow && s->visualize_bounding_box && !s->aabb && fabsf(dot2(uv, uv) - 9.0f) < 1e-4f) {
+                    /* ... and one at fs_main's OBB discard threshold is the opaque frame colour or nothing */
+                    ORACLE_DM();
+                    arow[x - x0] += 1.0f + dm;
+                }
                 if (arow && s->visualize_bounding_box && drawn) {
                     /* VISUALIZE_BOUNDING_BOX: a fragment whose |uv| sits within rounding distance of the frame's inner
                      * edge (0.84) is the splat's colour in one evaluation and the opaque frame colour in another: the

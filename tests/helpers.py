@@ -224,7 +224,8 @@ def emulate_render(cloud: PlanarGaussian3d, view: View, settings: CloudSettings,
                 v = p[2] * dx + p[3] * dy
                 cov = [(np.abs(u + (p[0] * np.float32(ox) + p[1] * np.float32(oy))) <= 1) &
                        (np.abs(v + (p[2] * np.float32(ox) + p[3] * np.float32(oy))) <= 1) for ox, oy in offs]
-                hit = np.ones_like(u, bool)
+                # fs_main's OBB discard (gaussian.wgsl:481-483): only a fragment shaded at a centre outside a small quad gets there
+                hit = ~((u * u + v * v) > np.float32(9.0))
                 sigma = np.float32(1.0) / np.float32(3.0)
                 power = (u * u + v * v) * (np.float32(-1.0) / (np.float32(2.0) * sigma * sigma))
             elif not surfel:

@@ -2020,28 +2020,32 @@ def test_bounding_box_overlay_matches_the_oracle(plugin, oracle, binning, varian
     c = random_gaussians_3d_seeded(30_000, 41)
     v = View.headless(480, 270, msaa_samples=samples)
     v.clear_color = (0.05, 0.1, 0.2, 1.0)
-    kw = dict(global_scale=0.25, **_MS_VARIANTS[variant])
-    s = CloudSettings(visualize_bounding_box=True, **kw)
     h = plugin.upload(c)
-    dhost, dptr = None, None
-    if depth:
-        dhost = H.random_depth_buffer(c, v, s, np.random.default_rng(5))
-        dptr = plugin.upload_depth(dhost)
-        v.depth_device_ptr = dptr
-    try:
-        got = plugin.render(h, v, s)
-        plain = plugin.render(h, v, CloudSettings(**kw))
-    finally:
-        if dptr is not None:
-            plugin.device_free(dptr)
-            v.depth_device_ptr = 0
-    e = oracle.sort(c, v, s)
-    ref, amb = oracle.render(c, e, v, s, with_ambiguity=True, depth=dhost)
-    _assert_image(ref, got, amb, frac_slack=0.02, what=f"bbox {variant} x{samples} depth={depth} {binning}", overlay=True)
-    assert np.abs(got - plain).max() > 0.2
-    # the frame colour really is there: pixels that are (nearly) pure (0.3, 1, 0.1) with alpha 1
-    frame_px = (np.abs(got[..., :3] - np.array([0.3, 1.0, 0.1], np.float32)).max(axis=2) < 1e-3) & (np.abs(got[..., 3] - 1.0) < 1e-3)
-    assert frame_px.sum() > 50
+    # (global_scale 0.02: sub-pixel quads. A sample can be covered while the pixel centre the fragment is shaded at lies
+    # several quad widths outside: fs_main's OBB discard, dot(uv, uv) > 9, fires BEFORE the overlay's test — found by the
+    # round-5 exploratory sweep, seeds 70137 / 71390: one sample's share of an opaque frame fragment the reference drops)
+    for gs in (0.25, 0.02):
+        kw = dict(global_scale=gs, **_MS_VARIANTS[variant])
+        s = CloudSettings(visualize_bounding_box=True, **kw)
+        dhost, dptr = None, None
+        if depth:
+            dhost = H.random_depth_buffer(c, v, s, np.random.default_rng(5))
+            dptr = plugin.upload_depth(dhost)
+            v.depth_device_ptr = dptr
+        try:
+            got = plugin.render(h, v, s)
+            plain = plugin.render(h, v, CloudSettings(**kw))
+        finally:
+            if dptr is not None:
+                plugin.device_free(dptr)
+                v.depth_device_ptr = 0
+        e = oracle.sort(c, v, s)
+        ref, amb = oracle.render(c, e, v, s, with_ambiguity=True, depth=dhost)
+        _assert_image(ref, got, amb, frac_slack=0.02, what=f"bbox {variant} gs={gs} x{samples} depth={depth} {binning}", overlay=True)
+        assert np.abs(got - plain).max() > 0.2
+        # the frame colour really is there: pixels that are (nearly) pure (0.3, 1, 0.1) with alpha 1
+        frame_px = (np.abs(got[..., :3] - np.array([0.3, 1.0, 0.1], np.float32)).max(axis=2) < 1e-3) & (np.abs(got[..., 3] - 1.0) < 1e-3)
+        assert frame_px.sum() > (50 if gs > 0.1 else 5)
     h.free()
 
 
