@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void project_kernel(const FrameParams* __restr
 // costs throughput (like the wide keygen and bucket sort, kernels.h): WAVES = 4 (256 threads, four groups per wave:
 // slower alone — 31 / 130 us on those two frames — and +15 % / +11 % frames per second in flight on the 5 M-splat
 // frames, +1-2 % at 1 M) is what pipelined frames run. Same-box A/B: profiles/r4_experiments/project_bin_split.txt.
+#ifndef BGS_BIN_LOOKBACK
+#define BGS_BIN_LOOKBACK 4   // status words per look-back hop (profiles/r5_experiments/bin_lookback.txt)
+#endif
 constexpr uint32_t BIN_GROUPS = 16u, BIN_RANKS = 64u * BIN_GROUPS;
 template <uint32_t WAVES>
 __global__ __launch_bounds__(64u * WAVES) void bin_kernel(const uint32_t* __restrict__ rects, Control* ctl, uint32_t* bin_status,
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(64u * WAVES) void bin_kernel(const uint32_t* __rest
             if (tile > 0u) {
                 __hip_atomic_store(my_status, STATUS_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // 4 words per hop at every size (measured on the fused kernel of rounds 1-3: 16 per hop 4 % slower, 32: 11 %)
-                excl = lookback_u32<4>(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u);
+                excl = lookback_u32<BGS_BIN_LOOKBACK>(bin_status + tid, tile, MAX_SUPERTILES, &ctl->error, 4u);
             }
             __hip_atomic_store(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1,0 +1,30 @@
+"""Device time of blocking bgs_sort calls (keygen + depth sort) with and without the bucket path, on lists with every splat
+drawable and on the headline camera's: python scripts/sort_rates.py  (profiles/r5_notes.md section 1)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bevy_gaussian_splatting_amd import (CloudSettings, GaussianSplattingPlugin, SortMode, View,  # noqa: E402
+                                         random_gaussians_3d_seeded, transform_from)
+
+p = GaussianSplattingPlugin(0)
+for n, seed in ((1_000_000, 2), (2_000_000, 5), (5_000_000, 3)):
+    c = random_gaussians_3d_seeded(n, seed)
+    h = p.upload(c)
+    far = View.perspective(transform_from((0.0, 0.0, 120.0), (0.0, 0.0, 0.0, 1.0)), 1920, 1080)
+    for name, v, s in (("rayon", View.headless(1920, 1080), CloudSettings(sort_mode=SortMode.Rayon)), ("radix_far", far, CloudSettings()),
+                       ("radix_headline", View.headless(1920, 1080), CloudSettings())):
+        for flags in (0x80000, 0):   # 0x80000: never the bucket path
+            p.set_debug_flags(flags); p.reset_adaptive_state(); p.set_profiling_stride(1)
+            for _ in range(4):
+                p.sort(h, v, s, download=False)
+            ms = kg = ds = 0.0
+            for _ in range(20):
+                p.sort(h, v, s, download=False)
+                st = p.stats()
+                ms += st["total_ms"]; kg += st["stage_ms"]["keygen"]; ds += st["stage_ms"]["depth_sort"]
+            print(f"{n:8d} {name:15s} flags {flags:#8x} {st['sort_path']:9s} D={st['draw_count']:8d} total {ms / 20 * 1e3:7.1f} us "
+                  f"keygen {kg / 20 * 1e3:6.1f} sort {ds / 20 * 1e3:6.1f}  {n / (ms / 20 * 1e-3) / 1e9:6.2f} Gsplats/s "
+                  f"{88.0 * n / (ms / 20 * 1e-3) / 1e9:7.1f} GB/s on 88 B per splat", flush=True)
+    p.set_debug_flags(0)
+    h.free()
