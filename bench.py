@@ -668,8 +668,9 @@ def main():
                 ms += stt["total_ms"]; kg += stt["stage_ms"]["keygen"]; ds += stt["stage_ms"]["depth_sort"]
             ms, kg, ds = ms / reps_, kg / reps_, ds / reps_
             stt = plugin.stats()
-            return {"device_ms": round(ms, 4), "keygen_ms": round(kg, 4), "digit_passes_ms": round(ds, 4),
-                    "passes": stt["depth_passes"], "ms_per_pass": round(ds / max(stt["depth_passes"], 1), 4),
+            launches = 1 if stt["sort_path"] == "bucket" else stt["depth_passes"]   # one bucket-sort launch, or a launch per digit place
+            return {"device_ms": round(ms, 4), "keygen_ms": round(kg, 4), "depth_sort_ms": round(ds, 4),
+                    "depth_sort_launches": launches, "ms_per_launch": round(ds / max(launches, 1), 4),
                     "drawable": stt["draw_count"], "splats": n, "sort_path": stt["sort_path"],
                     "Msplats_per_s": round(n / (ms * 1e-3) / 1e6, 1) if ms > 0 else None,
                     "GBps_on_88B_per_splat": round(88.0 * n / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,

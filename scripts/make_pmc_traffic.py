@@ -13,7 +13,8 @@ from bench import kernel_source_sha256  # noqa: E402
 
 vals = collections.defaultdict(dict)
 for line in open(sys.argv[1]):
-    m = re.match(r"\s*(?:void )?(?:bgs::)?([a-z_]+kernel)(?:<[^>]*>)?\s+(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|"
+    # (the counters file cuts kernel names at 60 characters: a template argument list may end without its '>')
+    m = re.match(r"\s*(?:void )?(?:bgs::)?([a-z_]+kernel)(?:<.*?)?\s{2,}(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|"
                  r"SQ_ACTIVE_INST_VALU|SQ_WAVE_CYCLES|GRBM_GUI_ACTIVE|SQ_INSTS_VALU_[A-Z0-9_]+)\s+calls\s+(\d+)\s+mean\s+([\d.]+)", line)
     if m:
         vals[m.group(1)][m.group(2)] = float(m.group(4))

@@ -1924,18 +1924,23 @@ def test_zz_report_ambiguity_slack_use(oracle):
     every oracle comparison of this run: how many values were accepted only through the oracle's per-pixel ambiguity bound
     (quad-edge coverage flips, ill-conditioned surfel intersections / AABB conics) rather than the plain
     1e-3 + 1e-4 |ref| tolerance, and by how much the worst of them exceeds that tolerance. Teeth (from the runs under
-    profiles/r5/tolerance_accounting_*.json, at both edge bands): at most 2e-5 of the values, none more than 0.05 beyond —
-    one sample's share (a quarter) of a fragment of alpha exp(-4.5) * 0.8 and a colour of magnitude 15, the brightest the
-    synthetic clouds hold, is 0.033."""
+    profiles/r5_v1/ and profiles/r5/, at both edge bands): at most 2e-5 of the values; on the FIXED configurations (whole
+    frames, variants, depth buffers, f16, ...) none more than 0.05 beyond — one sample's share (a quarter) of a fragment
+    of alpha exp(-4.5) * 0.8 and a colour of magnitude 15, the brightest the synthetic clouds hold, is 0.033; on the
+    RANDOMIZED configurations (Msaa::Off on a third of the seeds: a flip is a whole fragment; global_opacity up to 2;
+    every raster mode) none more than 0.25 (largest seen in 9 000 configurations: 0.19)."""
     t = H.TOLERANCE
     v, n = t["values"], t["checked"]
     print(f"[tolerance accounting] edge band {oracle.lib().oracle_edge_band_px():g} px: {v} of {n} compared values "
-          f"({100.0 * v / max(n, 1):.5f} %) beyond 1e-3 + 1e-4 |ref|, largest excess {t['max_excess']:.3e} "
+          f"({100.0 * v / max(n, 1):.5f} %) beyond 1e-3 + 1e-4 |ref|, largest excess {t['max_excess']:.3e} on the fixed "
+          f"configurations, {t['max_excess_randomized']:.3e} on the randomized ones "
           f"(frames with the bounding-box overlay, where a flip is a whole opaque fragment: {t['max_excess_overlay']:.3e})")
     for rec in sorted(t["comparisons"], key=lambda r: -r["max_excess"])[:12]:
-        print(f"    {rec['what']}: {rec['beyond_strict']} of {rec['values']}, excess {rec['max_excess']:.2e}, max |err| {rec['max_err']:.2e}")
+        print(f"    {rec['what'][:60]}: {rec['beyond_strict']} of {rec['values']}, excess {rec['max_excess']:.2e}, max |err| {rec['max_err']:.2e}, "
+              f"max |ref| {rec['ref_absmax']:.2f}")
     assert v <= 2e-5 * max(n, 1) + 50
     assert t["max_excess"] <= 0.05
+    assert t["max_excess_randomized"] <= 0.25
 
 
 # ---------------------------------------------------------------------------------------------
