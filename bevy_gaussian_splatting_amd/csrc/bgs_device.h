@@ -116,16 +116,22 @@ constexpr uint32_t BUCKET_FINE_MAX = 1024;   // more pairs than this in one fine
 // 256 * sub buckets, sub <= BUCKET_SUB_MAX, with the 256 * sub - 1 keys at the 1 / (256 sub)-quantiles of a completed
 // frame's list as splitters — exact quantiles, so the buckets stay balanced whatever the key distribution is (equal KEY
 // intervals inside a 1/256-quantile range were tried first: the first and the last range of a distance-keyed list
-// span many binades and nearly all of their pairs fall into one interval). sub <= 3 is what fits the table into a
-// kernel's 4 KB of arguments: 768 buckets, 2.36 M drawable pairs; longer lists take the digit passes.
-constexpr uint32_t BUCKET_SUB_MAX = 3;
+// span many binades and nearly all of their pairs fall into one interval). Up to sub = BUCKET_SUB_KERNARG the table
+// travels in keygen's kernel arguments (4 KB in all); a longer one (up to 4095 keys: 12.6 M drawable pairs) is copied to
+// the lane's device table ahead of keygen (one 16 KB host-to-device copy on the frame's stream: frames of that size last
+// hundreds of microseconds).
+constexpr uint32_t BUCKET_SUB_MAX = 16;
+constexpr uint32_t BUCKET_SUB_KERNARG = 3;
 constexpr uint32_t BUCKET_MAX = BUCKET_COUNT * BUCKET_SUB_MAX;
 constexpr uint32_t BUCKET_TARGET = 2048;     // pairs per bucket the host aims at when it picks `sub`
 struct SplitterTable {
-    uint32_t key[BUCKET_MAX];     // key[0 .. 256 * sub - 2] ascending quantile keys (the rest unused)
-    uint32_t sub;                 // 1 .. BUCKET_SUB_MAX: the table defines 256 * sub buckets
-    uint32_t pad[3];
+    uint32_t key[BUCKET_COUNT * BUCKET_SUB_KERNARG];   // sub <= BUCKET_SUB_KERNARG: key[0 .. 256 * sub - 2] ascending quantile keys
+    const uint32_t* device_keys;                       // sub > BUCKET_SUB_KERNARG: the same, in device memory
+    uint32_t sub;                                      // 1 .. BUCKET_SUB_MAX: the table defines 256 * sub buckets
+    uint32_t pad;
 };
+// what the host keeps per view slot (a completed frame's quantile keys, any sub)
+struct SplitterKeys { uint32_t key[BUCKET_MAX]; uint32_t sub; };
 
 // Device-resident control block, zeroed at the start of every frame by one memset.
 struct Control {

@@ -111,10 +111,11 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     __shared__ uint32_t s_off[ROWS];   // ... and of the rows before it
     __shared__ uint32_t s_keys[THREADS * KG_ITEMS];  // the tile's drawable keys, compacted (for the histograms / the buckets)
     __shared__ uint32_t s_idx[BUCKET ? THREADS * KG_ITEMS : 1];  // their splat indices (BUCKET)
-    __shared__ uint32_t s_split[BUCKET ? 1024 : 1];           // the nb - 1 splitters, then ~0 up to the next power of two
-    extern __shared__ uint32_t s_dyn[];                       // BUCKET: 2 x nb words (nb = 256 * split.sub buckets)
-    uint32_t* const s_bcnt = s_dyn;                           // pairs of this tile per bucket
-    uint32_t* const s_bexcl = s_dyn + (BUCKET ? BUCKET_COUNT * split.sub : 0u);   // pairs of earlier tiles per bucket
+    // BUCKET: dynamic LDS = nb counters (nb = 256 * split.sub buckets) + the nb - 1 splitters padded with ~0 to a power of two
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t* const s_bcnt = s_dyn;     // pairs of this tile per bucket; then, IN PLACE, the bucket's pairs of earlier tiles
+    uint32_t* const s_bexcl = s_dyn;    // (thread f reads its count and leaves the returning atomic's value in the same word)
+    uint32_t* const s_split = s_dyn + (BUCKET ? BUCKET_COUNT * split.sub : 0u);
     __shared__ uint16_t s_at[BUCKET ? THREADS * KG_ITEMS : 1];  // arrival slot of compacted pair j inside its bucket (this tile)
     __shared__ uint16_t s_bk[BUCKET ? THREADS * KG_ITEMS : 1];  // its bucket
     __shared__ uint32_t s_total;
@@ -128,9 +129,12 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
         reinterpret_cast<uint32_t*>(fp_out)[tid] = reinterpret_cast<const uint32_t*>(&fp)[tid];
     if (zero_word && blockIdx.x == 0 && tid == 0) *zero_word = 0u;
     const uint32_t nsub = BUCKET ? split.sub : 1u, nb = BUCKET_COUNT * nsub;   // buckets of the frame
+    uint32_t p2 = 256u;                 // the splitter table's padded length: the power of two >= nb
+    while (p2 < nb) p2 <<= 1;
     if constexpr (BUCKET) {
-        for (uint32_t t = (uint32_t)tid; t < (nsub == 1u ? 256u : 1024u); t += (uint32_t)THREADS)
-            s_split[t] = t < nb - 1u ? split.key[t] : 0xFFFFFFFFu;
+        const uint32_t* __restrict__ keys = nsub <= BUCKET_SUB_KERNARG ? split.key : split.device_keys;
+        for (uint32_t t = (uint32_t)tid; t < p2; t += (uint32_t)THREADS)
+            s_split[t] = t < nb - 1u ? keys[t] : 0xFFFFFFFFu;
     } else if (tid < 256) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
@@ -146,19 +150,52 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     const bool single_shot = gridDim.x >= num_tiles;
 
     // bucket of a key = the number of splitters <= key (the entries behind the table's end are ~0: never counted unless the
-    // key is ~0 itself, hence the min): 8 steps over the 255 splitters of the usual frame, 10 over up to 767
+    // key is ~0 itself, hence the min): 8 steps over the 255 splitters of the usual frame, up to 12 over 4095
     auto bucket_of = [&](const uint32_t kk) -> uint32_t {
         uint32_t lo = 0u;
         if (nsub == 1u) {
 #pragma unroll
             for (uint32_t step = 128u; step > 0u; step >>= 1)
                 if (s_split[lo + step - 1u] <= kk) lo += step;
-        } else {
+        } else if (p2 == 512u) {
+#pragma unroll
+            for (uint32_t step = 256u; step > 0u; step >>= 1)
+                if (s_split[lo + step - 1u] <= kk) lo += step;
+        } else if (p2 == 1024u) {
 #pragma unroll
             for (uint32_t step = 512u; step > 0u; step >>= 1)
                 if (s_split[lo + step - 1u] <= kk) lo += step;
+        } else {
+            for (uint32_t step = p2 >> 1; step > 0u; step >>= 1)
+                if (s_split[lo + step - 1u] <= kk) lo += step;
         }
         return min(lo, nb - 1u);
+    };
+    // thread = bucket(s): the tile's pairs of a bucket take the next `mine` slots of the bucket, whoever comes first — one
+    // returning atomic per (tile, bucket); the word that held the tile's count then holds the bucket's pairs of earlier
+    // tiles. With more buckets than threads a thread's atomics are issued eight at a time (each is a round trip to L2).
+    auto claim_bucket_slots = [&]() {
+        if (nb <= (uint32_t)THREADS) {
+            if ((uint32_t)tid < nb) {
+                const uint32_t mine = s_bcnt[tid];
+                s_bexcl[tid] = mine ? atomicAdd(&ctl->bucket_count[tid], mine) : 0u;
+            }
+            return;
+        }
+        for (uint32_t f0 = (uint32_t)tid; f0 < nb; f0 += 8u * (uint32_t)THREADS) {
+            uint32_t ex[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const uint32_t f = f0 + k * (uint32_t)THREADS;
+                const uint32_t mine = f < nb ? s_bcnt[f] : 0u;
+                ex[k] = mine ? atomicAdd(&ctl->bucket_count[f], mine) : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const uint32_t f = f0 + k * (uint32_t)THREADS;
+                if (f < nb) s_bexcl[f] = ex[k];
+            }
+        }
     };
     if constexpr (BUCKET && !ORDERED) {
         if (blockIdx.x == 0 && tid == 0) ctl->splat_count = fp.n;
@@ -230,11 +267,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                 }
             }
             __syncthreads();
-            // thread = bucket: the tile's pairs of a bucket take the next `mine` slots of the bucket, whoever comes first
-            for (uint32_t f = (uint32_t)tid; f < nb; f += (uint32_t)THREADS) {
-                const uint32_t mine = s_bcnt[f];
-                s_bexcl[f] = mine ? atomicAdd(&ctl->bucket_count[f], mine) : 0u;
-            }
+            claim_bucket_slots();
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < KG_ITEMS; ++r) {
@@ -359,10 +392,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                 }
             }
             __syncthreads();
-            for (uint32_t f = (uint32_t)tid; f < nb; f += (uint32_t)THREADS) {
-                const uint32_t mine = s_bcnt[f];
-                s_bexcl[f] = mine ? atomicAdd(&ctl->bucket_count[f], mine) : 0u;
-            }
+            claim_bucket_slots();
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < KG_ITEMS; ++r) {
@@ -443,11 +473,20 @@ bool KeygenLaunch::prepare(int max_blocks) {
     argv[5] = &part_status; argv[6] = &places; argv[7] = &ticket_slot; argv[8] = &fp_out; argv[9] = &bucket_slots;
     argv[10] = &bucket_status; argv[11] = &split; argv[12] = &zero_word;
     if (split.sub < 1u || split.sub > BUCKET_SUB_MAX) split.sub = 1u;
-    lds_bytes = bucket ? 2u * BUCKET_COUNT * split.sub * (uint32_t)sizeof(uint32_t) : 0u;   // s_bcnt + s_bexcl
+    {   // the per-bucket counters + the padded splitter table
+        uint32_t nbk = BUCKET_COUNT * split.sub, pad2 = 256u;
+        while (pad2 < nbk) pad2 <<= 1;
+        lds_bytes = bucket ? (nbk + pad2) * (uint32_t)sizeof(uint32_t) : 0u;
+    }
     return true;
 }
 
 hipError_t KeygenLaunch::launch(hipStream_t stream) {
+    // (a long splitter table takes static + dynamic LDS past the runtime's default 64 KB per workgroup; the chip allows 160 KB)
+    if (lds_bytes > 12288u) {
+        const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
     return hipLaunchKernel(func, dim3(blocks), dim3(threads), argv, lds_bytes, stream);
 }
 

@@ -23,7 +23,9 @@ extern "C" {
  * separate encode pass instead of the rasteriser's fused output), 0x80000 (depth sort always by the
  * onesweep digit passes, never the bucket sort), 0x200000 (bucket sort even before a completed frame has
  * told the key range: full 32-bit range guessed), 0x100000 (supertile lists start at 64 entries, to
- * exercise the overflow -> re-run path) keep images correct and exist for A/B timing and tests.
+ * exercise the overflow -> re-run path), 0x200 / 0x400 (the bucket sort with at least 768 / 1280 buckets whatever the list's
+ * length: the finer splitter tables, in keygen's arguments / in the lane's device table) keep images correct and exist for
+ * A/B timing and tests.
  * 0x8000000: every BINNING_SCAN frame is run twice, as if a data-dependent capacity had been too small (exercises the
  * re-run path). 0x10000000: no tile-cost feedback / cost-ordered raster workgroups; 0x20000000: none at pipeline
  * depths > 1; 0x40000000: the order is made anew with every frame (default: every 8th).

@@ -1610,15 +1610,15 @@ def test_first_frames_of_a_context_learn_one_by_one(plugin):
 
 
 @pytest.mark.parametrize("n,mode", [(300_000, "rayon"), (1_000_000, "rayon"), (1_000_000, "radix_far"), (2_000_000, "radix_far"),
-                                    (2_600_000, "radix_far"), (700_000, "std")])
+                                    (2_600_000, "radix_far"), (5_000_000, "rayon"), (700_000, "std")])
 def test_bucket_sort_with_every_splat_drawable(plugin, oracle, n, mode):
     """D = N (round 4's verdict, weak item 9: the headline camera's list is 88 % culled sentinels, and more than 786 k
     drawable pairs went through four digit passes): SortMode::Rayon / Std never cull (src/sort/rayon.rs:86-104), and a
-    SortMode::Radix camera that sees the whole cloud keys every splat. Since round 5 the bucket path takes up to 768
-    buckets (the 256 * sub - 1 exact quantile keys of a completed frame's list, sub = 2 at 1 M, 3 at 2 M; 2.6 M is beyond
-    its geometry and stays on the digit passes) and bgs_sort's ordered keygen places its pairs by atomics plus ONE chain
-    for the culled tail. Bit-exact with the oracle on the first call (digit passes) and on the later ones, under a slowly
-    moving camera as well."""
+    SortMode::Radix camera that sees the whole cloud keys every splat. Since round 5 the bucket path takes 256 * sub
+    buckets — the 256 * sub - 1 exact quantile keys of a completed frame's list: sub = 2 at 1 M, 3 at 2 M (the table still
+    travels in keygen's arguments), 6 at 2.6 M and 11 at 5 M (copied to the lane's device table ahead of keygen) — and
+    bgs_sort's ordered keygen places its pairs by atomics plus ONE chain for the culled tail. Bit-exact with the oracle on
+    the first call (digit passes) and on the later ones, under a slowly moving camera as well."""
     c = random_gaussians_3d_seeded(n, 300 + n % 97)
     if mode == "radix_far":
         s = CloudSettings()
@@ -1641,23 +1641,24 @@ def test_bucket_sort_with_every_splat_drawable(plugin, oracle, n, mode):
             else:   # the reference's CPU sort is unstable: equal keys may come in any order; ours is (key, index)
                 assert np.array_equal(np.sort(got["index"]), np.arange(n, dtype=np.uint32))
                 assert np.array_equal(got["index"], ref["index"])
-        assert paths[0] == "onesweep" and paths[-1] == ("bucket" if n <= 2_000_000 else "onesweep"), paths
+        assert paths[0] == "onesweep" and paths[-1] == "bucket", paths
     finally:
         plugin.reset_adaptive_state()
     h.free()
 
 
 def test_fine_buckets_on_small_lists_give_the_same_frames(plugin, oracle):
-    """Debug flag 0x200: the finest table (767 quantile keys, 768 buckets) whatever the list's length — headline-sized
-    lists normally take 256 buckets: rendered frames (chainless keygen) and bgs_sort (ordered keygen, culled tail) give the
-    bits of the 256-bucket path and of the digit passes."""
+    """Debug flags 0x200 / 0x400: at least 768 buckets (767 quantile keys in keygen's arguments) / at least 1280 (1279 keys in
+    the lane's device table) whatever the list's length — headline-sized lists normally take 256 buckets: rendered frames
+    (chainless keygen) and bgs_sort (ordered keygen, culled tail) give the bits of the 256-bucket path and of the digit
+    passes."""
     c = random_gaussians_3d_seeded(250_000, 71)
     v, s = View.headless(1280, 720), CloudSettings()
     h = plugin.upload(c)
     ref_entries = oracle.sort(c, v, s)
     try:
         out = {}
-        for name, flags in (("passes", 0x80000), ("coarse", 0), ("fine", 0x200)):
+        for name, flags in (("passes", 0x80000), ("coarse", 0), ("fine", 0x200), ("device_table", 0x400)):
             plugin.reset_adaptive_state()
             plugin.set_debug_flags(flags)
             for _ in range(3):
@@ -1668,7 +1669,7 @@ def test_fine_buckets_on_small_lists_give_the_same_frames(plugin, oracle):
                 e = plugin.sort(h, v, s)
             assert plugin.stats()["sort_path"] == ("onesweep" if name == "passes" else "bucket")
             out[name] = (img, e)
-        for name in ("coarse", "fine"):
+        for name in ("coarse", "fine", "device_table"):
             assert np.array_equal(out[name][0], out["passes"][0]), name
             assert np.array_equal(out[name][1]["key"], ref_entries["key"]) and np.array_equal(out[name][1]["index"], ref_entries["index"]), name
     finally:
