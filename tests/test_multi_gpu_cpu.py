@@ -218,3 +218,82 @@ def test_bench_measure_issues_the_same_collectives_on_every_rank():
     expected = 2 + 3 + 3 * 8 + 3 * 5
     assert rendered == expected and received == expected * world and ntrials == 3
     assert all(d > 5 * 0.0015 * 0.5 for d in dts)   # a trial lasts as long as its slowest rank
+
+
+class _FakeCommPlugin:
+    """The plugin surface NativeFrameGather uses (device_alloc / comm_*), on host memory: ranks of one process share a
+    mailbox, a gather copies every rank's staging batch into the root's receive buffer when the last rank has called."""
+
+    mailbox = {}
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.mem, self.next_ptr, self.tickets, self.waited = rank, world, {}, 0x1000, 0, []
+
+    def device_alloc(self, nbytes):
+        p = self.next_ptr
+        self.mem[p] = np.zeros(nbytes, np.uint8)
+        self.next_ptr += (nbytes + 0xFFF) & ~0xFFF
+        return p
+
+    def device_free(self, p):
+        self.mem.pop(p)
+
+    def view(self, p, n):
+        base = max(b for b in self.mem if b <= p)
+        return self.mem[base][p - base:p - base + n]
+
+    def comm_create(self, uid, world, rank):
+        assert len(uid) == 128 and world == self.world and rank == self.rank
+        return 7
+
+    def comm_gather(self, comm, root, send, nbytes, recv):
+        self.tickets += 1
+        box = _FakeCommPlugin.mailbox.setdefault(self.tickets, {})
+        box[self.rank] = (self.view(send, nbytes).copy(), recv, self)
+        if len(box) == self.world:
+            data_root, recv_root, plug_root = box[root]
+            assert recv_root is not None
+            for r in range(self.world):
+                plug_root.view(recv_root + r * nbytes, nbytes)[:] = box[r][0]
+        return self.tickets
+
+    def comm_wait(self, comm, ticket=0):
+        self.waited.append(ticket)
+
+    def comm_destroy(self, comm):
+        pass
+
+
+def test_native_frame_gather_batches_and_flushes_like_the_torch_one():
+    """NativeFrameGather (the bgs_comm_* loop bench.py runs for N > 1) on a fake two-rank communicator: zero-copy slots,
+    one gather per `batch` completed frames, double buffering (the ticket of the gather out of a staging buffer is waited
+    for before that buffer is handed out again), a partial batch at flush, every frame of every rank on the root in order."""
+    from bevy_gaussian_splatting_amd.multiview import NativeFrameGather
+    _FakeCommPlugin.mailbox = {}
+    frame_bytes, batch, frames, world = 64, 4, 11, 2
+    got = []
+    plugs = [_FakeCommPlugin(r, world) for r in range(world)]
+
+    def on_batch(recv_ptr, count):
+        blk = plugs[0].view(recv_ptr, world * batch * frame_bytes).reshape(world, batch, frame_bytes)
+        got.append(blk[:, :count].copy())
+
+    gs = [NativeFrameGather(plugs[r], frame_bytes, world, r, bytes([1]) * 128, batch=batch, on_batch=on_batch if r == 0 else None)
+          for r in range(world)]
+    for i in range(frames):
+        for r in reversed(range(world)):  # (two ranks in lock step, the root last: every rank issues the same collectives)
+            slot = gs[r].next_target()
+            plugs[r].view(slot, frame_bytes)[:] = (17 * r + i) % 251
+            gs[r].frame_completed()
+    for r in reversed(range(world)):     # (the fake's wait does not block: the root flushes last, when every rank has posted)
+        gs[r].flush()
+    assert gs[0].frames_received == world * frames and gs[0].gathers == gs[1].gathers == 3
+    allf = np.concatenate(got, axis=1)
+    assert allf.shape == (world, frames, frame_bytes)
+    for r in range(world):
+        for i in range(frames):
+            assert (allf[r, i] == (17 * r + i) % 251).all(), (r, i)
+    # buffer 0 was handed out again for frames 8..10 only after the gather out of it (ticket 1) had been waited for
+    assert plugs[0].waited[0] == 1 and set(plugs[0].waited) == {1, 2, 3}
+    for g in gs:
+        g.close()
