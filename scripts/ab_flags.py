@@ -2,6 +2,7 @@
 python scripts/ab_flags.py "<configs>" "<flags>"    configs: dense scene surfel surfel_scene 5m_dense 5m_scene 2d_obb
                                                      flags: comma-separated debug flag words (0 = the product)
 Prints, per (config, flags): frames/s with 8 lanes on 4 streams, single-stream frames/s and its stage times."""
+import dataclasses
 import json
 import os
 import sys
@@ -59,10 +60,13 @@ SPEC = {"dense": ("1m", CloudSettings(), 300), "scene": ("1m", CloudSettings(glo
 p = GaussianSplattingPlugin(0)
 # BGS_AB_MSAA="1,4": samples per pixel of the views (default 4 = Msaa::Sample4, Bevy's default)
 msaas = [int(x) for x in os.environ.get("BGS_AB_MSAA", "4").split(",")]
+bbox = os.environ.get("BGS_AB_BBOX", "0") != "0"   # BGS_AB_BBOX=1: CloudSettings::visualize_bounding_box on every workload
 handles = {}
 for _ in range(rounds):   # every variant is measured `rounds` times, interleaved (clock / thermal drift shows up as spread)
     for c in configs:
         kind, s, steps = SPEC[c]
+        if bbox:
+            s = dataclasses.replace(s, visualize_bounding_box=True)
         if kind not in handles:
             handles[kind] = p.upload(cloud(kind))
         for fl in flags:
@@ -71,5 +75,5 @@ for _ in range(rounds):   # every variant is measured `rounds` times, interleave
             p.set_debug_flags(fl)
             p.reset_adaptive_state()
             fps, fps1, stages = run(p, handles[kind], v, s, steps)
-            print(f"{c:13s} x{m} flags {fl:#10x}: {fps:9.1f} fps (8 lanes / 4 streams)  {fps1:9.1f} single stream  {json.dumps(stages)}", flush=True)
+            print(f"{c + ('+bbox' if bbox else ''):13s} x{m} flags {fl:#10x}: {fps:9.1f} fps (8 lanes / 4 streams)  {fps1:9.1f} single stream  {json.dumps(stages)}", flush=True)
 p.set_debug_flags(0)
