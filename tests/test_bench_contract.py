@@ -53,6 +53,27 @@ def test_pmc_counters_are_only_quoted_for_the_kernels_they_were_measured_on(tmp_
     assert d2 is None and "this run is 000000000000" in note2
 
 
+def test_committed_counter_file_follows_from_the_committed_raw_counters(tmp_path):
+    """profiles/pmc_traffic.json (what roofline.traffic / roofline.valu quote) is scripts/make_pmc_traffic.py applied to the
+    raw per-kernel counter means of the evidence set named in its `measured` field: re-deriving it here gives the same
+    kernels and numbers, every template instance of the rasteriser included (the counters file cuts kernel names at 60
+    characters; a parser that wants the closing '>' silently drops the rasteriser: round 5's first stamped line had no
+    traffic for that reason)."""
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        on_disk = json.load(f)
+    raw = os.path.join(ROOT, "profiles", on_disk["measured"], "dense_pmc_counters.txt")
+    assert os.path.exists(raw), raw
+    out = tmp_path / "pmc.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "make_pmc_traffic.py"), raw, str(out), on_disk["measured"]],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    again = json.loads(out.read_text())
+    assert again["kernels"] == on_disk["kernels"]
+    for k in ("keygen_kernel", "bucket_sort_kernel", "project_kernel", "bin_kernel", "raster_scan_kernel"):
+        assert k in again["kernels"], k
+        assert again["kernels"][k]["hbm_bytes_per_launch"] > 0 and again["kernels"][k]["valu_wave_instructions"] > 0
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "4"],
