@@ -1077,6 +1077,107 @@ __device__ __forceinline__ float srgb_oetf(float x) {
     x = fminf(fmaxf(x, 0.0f), 1.0f);
     return x <= 0.0031308f ? 12.92f * x : fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)), -0.055f);
 }
+// ---------------------------------------------------------------------------------------
+// INTERIOR records (round 6). What the record loop of a tile wave costs is its instruction COUNT, scalar ones included:
+// a SIMD retires one (record, tile) pair per ~296 clocks whether three or five tile waves share it (per-tile trace of the
+// dense frame), 16 more scalar moves per record cost 7 us of the launch and 16 more vector moves 5 us
+// (profiles/r6_notes.md) — and the compiled loop is ~87 vector + ~76 scalar instructions per pair: two exec-mask regions,
+// a ballot and three branches per 16 x 4 strip around 16 vector instructions. Most of that decides things that are the
+// same for all 256 pixels when the quad covers the tile with room to spare, which is what nearly every blended pair of a
+// frame with large splats is: the lane that stages a record decides once per (record, tile) whether every SAMPLE of every
+// pixel of the tile lies inside the quad — |u| + 7.5 (|m00| + |m01|) + margin <= 0.9999 lim on both axes, `margin` the one
+// blend_px_ms compares with (the slack covers the rounding of the per-pixel fmas by three orders of magnitude) — and the
+// verdicts of a staging round travel as two wave-wide bit masks in scalar registers (kept / interior). For an interior
+// record every pixel passes blend_px_ms's `gmax <= lim - m`, every strip takes its fast update, and all that is left to
+// decide per pixel is `T >= t_eps`: blend_interior_ms below is that update for two strips, written out — v_cmpx narrows
+// exec (no scalar mask juggling), 13 vector + 3 scalar instructions per strip where the compiled path has 16 + ~19, the
+// same operations in the same order on every active pixel, so the image keeps every bit (both rasterisers, every
+// instantiation: test_binning_modes_give_bit_identical_images). Records that are not interior go through blend_px_ms as
+// before; the two kinds run in separate inner loops (runs of a kind), so that neither loop's register assignment has to
+// agree with the other's inside the loop (one loop with two bodies made the compiler copy the whole pixel state, 35
+// moves, at every join).
+// Hazards the assembler does not see inside an asm block (gfx940-class): one wait state between a transcendental and
+// the use of its result (s_nop 0).
+// ---------------------------------------------------------------------------------------
+#ifndef BGS_INTERIOR_PATH
+#define BGS_INTERIOR_PATH 1
+#endif
+#define BGS_IA_STRIP_MS(S, RB, CX, CY, CB, QY, L)                                  \
+    "v_mul_f32 %[tm], " S ", " RB "\n\t"                                           \
+    "v_cmpx_le_f32 vcc, %[te], %[tm]\n\t"                                          \
+    "v_fma_f32 %[u], %[m01], " QY ", %[ux]\n\t"                                    \
+    "v_fma_f32 %[v], %[m11], " QY ", %[vx]\n\t"                                    \
+    "s_cbranch_execz " L "\n\t"                                                    \
+    "v_mul_f32 %[v], %[v], %[v]\n\t"                                               \
+    "v_fmac_f32 %[v], %[u], %[u]\n\t"                                              \
+    "v_exp_f32_e64 %[v], -%[v]\n\t"                                                \
+    "s_nop 0\n\t"                                                                  \
+    "v_mul_f32 %[v], %[v], %[al]\n\t"                                              \
+    "v_min_f32 %[v], 0x3f7fbe77, %[v]\n\t"                                         \
+    "v_mul_f32 %[u], %[tm], %[v]\n\t"                                              \
+    "v_fma_f32 " S ", -%[v], " S ", " S "\n\t"                                     \
+    "v_fma_f32 " CX ", %[u], %[cr], " CX "\n\t"                                    \
+    "v_fma_f32 " CY ", %[u], %[cg], " CY "\n\t"                                    \
+    "v_fma_f32 " CB ", %[u], %[cb], " CB "\n"                                      \
+    L ":\n\t"                                                                      \
+    "s_mov_b64 exec, %[sv]\n\t"
+// two strips (pixel rows) of a tile wave, one interior record; 4 samples per pixel: T_s = S r[s], only S moves
+__device__ __forceinline__ void blend_interior_ms(const float ux, const float vx, const float m01, const float m11,
+                                                  const float al, const float cr, const float cg, const float cbl,
+                                                  const float t_eps, const float qy0, const float qy1,
+                                                  PxMs& t0, v2f& c0, float& b0, PxMs& t1, v2f& c1, float& b1) {
+    float tm, u, v;
+    unsigned long long sv;
+    float c0x = c0.x, c0y = c0.y, c1x = c1.x, c1y = c1.y;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 BGS_IA_STRIP_MS("%[s0]", "%[r0]", "%[c0x]", "%[c0y]", "%[b0]", "%[q0]", "BGS_IA0_%=")
+                 BGS_IA_STRIP_MS("%[s1]", "%[r1]", "%[c1x]", "%[c1y]", "%[b1]", "%[q1]", "BGS_IA1_%=")
+                 : [s0] "+v"(t0.S), [c0x] "+v"(c0x), [c0y] "+v"(c0y), [b0] "+v"(b0),
+                   [s1] "+v"(t1.S), [c1x] "+v"(c1x), [c1y] "+v"(c1y), [b1] "+v"(b1),
+                   [tm] "=&v"(tm), [u] "=&v"(u), [v] "=&v"(v), [sv] "=&s"(sv)
+                 : [r0] "v"(t0.rb), [r1] "v"(t1.rb), [q0] "v"(qy0), [q1] "v"(qy1), [ux] "v"(ux), [vx] "v"(vx),
+                   [m01] "v"(m01), [m11] "v"(m11), [al] "v"(al), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cbl), [te] "s"(t_eps)
+                 : "vcc");
+    c0.x = c0x; c0.y = c0y; c1.x = c1x; c1.y = c1y;
+}
+// the single-sampled twin (blend_px with hit == true): T is the pixel's transmittance
+#define BGS_IA_STRIP_1(T, CX, CY, CB, QY, L)                                       \
+    "v_cmpx_le_f32 vcc, %[te], " T "\n\t"                                          \
+    "v_fma_f32 %[u], %[m01], " QY ", %[ux]\n\t"                                    \
+    "v_fma_f32 %[v], %[m11], " QY ", %[vx]\n\t"                                    \
+    "s_cbranch_execz " L "\n\t"                                                    \
+    "v_mul_f32 %[v], %[v], %[v]\n\t"                                               \
+    "v_fmac_f32 %[v], %[u], %[u]\n\t"                                              \
+    "v_exp_f32_e64 %[v], -%[v]\n\t"                                                \
+    "s_nop 0\n\t"                                                                  \
+    "v_mul_f32 %[v], %[v], %[al]\n\t"                                              \
+    "v_min_f32 %[v], 0x3f7fbe77, %[v]\n\t"                                         \
+    "v_mul_f32 %[u], " T ", %[v]\n\t"                                              \
+    "v_fma_f32 " CX ", %[u], %[cr], " CX "\n\t"                                    \
+    "v_fma_f32 " CY ", %[u], %[cg], " CY "\n\t"                                    \
+    "v_fma_f32 " CB ", %[u], %[cb], " CB "\n\t"                                    \
+    "v_sub_f32 " T ", " T ", %[u]\n"                                               \
+    L ":\n\t"                                                                      \
+    "s_mov_b64 exec, %[sv]\n\t"
+__device__ __forceinline__ void blend_interior_1(const float ux, const float vx, const float m01, const float m11,
+                                                 const float al, const float cr, const float cg, const float cbl,
+                                                 const float t_eps, const float qy0, const float qy1,
+                                                 float& t0, v2f& c0, float& b0, float& t1, v2f& c1, float& b1) {
+    float u, v;
+    unsigned long long sv;
+    float c0x = c0.x, c0y = c0.y, c1x = c1.x, c1y = c1.y;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 BGS_IA_STRIP_1("%[s0]", "%[c0x]", "%[c0y]", "%[b0]", "%[q0]", "BGS_IB0_%=")
+                 BGS_IA_STRIP_1("%[s1]", "%[c1x]", "%[c1y]", "%[b1]", "%[q1]", "BGS_IB1_%=")
+                 : [s0] "+v"(t0), [c0x] "+v"(c0x), [c0y] "+v"(c0y), [b0] "+v"(b0),
+                   [s1] "+v"(t1), [c1x] "+v"(c1x), [c1y] "+v"(c1y), [b1] "+v"(b1),
+                   [u] "=&v"(u), [v] "=&v"(v), [sv] "=&s"(sv)
+                 : [q0] "v"(qy0), [q1] "v"(qy1), [ux] "v"(ux), [vx] "v"(vx),
+                   [m01] "v"(m01), [m11] "v"(m11), [al] "v"(al), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cbl), [te] "s"(t_eps)
+                 : "vcc");
+    c0.x = c0x; c0.y = c0y; c1.x = c1x; c1.y = c1y;
+}
+
 // Rgba16Float texel: IEEE binary16, round to nearest even, overflow to inf (what a float16 target stores)
 __device__ __forceinline__ uint2 pack_rgba16f(const float4 c) {
     const _Float16 h[4] = {(_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};
@@ -1331,14 +1432,19 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                                                float4* __restrict__ fb, uint32_t* __restrict__ fb8_default,
                                                const uint32_t want_srgb8, const float t_eps, const float surfel_limit,
                                                float4* const s_rec, uint32_t* const s_queue, float4* const s_depth, const int lane,
-                                               const uint32_t tile, const int row0, uint32_t& trace_scanned,
+                                               const uint32_t tile_v, const int row0, uint32_t& trace_scanned,
                                                uint32_t& trace_blended, uint32_t& trace_staged, uint32_t& work) {
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     constexpr uint32_t STAGE = 64u;
     constexpr bool ABLATE = BGS_ABLATION != 0;
+    // the interior-record loop (blend_interior_ms): whole tiles of OBB quads without overlay or depth buffer, 1 or 4 samples
+    constexpr bool FAST = BGS_INTERIOR_PATH != 0 && !ABLATE && VARIANT == RV_OBB && !BBOX && !DEPTH && ROWS == 4 && (MSAA == 4 || MSAA == 1);
     // half extent of the box the tile's sample positions span around the tile centre (the exact quad-vs-tile test)
     constexpr float HALF = 7.5f + ms_reach(MSAA);
 
+    // (the tile is the wave's: scalar registers for everything derived from it — the tile origin the staging folds into
+    // every record used to sit in VGPRs across the blend loop; 92 -> 86 VGPRs for the headline's instantiation)
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_v);
     const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
     const int px = (int)tx * TILE_PX + (lane & 15), py0 = (int)ty * TILE_PX + row0 + (lane >> 4);
     // OBB and surfel records are staged tile-local (stage_obb / stage_surfel): pixels are then addressed inside the tile
@@ -1444,6 +1550,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             const uint32_t ccnt = min(STAGE, cnt - c0);
             work += WORK_ROUND + ccnt * WORK_STAGED;
             __builtin_amdgcn_wave_barrier();
+            [[maybe_unused]] bool keep_lane = false, interior_lane = false;   // this lane's record: blended at all / INTERIOR (FAST)
             if ((uint32_t)lane < ccnt) {
                 const float4* src = records + (size_t)s_queue[c0 + (uint32_t)lane] * REC_V4;
                 float4 r0 = src[0], r1 = src[1];
@@ -1471,6 +1578,14 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                 if constexpr (VARIANT == RV_OBB) {
                     float4 r2 = src[2];
                     stage_obb_margin<MSAA>(r0, r1);   // p[4] is unused by the OBB record
+                    if constexpr (FAST) {
+                        // every sample of every pixel of the tile inside the quad (INTERIOR records, above): the pixel centres
+                        // reach 7.5 px from the tile centre; ONE margin for both axes, as in blend_px_ms; false for a NaN
+                        const float su = 7.5f * (fabsf(r0.z) + fabsf(r0.w)), sv = 7.5f * (fabsf(r1.x) + fabsf(r1.y));
+                        const float ucc = fmaf(r0.w, 7.5f, fmaf(r0.z, 7.5f, r0.x)), vcc = fmaf(r1.y, 7.5f, fmaf(r1.x, 7.5f, r0.y));
+                        keep_lane = keep;
+                        interior_lane = keep && (fabsf(ucc) + su + r1.z <= 0.9999f * OBB_C) && (fabsf(vcc) + sv + r1.z <= 0.9999f * OBB_C);
+                    }
                     r2.w = keepz_of(keep && (!DEPTH || r2.w >= tile_dmin), r2.w);
                     s_rec[lane * REC_V4 + 0] = r0;
                     s_rec[lane * REC_V4 + 1] = r1;
@@ -1496,6 +1611,50 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t kend = (ABLATE && (fp.debug & 16u)) ? min(ccnt, 1u) : ccnt;  // ablation bit 16: stage, blend 1
+            if constexpr (FAST) {
+                // the round's records as two bit masks in scalar registers: which to blend, which of those are interior
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(keep_lane);
+                const unsigned long long inter = __builtin_amdgcn_ballot_w64(interior_lane);
+                if constexpr (TRACE) trace_staged += ccnt;
+                uint32_t since = 0u;   // records since the last look at the tile's saturation
+                bool out = false;
+                while (todo != 0ull && !out) {
+                    // a run of interior records
+                    while (todo != 0ull && ((inter >> (uint32_t)__builtin_ctzll(todo)) & 1ull) != 0ull) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const float4 a0 = s_rec[k * REC_V4 + 0], a1 = s_rec[k * REC_V4 + 1], a2 = s_rec[k * REC_V4 + 2];
+                        if constexpr (TRACE) trace_blended += 1u;
+                        work += WORK_BLENDED;
+                        const float ux = fmaf(a0.z, qx, a0.x), vx = fmaf(a1.x, qx, a0.y);
+                        if constexpr (MSAA == 4) {
+                            blend_interior_ms(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[0], qy[1], T[0], crg[0], cb[0], T[1], crg[1], cb[1]);
+                            blend_interior_ms(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[2], qy[3], T[2], crg[2], cb[2], T[3], crg[3], cb[3]);
+                        } else {
+                            blend_interior_1(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[0], qy[1], T[0], crg[0], cb[0], T[1], crg[1], cb[1]);
+                            blend_interior_1(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[2], qy[3], T[2], crg[2], cb[2], T[3], crg[3], cb[3]);
+                        }
+                        if constexpr (MIDROUND_EXIT)
+                            if (++since == BGS_MIDROUND_PERIOD) { since = 0u; if (__all(all_saturated(T, t_eps))) { out = true; break; } }
+                    }
+                    // a run of the others: strip by strip through blend_px_ms / blend_px
+                    while (!out && todo != 0ull && ((inter >> (uint32_t)__builtin_ctzll(todo)) & 1ull) == 0ull) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        StagedRecord<VARIANT> sr;
+                        sr.load(s_rec + k * REC_V4);
+                        if constexpr (TRACE) trace_blended += 1u;
+                        work += WORK_BLENDED;
+#pragma unroll
+                        for (int r = 0; r < ROWS; ++r) {
+                            if constexpr (MSAA == 4) blend_px_ms<VARIANT, false, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], 0.0f, false, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                            else blend_px<VARIANT, false, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
+                        }
+                        if constexpr (MIDROUND_EXIT)
+                            if (++since == BGS_MIDROUND_PERIOD) { since = 0u; if (__all(all_saturated(T, t_eps))) { out = true; break; } }
+                    }
+                }
+            } else
             for (uint32_t k = 0; k < kend; ++k) {
                 StagedRecord<VARIANT> sr;
                 sr.load(s_rec + k * REC_V4);
@@ -1663,7 +1822,8 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
             host[COARSE_OFF + (uint32_t)tid] = src[COARSE_OFF + (uint32_t)tid];
             // the 1 / (256 sub)-quantile keys of this frame's sorted list: later frames' bucket splitters
             const uint32_t nbk = BUCKET_COUNT * min(max(cl.split_sub, 1u), BUCKET_SUB_MAX);
-            for (uint32_t t = (uint32_t)tid; t < BUCKET_MAX; t += 256u)
+            // (only the nbk - 1 keys the host reads, plus one ~0 terminator: 1 KB for the headline's sub = 1, not 16 KB)
+            for (uint32_t t = (uint32_t)tid; t < nbk; t += 256u)
                 host[SPLIT_OFF + t] = (draw_count != 0u && t < nbk - 1u)
                                           ? (cl.sorted[(uint32_t)(((unsigned long long)(t + 1u) * draw_count) / nbk)].x ^ cl.key_xor)
                                           : 0xFFFFFFFFu;
