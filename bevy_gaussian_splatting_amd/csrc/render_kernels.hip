@@ -1379,6 +1379,17 @@ __global__ __launch_bounds__(256) void raster_kernel(FrameParams fp, const float
 // worth), a group of 64 candidates scanned. Scalar additions on wave-uniform counts; the same frame gives the same
 // numbers whatever else runs on the chip, which a wave's lifetime does not.
 constexpr uint32_t WORK_BLENDED = 8u, WORK_STAGED = 1u, WORK_ROUND = 40u, WORK_GROUP = 3u;
+// -DBGS_PHASE_TRACE=1 (experiment builds, scripts/tile_phases.py): the traced instantiations also stamp where a tile
+// wave's life goes — s_memtime at: entering raster_tile, first candidates tested, first staging round staged, last record
+// blended — into a third uint4 per tile (trace[2 * ntiles + tile], ticks since the wave's start)
+#ifndef BGS_PHASE_TRACE
+#define BGS_PHASE_TRACE 0
+#endif
+#if BGS_PHASE_TRACE
+#define BGS_PHASE(i) do { if constexpr (TRACE) { if (phase[i] == 0u) phase[i] = (uint32_t)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define BGS_PHASE(i) do { } while (0)
+#endif
 #ifndef BGS_DENSE_RUNS_MS
 #define BGS_DENSE_RUNS_MS 2u
 #endif
@@ -1433,7 +1444,9 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                                                const uint32_t want_srgb8, const float t_eps, const float surfel_limit,
                                                float4* const s_rec, uint32_t* const s_queue, float4* const s_depth, const int lane,
                                                const uint32_t tile_v, const int row0, uint32_t& trace_scanned,
-                                               uint32_t& trace_blended, uint32_t& trace_staged, uint32_t& work) {
+                                               uint32_t& trace_blended, uint32_t& trace_staged, uint32_t& work,
+                                               [[maybe_unused]] uint32_t (&phase)[4]) {
+    BGS_PHASE(0);
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     constexpr uint32_t STAGE = 64u;
     constexpr bool ABLATE = BGS_ABLATION != 0;
@@ -1526,6 +1539,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                          (ty >= ((rect_cur >> 16) & 255u)) & (ty <= (rect_cur >> 24));
         const unsigned long long b = __ballot(hit);
         const uint32_t hits = (uint32_t)__popcll(b);
+        BGS_PHASE(1);
         const bool fits = qn + hits <= 64u;
         if (have && fits) {  // queue this group's hits and advance the candidate stream
             const uint32_t i2 = base + 128u + (uint32_t)lane;
@@ -1610,6 +1624,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            BGS_PHASE(2);
             const uint32_t kend = (ABLATE && (fp.debug & 16u)) ? min(ccnt, 1u) : ccnt;  // ablation bit 16: stage, blend 1
             if constexpr (FAST) {
                 // the round's records as two bit masks in scalar registers: which to blend, which of those are interior
@@ -1691,6 +1706,9 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
         if constexpr (ABLATE) if (fp.debug & 32u) qn = 0u;
         if (end && qn == 0u) break;
     }
+#if BGS_PHASE_TRACE
+    if constexpr (TRACE) phase[3] = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     {
         // pixel coordinates are recomputed from an opaque copy of the lane id: keeping the four row
         // indices alive across the blend loop costs registers the loop needs (they were spilled)
@@ -1840,18 +1858,19 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
         for (uint32_t i = g; i < bin_v4; i += gn) bdst[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     uint32_t tile_done = 0xFFFFFFFFu;
+    [[maybe_unused]] uint32_t phase[4] = {0u, 0u, 0u, 0u};
     if (tile < ntiles) {  // whole wave; nothing in here synchronises across waves
         uint32_t rounds;
         bool reports = true;   // which wave speaks for the tile in the feedback
         if (MIDROUND_EXIT && strip_block) {
             rounds = raster_tile<VARIANT, false, MIDROUND_EXIT, 1, MSAA, DEPTH, BBOX>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
                                                                    t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 4 * wave,
-                                                                   trace_scanned, trace_blended, trace_staged, work);
+                                                                   trace_scanned, trace_blended, trace_staged, work, phase);
             reports = wave == 0;
         } else {
             rounds = raster_tile<VARIANT, TRACE, MIDROUND_EXIT, 4, MSAA, DEPTH, BBOX>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
                                                                    t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 0,
-                                                                   trace_scanned, trace_blended, trace_staged, work);
+                                                                   trace_scanned, trace_blended, trace_staged, work, phase);
             tile_done = tile;
         }
         // what the tile cost, for the order of the frames behind this one (kernels.h TileCost): whoever drew it says so —
@@ -1881,6 +1900,10 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
             const uint32_t xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
             trace[2u * tile_done] = make_uint4((uint32_t)trace_t0, (uint32_t)(trace_t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
             trace[2u * tile_done + 1u] = make_uint4(hw_id, xcc_id, trace_scanned, min(trace_blended, 0xFFFFu) | (min(trace_staged, 0xFFFFu) << 16));
+#if BGS_PHASE_TRACE
+            const uint32_t t0w = (uint32_t)trace_t0;
+            trace[2u * ntiles + tile_done] = make_uint4(phase[0] - t0w, phase[1] - t0w, phase[2] - t0w, phase[3] - t0w);
+#endif
         }
     }
 }
