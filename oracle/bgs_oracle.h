@@ -188,7 +188,7 @@ int oracle_instance_stats(const oracle_cloud* cloud, const bgs_sort_entry* entri
  * unpinned), round to nearest unorm8; alpha linear. out = n*4 bytes R,G,B,A. */
 void oracle_encode_srgb8(const float* rgba, uint32_t n, uint8_t* out);
 
-/* The quad-edge ambiguity band of oracle_render's ambiguity bound, in pixels (default 2e-3; accepted range [0, 0.5]). */
+/* The quad-edge ambiguity band of oracle_render's ambiguity bound, in pixels (default 5e-4 since round 6, 2e-3 before; accepted range [0, 0.5]). */
 void oracle_set_edge_band_px(double px);
 double oracle_edge_band_px(void);
 

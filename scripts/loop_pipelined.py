@@ -21,6 +21,8 @@ p.set_pipeline_depth(depth)
 p.set_pipeline_streams(streams)
 p.set_profiling(prof)
 p.set_debug_flags(flags)
+if os.environ.get("BGS_LOOP_GRAPHS"):
+    p.set_graphs(True)   # frames replayed from a captured hipGraph
 pv = p.prepare(v, s)
 for _ in range(10):
     p.render(h, pv, download=False)

@@ -60,7 +60,7 @@ def pytest_sessionfinish(session, exitstatus):
         t = H.TOLERANCE
         if not t["checked"]:
             return
-        band = os.environ.get("BGS_ORACLE_EDGE_BAND_PX", "2e-3")
+        band = os.environ.get("BGS_ORACLE_EDGE_BAND_PX", "5e-4")
         outdir = os.path.join(ROOT, "gpurun_out")
         os.makedirs(outdir, exist_ok=True)
         with open(os.path.join(outdir, f"tolerance_accounting_band_{band}.json"), "w") as f:

@@ -1299,16 +1299,19 @@ def _whole_frame_parity(plugin, oracle, dec, handle, v, s, what, whole_frame_sam
     """Every pixel of the 1920x1080 frame against the oracle's frame of the same inputs (the crops of the tests above
     stay as the fast path). The oracle rasterises every quad in full, back to front: seconds to minutes of CPU.
     whole_frame_samples = 1: the two frames whose multisampled oracle frame takes minutes (5 M dense splats, 1 M dense
-    surfels) are compared whole on a camera with Msaa::Off, and at the view's own sample count on three 64 x 64 crops
-    (centre, the heavy bottom-right corner, the top-left corner)."""
+    surfels) are compared whole on a camera with Msaa::Off, and at the view's own sample count on a 480 x 270 window in
+    the middle of the frame (a sixteenth of it: 129 600 pixels, 510 tiles; round 6 — three 64 x 64 crops before) plus the
+    three 64 x 64 corners that are not the window's (the heavy bottom-right one, top-left, top-right)."""
     import time
     if whole_frame_samples is not None and whole_frame_samples != v.msaa_samples:
         got4 = plugin.render(handle, v, s)
         e4 = oracle.sort(dec, v, s)
-        for (x0, y0) in ((928, 508), (1856, 1016), (0, 0)):
-            win = (x0, y0, x0 + 64, y0 + 64)
+        t0 = time.time()
+        for (x0, y0, w, hh) in ((720, 405, 480, 270), (1856, 1016, 64, 64), (0, 0, 64, 64), (1856, 0, 64, 64)):
+            win = (x0, y0, x0 + w, y0 + hh)
             ref, amb = oracle.render(dec, e4, v, s, window=win, with_ambiguity=True)
-            _assert_image(ref, got4[y0:y0 + 64, x0:x0 + 64], amb, frac_slack=0.01, what=f"{what} x{v.msaa_samples} {win}")
+            _assert_image(ref, got4[y0:y0 + hh, x0:x0 + w], amb, frac_slack=0.01 if w == 64 else 0.002, what=f"{what} x{v.msaa_samples} {win}")
+        print(f"[windows at x{v.msaa_samples}: {what}] 480 x 270 + three 64 x 64 corners, oracle {time.time() - t0:.0f} s")
         v = View(v.world_from_view, v.view_from_world, v.clip_from_view, v.clip_from_world, v.viewport, v.clear_color,
                  msaa_samples=whole_frame_samples)
         what = f"{what} (whole frame at x{whole_frame_samples}, crops at the view's own sample count)"
@@ -1925,11 +1928,13 @@ def test_zz_report_ambiguity_slack_use(oracle):
     every oracle comparison of this run: how many values were accepted only through the oracle's per-pixel ambiguity bound
     (quad-edge coverage flips, ill-conditioned surfel intersections / AABB conics) rather than the plain
     1e-3 + 1e-4 |ref| tolerance, and by how much the worst of them exceeds that tolerance. Teeth (from the runs under
-    profiles/r5_v1/ and profiles/r5/, at both edge bands): at most 2e-5 of the values; on the FIXED configurations (whole
-    frames, variants, depth buffers, f16, ...) none more than 0.05 beyond — one sample's share (a quarter) of a fragment
+    profiles/r5_v1/, profiles/r5/ and profiles/r5_v2/, at both edge bands; the default band is 5e-4 px since round 6): at
+    most 2e-5 of the values; on the FIXED configurations (whole frames, variants, depth buffers, f16, ...) none more than
+    0.025 beyond (largest seen: 0.0199) — one sample's share (a quarter) of a fragment
     of alpha exp(-4.5) * 0.8 and a colour of magnitude 15, the brightest the synthetic clouds hold, is 0.033; on the
     RANDOMIZED configurations (Msaa::Off on a third of the seeds: a flip is a whole fragment; global_opacity up to 2;
-    every raster mode) none more than 0.25 (largest seen in 9 000 configurations: 0.19)."""
+    every raster mode) none more than 0.24 (largest seen in 36 000 configurations: 0.19); under the bounding-box overlay,
+    where a flip is a whole opaque fragment, none more than 0.48 (largest seen: 0.38)."""
     t = H.TOLERANCE
     v, n = t["values"], t["checked"]
     print(f"[tolerance accounting] edge band {oracle.lib().oracle_edge_band_px():g} px: {v} of {n} compared values "
@@ -1939,9 +1944,12 @@ def test_zz_report_ambiguity_slack_use(oracle):
     for rec in sorted(t["comparisons"], key=lambda r: -r["max_excess"])[:12]:
         print(f"    {rec['what'][:60]}: {rec['beyond_strict']} of {rec['values']}, excess {rec['max_excess']:.2e}, max |err| {rec['max_err']:.2e}, "
               f"max |ref| {rec['ref_absmax']:.2f}")
+    # (round 6: the ceilings are what five rounds of runs showed plus a quarter — 1.99e-2 on the fixed configurations,
+    # 0.19 on the randomized ones, 0.38 under the overlay; 0.05 / 0.25 / unchecked before)
     assert v <= 2e-5 * max(n, 1) + 50
-    assert t["max_excess"] <= 0.05
-    assert t["max_excess_randomized"] <= 0.25
+    assert t["max_excess"] <= 0.025
+    assert t["max_excess_randomized"] <= 0.24
+    assert t["max_excess_overlay"] <= 0.48
 
 
 # ---------------------------------------------------------------------------------------------
