@@ -16,6 +16,7 @@ from .gaussian import (
     covariance_3d_opacity,
     random_gaussians_3d,
     random_gaussians_3d_seeded,
+    trained_like_gaussians_3d_seeded,
 )
 from .settings import (
     CloudSettings,
@@ -41,7 +42,7 @@ from .plugin import (
 __all__ = [
     "GaussianCamera", "View", "transform_from", "rotation_y",
     "Gaussian3d", "PlanarGaussian3d", "PlanarGaussian3dF16", "SphericalHarmonicCoefficients",
-    "SH_COEFF_COUNT", "compute_covariance_3d", "covariance_3d_opacity", "random_gaussians_3d", "random_gaussians_3d_seeded",
+    "SH_COEFF_COUNT", "compute_covariance_3d", "covariance_3d_opacity", "random_gaussians_3d", "random_gaussians_3d_seeded", "trained_like_gaussians_3d_seeded",
     "CloudSettings", "DrawMode", "GaussianColorSpace", "GaussianMode", "RadixSortDepthBits",
     "RasterizeMode", "ShaderDefines", "SortMode", "compute_aabb",
     "parse_ply_3d", "write_ply_3d", "decode_gcloud", "encode_gcloud", "read_gcloud", "write_gcloud", "SortConfig", "SortTrigger", "update_sort_trigger",

@@ -208,6 +208,81 @@ def random_gaussians_3d_seeded(n: int, seed: int) -> PlanarGaussian3d:
     return PlanarGaussian3d(pv, sh, rot, so)
 
 
+def trained_like_gaussians_3d_seeded(n: int, seed: int, patches: int = 96) -> PlanarGaussian3d:
+    """A synthetic cloud with the STATISTICS of a trained 3DGS asset, for workloads the reference's own generator does
+    not give (round 6; the reference demos trained assets — README.md:88 `scenes/icecream.gcloud` — but ships none, and
+    `random_gaussians_3d` above is unit-scale splats with SH ~ U(-1, 1)^48: colours up to 15, a camera inside the cloud):
+
+    * positions on SURFACES: `patches` rectangles (2-12 units wide, random pose inside the (-20, 20)^3 box the random
+      clouds fill, so the headless camera sees the scene the same way) with a splat density proportional to their area
+      and N(0, 0.02) of noise along the normal — what structure-from-motion points and the splats grown from them look like;
+    * scales LOG-NORMAL around the spacing of the splats on their patch (median ~ sqrt(area per splat), sigma_ln 0.6),
+      FLAT: the axis along the patch normal is 5-25 % of the tangential ones;
+    * rotations: unit quaternions that turn the local z axis onto the patch normal, a random angle about it (the PLY
+      loader normalises quaternions, src/io/ply.rs:118-124);
+    * opacity BIMODAL: 60 % Beta(8, 1.2) (opaque surface splats), 40 % Beta(1.2, 6) (the translucent haze training leaves);
+    * SH: the DC term such that the colour 0.5 + 0.2821 sh0 lies in [0.05, 0.95] (a base colour per patch plus per-splat
+      variation), the higher bands N(0, 0.015) halving by band — the view-dependent part moves a colour by a few
+      hundredths, so colours stay in [0, 1] but for the odd splat at the ends of the range.
+
+    Meant for `CloudSettings(global_scale=1.0)`. Same per-field order in `bgs::PlanarGaussian3d::trained_like`
+    (include/bgs.hpp; std::mt19937_64 there, numpy PCG64 here: the same statistics, not the same bits)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    P = int(patches)
+    centre = rng.uniform(-18.0, 18.0, size=(P, 3))
+    # patch frames: normal from a random direction, two tangents
+    nrm = rng.normal(size=(P, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    helper = np.where(np.abs(nrm[:, :1]) < 0.9, np.array([[1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0]]))
+    tu = np.cross(nrm, helper)
+    tu /= np.linalg.norm(tu, axis=1, keepdims=True)
+    tv = np.cross(nrm, tu)
+    size = rng.uniform(2.0, 12.0, size=(P, 2))
+    area = size[:, 0] * size[:, 1]
+    base_rgb = rng.uniform(0.15, 0.85, size=(P, 3))
+    pid = rng.choice(P, size=n, p=area / area.sum())
+    uv = rng.uniform(-0.5, 0.5, size=(n, 2)) * size[pid]
+    off = rng.normal(0.0, 0.02, size=n)
+    pos = centre[pid] + uv[:, :1] * tu[pid] + uv[:, 1:] * tv[pid] + off[:, None] * nrm[pid]
+    pv = np.empty((n, 4), np.float32)
+    pv[:, :3] = pos.astype(np.float32)
+    pv[:, 3] = 1.0
+    # scales: log-normal around the splat spacing of the patch, flat along the normal
+    spacing = np.sqrt(area.sum() / max(n, 1))
+    tang = spacing * np.exp(rng.normal(0.0, 0.6, size=(n, 2)))
+    flat = rng.uniform(0.05, 0.25, size=n) * np.sqrt(tang[:, 0] * tang[:, 1])
+    so = np.empty((n, 4), np.float32)
+    so[:, 0] = tang[:, 0]; so[:, 1] = tang[:, 1]; so[:, 2] = flat
+    pick = rng.uniform(size=n) < 0.6
+    so[:, 3] = np.where(pick, rng.beta(8.0, 1.2, size=n), rng.beta(1.2, 6.0, size=n)).astype(np.float32)
+    # rotation [w, x, y, z]: local axes (tu', tv', normal) with tu' = tu turned by a random angle about the normal
+    ang = rng.uniform(0.0, 2.0 * np.pi, size=n)
+    ca, sa = np.cos(ang)[:, None], np.sin(ang)[:, None]
+    ax = ca * tu[pid] + sa * tv[pid]
+    ay = -sa * tu[pid] + ca * tv[pid]
+    az = nrm[pid]
+    # the shader's rotation matrix is built COLUMN-wise from the quaternion and used as M = S * R (rows of R scaled): row i
+    # of R is the world direction of local axis i (helpers.wgsl:137-168) -> quaternion of the matrix whose ROWS are ax, ay, az
+    R = np.stack([ax, ay, az], axis=1)                      # R[n, row, col]
+    # the reference's constructor: R[row 0] = (1 - 2(y^2 + z^2), 2(xy - rz), 2(xz + ry)), ... (see compute_covariance_3d):
+    # it is the transpose of the usual rotation matrix of (r, x, y, z), so take the quaternion of R^T
+    Rt = np.transpose(R, (0, 2, 1))
+    tr = Rt[:, 0, 0] + Rt[:, 1, 1] + Rt[:, 2, 2]
+    qw = np.sqrt(np.maximum(1.0 + tr, 1e-12)) / 2.0
+    qx = np.copysign(np.sqrt(np.maximum(1.0 + Rt[:, 0, 0] - Rt[:, 1, 1] - Rt[:, 2, 2], 0.0)) / 2.0, Rt[:, 2, 1] - Rt[:, 1, 2])
+    qy = np.copysign(np.sqrt(np.maximum(1.0 - Rt[:, 0, 0] + Rt[:, 1, 1] - Rt[:, 2, 2], 0.0)) / 2.0, Rt[:, 0, 2] - Rt[:, 2, 0])
+    qz = np.copysign(np.sqrt(np.maximum(1.0 - Rt[:, 0, 0] - Rt[:, 1, 1] + Rt[:, 2, 2], 0.0)) / 2.0, Rt[:, 1, 0] - Rt[:, 0, 1])
+    rot = np.stack([qw, qx, qy, qz], axis=1)
+    rot /= np.linalg.norm(rot, axis=1, keepdims=True)
+    # SH: DC-dominated, colours in [0.05, 0.95]
+    rgb = np.clip(base_rgb[pid] + rng.normal(0.0, 0.08, size=(n, 3)), 0.05, 0.95)
+    sh = np.zeros((n, SH_COEFF_COUNT), np.float32)
+    sh[:, 0:3] = ((rgb - 0.5) / 0.2820947917738781).astype(np.float32)
+    band_sigma = np.concatenate([np.full(3, 0.015), np.full(5, 0.0075), np.full(7, 0.004)])   # coefficients 1..15
+    sh[:, 3:] = (rng.normal(size=(n, 15, 3)) * band_sigma[None, :, None]).reshape(n, 45).astype(np.float32)
+    return PlanarGaussian3d(pv, sh, rot.astype(np.float32), so)
+
+
 def random_gaussians_3d(n: int) -> PlanarGaussian3d:
     """src/gaussian/formats/planar_3d.rs:171-180 (thread RNG -> OS entropy seed)."""
     return random_gaussians_3d_seeded(n, int(np.random.SeedSequence().entropy % (1 << 63)))

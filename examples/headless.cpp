@@ -99,17 +99,49 @@ bgs::PlanarGaussian3d read_planes(const std::string& path) {
 
 int main(int argc, char** argv) {
     uint32_t count = 10000, width = 1920, height = 1080, frames = 40, depth = 6;
+    uint32_t msaa_samples = 0;   // 0 = not given: the view keeps Bevy's default Msaa (4 samples), as examples/headless.rs does
     uint64_t seed = 0;
     std::string out_dir = "headless_output", cloud_path, dump_path, ply_path;
-    bool f16 = false;
+    bool f16 = false, trained_like = false;
+    bgs::CloudSettings settings;   // CloudSettings::default()
+    // value names as clap's ValueEnum derives them from the reference's enums (kebab case; src/gaussian/settings.rs:17-57)
+    auto gaussian_mode = [](const std::string& v) {
+        if (v == "gaussian2d") return bgs::GaussianMode::Gaussian2d;
+        if (v == "gaussian3d") return bgs::GaussianMode::Gaussian3d;
+        std::fprintf(stderr, "--gaussian-mode %s: gaussian2d | gaussian3d (gaussian4d clouds are outside this path)\n", v.c_str());
+        std::exit(2);
+    };
+    auto rasterize_mode = [](const std::string& v) {
+        static const std::pair<const char*, bgs::RasterizeMode> names[] = {
+            {"classification", bgs::RasterizeMode::Classification}, {"color", bgs::RasterizeMode::Color},
+            {"depth", bgs::RasterizeMode::Depth}, {"normal", bgs::RasterizeMode::Normal},
+            {"optical-flow", bgs::RasterizeMode::OpticalFlow}, {"position", bgs::RasterizeMode::Position},
+            {"velocity", bgs::RasterizeMode::Velocity}};
+        for (const auto& nv : names) if (v == nv.first) return nv.second;
+        std::fprintf(stderr, "--rasterization-mode %s: classification | color | depth | normal | optical-flow | position | velocity\n", v.c_str());
+        std::exit(2);
+    };
+    auto depth_bits = [](const std::string& v) {
+        if (v == "bits16") return bgs::RadixSortDepthBits::Bits16;
+        if (v == "bits24") return bgs::RadixSortDepthBits::Bits24;
+        if (v == "bits32") return bgs::RadixSortDepthBits::Bits32;
+        std::fprintf(stderr, "--radix-sort-depth-bits %s: bits16 | bits24 | bits32\n", v.c_str());
+        std::exit(2);
+    };
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string {
             if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", a.c_str()); std::exit(2); }
             return argv[++i];
         };
+        // the reference's flag names (GaussianSplattingViewer, src/utils.rs:25-74; --seed stays as an alias)
         if (a == "--gaussian-count") count = (uint32_t)std::stoul(next());
-        else if (a == "--seed") seed = std::stoull(next());
+        else if (a == "--gaussian-seed" || a == "--seed") seed = std::stoull(next());
+        else if (a == "--gaussian-mode") settings.gaussian_mode = gaussian_mode(next());
+        else if (a == "--rasterization-mode") settings.rasterize_mode = rasterize_mode(next());
+        else if (a == "--radix-sort-depth-bits") settings.radix_sort_depth_bits = depth_bits(next());
+        else if (a == "--msaa-samples") msaa_samples = (uint32_t)std::stoul(next());
+        else if (a == "--trained-like") trained_like = true;   // (this build's: the trained-asset statistics instead of the reference's random cloud)
         else if (a == "--width") width = (uint32_t)std::stoul(next());
         else if (a == "--height") height = (uint32_t)std::stoul(next());
         else if (a == "--frames") frames = (uint32_t)std::stoul(next());
@@ -127,12 +159,13 @@ int main(int argc, char** argv) {
         if (!ply_path.empty()) {
             cloud = bgs::load_cloud(ply_path);  // .ply or .gcloud, like the reference's Gaussian3dLoader
         } else {
-            cloud = cloud_path.empty() ? bgs::PlanarGaussian3d::random(count, seed) : read_planes(cloud_path);
+            cloud = !cloud_path.empty() ? read_planes(cloud_path)
+                  : (trained_like ? bgs::PlanarGaussian3d::trained_like(count, seed) : bgs::PlanarGaussian3d::random(count, seed));
         }
         bgs::PlanarGaussian3dHandle handle =
             f16 ? bgs::upload(plugin, bgs::PlanarGaussian3dF16::from_f32(cloud)) : plugin.upload(cloud);
-        const bgs::View view = bgs::View::headless(width, height);  // Camera3d at (0, 1.5, 5), black clear colour
-        const bgs::CloudSettings settings;                          // CloudSettings::default()
+        bgs::View view = bgs::View::headless(width, height);  // Camera3d at (0, 1.5, 5), black clear colour
+        if (msaa_samples) view.set_msaa_samples(msaa_samples);
         const bgs_settings native = settings.to_native();
 
         plugin.set_output_srgb8(true);  // the reference's target is TextureFormat::Rgba8UnormSrgb

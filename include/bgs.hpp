@@ -15,6 +15,7 @@
 #ifndef BGS_HPP
 #define BGS_HPP
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -165,6 +166,77 @@ struct PlanarGaussian3d {
             c.position_visibility[i] = {uni(-20.0f, 20.0f), uni(-20.0f, 20.0f), uni(-20.0f, 20.0f), 1.0f};
             c.scale_opacity[i] = {uni(0.0f, 1.0f), uni(0.0f, 1.0f), uni(0.0f, 1.0f), uni(0.0f, 0.8f)};
             for (auto& v : c.spherical_harmonic[i]) v = uni(-1.0f, 1.0f);
+        }
+        return c;
+    }
+
+    // A synthetic cloud with the STATISTICS of a trained 3DGS asset (round 6; the Python twin and the reasoning:
+    // bevy_gaussian_splatting_amd/gaussian.py trained_like_gaussians_3d_seeded): positions on `patches` rectangular
+    // surfaces inside the (-20, 20)^3 box with N(0, 0.02) of noise along the normal, log-normal scales around the splat
+    // spacing with a flat normal axis, unit quaternions aligned with the patch, bimodal opacity (60 % Beta(8, 1.2), 40 %
+    // Beta(1.2, 6)), DC-dominated SH with colours in [0.05, 0.95]. Same per-field order as the Python generator;
+    // std::mt19937_64 here, numpy PCG64 there: the same statistics, not the same bits. For `global_scale = 1`.
+    static PlanarGaussian3d trained_like(size_t n, uint64_t seed, size_t patches = 96) {
+        std::mt19937_64 rng(seed);
+        auto uni = [&](double lo, double hi) { return std::uniform_real_distribution<double>(lo, hi)(rng); };
+        auto nrm = [&](double mu, double sd) { return std::normal_distribution<double>(mu, sd)(rng); };
+        auto beta = [&](double a, double b) {
+            const double x = std::gamma_distribution<double>(a, 1.0)(rng), y = std::gamma_distribution<double>(b, 1.0)(rng);
+            return x / (x + y);
+        };
+        struct Patch { double c[3], n[3], tu[3], tv[3], su, sv, rgb[3]; };
+        std::vector<Patch> P(patches);
+        std::vector<double> cdf(patches);
+        double area_sum = 0.0;
+        auto cross = [](const double* a, const double* b, double* o) {
+            o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+        };
+        auto normalise = [](double* v) { const double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); for (int k = 0; k < 3; ++k) v[k] /= l; };
+        for (auto& p : P) for (double& v : p.c) v = uni(-18.0, 18.0);
+        for (auto& p : P) {
+            for (double& v : p.n) v = nrm(0.0, 1.0);
+            normalise(p.n);
+            const double helper[3] = {std::fabs(p.n[0]) < 0.9 ? 1.0 : 0.0, std::fabs(p.n[0]) < 0.9 ? 0.0 : 1.0, 0.0};
+            cross(p.n, helper, p.tu);
+            normalise(p.tu);
+            cross(p.n, p.tu, p.tv);
+        }
+        for (auto& p : P) { p.su = uni(2.0, 12.0); p.sv = uni(2.0, 12.0); area_sum += p.su * p.sv; }
+        for (auto& p : P) for (double& v : p.rgb) v = uni(0.15, 0.85);
+        { double acc = 0.0; for (size_t i = 0; i < patches; ++i) { acc += P[i].su * P[i].sv / area_sum; cdf[i] = acc; } }
+        const double spacing = std::sqrt(area_sum / (double)std::max<size_t>(n, 1));
+        PlanarGaussian3d c;
+        c.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            const size_t pid = std::min<size_t>(std::lower_bound(cdf.begin(), cdf.end(), uni(0.0, 1.0)) - cdf.begin(), patches - 1);
+            const Patch& p = P[pid];
+            const double u = uni(-0.5, 0.5) * p.su, v = uni(-0.5, 0.5) * p.sv, off = nrm(0.0, 0.02);
+            for (int k = 0; k < 3; ++k) c.position_visibility[i][k] = (float)(p.c[k] + u * p.tu[k] + v * p.tv[k] + off * p.n[k]);
+            c.position_visibility[i][3] = 1.0f;
+            const double t0 = spacing * std::exp(nrm(0.0, 0.6)), t1 = spacing * std::exp(nrm(0.0, 0.6));
+            const double flat = uni(0.05, 0.25) * std::sqrt(t0 * t1);
+            const double op = uni(0.0, 1.0) < 0.6 ? beta(8.0, 1.2) : beta(1.2, 6.0);
+            c.scale_opacity[i] = {(float)t0, (float)t1, (float)flat, (float)op};
+            // local axes (tu turned about the normal, the normal): the quaternion whose rotation maps e_i onto them
+            const double ang = uni(0.0, 6.283185307179586), ca = std::cos(ang), sa = std::sin(ang);
+            double m[3][3];   // columns = ax, ay, az
+            for (int k = 0; k < 3; ++k) { m[k][0] = ca * p.tu[k] + sa * p.tv[k]; m[k][1] = -sa * p.tu[k] + ca * p.tv[k]; m[k][2] = p.n[k]; }
+            const double tr = m[0][0] + m[1][1] + m[2][2];
+            double q[4] = {std::sqrt(std::max(1.0 + tr, 1e-12)) / 2.0,
+                           std::copysign(std::sqrt(std::max(1.0 + m[0][0] - m[1][1] - m[2][2], 0.0)) / 2.0, m[2][1] - m[1][2]),
+                           std::copysign(std::sqrt(std::max(1.0 - m[0][0] + m[1][1] - m[2][2], 0.0)) / 2.0, m[0][2] - m[2][0]),
+                           std::copysign(std::sqrt(std::max(1.0 - m[0][0] - m[1][1] + m[2][2], 0.0)) / 2.0, m[1][0] - m[0][1])};
+            const double ql = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            c.rotation[i] = {(float)(q[0] / ql), (float)(q[1] / ql), (float)(q[2] / ql), (float)(q[3] / ql)};
+            auto& sh = c.spherical_harmonic[i];
+            for (int ch = 0; ch < 3; ++ch) {
+                const double rgb = std::min(std::max(p.rgb[ch] + nrm(0.0, 0.08), 0.05), 0.95);
+                sh[ch] = (float)((rgb - 0.5) / 0.2820947917738781);
+            }
+            for (int k = 1; k < 16; ++k) {
+                const double sd = k < 4 ? 0.015 : (k < 9 ? 0.0075 : 0.004);
+                for (int ch = 0; ch < 3; ++ch) sh[3 * k + ch] = (float)nrm(0.0, sd);
+            }
         }
         return c;
     }

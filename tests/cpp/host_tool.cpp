@@ -51,6 +51,8 @@ int main(int argc, char** argv) {
                 const float row[8] = {s6[0], s6[1], s6[2], s6[3], s6[4], s6[5], c.scale_opacity[i][3], 0.0f};
                 f.write((const char*)row, 32);
             }
+        } else if (cmd == "trained" && argc == 5) {   // trained <n> <seed> <out.bin>: PlanarGaussian3d::trained_like
+            write_planes(argv[4], bgs::PlanarGaussian3d::trained_like(std::stoul(argv[2]), std::stoull(argv[3])));
         } else if (cmd == "ply" && argc == 4) {
             std::ifstream in(argv[2], std::ios::binary);
             write_planes(argv[3], bgs::parse_ply_3d(in));

@@ -379,6 +379,13 @@ def random_case(seed: int, medium: bool = False):
     rng = np.random.default_rng(seed)
     n = int(rng.integers(40_000, 250_000)) if medium else int(rng.integers(1500, 5000))
     c = random_gaussians_3d_seeded(n, 100 + seed)
+    # (a fourth stream, round 6: a sixth of the seeds draw a cloud with trained-asset statistics instead — surfaces, flat
+    # log-normal splats, bimodal opacity, colours in [0, 1]; every other seed keeps the configuration it always had)
+    rng4 = np.random.default_rng(11_000_000 + seed)
+    trained = rng4.random() < 1.0 / 6.0
+    if trained:
+        from bevy_gaussian_splatting_amd import trained_like_gaussians_3d_seeded
+        c = trained_like_gaussians_3d_seeded(n, 100 + seed, patches=24 if not medium else 96)
     c.position_visibility[:, 3] = rng.integers(0, 7, n).astype(np.float32)
     if medium:
         w, h = int(rng.integers(300, 1281)), int(rng.integers(200, 721))
@@ -412,6 +419,8 @@ def random_case(seed: int, medium: bool = False):
         sh_degree=int(rng.integers(0, 4)), rasterize_mode=mode[int(rng.integers(0, len(mode)))],
         num_classes=int(rng.integers(1, 6)), position_min=mn, position_max=mx, transform=tr,
         draw_mode=DrawMode(int(rng.choice([0, 0, 0, 1, 2]))))
+    if trained:   # its scales are world units already; small clouds are sparse on their patches: draw them larger
+        s.global_scale = float(rng4.choice([1.0, 2.0, 4.0]))
     # (a second stream, so that the configurations of the earlier rounds' sweeps keep everything above)
     rng2 = np.random.default_rng(7_000_000 + seed)
     v.msaa_samples = int(rng2.choice([1, 4, 4]))      # Msaa::Off or Bevy's default Sample4

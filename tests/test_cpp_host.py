@@ -320,6 +320,90 @@ def test_cpp_compute_covariance_3d_matches_the_python_mirror(host_tool, tmp_path
     assert np.array_equal(got, covariance_3d_opacity(c))
 
 
+def _trained_like_statistics(pv, sh, rot, so):
+    """What makes a cloud 'trained-like' (gaussian.py trained_like_gaussians_3d_seeded), as numbers two generators can be held to."""
+    from bevy_gaussian_splatting_amd import compute_covariance_3d
+    tang = np.sqrt(so[:, 0] * so[:, 1])
+    rgb0 = 0.5 + 0.2820947917738781 * sh[:, :3]
+    cov = compute_covariance_3d(rot[:2000], so[:2000, :3])
+    S = np.zeros((len(cov), 3, 3))
+    for k, (i, j) in enumerate([(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]):
+        S[:, i, j] = S[:, j, i] = cov[:, k]
+    w = np.linalg.eigvalsh(S)
+    return {"quat_norm_err": float(np.abs(np.linalg.norm(rot, axis=1) - 1.0).max()),
+            "eig_vs_scale": float(np.abs(np.sqrt(np.maximum(w, 0.0)) - np.sort(so[:2000, :3], axis=1)).max()),
+            "tang_median": float(np.median(tang)), "tang_ln_sigma": float(np.std(np.log(tang))),
+            "flat_ratio_median": float(np.median(so[:, 2] / tang)),
+            "opaque_share": float((so[:, 3] > 0.6).mean()), "faint_share": float((so[:, 3] < 0.3).mean()),
+            "opacity_range": (float(so[:, 3].min()), float(so[:, 3].max())),
+            "dc_colour_range": (float(rgb0.min()), float(rgb0.max())), "higher_band_absmax": float(np.abs(sh[:, 3:]).max()),
+            "extent": float(np.abs(pv[:, :3]).max()), "visibility": float(pv[:, 3].min())}
+
+
+def test_trained_like_cloud_has_the_statistics_it_promises_in_both_generators(host_tool, tmp_path):
+    """`trained_like_gaussians_3d_seeded` (Python) and `bgs::PlanarGaussian3d::trained_like` (C++): surfaces, log-normal flat
+    splats aligned with them, bimodal opacity, DC-dominated SH with colours in [0, 1] — the same statistics from both."""
+    from bevy_gaussian_splatting_amd import trained_like_gaussians_3d_seeded
+    n = 60_000
+    c = trained_like_gaussians_3d_seeded(n, 5)
+    assert np.array_equal(c.position_visibility, trained_like_gaussians_3d_seeded(n, 5).position_visibility)   # seeded
+    py = _trained_like_statistics(c.position_visibility, c.spherical_harmonic, c.rotation, c.scale_opacity)
+    subprocess.run([host_tool, "trained", str(n), "5", str(tmp_path / "t.bin")], check=True)
+    cpp = _trained_like_statistics(*_read_planes(tmp_path / "t.bin"))
+    for st in (py, cpp):
+        assert st["quat_norm_err"] < 1e-6 and st["eig_vs_scale"] < 1e-5          # unit quaternions; Sigma's axes are the scales
+        assert 0.35 < st["tang_ln_sigma"] < 0.5 and 0.1 < st["flat_ratio_median"] < 0.2   # (geometric mean of two axes of sigma_ln 0.6)
+        assert 0.5 < st["opaque_share"] < 0.62 and 0.3 < st["faint_share"] < 0.42   # bimodal
+        assert 0.0 <= st["opacity_range"][0] and st["opacity_range"][1] <= 1.0
+        assert 0.049 <= st["dc_colour_range"][0] and st["dc_colour_range"][1] <= 0.951 and st["higher_band_absmax"] < 0.1
+        assert st["extent"] < 30.0 and st["visibility"] == 1.0
+    assert abs(py["tang_median"] / cpp["tang_median"] - 1.0) < 0.35   # (different patch draws: the area per splat differs a little)
+    # the view-dependent part is small next to the DC colour: per channel |sum_k c_k Y_k| <= 1.1 sum_k |c_k| (every basis
+    # function of degree 1-3 is below 1.1 in magnitude), a few hundredths for nearly every splat
+    dev = 1.1 * np.abs(c.spherical_harmonic[:, 3:].reshape(n, 15, 3)).sum(axis=1)
+    assert float(np.quantile(dev, 0.999)) < 0.2 and float(np.median(dev)) < 0.12
+
+
+def test_cpp_example_takes_the_reference_flag_names():
+    """examples/headless.cpp parses the flag names of the reference's `GaussianSplattingViewer` (src/utils.rs:25-74:
+    --width / --height / --msaa-samples / --input-cloud / --gaussian-count / --gaussian-seed / --gaussian-mode /
+    --rasterization-mode / --radix-sort-depth-bits) with clap's value names (kebab case of the enum variants); a wrong
+    value is refused before anything touches a GPU."""
+    _build()
+    for flag, bad, names in (("--gaussian-mode", "gaussian5d", ("gaussian2d", "gaussian3d")),
+                             ("--rasterization-mode", "colour", ("classification", "color", "depth", "normal", "optical-flow", "position", "velocity")),
+                             ("--radix-sort-depth-bits", "32", ("bits16", "bits24", "bits32"))):
+        r = subprocess.run([EXAMPLE, flag, bad], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and all(nm in r.stderr for nm in names), (flag, r.stderr)
+    src = open(os.path.join(ROOT, "examples", "headless.cpp")).read()
+    for flag in ("--width", "--height", "--msaa-samples", "--input-cloud", "--gaussian-count", "--gaussian-seed", "--gaussian-mode",
+                 "--rasterization-mode", "--radix-sort-depth-bits"):
+        assert f'"{flag}"' in src, flag
+
+
+@pytest.mark.gpu
+def test_cpp_example_with_the_reference_flags_renders_what_the_settings_say(tmp_path):
+    """--gaussian-mode gaussian2d --radix-sort-depth-bits bits24 --msaa-samples 1 on a cloud handed over as planes: the
+    frame is bit for bit the Python plugin's with the same CloudSettings and Msaa::Off."""
+    from bevy_gaussian_splatting_amd import (CloudSettings, GaussianMode, GaussianSplattingPlugin, RadixSortDepthBits, View,
+                                             trained_like_gaussians_3d_seeded)
+    _build()
+    c = trained_like_gaussians_3d_seeded(30_000, 3)
+    _write_planes(tmp_path / "c.bin", c)
+    r = subprocess.run([EXAMPLE, "--cloud", str(tmp_path / "c.bin"), "--width", "480", "--height", "270", "--frames", "4",
+                        "--gaussian-mode", "gaussian2d", "--radix-sort-depth-bits", "bits24", "--msaa-samples", "1",
+                        "--output-dir", str(tmp_path), "--dump-f32", str(tmp_path / "frame.f32")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "frame.f32", np.float32).reshape(270, 480, 4)
+    p = GaussianSplattingPlugin(0)
+    h = p.upload(c)
+    want = p.render(h, View.headless(480, 270, msaa_samples=1),
+                    CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, radix_sort_depth_bits=RadixSortDepthBits.Bits24))
+    assert np.array_equal(got, want)
+    h.free()
+    p.close()
+
+
 @pytest.mark.gpu
 def test_cpp_example_loads_a_gcloud_file(tmp_path):
     """examples/headless --input-cloud x.gcloud (the reference viewer's flag; loader dispatch src/io/loader.rs:22-61):

@@ -1338,6 +1338,17 @@ def test_whole_frame_parity_1m_3dgs(plugin, oracle, cloud_1m, global_scale):
     h.free()
 
 
+def test_whole_frame_parity_1m_trained_like(plugin, oracle):
+    """A cloud with trained-asset statistics (round 6: surfaces, flat log-normal splats, bimodal opacity, DC-dominated SH
+    with colours in [0, 1]; gaussian.py trained_like_gaussians_3d_seeded) at the headline's size and camera: every pixel
+    of the 1080p frame at the reference's sample count."""
+    from bevy_gaussian_splatting_amd import trained_like_gaussians_3d_seeded
+    c = trained_like_gaussians_3d_seeded(1_000_000, 7)
+    h = plugin.upload(c)
+    _whole_frame_parity(plugin, oracle, c, h, View.headless(1920, 1080), CloudSettings(), "trained-like 1M 3DGS f32")
+    h.free()
+
+
 @pytest.mark.parametrize("global_scale", [1.0, 0.05])
 def test_whole_frame_parity_5m_f16(plugin, oracle, global_scale):
     """configs[2]: 5 M-splat f16 planar cloud at 1080p; dense and scene-like."""
