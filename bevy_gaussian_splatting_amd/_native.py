@@ -82,6 +82,7 @@ EXPORTED_SYMBOLS = (
     "bgs_comm_unique_id",
     "bgs_comm_create",
     "bgs_comm_gather",
+    "bgs_comm_gather_after",
     "bgs_comm_wait",
     "bgs_comm_stream",
     "bgs_comm_destroy",
@@ -317,6 +318,8 @@ def load() -> ctypes.CDLL:
     lib.bgs_comm_create.restype = ctypes.c_int
     lib.bgs_comm_gather.argtypes = [vp, vp, u32, vp, ctypes.c_uint64, vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.bgs_comm_gather.restype = ctypes.c_int
+    lib.bgs_comm_gather_after.argtypes = [vp, vp, u32, vp, ctypes.c_uint64, vp, vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.bgs_comm_gather_after.restype = ctypes.c_int
     lib.bgs_comm_wait.argtypes = [vp, vp, ctypes.c_uint64]
     lib.bgs_comm_wait.restype = ctypes.c_int
     lib.bgs_comm_stream.argtypes = [vp, vp, ctypes.POINTER(vp)]

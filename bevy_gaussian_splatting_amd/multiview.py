@@ -186,9 +186,17 @@ class NativeFrameGather:
     recv_ptr + (r * batch + k) * frame_bytes, k < count."""
 
     def __init__(self, plugin, frame_bytes: int, world: int, rank: int, unique_id: bytes, batch: int = 8, dst: int = 0,
-                 on_batch=None):
+                 on_batch=None, device_wait: bool = False):
         self.plugin, self.frame_bytes, self.world, self.rank, self.dst = plugin, int(frame_bytes), int(world), int(rank), int(dst)
         self.batch = max(1, int(batch))
+        # device_wait (round 6, `bgs_comm_gather_after`): a batch goes out as soon as its last frame is ENQUEUED — the
+        # gather waits on the device for the context's frames in flight — instead of once its frames were popped; the
+        # producer calls frame_enqueued() after every render and pops frames whenever it likes (frame_completed() then only
+        # counts). A frame the library re-ran after its batch went out is counted in `stale_frames` (watch
+        # adaptive_counters' reruns_* around the pops and call note_rerun()).
+        self.device_wait = bool(device_wait)
+        self.enqueued = 0
+        self.stale_frames = 0
         self.comm = plugin.comm_create(unique_id, world, rank)
         self.stage = [plugin.device_alloc(self.batch * self.frame_bytes) for _ in range(2)]
         self.recv = [plugin.device_alloc(self.world * self.batch * self.frame_bytes) if rank == dst else None for _ in range(2)]
@@ -215,27 +223,49 @@ class NativeFrameGather:
         # every rank sends the whole staging batch (a partial batch only at the very end): one message size per
         # collective on every rank, whatever `count` is
         self.count_in_flight[s] = count
-        self.ticket[s] = self.plugin.comm_gather(self.comm, self.dst, self.stage[s], self.batch * self.frame_bytes, self.recv[s])
+        gather = self.plugin.comm_gather_after if self.device_wait else self.plugin.comm_gather
+        self.ticket[s] = gather(self.comm, self.dst, self.stage[s], self.batch * self.frame_bytes, self.recv[s])
         self.gathers += 1
 
     def next_target(self) -> int:
         s, slot = (self.issued // self.batch) % 2, self.issued % self.batch
         if slot == 0:
+            # The buffer is about to be overwritten: every frame of its previous use must have gone out. That is the case
+            # when at most `batch` frames are outstanding — then they all sit in the OTHER buffer. (Round 5's advisor:
+            # with a pipeline deeper than `batch` the previous batch of this buffer had not been sent yet, its ticket
+            # was 0, and next_target handed the slot out over frames nobody had gathered.)
+            sent = self.enqueued if self.device_wait else self.pushed
+            if self.issued - sent > self.batch:
+                raise RuntimeError(f"NativeFrameGather: {self.issued - sent} frames outstanding with batch {self.batch}: the staging "
+                                   "ring holds two batches — complete frames before asking for more slots, or gather larger batches "
+                                   "(batch >= the pipeline depth)")
             self._complete(s)  # the previous gather out of this staging buffer must have finished
         self.issued += 1
         return self.stage[s] + slot * self.frame_bytes
 
+    def frame_enqueued(self) -> None:
+        """device_wait mode: the frame that was given the last next_target() slot has been enqueued (bgs_render returned)."""
+        self.enqueued += 1
+        if self.device_wait and self.enqueued % self.batch == 0:
+            self._send((self.enqueued // self.batch - 1) % 2, self.batch)
+
+    def note_rerun(self, frames: int = 1) -> None:
+        """device_wait mode: the library re-ran `frames` frames whose batch may already have gone out."""
+        self.stale_frames += int(frames)
+
     def frame_completed(self) -> None:
         self.pushed += 1
-        if self.pushed % self.batch == 0:
+        if not self.device_wait and self.pushed % self.batch == 0:
             self._send((self.pushed // self.batch - 1) % 2, self.batch)
 
     def flush(self) -> None:
+        if self.device_wait:
+            self.pushed = self.enqueued   # (the batch phase follows the frames ENQUEUED; the caller has synchronised / popped them)
         s, slot = (self.pushed // self.batch) % 2, self.pushed % self.batch
         if slot:
             self._send(s, slot)
             self.pushed += self.batch - slot  # keep the batch phase of every rank aligned
-            self.issued = self.pushed
+            self.issued = self.enqueued = self.pushed
             self._complete(1 - s)
             self._complete(s)
         else:

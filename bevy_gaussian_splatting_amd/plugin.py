@@ -457,6 +457,16 @@ class GaussianSplattingPlugin:
                                               ctypes.c_void_p(recv_ptr or 0), ctypes.byref(ticket)))
         return ticket.value
 
+    def comm_gather_after(self, comm: int, root: int, send_ptr: int, nbytes: int, recv_ptr: Optional[int],
+                          hip_stream: Optional[int] = None) -> int:
+        """`bgs_comm_gather_after`: the gather ordered ON THE DEVICE behind everything enqueued so far on `hip_stream` (None:
+        behind every frame this context still has in flight) — no pop / synchronise before the batch goes out. Returns the
+        ticket. A frame re-run later (adaptive_counters: reruns_*) went out in the state of its first attempt."""
+        t = ctypes.c_uint64(0)
+        self._check(self._lib.bgs_comm_gather_after(self._ctx, comm, int(root), ctypes.c_void_p(send_ptr), int(nbytes),
+                                                    ctypes.c_void_p(recv_ptr or 0), ctypes.c_void_p(hip_stream or 0), ctypes.byref(t)))
+        return int(t.value)
+
     def comm_wait(self, comm: int, ticket: int = 0) -> None:
         """Block until the gather with `ticket` (and every earlier one) has completed; 0 = all of them."""
         self._check(self._lib.bgs_comm_wait(self._ctx, comm, int(ticket)))

@@ -392,6 +392,16 @@ int bgs_comm_unique_id(uint8_t id_out[BGS_COMM_ID_BYTES]);
 int bgs_comm_create(bgs_ctx* ctx, const uint8_t id[BGS_COMM_ID_BYTES], uint32_t world_size, uint32_t rank, bgs_comm** out);
 int bgs_comm_gather(bgs_ctx* ctx, bgs_comm* comm, uint32_t root, const void* send_device_ptr, uint64_t bytes_per_rank,
                     void* recv_device_ptr_root_only, uint64_t* ticket_out_or_null);
+/* The same gather ORDERED ON THE DEVICE behind work that is still running (round 6): the communicator's stream first
+ * waits — a stream-to-stream dependency, no host round trip — for everything enqueued so far on `hip_stream`, or, with
+ * hip_stream == NULL, for every frame this context has enqueued and not yet completed (all lanes). The host may then
+ * enqueue the gather of a batch right behind the batch's last bgs_render instead of popping / synchronising its frames
+ * first (bgs_comm_gather's contract, a host round trip per batch and rank). What it cannot know: a frame the library
+ * re-runs later because a data-dependent capacity turned out too small (bgs_adaptive_counters: reruns_sort, reruns_lists)
+ * has been sent in the state of its first attempt — a host that gathers this way checks those counters when it pops the
+ * batch's frames (they do not move on a settled view) and gathers the batch again, or uses bgs_comm_gather. */
+int bgs_comm_gather_after(bgs_ctx* ctx, bgs_comm* comm, uint32_t root, const void* send_device_ptr, uint64_t bytes_per_rank,
+                          void* recv_device_ptr_root_only, void* hip_stream_or_null, uint64_t* ticket_out_or_null);
 int bgs_comm_wait(bgs_ctx* ctx, bgs_comm* comm, uint64_t ticket);
 int bgs_comm_stream(bgs_ctx* ctx, bgs_comm* comm, void** hip_stream); /* the stream the gathers run on */
 void bgs_comm_destroy(bgs_ctx* ctx, bgs_comm* comm);

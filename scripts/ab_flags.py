@@ -47,12 +47,16 @@ CLOUDS = {}
 
 def cloud(kind):
     if kind not in CLOUDS:
-        CLOUDS[kind] = (random_gaussians_3d_seeded(5_000_000, 3).to_f16() if kind == "5m" else
-                        random_gaussians_3d_seeded(1_000_000, 4 if kind == "2d" else 2))
+        if kind == "trained":
+            from bevy_gaussian_splatting_amd import trained_like_gaussians_3d_seeded
+            CLOUDS[kind] = trained_like_gaussians_3d_seeded(1_000_000, 7)
+        else:
+            CLOUDS[kind] = (random_gaussians_3d_seeded(5_000_000, 3).to_f16() if kind == "5m" else
+                            random_gaussians_3d_seeded(1_000_000, 4 if kind == "2d" else 2))
     return CLOUDS[kind]
 
 
-SPEC = {"dense": ("1m", CloudSettings(), 300), "scene": ("1m", CloudSettings(global_scale=0.05), 300),
+SPEC = {"trained": ("trained", CloudSettings(), 120), "dense": ("1m", CloudSettings(), 300), "scene": ("1m", CloudSettings(global_scale=0.05), 300),
         "surfel": ("2d", CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, aabb=True), 60),
         "surfel_scene": ("2d", CloudSettings(gaussian_mode=GaussianMode.Gaussian2d, aabb=True, global_scale=0.05), 200),
         "2d_obb": ("2d", CloudSettings(gaussian_mode=GaussianMode.Gaussian2d), 300),

@@ -34,7 +34,7 @@ def test_the_seam_header_carries_no_diagnostics():
             "bgs_set_queue_holders", "bgs_adaptive_counters", "bgs_graph_counters", "bgs_learning_counters",
             "bgs_tile_order_counters", "bgs_selftest_tile_order"} == diag
     # the seam proper, plus the multi-GPU frame gather ("ncclGather ... behind the boundary")
-    assert {n for n in seam if n.startswith("bgs_comm_")} == {"bgs_comm_unique_id", "bgs_comm_create", "bgs_comm_gather",
+    assert {n for n in seam if n.startswith("bgs_comm_")} == {"bgs_comm_unique_id", "bgs_comm_create", "bgs_comm_gather", "bgs_comm_gather_after",
                                                                "bgs_comm_wait", "bgs_comm_stream", "bgs_comm_destroy"}
     assert len(seam) <= 48
 

@@ -947,6 +947,55 @@ def test_frame_graphs_follow_changing_inputs(plugin):
         h.free()
 
 
+def test_frame_graphs_are_captured_anew_when_the_splitter_table_grows(plugin):
+    """Round 5's advisor (medium): the number of quantile keys a frame's clean-up leaves (FrameCleanup::split_sub, 256 * sub
+    - 1 keys) is a rasteriser argument baked into a captured frame graph, but the graph's key did not hold it — when the
+    draw-count hint crossed a 524 288-pair step under bgs_set_graphs, replays kept writing the CAPTURED sub's table under
+    the new sub's label: a badly balanced (yet ascending) table, a bucket overflow and an onesweep re-run on every frame,
+    silently. A camera that sees 60 k pairs, then one that sees all 700 k (sub 1 -> 2): the step must re-capture, and the
+    frames behind it must sort on the bucket path without a single re-run."""
+    from bevy_gaussian_splatting_amd import transform_from
+    c = random_gaussians_3d_seeded(700_000, 23)
+    h = plugin.upload(c)
+    near = View.headless(480, 270)
+    far = View.perspective(transform_from((0.0, 0.0, 120.0)), 480, 270)   # the whole cloud inside the frustum
+    s = CloudSettings(global_scale=0.05)
+    direct_far = plugin.render(h, far, s)
+    assert plugin.stats()["draw_count"] > 600_000
+    plugin.reset_adaptive_state()
+    plugin.set_profiling(0)
+    plugin.set_async(True)
+    plugin.set_graphs(True)
+    plugin.set_pipeline_depth(2)
+    from bevy_gaussian_splatting_amd.multiview import framebuffer_as_tensor
+    try:
+        for _ in range(12):
+            plugin.render(h, near, s, download=False)
+        plugin.synchronize()
+        c0, r0 = plugin.graph_counters()
+        assert r0 > 0
+        for _ in range(6):    # the hint jumps: frames here may re-run while the context learns the longer list
+            plugin.render(h, far, s, download=False)
+        plugin.synchronize()
+        c1, _ = plugin.graph_counters()
+        assert c1 > c0                                          # captured anew, not replayed with the old arguments
+        a0 = plugin.adaptive_counters()
+        for _ in range(24):
+            plugin.render(h, far, s, download=False)
+        plugin.synchronize()
+        a1 = plugin.adaptive_counters()
+        assert a1["reruns_sort"] == a0["reruns_sort"]           # the table under the label sub = 2 IS a sub = 2 table
+        assert a1["bucket_frames"] - a0["bucket_frames"] >= 20
+        assert np.array_equal(framebuffer_as_tensor(plugin, 270, 480).cpu().numpy(), direct_far)
+    finally:
+        plugin.set_graphs(False)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.set_profiling(2)
+        plugin.reset_adaptive_state()
+    h.free()
+
+
 def test_framebuffer_zero_copy_tensor_and_rccl_gather_single_rank(plugin):
     """The multi-GPU leg of bench.py: the device framebuffer wrapped zero-copy as a torch tensor
     (what RCCL sends) and gathered with the nccl backend (world_size 1 here; world_size 2 is
@@ -1777,6 +1826,33 @@ def test_a_kind_that_never_runs_clean_is_settled_on_anyway(plugin):
                 assert np.array_equal(device_ptr_as_tensor(f32, (240, 416, 4), "<f4", "cuda:0").cpu().numpy(), ref)
         plugin.synchronize()
         assert plugin.learning_counters()["early_frames"] - e0 == 3
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.reset_adaptive_state()
+    h.free()
+
+
+def test_two_alternating_kinds_that_never_run_clean_are_settled_on_too(plugin):
+    """Round 5's advisor: the bound counted early frames of one kind "in a row", so a host that alternates two kinds which
+    never run clean (two cameras with different viewports, every frame re-run) reset the streak with every frame and was
+    completed inside bgs_render for ever. Counted per kind: LEARN_MAX early frames of EACH kind, none after."""
+    c = random_gaussians_3d_seeded(40_000, 76)
+    h = plugin.upload(c)
+    va, vb, s = View.headless(416, 240), View.headless(384, 224), CloudSettings()
+    try:
+        plugin.reset_adaptive_state()
+        plugin.set_debug_flags(0x8000000)   # every frame is re-run: no frame of either kind ever runs clean
+        plugin.set_async(True)
+        plugin.set_pipeline_depth(4)
+        e0 = plugin.learning_counters()["early_frames"]
+        for i in range(24):
+            plugin.render(h, va if i % 2 == 0 else vb, s, download=False)
+            if plugin.frames_in_flight() >= 4:
+                plugin.pipeline_pop()
+        plugin.synchronize()
+        assert plugin.learning_counters()["early_frames"] - e0 == 6
     finally:
         plugin.set_debug_flags(0)
         plugin.set_async(False)

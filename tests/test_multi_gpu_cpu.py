@@ -257,6 +257,10 @@ class _FakeCommPlugin:
                 plug_root.view(recv_root + r * nbytes, nbytes)[:] = box[r][0]
         return self.tickets
 
+    def comm_gather_after(self, comm, root, send, nbytes, recv, hip_stream=None):
+        self.after_calls = getattr(self, "after_calls", 0) + 1   # (the device-side wait is the library's: nothing to fake)
+        return self.comm_gather(comm, root, send, nbytes, recv)
+
     def comm_wait(self, comm, ticket=0):
         self.waited.append(ticket)
 
@@ -297,3 +301,82 @@ def test_native_frame_gather_batches_and_flushes_like_the_torch_one():
     assert plugs[0].waited[0] == 1 and set(plugs[0].waited) == {1, 2, 3}
     for g in gs:
         g.close()
+
+
+def test_native_frame_gather_world_8_partial_last_batch_offsets():
+    """BASELINE configs[4]'s shape on the fake communicator: eight ranks, batches of 8 frames, 19 frames per rank — two full
+    batches and a partial one of 3. On the root, rank r's frame k of a batch lies at (r * batch + k) * frame_bytes of the
+    receive buffer whatever the batch's count is (every rank always sends the whole staging batch), `on_batch` is told the
+    count, and every frame of every rank arrives exactly once, in order."""
+    from bevy_gaussian_splatting_amd.multiview import NativeFrameGather
+    _FakeCommPlugin.mailbox = {}
+    frame_bytes, batch, frames, world = 48, 8, 19, 8
+    seen = []
+    plugs = [_FakeCommPlugin(r, world) for r in range(world)]
+
+    def on_batch(recv_ptr, count):
+        raw = plugs[0].view(recv_ptr, world * batch * frame_bytes)
+        for r in range(world):
+            for k in range(count):
+                at = (r * batch + k) * frame_bytes
+                seen.append((r, int(raw[at]), bytes(raw[at:at + frame_bytes])))
+
+    gs = [NativeFrameGather(plugs[r], frame_bytes, world, r, bytes([2]) * 128, batch=batch, on_batch=on_batch if r == 0 else None)
+          for r in range(world)]
+    for i in range(frames):
+        for r in reversed(range(world)):
+            slot = gs[r].next_target()
+            plugs[r].view(slot, frame_bytes)[:] = (31 * r + i) % 251
+            gs[r].frame_completed()
+    for r in reversed(range(world)):
+        gs[r].flush()
+    assert all(g.gathers == 3 for g in gs) and gs[0].frames_received == world * frames
+    assert len(seen) == world * frames
+    for r in range(world):
+        mine = [v for (rr, v, _) in seen if rr == r]
+        assert mine == [(31 * r + i) % 251 for i in range(frames)], r          # in order, once each
+    assert all(blob == bytes([v]) * frame_bytes for (_, v, blob) in seen)       # whole frames, not shifted ones
+    for g in gs:
+        g.close()
+
+
+def test_native_frame_gather_device_wait_sends_at_enqueue_and_guards_its_ring():
+    """device_wait (bgs_comm_gather_after): a batch goes out when its last frame has been ENQUEUED — the gather waits on the
+    device — so frames may be popped long after; and the staging ring refuses to hand out a slot over frames that have not
+    gone out (round 5's advisor: a pipeline deeper than the batch overwrote them silently)."""
+    from bevy_gaussian_splatting_amd.multiview import NativeFrameGather
+    _FakeCommPlugin.mailbox = {}
+    frame_bytes, batch, frames, world = 32, 4, 10, 2
+    got = []
+    plugs = [_FakeCommPlugin(r, world) for r in range(world)]
+
+    def on_batch(recv_ptr, count):
+        got.append(plugs[0].view(recv_ptr, world * batch * frame_bytes).reshape(world, batch, frame_bytes)[:, :count].copy())
+
+    gs = [NativeFrameGather(plugs[r], frame_bytes, world, r, bytes([3]) * 128, batch=batch, on_batch=on_batch if r == 0 else None,
+                            device_wait=True) for r in range(world)]
+    for i in range(frames):
+        for r in reversed(range(world)):
+            slot = gs[r].next_target()
+            plugs[r].view(slot, frame_bytes)[:] = (5 * r + i) % 251
+            gs[r].frame_enqueued()          # no pop, no frame_completed: the batch leaves at its 4th enqueue
+    assert gs[1].gathers == 2 and plugs[1].after_calls == 2
+    for r in reversed(range(world)):
+        gs[r].flush()
+    allf = np.concatenate(got, axis=1)
+    assert allf.shape == (world, frames, frame_bytes) and gs[0].frames_received == world * frames
+    for r in range(world):
+        assert [int(allf[r, i, 0]) for i in range(frames)] == [(5 * r + i) % 251 for i in range(frames)]
+    assert gs[0].stale_frames == 0
+    gs[0].note_rerun(2)
+    assert gs[0].stale_frames == 2
+    for g in gs:
+        g.close()
+    # the guard, in the default mode: nine slots handed out, none completed, batch 4 -> the ninth would overwrite frame 0
+    _FakeCommPlugin.mailbox = {}
+    one = _FakeCommPlugin(0, 1)
+    g = NativeFrameGather(one, frame_bytes, 1, 0, bytes([4]) * 128, batch=4)
+    for _ in range(8):
+        g.next_target()
+    with pytest.raises(RuntimeError, match="outstanding"):
+        g.next_target()

@@ -49,19 +49,25 @@ def _worker(rank, world, outdir):
             p.download(recv_ptr, blk)
             got.append(blk[:, :count].copy())
 
-        bg = NativeFrameGather(p, W * H * 4, world, rank, uid, batch=BATCH, on_batch=on_batch)
+        device_wait = os.environ.get("BGS_TEST_GATHER_AFTER") == "1"   # bgs_comm_gather_after: batches leave at enqueue
+        bg = NativeFrameGather(p, W * H * 4, world, rank, uid, batch=BATCH, on_batch=on_batch, device_wait=device_wait)
         p.set_async(True)
         p.set_pipeline_depth(4)
         p.set_packed_only(True)
+        reruns0 = sum(p.adaptive_counters()[k] for k in ("reruns_sort", "reruns_lists"))
         for _ in range(FRAMES):
             p.set_srgb8_target(bg.next_target())
             p.render(h, v, s, download=False)
+            bg.frame_enqueued()
             if p.frames_in_flight() >= 4:
                 p.pipeline_pop()
                 bg.frame_completed()
         while p.frames_in_flight():
             p.pipeline_pop()
             bg.frame_completed()
+        if device_wait:   # a frame re-run after its batch went out would have been sent stale: none on a settled view
+            bg.note_rerun(sum(p.adaptive_counters()[k] for k in ("reruns_sort", "reruns_lists")) - reruns0)
+            assert bg.stale_frames == 0
         bg.flush()
         if rank == 0:
             np.save(os.path.join(outdir, "received.npy"), np.array([bg.frames_received, bg.gathers]))
@@ -100,6 +106,15 @@ def _run(world, tmp_path):
 def test_native_gather_with_one_rank(tmp_path):
     """World size 1 on the one device every box has: communicator, staged batches, tickets, flush — every frame arrives
     and holds exactly the bytes of the rank's own blocking frame."""
+    _run(1, tmp_path)
+
+
+@pytest.mark.timeout(600)
+def test_native_gather_after_with_one_rank(tmp_path, monkeypatch):
+    """The same through bgs_comm_gather_after (round 6): a batch is handed to the communicator when its last frame has been
+    ENQUEUED, the gather waits on the device for the context's frames in flight — and the bytes on the root are still each
+    frame's own."""
+    monkeypatch.setenv("BGS_TEST_GATHER_AFTER", "1")
     _run(1, tmp_path)
 
 
