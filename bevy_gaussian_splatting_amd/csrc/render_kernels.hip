@@ -910,16 +910,11 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
         alpha = frame ? 1.0f : alpha; r = frame ? 0.3f : r; g = frame ? 1.0f : g; b = frame ? 0.1f : b;
     }
     // beyond lim + m no sample of the pixel is covered; within lim - m all four are
-#ifndef BGS_ONE_REGION
-#define BGS_ONE_REGION 0
-#endif
-#if BGS_ONE_REGION
-    // (bitwise: both compares up front and ONE exec-mask region — the short-circuit form nests two, three scalar
-    // instructions more per visited strip for one multiplication and one compare less per missed one)
+    // (bitwise on purpose, round 6: both compares up front and ONE exec-mask region — the short-circuit form nests two:
+    // three scalar instructions more per visited strip, for one multiplication and one compare less per missed one. What
+    // the record loop costs is its instruction count, scalar ones included: scene-like 1 M +1.3 %, trained-like +2.5 %
+    // frames/s, rasteriser alone -3 % / -8 %; profiles/r6_experiments/one_region_ab.txt)
     if ((gmax <= lim + m) & ok & (t.S * t.rb >= t_eps)) {
-#else
-    if (gmax <= lim + m && ok && t.S * t.rb >= t_eps) {
-#endif
         asm volatile("");  // keeps this a branch (see blend_px)
         const bool full = gmax <= lim - m;
         float w;
@@ -1027,7 +1022,7 @@ __device__ __forceinline__ void blend_px_msn(const StagedRecord<VARIANT>& s, con
         const bool frame = gmax > BBOX_EDGE * lim;
         alpha = frame ? 1.0f : alpha; r = frame ? 0.3f : r; g = frame ? 1.0f : g; b = frame ? 0.1f : b;
     }
-    if (gmax <= lim + m && ok && t.S * t.rb >= t_eps) {
+    if ((gmax <= lim + m) & ok & (t.S * t.rb >= t_eps)) {   // (one exec-mask region: see blend_px_ms)
         asm volatile("");  // keeps this a branch (see blend_px)
         const bool full = gmax <= lim - m;
         float w;
