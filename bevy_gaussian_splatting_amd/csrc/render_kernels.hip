@@ -1182,6 +1182,82 @@ __device__ __forceinline__ void blend_interior_1(const float ux, const float vx,
     c0.x = c0x; c0.y = c0y; c1.x = c1x; c1.y = c1y;
 }
 
+// The 2DGS surfel twin (RV_SURFEL: the ray-splat intersection, gaussian_2d.wgsl:134-156 as staged by stage_surfel): ONE strip
+// per block (the operands of two do not fit an asm statement). pxq / pyq / pzq = the parts of p that depend on the pixel's
+// column only (formed once per record by the caller), ddx likewise. Same operations in the same order as blend_px_ms /
+// blend_px's surfel branch on a pixel whose samples all lie inside the quad: u, v are not even formed.
+#define BGS_IA_SURFEL_BODY(TM)                                                     \
+    "v_fma_f32 %[a], %[pyx], %[qy], %[pxq]\n\t"                                    \
+    "v_fma_f32 %[b], %[pyy], %[qy], %[pyq]\n\t"                                    \
+    "v_fma_f32 %[c], %[pyz], %[qy], %[pzq]\n\t"                                    \
+    "s_cbranch_execz BGS_IS_%=\n\t"                                                \
+    "v_rcp_f32 %[c], %[c]\n\t"                                                     \
+    "s_nop 0\n\t"                                                                  \
+    "v_mul_f32 %[a], %[a], %[c]\n\t"                                               \
+    "v_mul_f32 %[b], %[b], %[c]\n\t"                                               \
+    "v_fma_f32 %[c], %[ddyk], %[qy], %[dy0]\n\t"                                   \
+    "v_mul_f32 %[b], %[b], %[b]\n\t"                                               \
+    "v_fmac_f32 %[b], %[a], %[a]\n\t"                                              \
+    "v_mul_f32 %[c], %[c], %[c]\n\t"                                               \
+    "v_fmac_f32 %[c], %[ddx], %[ddx]\n\t"                                          \
+    "v_min_f32 %[b], %[b], %[c]\n\t"                                               \
+    "v_exp_f32_e64 %[b], -%[b]\n\t"                                                \
+    "s_nop 0\n\t"                                                                  \
+    "v_mul_f32 %[b], %[b], %[al]\n\t"                                              \
+    "v_min_f32 %[b], 0x3f7fbe77, %[b]\n\t"                                         \
+    "v_mul_f32 %[a], " TM ", %[b]\n\t"
+__device__ __forceinline__ void blend_interior_surfel_ms(const float pxq, const float pyq, const float pzq, const float ddx,
+                                                         const float pyx, const float pyy, const float pyz, const float ddyk,
+                                                         const float dy0, const float al, const float cr, const float cg,
+                                                         const float cbl, const float t_eps, const float qy,
+                                                         PxMs& t, v2f& c, float& bl) {
+    float tm, a, b, cc;
+    unsigned long long sv;
+    float cx = c.x, cy = c.y;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_mul_f32 %[tm], %[s], %[rb]\n\t"
+                 "v_cmpx_le_f32 vcc, %[te], %[tm]\n\t"
+                 BGS_IA_SURFEL_BODY("%[tm]")
+                 "v_fma_f32 %[s], -%[b], %[s], %[s]\n\t"
+                 "v_fma_f32 %[cx], %[a], %[cr], %[cx]\n\t"
+                 "v_fma_f32 %[cy], %[a], %[cg], %[cy]\n\t"
+                 "v_fma_f32 %[bl], %[a], %[cb], %[bl]\n"
+                 "BGS_IS_%=:\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 : [s] "+v"(t.S), [cx] "+v"(cx), [cy] "+v"(cy), [bl] "+v"(bl),
+                   [tm] "=&v"(tm), [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(cc), [sv] "=&s"(sv)
+                 : [rb] "v"(t.rb), [qy] "v"(qy), [pxq] "v"(pxq), [pyq] "v"(pyq), [pzq] "v"(pzq), [ddx] "v"(ddx),
+                   [pyx] "v"(pyx), [pyy] "v"(pyy), [pyz] "v"(pyz), [ddyk] "v"(ddyk), [dy0] "v"(dy0), [al] "v"(al),
+                   [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cbl), [te] "s"(t_eps)
+                 : "vcc");
+    c.x = cx; c.y = cy;
+}
+__device__ __forceinline__ void blend_interior_surfel_1(const float pxq, const float pyq, const float pzq, const float ddx,
+                                                        const float pyx, const float pyy, const float pyz, const float ddyk,
+                                                        const float dy0, const float al, const float cr, const float cg,
+                                                        const float cbl, const float t_eps, const float qy,
+                                                        float& t, v2f& c, float& bl) {
+    float a, b, cc;
+    unsigned long long sv;
+    float cx = c.x, cy = c.y;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_le_f32 vcc, %[te], %[s]\n\t"
+                 BGS_IA_SURFEL_BODY("%[s]")
+                 "v_fma_f32 %[cx], %[a], %[cr], %[cx]\n\t"
+                 "v_fma_f32 %[cy], %[a], %[cg], %[cy]\n\t"
+                 "v_fma_f32 %[bl], %[a], %[cb], %[bl]\n\t"
+                 "v_sub_f32 %[s], %[s], %[a]\n"
+                 "BGS_IS_%=:\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 : [s] "+v"(t), [cx] "+v"(cx), [cy] "+v"(cy), [bl] "+v"(bl),
+                   [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(cc), [sv] "=&s"(sv)
+                 : [qy] "v"(qy), [pxq] "v"(pxq), [pyq] "v"(pyq), [pzq] "v"(pzq), [ddx] "v"(ddx),
+                   [pyx] "v"(pyx), [pyy] "v"(pyy), [pyz] "v"(pyz), [ddyk] "v"(ddyk), [dy0] "v"(dy0), [al] "v"(al),
+                   [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cbl), [te] "s"(t_eps)
+                 : "vcc");
+    c.x = cx; c.y = cy;
+}
+
 // Rgba16Float texel: IEEE binary16, round to nearest even, overflow to inf (what a float16 target stores)
 __device__ __forceinline__ uint2 pack_rgba16f(const float4 c) {
     const _Float16 h[4] = {(_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};
@@ -1455,7 +1531,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     constexpr uint32_t STAGE = 64u;
     constexpr bool ABLATE = BGS_ABLATION != 0;
     // the interior-record loop (blend_interior_ms): whole tiles of OBB quads without overlay or depth buffer, 1 or 4 samples
-    constexpr bool FAST = BGS_INTERIOR_PATH != 0 && !ABLATE && VARIANT == RV_OBB && !BBOX && !DEPTH && ROWS == 4 && (MSAA == 4 || MSAA == 1);
+    constexpr bool FAST = BGS_INTERIOR_PATH != 0 && !ABLATE && (VARIANT == RV_OBB || VARIANT == RV_SURFEL) && !BBOX && !DEPTH && ROWS == 4 && (MSAA == 4 || MSAA == 1);
     // half extent of the box the tile's sample positions span around the tile centre (the exact quad-vs-tile test)
     constexpr float HALF = 7.5f + ms_reach(MSAA);
 
@@ -1620,6 +1696,15 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                     if constexpr (!BBOX) keep = keep && !(surfel_negligible_in_tile(st, surfel_limit) && !(ABLATE && (fp.debug & 64u)));
                     const float z = src[5].x;
                     st[5].y = keepz_of(keep && (!DEPTH || z >= tile_dmin), z);
+                    if constexpr (FAST) {
+                        // INTERIOR (above): the quad is the square |u|, |v| <= 1 with u = du xl + U0, v = dv yl + V0 over the
+                        // tile's pixel centres xl, yl in [0, 15]; blend_px_ms asks for max(|u|, |v|) <= 1 - m, m = 0.375 max(|du|, |dv|)
+                        const float um = fmaxf(fabsf(st[0].x), fabsf(fmaf(st[0].y, 15.0f, st[0].x)));
+                        const float vm = fmaxf(fabsf(st[0].z), fabsf(fmaf(st[0].w, 15.0f, st[0].z)));
+                        const float mg = MSAA == 1 ? 0.0f : ms_reach(MSAA) * fmaxf(fabsf(st[0].y), fabsf(st[0].w));
+                        keep_lane = keep;
+                        interior_lane = keep && (fmaxf(um, vm) + mg <= 0.9999f);
+                    }
 #pragma unroll
                     for (int v = 0; v < 6; ++v) s_rec[lane * REC_V4 + v] = st[v];
                 }
@@ -1642,16 +1727,30 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                     while (todo != 0ull && ((inter >> (uint32_t)__builtin_ctzll(todo)) & 1ull) != 0ull) {
                         const uint32_t k = (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
-                        const float4 a0 = s_rec[k * REC_V4 + 0], a1 = s_rec[k * REC_V4 + 1], a2 = s_rec[k * REC_V4 + 2];
                         if constexpr (TRACE) trace_blended += 1u;
                         work += WORK_BLENDED;
-                        const float ux = fmaf(a0.z, qx, a0.x), vx = fmaf(a1.x, qx, a0.y);
-                        if constexpr (MSAA == 4) {
-                            blend_interior_ms(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[0], qy[1], T[0], crg[0], cb[0], T[1], crg[1], cb[1]);
-                            blend_interior_ms(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[2], qy[3], T[2], crg[2], cb[2], T[3], crg[3], cb[3]);
+                        if constexpr (VARIANT == RV_OBB) {
+                            const float4 a0 = s_rec[k * REC_V4 + 0], a1 = s_rec[k * REC_V4 + 1], a2 = s_rec[k * REC_V4 + 2];
+                            const float ux = fmaf(a0.z, qx, a0.x), vx = fmaf(a1.x, qx, a0.y);
+                            if constexpr (MSAA == 4) {
+                                blend_interior_ms(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[0], qy[1], T[0], crg[0], cb[0], T[1], crg[1], cb[1]);
+                                blend_interior_ms(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[2], qy[3], T[2], crg[2], cb[2], T[3], crg[3], cb[3]);
+                            } else {
+                                blend_interior_1(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[0], qy[1], T[0], crg[0], cb[0], T[1], crg[1], cb[1]);
+                                blend_interior_1(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[2], qy[3], T[2], crg[2], cb[2], T[3], crg[3], cb[3]);
+                            }
                         } else {
-                            blend_interior_1(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[0], qy[1], T[0], crg[0], cb[0], T[1], crg[1], cb[1]);
-                            blend_interior_1(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[2], qy[3], T[2], crg[2], cb[2], T[3], crg[3], cb[3]);
+                            // a1 = P0x P0y P0z Pxx | a2 = Pxy Pxz Pyx Pyy | a3 = Pyz Dx0 dDx Dy0 | a4 = dDy r g b | a5 = opacity ...
+                            const float4 a1 = s_rec[k * REC_V4 + 1], a2 = s_rec[k * REC_V4 + 2], a3 = s_rec[k * REC_V4 + 3],
+                                         a4 = s_rec[k * REC_V4 + 4];
+                            const float opa = s_rec[k * REC_V4 + 5].x;
+                            const float pxq = fmaf(a1.w, qx, a1.x), pyq = fmaf(a2.x, qx, a1.y), pzq = fmaf(a2.y, qx, a1.z);
+                            const float ddx = fmaf(a3.z, qx, a3.y);
+#pragma unroll
+                            for (int r = 0; r < ROWS; ++r) {
+                                if constexpr (MSAA == 4) blend_interior_surfel_ms(pxq, pyq, pzq, ddx, a2.z, a2.w, a3.x, a4.x, a3.w, opa, a4.y, a4.z, a4.w, t_eps, qy[r], T[r], crg[r], cb[r]);
+                                else blend_interior_surfel_1(pxq, pyq, pzq, ddx, a2.z, a2.w, a3.x, a4.x, a3.w, opa, a4.y, a4.z, a4.w, t_eps, qy[r], T[r], crg[r], cb[r]);
+                            }
                         }
                         if constexpr (MIDROUND_EXIT)
                             if (++since == BGS_MIDROUND_PERIOD) { since = 0u; if (__all(all_saturated(T, t_eps))) { out = true; break; } }
