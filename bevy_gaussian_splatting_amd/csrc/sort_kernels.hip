@@ -25,6 +25,7 @@
 //      look-back over predecessor tiles (relaxed agent-scope 4-byte words: the data is the flag)
 //   4. scatter pairs into LDS in digit order, then write runs to HBM coalesced.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "kernels.h"
 #include "lookback.h"
@@ -534,8 +535,16 @@ void launch_histogram(hipStream_t stream, const uint2* pairs, uint32_t n, uint32
 // ---------------------------------------------------------------------------------------
 // Onesweep digit pass
 // ---------------------------------------------------------------------------------------
+#ifndef BGS_ONESWEEP_WAVES
+#define BGS_ONESWEEP_WAVES 0
+#endif
 template <int KPT>
-__global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__ in,
+#if BGS_ONESWEEP_WAVES
+__global__ __launch_bounds__(256, BGS_ONESWEEP_WAVES) void onesweep_kernel(
+#else
+__global__ __launch_bounds__(256) void onesweep_kernel(
+#endif
+const uint2* __restrict__ in,
                                                        uint2* __restrict__ out,
                                                        const uint32_t* __restrict__ n_ptr,
                                                        const uint32_t* __restrict__ hist,
@@ -545,7 +554,6 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
     constexpr uint32_t TILE = 256u * KPT;
     __shared__ uint2 s_pairs[TILE];
     __shared__ uint32_t s_wave_hist[4][RADIX_BASE];
-    __shared__ uint32_t s_block_excl[RADIX_BASE];   // first slot of each digit in the LDS order
     __shared__ uint32_t s_global_base[RADIX_BASE];  // dst = s_global_base[d] + slot
     __shared__ uint32_t s_hist_excl[RADIX_BASE];
     __shared__ uint32_t s_tot[4];
@@ -563,7 +571,6 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
         uint32_t total;
         s_hist_excl[tid] = block_exclusive_scan_256(h, s_tot, total);
     }
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const bool single_shot = gridDim.x >= num_tiles;  // see keygen_kernel
 
     for (;;) {
@@ -573,94 +580,109 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const uint2* __restrict__
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= num_tiles) break;
-        const uint32_t tile_base = tile * TILE;
-        const uint32_t row_base = tile_base + (uint32_t)wave * (uint32_t)(KPT * 64) + (uint32_t)lane;
+        // a tile that lies wholly inside the list (all but the last) runs without the per-key bounds tests: 16 exec-mask
+        // regions in the loads, 16 ballots of `valid` and 32 compares in the two scatters less (round 6)
+        auto process = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+            const uint32_t tile_base = tile * TILE;
+            const uint32_t row_base = tile_base + (uint32_t)wave * (uint32_t)(KPT * 64) + (uint32_t)lane;
 
-        uint2 kv[KPT];
-        uint32_t rank[KPT];
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const uint32_t idx = row_base + (uint32_t)k * 64u;
-            kv[k] = idx < n ? in[idx] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        }
-        // wave-private ranking, one 64-pair row at a time (rows in input order => stable).
-        // DS operations of one wave execute in issue order, so the row leader's counter update
-        // is seen by the next row's read; volatile keeps the compiler from caching the counters.
-        volatile uint32_t* const wh = s_wave_hist[wave];
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const uint32_t idx = row_base + (uint32_t)k * 64u;
-            const bool valid = idx < n;
-            const uint32_t d = (kv[k].x >> shift) & (RADIX_BASE - 1u);
-            unsigned long long m = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const unsigned long long bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
+            uint2 kv[KPT];
+            uint32_t rank[KPT];
+    #pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t idx = row_base + (uint32_t)k * 64u;
+                kv[k] = (FULL || idx < n) ? in[idx] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
             }
-            const uint32_t below = (uint32_t)__popcll(m & lanes_below);
-            const uint32_t prev = wh[d];
-            __builtin_amdgcn_wave_barrier();
-            if (valid && below == 0u) wh[d] = prev + (uint32_t)__popcll(m);
-            __builtin_amdgcn_wave_barrier();
-            rank[k] = prev + below;
-        }
-        __syncthreads();
-
-        // thread = digit: scan over the 4 waves
-        uint32_t total;
-        {
-            const uint32_t c0 = s_wave_hist[0][tid], c1 = s_wave_hist[1][tid];
-            const uint32_t c2 = s_wave_hist[2][tid], c3 = s_wave_hist[3][tid];
-            s_wave_hist[0][tid] = 0u;
-            s_wave_hist[1][tid] = c0;
-            s_wave_hist[2][tid] = c0 + c1;
-            s_wave_hist[3][tid] = c0 + c1 + c2;
-            total = c0 + c1 + c2 + c3;
-        }
-        // chained scan with decoupled look-back, one chain per digit
-        uint32_t* const my_status = status + (size_t)tile * RADIX_BASE + tid;
-        uint32_t excl = 0u;
-        if (tile > 0u) {
-            st_agent(my_status, STATUS_AGGREGATE | total);
-            // 4 predecessors per round trip up to ~1000 tiles (measured at 74 tiles, 4 passes: 46.6 us
-            // with 4, 48.3 with 2, 49.7 with 16, 52.6 with 32, 65.6 with 64: a prefix is usually met
-            // within the first few words, and every extra word polled is fabric traffic), 16 beyond
-            excl = num_tiles > 1024u ? lookback_u32<16>(status + tid, tile, RADIX_BASE, error_flag, 1u)
-                                     : lookback_u32<4>(status + tid, tile, RADIX_BASE, error_flag, 1u);
-        }
-        st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
-
-        uint32_t blk_total;
-        const uint32_t bexcl = block_exclusive_scan_256(total, s_tot, blk_total);
-        s_block_excl[tid] = bexcl;
-        s_global_base[tid] = s_hist_excl[tid] + excl - bexcl;
-        __syncthreads();
-
-        // scatter into LDS in digit order
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const uint32_t idx = row_base + (uint32_t)k * 64u;
-            if (idx < n) {
+            // wave-private ranking, one 64-pair row at a time (rows in input order => stable).
+            // DS operations of one wave execute in issue order, so the row leader's counter update
+            // is seen by the next row's read; volatile keeps the compiler from caching the counters.
+            // (round 6: the lanes with this lane's digit as two 32-bit words narrowed by v_xnor + v_and against each bit's
+            // ballot — six vector instructions per bit where the 64-bit select form compiled to nine — and the wave's
+            // counters through relaxed LDS atomics: `volatile` made every access a FLAT load with system scope)
+            uint32_t* const wh = s_wave_hist[wave];
+    #pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t idx = row_base + (uint32_t)k * 64u;
+                const bool valid = FULL || idx < n;
                 const uint32_t d = (kv[k].x >> shift) & (RADIX_BASE - 1u);
-                const uint32_t slot = s_block_excl[d] + s_wave_hist[wave][d] + rank[k];
-                s_pairs[slot] = kv[k];
+                const unsigned long long mv = FULL ? ~0ull : __ballot(valid);
+                uint32_t m_lo = (uint32_t)mv, m_hi = (uint32_t)(mv >> 32);
+    #pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int32_t seli = __builtin_amdgcn_sbfe((int32_t)d, (uint32_t)b, 1u);   // all ones where the bit is set (v_bfe_i32)
+                    const uint32_t sel = (uint32_t)seli;
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(seli < 0);
+                    m_lo &= ~((uint32_t)bal ^ sel);                            // same-bit lanes: bal where set, ~bal where clear
+                    m_hi &= ~((uint32_t)(bal >> 32) ^ sel);
+                }
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+                const uint32_t prev = __atomic_load_n(&wh[d], __ATOMIC_RELAXED);
+                __builtin_amdgcn_wave_barrier();
+                if (valid && below == 0u) __atomic_store_n(&wh[d], prev + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi), __ATOMIC_RELAXED);
+                __builtin_amdgcn_wave_barrier();
+                rank[k] = prev + below;
             }
-        }
-        __syncthreads();
-        const uint32_t count = min(TILE, n - tile_base);
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const uint32_t slot = (uint32_t)k * 256u + (uint32_t)tid;
-            if (slot < count) {
-                uint2 e = s_pairs[slot];
-                const uint32_t d = (e.x >> shift) & (RADIX_BASE - 1u);
-                e.x ^= key_xor;
-                const uint32_t dst = s_global_base[d] + slot;
-                if (dst < n) out[dst] = e;  // always true unless the watchdog tripped
+            __syncthreads();
+
+            // thread = digit: scan over the 4 waves
+            uint32_t total;
+            {
+                const uint32_t c0 = s_wave_hist[0][tid], c1 = s_wave_hist[1][tid];
+                const uint32_t c2 = s_wave_hist[2][tid], c3 = s_wave_hist[3][tid];
+                s_wave_hist[0][tid] = 0u;
+                s_wave_hist[1][tid] = c0;
+                s_wave_hist[2][tid] = c0 + c1;
+                s_wave_hist[3][tid] = c0 + c1 + c2;
+                total = c0 + c1 + c2 + c3;
             }
-        }
+            // chained scan with decoupled look-back, one chain per digit
+            uint32_t* const my_status = status + (size_t)tile * RADIX_BASE + tid;
+            uint32_t excl = 0u;
+            if (tile > 0u) {
+                st_agent(my_status, STATUS_AGGREGATE | total);
+                // 4 predecessors per round trip up to ~1000 tiles (measured at 74 tiles, 4 passes: 46.6 us
+                // with 4, 48.3 with 2, 49.7 with 16, 52.6 with 32, 65.6 with 64: a prefix is usually met
+                // within the first few words, and every extra word polled is fabric traffic), 16 beyond
+                excl = num_tiles > 1024u ? lookback_u32<16>(status + tid, tile, RADIX_BASE, error_flag, 1u)
+                                         : lookback_u32<4>(status + tid, tile, RADIX_BASE, error_flag, 1u);
+            }
+            st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
+
+            uint32_t blk_total;
+            const uint32_t bexcl = block_exclusive_scan_256(total, s_tot, blk_total);
+            s_global_base[tid] = s_hist_excl[tid] + excl - bexcl;
+            // (the digit's first slot folded into the waves' offsets here, four additions per digit, instead of a second LDS
+            // read and an addition per KEY in the scatter below)
+    #pragma unroll
+            for (int w = 0; w < 4; ++w) s_wave_hist[w][tid] += bexcl;
+            __syncthreads();
+
+            // scatter into LDS in digit order
+    #pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t idx = row_base + (uint32_t)k * 64u;
+                if (FULL || idx < n) {
+                    const uint32_t d = (kv[k].x >> shift) & (RADIX_BASE - 1u);
+                    const uint32_t slot = s_wave_hist[wave][d] + rank[k];
+                    s_pairs[slot] = kv[k];
+                }
+            }
+            __syncthreads();
+            const uint32_t count = FULL ? TILE : min(TILE, n - tile_base);
+    #pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t slot = (uint32_t)k * 256u + (uint32_t)tid;
+                if (FULL || slot < count) {
+                    uint2 e = s_pairs[slot];
+                    const uint32_t d = (e.x >> shift) & (RADIX_BASE - 1u);
+                    e.x ^= key_xor;
+                    const uint32_t dst = s_global_base[d] + slot;
+                    if (dst < n) out[dst] = e;  // always true unless the watchdog tripped
+                }
+            }
+        };
+        if ((tile + 1u) * TILE <= n) process(std::true_type{}); else process(std::false_type{});
         if (single_shot) break;
         __syncthreads();
     }
