@@ -1126,10 +1126,11 @@ __device__ __forceinline__ float srgb_oetf(float x) {
     L ":\n\t"                                                                      \
     "s_mov_b64 exec, %[sv]\n\t"
 // two strips (pixel rows) of a tile wave, one interior record; 4 samples per pixel: T_s = S r[s], only S moves
+template <typename PX>   // PxMs (4 samples) or PxMsN<2 / 8>: T_s = S r[s] either way, an interior record moves S only
 __device__ __forceinline__ void blend_interior_ms(const float ux, const float vx, const float m01, const float m11,
                                                   const float al, const float cr, const float cg, const float cbl,
                                                   const float t_eps, const float qy0, const float qy1,
-                                                  PxMs& t0, v2f& c0, float& b0, PxMs& t1, v2f& c1, float& b1) {
+                                                  PX& t0, v2f& c0, float& b0, PX& t1, v2f& c1, float& b1) {
     float tm, u, v;
     unsigned long long sv;
     float c0x = c0.x, c0y = c0.y, c1x = c1.x, c1y = c1.y;
@@ -1206,11 +1207,12 @@ __device__ __forceinline__ void blend_interior_1(const float ux, const float vx,
     "v_mul_f32 %[b], %[b], %[al]\n\t"                                              \
     "v_min_f32 %[b], 0x3f7fbe77, %[b]\n\t"                                         \
     "v_mul_f32 %[a], " TM ", %[b]\n\t"
+template <typename PX>
 __device__ __forceinline__ void blend_interior_surfel_ms(const float pxq, const float pyq, const float pzq, const float ddx,
                                                          const float pyx, const float pyy, const float pyz, const float ddyk,
                                                          const float dy0, const float al, const float cr, const float cg,
                                                          const float cbl, const float t_eps, const float qy,
-                                                         PxMs& t, v2f& c, float& bl) {
+                                                         PX& t, v2f& c, float& bl) {
     float tm, a, b, cc;
     unsigned long long sv;
     float cx = c.x, cy = c.y;
@@ -1531,7 +1533,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     constexpr uint32_t STAGE = 64u;
     constexpr bool ABLATE = BGS_ABLATION != 0;
     // the interior-record loop (blend_interior_ms): whole tiles of OBB quads without overlay or depth buffer, 1 or 4 samples
-    constexpr bool FAST = BGS_INTERIOR_PATH != 0 && !ABLATE && (VARIANT == RV_OBB || VARIANT == RV_SURFEL) && !BBOX && !DEPTH && ROWS == 4 && (MSAA == 4 || MSAA == 1);
+    constexpr bool FAST = BGS_INTERIOR_PATH != 0 && !ABLATE && (VARIANT == RV_OBB || VARIANT == RV_SURFEL) && !BBOX && !DEPTH && ROWS == 4;   // (every sample count)
     // half extent of the box the tile's sample positions span around the tile centre (the exact quad-vs-tile test)
     constexpr float HALF = 7.5f + ms_reach(MSAA);
 
@@ -1732,7 +1734,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         if constexpr (VARIANT == RV_OBB) {
                             const float4 a0 = s_rec[k * REC_V4 + 0], a1 = s_rec[k * REC_V4 + 1], a2 = s_rec[k * REC_V4 + 2];
                             const float ux = fmaf(a0.z, qx, a0.x), vx = fmaf(a1.x, qx, a0.y);
-                            if constexpr (MSAA == 4) {
+                            if constexpr (MSAA != 1) {
                                 blend_interior_ms(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[0], qy[1], T[0], crg[0], cb[0], T[1], crg[1], cb[1]);
                                 blend_interior_ms(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[2], qy[3], T[2], crg[2], cb[2], T[3], crg[3], cb[3]);
                             } else {
@@ -1748,7 +1750,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                             const float ddx = fmaf(a3.z, qx, a3.y);
 #pragma unroll
                             for (int r = 0; r < ROWS; ++r) {
-                                if constexpr (MSAA == 4) blend_interior_surfel_ms(pxq, pyq, pzq, ddx, a2.z, a2.w, a3.x, a4.x, a3.w, opa, a4.y, a4.z, a4.w, t_eps, qy[r], T[r], crg[r], cb[r]);
+                                if constexpr (MSAA != 1) blend_interior_surfel_ms(pxq, pyq, pzq, ddx, a2.z, a2.w, a3.x, a4.x, a3.w, opa, a4.y, a4.z, a4.w, t_eps, qy[r], T[r], crg[r], cb[r]);
                                 else blend_interior_surfel_1(pxq, pyq, pzq, ddx, a2.z, a2.w, a3.x, a4.x, a3.w, opa, a4.y, a4.z, a4.w, t_eps, qy[r], T[r], crg[r], cb[r]);
                             }
                         }
@@ -1766,7 +1768,8 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
 #pragma unroll
                         for (int r = 0; r < ROWS; ++r) {
                             if constexpr (MSAA == 4) blend_px_ms<VARIANT, false, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], 0.0f, false, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                            else blend_px<VARIANT, false, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
+                            else if constexpr (MSAA == 1) blend_px<VARIANT, false, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
+                            else blend_px_msn<VARIANT, false, MSAA, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], 0.0f, false, s_depth_f);
                         }
                         if constexpr (MIDROUND_EXIT)
                             if (++since == BGS_MIDROUND_PERIOD) { since = 0u; if (__all(all_saturated(T, t_eps))) { out = true; break; } }
