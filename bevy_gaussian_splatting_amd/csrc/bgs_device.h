@@ -128,7 +128,12 @@ struct SplitterTable {
     uint32_t key[BUCKET_COUNT * BUCKET_SUB_KERNARG];   // sub <= BUCKET_SUB_KERNARG: key[0 .. 256 * sub - 2] ascending quantile keys
     const uint32_t* device_keys;                       // sub > BUCKET_SUB_KERNARG: the same, in device memory
     uint32_t sub;                                      // 1 .. BUCKET_SUB_MAX: the table defines 256 * sub buckets
-    uint32_t pad;
+    // TWO-LEVEL placement (round 6; tables in device memory, sub > BUCKET_SUB_KERNARG): keygen places a pair into one of the
+    // 256 COARSE buckets (bucket / sub; slot regions of BUCKET_CAP * sub pairs) — a tile's pairs of a coarse bucket are a
+    // coalesced run of ~16 where the one-level scatter into 256 * sub buckets left ~1.5 pairs per (tile, bucket), every
+    // 8-byte pair its own partial line — and bucket_sort_kernel's workgroup f picks the pairs of fine bucket f out of its
+    // coarse bucket's region (it lies in the L2 by then) while it loads them.
+    uint32_t coarse;
 };
 // what the host keeps per view slot (a completed frame's quantile keys, any sub)
 struct SplitterKeys { uint32_t key[BUCKET_MAX]; uint32_t sub; };

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_bcnt = s_dyn;     // pairs of this tile per bucket; then, IN PLACE, the bucket's pairs of earlier tiles
     uint32_t* const s_bexcl = s_dyn;    // (thread f reads its count and leaves the returning atomic's value in the same word)
-    uint32_t* const s_split = s_dyn + (BUCKET ? BUCKET_COUNT * split.sub : 0u);
+    uint32_t* const s_split = s_dyn + (BUCKET ? BUCKET_COUNT * (split.coarse ? 1u : split.sub) : 0u);
     __shared__ uint16_t s_at[BUCKET ? THREADS * KG_ITEMS : 1];  // arrival slot of compacted pair j inside its bucket (this tile)
     __shared__ uint16_t s_bk[BUCKET ? THREADS * KG_ITEMS : 1];  // its bucket
     __shared__ uint32_t s_total;
@@ -129,13 +129,17 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     if (fp_out && blockIdx.x == 0 && (uint32_t)tid < (uint32_t)(sizeof(FrameParams) / 4u))
         reinterpret_cast<uint32_t*>(fp_out)[tid] = reinterpret_cast<const uint32_t*>(&fp)[tid];
     if (zero_word && blockIdx.x == 0 && tid == 0) *zero_word = 0u;
-    const uint32_t nsub = BUCKET ? split.sub : 1u, nb = BUCKET_COUNT * nsub;   // buckets of the frame
+    // two-level placement (SplitterTable::coarse): the 256 coarse buckets, whose splitters are every sub-th key of the table
+    const uint32_t fsub = BUCKET ? split.sub : 1u;                                  // fine buckets per coarse one
+    const bool two_level = BUCKET && split.coarse != 0u;
+    const uint32_t nsub = two_level ? 1u : fsub, nb = BUCKET_COUNT * nsub;          // buckets keygen places into
+    const uint32_t bucket_cap = two_level ? BUCKET_CAP * fsub : BUCKET_CAP;         // pairs per slot region
     uint32_t p2 = 256u;                 // the splitter table's padded length: the power of two >= nb
     while (p2 < nb) p2 <<= 1;
     if constexpr (BUCKET) {
-        const uint32_t* __restrict__ keys = nsub <= BUCKET_SUB_KERNARG ? split.key : split.device_keys;
+        const uint32_t* __restrict__ keys = fsub <= BUCKET_SUB_KERNARG ? split.key : split.device_keys;
         for (uint32_t t = (uint32_t)tid; t < p2; t += (uint32_t)THREADS)
-            s_split[t] = t < nb - 1u ? keys[t] : 0xFFFFFFFFu;
+            s_split[t] = t < nb - 1u ? keys[two_level ? (t + 1u) * fsub - 1u : t] : 0xFFFFFFFFu;
     } else if (tid < 256) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
@@ -276,8 +280,8 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                 if (j < total) {
                     const uint32_t bkt = s_bk[j];
                     const uint32_t slot = s_bexcl[bkt] + (uint32_t)s_at[j];
-                    if (slot < BUCKET_CAP)  // a bucket over capacity is seen by bucket_sort_kernel (count > cap)
-                        bucket_slots[(size_t)bkt * BUCKET_CAP + slot] = make_uint2(s_keys[j], s_idx[j]);
+                    if (slot < bucket_cap)  // a bucket over capacity is seen by bucket_sort_kernel (count > cap)
+                        bucket_slots[(size_t)bkt * bucket_cap + slot] = make_uint2(s_keys[j], s_idx[j]);
                 }
             }
         }
@@ -401,8 +405,8 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                 if (j < total) {
                     const uint32_t bkt = s_bk[j];
                     const uint32_t slot = s_bexcl[bkt] + (uint32_t)s_at[j];
-                    if (slot < BUCKET_CAP)  // a bucket over capacity is seen by bucket_sort_kernel (count > cap)
-                        bucket_slots[(size_t)bkt * BUCKET_CAP + slot] = make_uint2(s_keys[j], s_idx[j]);
+                    if (slot < bucket_cap)  // a bucket over capacity is seen by bucket_sort_kernel (count > cap)
+                        bucket_slots[(size_t)bkt * bucket_cap + slot] = make_uint2(s_keys[j], s_idx[j]);
                 }
             }
         }
@@ -475,7 +479,7 @@ bool KeygenLaunch::prepare(int max_blocks) {
     argv[10] = &bucket_status; argv[11] = &split; argv[12] = &zero_word;
     if (split.sub < 1u || split.sub > BUCKET_SUB_MAX) split.sub = 1u;
     {   // the per-bucket counters + the padded splitter table
-        uint32_t nbk = BUCKET_COUNT * split.sub, pad2 = 256u;
+        uint32_t nbk = BUCKET_COUNT * (split.coarse ? 1u : split.sub), pad2 = 256u;   // (two-level placement: the 256 coarse buckets)
         while (pad2 < nbk) pad2 <<= 1;
         lds_bytes = bucket ? (nbk + pad2) * (uint32_t)sizeof(uint32_t) : 0u;
     }
@@ -727,10 +731,11 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
 #define BGS_BUCKET_SORT_THREADS 256
 #endif
 constexpr uint32_t BUCKET_SORT_THREADS = BGS_BUCKET_SORT_THREADS;
-template <uint32_t THREADS>  // 256 or 1024
+template <uint32_t THREADS, bool TWO = false>  // 256 or 1024; TWO: two-level placement (SplitterTable::coarse)
 __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __restrict__ slots,
                                                               uint2* __restrict__ out, Control* ctl,
-                                                              uint32_t key_xor, uint32_t nb /* buckets of the frame: 256 * sub */) {
+                                                              uint32_t key_xor, uint32_t nb /* buckets of the frame: 256 * sub */,
+                                                              [[maybe_unused]] uint32_t sub, [[maybe_unused]] const uint32_t* __restrict__ fine_keys) {
     constexpr uint32_t WAVES = THREADS / 64u;
     constexpr uint32_t EPT = BUCKET_CAP / THREADS;              // pairs per thread (strided)
     constexpr uint32_t NF = BUCKET_FINE, FPT = NF / THREADS;    // fine ranges per thread (contiguous)
@@ -741,13 +746,30 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     __shared__ uint32_t s_red[WAVES][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t b = blockIdx.x;
+    // TWO: this workgroup sorts fine bucket b = the keys in [lo, hi) of coarse bucket cb (hi open; the last bucket takes ~0 too).
+    // The `sub` workgroups of a coarse bucket all read its whole region: they are given to ONE XCD (workgroup w runs on XCD
+    // w % 8, an assumption about speed only), back to back in its dispatch order, so that the region comes out of HBM once
+    // and out of that XCD's L2 sub - 1 times (110 -> ? us at 5 M pairs with the buckets dealt round-robin over the XCDs).
+    uint32_t b = blockIdx.x;
+    if constexpr (TWO) {
+        const uint32_t x = b & 7u, i = b >> 3;           // BUCKET_COUNT % 8 == 0: 32 coarse buckets per XCD
+        b = (x + 8u * (i / sub)) * sub + i % sub;
+    }
+    const uint32_t cb = TWO ? b / sub : b, ncount = TWO ? BUCKET_COUNT : nb;
+    const uint32_t cap = TWO ? BUCKET_CAP * sub : BUCKET_CAP;
+    [[maybe_unused]] uint32_t lo = 0u, hi = 0xFFFFFFFFu;
+    if constexpr (TWO) {
+        if (b > 0u) lo = fine_keys[b - 1u];
+        if (b < nb - 1u) hi = fine_keys[b];
+    }
+    __shared__ uint32_t s_fill;
+    if constexpr (TWO) { if (tid == 0) s_fill = 0u; }
     // offset of this bucket in the sorted list, its own count, the fullest bucket (every thread takes a stride of the counts)
     uint32_t before = 0u, mine = 0u, mx = 0u;
-    for (uint32_t i = (uint32_t)tid; i < nb; i += THREADS) {
+    for (uint32_t i = (uint32_t)tid; i < ncount; i += THREADS) {
         const uint32_t cnt = ctl->bucket_count[i];
-        before += i < b ? cnt : 0u;
-        mine += i == b ? cnt : 0u;
+        before += i < cb ? cnt : 0u;
+        mine += i == cb ? cnt : 0u;
         mx = max(mx, cnt);
     }
 #pragma unroll
@@ -765,22 +787,64 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
 #pragma unroll
     for (uint32_t w = 0; w < WAVES; ++w) { base += s_red[w][0]; m += s_red[w][1]; mx = max(mx, s_tot[w]); }
     if (b == 0u && tid == 0) {
-        ctl->bucket_max = mx;
-        if (mx > BUCKET_CAP) {
+        if constexpr (!TWO) ctl->bucket_max = mx;
+        if (mx > cap) {
             // some bucket lost pairs: the list is void. draw_count = 0 keeps the kernels behind this one
             // (project, raster) away from the unwritten entries; the host re-runs the frame.
             ctl->sort_overflow = 1u;
             ctl->draw_count = 0u;
         }
     }
-    // the length of the list: the last bucket's offset + its pairs (a keygen without chains leaves only the per-bucket
-    // counts; one with chains has written the same number already)
-    if (b == nb - 1u && tid == 0 && mx <= BUCKET_CAP) ctl->draw_count = base + m;
-    if (m == 0u || mx > BUCKET_CAP) return;
+    if constexpr (!TWO) {
+        // the length of the list: the last bucket's offset + its pairs (a keygen without chains leaves only the per-bucket
+        // counts; one with chains has written the same number already)
+        if (b == nb - 1u && tid == 0 && mx <= BUCKET_CAP) ctl->draw_count = base + m;
+        if (m == 0u) return;
+    }
+    if (mx > cap) return;
     __syncthreads();  // s_red / s_tot are reused below
 
     // ---- 2. load ----
-    const uint2* __restrict__ src = slots + (size_t)b * BUCKET_CAP;
+    const uint2* __restrict__ src = slots + (size_t)cb * cap;
+    if constexpr (TWO) {
+        // the coarse bucket's m pairs (out of the L2: sub workgroups read the same region): those below this fine bucket's
+        // range only count towards its place in the list, those inside it are collected in s_el (any order)
+        uint32_t below = 0u;
+        for (uint32_t e0 = (uint32_t)tid; e0 < m; e0 += 8u * THREADS) {
+            uint2 in[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) { const uint32_t e = e0 + k * THREADS; in[k] = e < m ? src[e] : make_uint2(0xFFFFFFFFu, 0u); }
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const uint32_t e = e0 + k * THREADS;
+                if (e < m) {
+                    const uint32_t key = in[k].x;
+                    if (key < lo) below += 1u;
+                    else if (key < hi || b == nb - 1u) {
+                        const uint32_t at = atomicAdd(&s_fill, 1u);
+                        if (at < BUCKET_CAP) s_el[at] = in[k];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) below += (uint32_t)__shfl_xor((int)below, off, 64);
+        if (lane == 0) s_red[wave][0] = below;
+        __syncthreads();
+        m = s_fill;
+        below = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < WAVES; ++w) below += s_red[w][0];
+        base += below;
+        if (tid == 0) {
+            atomicMax(&ctl->bucket_max, m);
+            if (m > BUCKET_CAP) { ctl->sort_overflow = 1u; ctl->draw_count = 0u; }   // (sticky: see above)
+            else if (b == nb - 1u) ctl->draw_count = base + m;
+        }
+        if (m == 0u || m > BUCKET_CAP) return;
+        __syncthreads();  // s_red is reused below
+        src = s_el;       // (generic pointer into LDS: the loads below read the collected pairs)
+    }
     uint2 kv[EPT];
     uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
 #pragma unroll
@@ -788,7 +852,7 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
         const uint32_t e = k * THREADS + (uint32_t)tid;
         kv[k] = make_uint2(0u, 0u);
         if (e < m) {
-            kv[k] = src[e];
+            kv[k] = TWO ? s_el[e] : src[e];
             kmn = min(kmn, kv[k].x);
             kmx = max(kmx, kv[k].x);
         }
@@ -869,9 +933,16 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     }
 }
 
-void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor, uint32_t buckets) {
-    hipLaunchKernelGGL(bucket_sort_kernel<BUCKET_SORT_THREADS>, dim3(buckets), dim3(BUCKET_SORT_THREADS), 0, stream,
-                       bucket_slots, out, ctl, key_xor, buckets);
+void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor, uint32_t buckets,
+                        const uint32_t* two_level_keys) {
+    if (two_level_keys)   // two-level placement: the pairs lie in 256 coarse regions, the table's keys say which are workgroup f's
+        // (1024 threads: a workgroup walks its whole coarse region — sub times the pairs it sorts —, a chain of dependent
+        // loads per thread that is four times shorter than with 256)
+        hipLaunchKernelGGL((bucket_sort_kernel<1024u, true>), dim3(buckets), dim3(1024), 0, stream,
+                           bucket_slots, out, ctl, key_xor, buckets, buckets / BUCKET_COUNT, two_level_keys);
+    else
+        hipLaunchKernelGGL((bucket_sort_kernel<BUCKET_SORT_THREADS, false>), dim3(buckets), dim3(BUCKET_SORT_THREADS), 0, stream,
+                           bucket_slots, out, ctl, key_xor, buckets, 1u, (const uint32_t*)nullptr);
 }
 
 // The 255 keys at the 1/256-quantiles of a sorted draw list, in keygen's key space (key ^ key_xor): the

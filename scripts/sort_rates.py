@@ -10,6 +10,8 @@ from bevy_gaussian_splatting_amd import (CloudSettings, GaussianSplattingPlugin,
                                          random_gaussians_3d_seeded, transform_from)
 
 only = (int(sys.argv[1]), sys.argv[2], int(sys.argv[3], 0)) if len(sys.argv) > 3 else None
+if not only:
+    pass
 reps = 100 if only else 20
 p = GaussianSplattingPlugin(0)
 for n, seed in ((1_000_000, 2), (2_000_000, 5), (5_000_000, 3)):
@@ -20,7 +22,7 @@ for n, seed in ((1_000_000, 2), (2_000_000, 5), (5_000_000, 3)):
     far = View.perspective(transform_from((0.0, 0.0, 120.0), (0.0, 0.0, 0.0, 1.0)), 1920, 1080)
     for name, v, s in (("rayon", View.headless(1920, 1080), CloudSettings(sort_mode=SortMode.Rayon)), ("radix_far", far, CloudSettings()),
                        ("radix_headline", View.headless(1920, 1080), CloudSettings())):
-        for flags in (0x80000, 0):   # 0x80000: never the bucket path
+        for flags in (0x80000, 0, 0x100):   # 0x80000: never the bucket path; 0x100: the bucket path without two-level placement
             if only and (name, flags) != only[1:]:
                 continue
             p.set_debug_flags(flags); p.reset_adaptive_state(); p.set_profiling_stride(1)
