@@ -1857,7 +1857,11 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
 // Waves per SIMD: 8 for the single-sampled ellipse variants (<= 64 VGPRs), 6 for the surfel variant; the multisampled
 // instantiations carry six transmittance words per pixel instead of one (5 / 4 waves).
 #ifndef BGS_MS_WAVES
-#define BGS_MS_WAVES 5   // multisampled ellipse variants: 92-96 VGPRs; 6 (<= 80) spills (profiles/r5_experiments/occupancy_ms.txt)
+// multisampled ellipse variants: 6 since round 6. Round 5's kernel (92-96 VGPRs) spilled 10-25 registers INTO the record loop at
+// 80 and lost 10 %; with the tile id in scalar registers and the interior records in their own loop it is 83-86 and the 3-5
+// registers that spill at 80 are tile set-up values outside the loops: dense 1 M even, scene-like +1.9 %, trained-like +4.5 %
+// frames/s (profiles/r6_experiments/ms_waves_6_ab.txt)
+#define BGS_MS_WAVES 6
 #endif
 constexpr int raster_waves_per_simd(const int variant, const int msaa, const bool depth) {
     return msaa == 8 ? (variant == 2 ? (depth ? 2 : 3) : (depth ? 3 : 4))   // ten transmittance words per pixel; 8 KB of depth samples per wave
