@@ -1553,7 +1553,9 @@ def test_cost_ordered_raster_workgroups_give_the_same_bits(plugin, cloud_1m, wha
     kw = {"dense": {}, "scene_like": {"global_scale": 0.05},
           "surfel": {"gaussian_mode": GaussianMode.Gaussian2d, "aabb": True, "global_scale": 0.3},
           "aabb3d_depth": {"aabb": True}}[what]
-    W, Hh = (1336, 1000) if what == "scene_like" else (1920, 1080)   # 84 x 63 tiles: 1323 workgroups = 8 * 165 + 3
+    # (114 x 63 tiles: 1796 workgroups = 8 * 224 + 4 — no multiple of 8 — and more tile waves than the chip holds at six per
+    # SIMD, so that the frame is ordered at all; 1336 x 1000 until the multisampled kernels went from five to six in round 6)
+    W, Hh = (1816, 1000) if what == "scene_like" else (1920, 1080)
     s = CloudSettings(**kw)
     v = View.headless(W, Hh)
     views = [View.headless(W, Hh, yaw=0.03 * (k + 1)) for k in range(3)]
@@ -2026,7 +2028,7 @@ def test_zz_report_ambiguity_slack_use(oracle):
     v, n = t["values"], t["checked"]
     print(f"[tolerance accounting] edge band {oracle.lib().oracle_edge_band_px():g} px: {v} of {n} compared values "
           f"({100.0 * v / max(n, 1):.5f} %) beyond 1e-3 + 1e-4 |ref|, largest excess {t['max_excess']:.3e} on the fixed "
-          f"configurations, {t['max_excess_randomized']:.3e} on the randomized ones "
+          f"configurations, {t['max_excess_randomized']:.3e} on the randomized ones ({t['max_excess_randomized_surfel']:.3e} on their 2DGS surfel frames) "
           f"(frames with the bounding-box overlay, where a flip is a whole opaque fragment: {t['max_excess_overlay']:.3e})")
     for rec in sorted(t["comparisons"], key=lambda r: -r["max_excess"])[:12]:
         print(f"    {rec['what'][:60]}: {rec['beyond_strict']} of {rec['values']}, excess {rec['max_excess']:.2e}, max |err| {rec['max_err']:.2e}, "
@@ -2036,6 +2038,7 @@ def test_zz_report_ambiguity_slack_use(oracle):
     assert v <= 2e-5 * max(n, 1) + 50
     assert t["max_excess"] <= 0.025
     assert t["max_excess_randomized"] <= 0.24
+    assert t["max_excess_randomized_surfel"] <= 0.57   # (0.453 seen in 1 100 forced-surfel configurations: a whole ambiguous fragment)
     assert t["max_excess_overlay"] <= 0.48
 
 
