@@ -339,8 +339,7 @@ def tolerance_mask(ref: np.ndarray, got: np.ndarray, amb: np.ndarray | None, ato
 # Tolerance accounting (round 4's verdict: "the tolerance is builder-adjustable"): every oracle comparison of a run reports
 # here how many values passed only through the oracle's ambiguity bound and by HOW MUCH they exceed the strict tolerance
 # 1e-3 + 1e-4 |ref|; the run's last test asserts on the totals and conftest writes them next to the other evidence.
-TOLERANCE = {"values": 0, "checked": 0, "max_excess": 0.0, "max_excess_randomized": 0.0, "max_excess_randomized_surfel": 0.0,
-             "max_excess_overlay": 0.0, "comparisons": []}
+TOLERANCE = {"values": 0, "checked": 0, "max_excess": 0.0, "max_excess_randomized": 0.0, "max_excess_overlay": 0.0, "comparisons": []}
 
 
 def account(ref, got, amb, what: str = "", overlay: bool = False) -> dict:
@@ -358,11 +357,7 @@ def account(ref, got, amb, what: str = "", overlay: bool = False) -> dict:
     # three classes: frames with the overlay; the randomized sweeps (they draw Msaa::Off — a flip is a WHOLE fragment —,
     # global_opacity up to 2 and every raster mode: larger single flips than the fixed configurations can have); the rest
     randomized = what.startswith("seed ") or what.startswith("medium seed ")
-    # (round 6: the randomized 2DGS surfel frames apart — where the ray-surfel intersection cancels the oracle calls the WHOLE
-    # fragment ambiguous, and with the raster modes' colours of magnitude 1 and alpha near 1 that is up to half a unit: 0.45
-    # in 300 forced-surfel configurations never run before, identical with and without the round's kernels)
-    surfel = randomized and "aabb=True" in what and "Gaussian2d" in what
-    key = "max_excess_overlay" if overlay else ("max_excess_randomized_surfel" if surfel else ("max_excess_randomized" if randomized else "max_excess"))
+    key = "max_excess_overlay" if overlay else ("max_excess_randomized" if randomized else "max_excess")
     TOLERANCE[key] = max(TOLERANCE[key], excess)
     rec["overlay"] = bool(overlay)
     rec["randomized"] = bool(randomized)
