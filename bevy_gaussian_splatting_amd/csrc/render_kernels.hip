@@ -1533,7 +1533,9 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     constexpr uint32_t STAGE = 64u;
     constexpr bool ABLATE = BGS_ABLATION != 0;
     // the interior-record loop (blend_interior_ms): whole tiles of OBB quads without overlay or depth buffer, 1 or 4 samples
-    constexpr bool FAST = BGS_INTERIOR_PATH != 0 && !ABLATE && (VARIANT == RV_OBB || VARIANT == RV_SURFEL) && !BBOX && !DEPTH && ROWS == 4;   // (every sample count)
+    // (every sample count; under a depth buffer too: a record the tile's depths leave whole — in front of everything the tile
+    // holds — is interior like any other, one they split goes through the per-sample path with the others)
+    constexpr bool FAST = BGS_INTERIOR_PATH != 0 && !ABLATE && (VARIANT == RV_OBB || VARIANT == RV_SURFEL) && !BBOX && ROWS == 4;
     // half extent of the box the tile's sample positions span around the tile centre (the exact quad-vs-tile test)
     constexpr float HALF = 7.5f + ms_reach(MSAA);
 
@@ -1679,8 +1681,9 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         // reach 7.5 px from the tile centre; ONE margin for both axes, as in blend_px_ms; false for a NaN
                         const float su = 7.5f * (fabsf(r0.z) + fabsf(r0.w)), sv = 7.5f * (fabsf(r1.x) + fabsf(r1.y));
                         const float ucc = fmaf(r0.w, 7.5f, fmaf(r0.z, 7.5f, r0.x)), vcc = fmaf(r1.y, 7.5f, fmaf(r1.x, 7.5f, r0.y));
-                        keep_lane = keep;
-                        interior_lane = keep && (fabsf(ucc) + su + r1.z <= 0.9999f * OBB_C) && (fabsf(vcc) + sv + r1.z <= 0.9999f * OBB_C);
+                        keep_lane = keep && (!DEPTH || r2.w >= tile_dmin);
+                        interior_lane = keep && (!DEPTH || r2.w >= tile_dmax) &&
+                                        (fabsf(ucc) + su + r1.z <= 0.9999f * OBB_C) && (fabsf(vcc) + sv + r1.z <= 0.9999f * OBB_C);
                     }
                     r2.w = keepz_of(keep && (!DEPTH || r2.w >= tile_dmin), r2.w);
                     s_rec[lane * REC_V4 + 0] = r0;
@@ -1704,8 +1707,8 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         const float um = fmaxf(fabsf(st[0].x), fabsf(fmaf(st[0].y, 15.0f, st[0].x)));
                         const float vm = fmaxf(fabsf(st[0].z), fabsf(fmaf(st[0].w, 15.0f, st[0].z)));
                         const float mg = MSAA == 1 ? 0.0f : ms_reach(MSAA) * fmaxf(fabsf(st[0].y), fabsf(st[0].w));
-                        keep_lane = keep;
-                        interior_lane = keep && (fmaxf(um, vm) + mg <= 0.9999f);
+                        keep_lane = keep && (!DEPTH || z >= tile_dmin);
+                        interior_lane = keep && (!DEPTH || z >= tile_dmax) && (fmaxf(um, vm) + mg <= 0.9999f);
                     }
 #pragma unroll
                     for (int v = 0; v < 6; ++v) s_rec[lane * REC_V4 + v] = st[v];
@@ -1765,11 +1768,22 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         sr.load(s_rec + k * REC_V4);
                         if constexpr (TRACE) trace_blended += 1u;
                         work += WORK_BLENDED;
+                        // the record's depth (a kept record's: > 0), wave-uniform; zmixed: the tile's depths split it
+                        [[maybe_unused]] float zr = 0.0f;
+                        if constexpr (DEPTH) zr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(VARIANT == RV_SURFEL ? sr.a5.y : sr.a2.w)));
+                        const bool zmixed = DEPTH && zr < tile_dmax;
 #pragma unroll
                         for (int r = 0; r < ROWS; ++r) {
-                            if constexpr (MSAA == 4) blend_px_ms<VARIANT, false, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], 0.0f, false, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                            else if constexpr (MSAA == 1) blend_px<VARIANT, false, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r]);
-                            else blend_px_msn<VARIANT, false, MSAA, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], 0.0f, false, s_depth_f);
+                            if constexpr (MSAA == 4) {
+                                float4 d4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                if constexpr (DEPTH) if (zmixed) d4 = s_depth[r * 64 + lane];
+                                blend_px_ms<VARIANT, DEPTH, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, zmixed, d4);
+                            } else if constexpr (MSAA == 1) {
+                                blend_px<VARIANT, DEPTH, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, dpx[r]);
+                            } else {
+                                blend_px_msn<VARIANT, DEPTH, MSAA, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, zmixed,
+                                                                          s_depth_f + (r * 64 + lane) * MSAA);
+                            }
                         }
                         if constexpr (MIDROUND_EXIT)
                             if (++since == BGS_MIDROUND_PERIOD) { since = 0u; if (__all(all_saturated(T, t_eps))) { out = true; break; } }
