@@ -119,7 +119,7 @@ class BgsStats(ctypes.Structure):
         ("list_capacity", ctypes.c_uint32),
         ("list_entries_allocated", ctypes.c_uint64),
         ("strip_tiles", ctypes.c_uint32),
-        ("reserved_stats", ctypes.c_uint32),
+        ("tile_saturation", ctypes.c_uint32),
     ]
 
 
@@ -287,7 +287,7 @@ def load() -> ctypes.CDLL:
     lib.bgs_graph_counters.restype = ctypes.c_int
     lib.bgs_tile_order_counters.argtypes = [vp] + [ctypes.POINTER(ctypes.c_uint64)] * 3
     lib.bgs_tile_order_counters.restype = ctypes.c_int
-    lib.bgs_selftest_tile_order.argtypes = [vp, vp, u32, u32, vp]
+    lib.bgs_selftest_tile_order.argtypes = [vp, vp, u32, u32, vp, vp]
     lib.bgs_selftest_tile_order.restype = ctypes.c_int
     lib.bgs_cloud_upload_cov3d_f32.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                                ctypes.POINTER(ctypes.c_float), ctypes.POINTER(vp)]

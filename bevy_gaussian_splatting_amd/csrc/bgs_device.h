@@ -150,7 +150,10 @@ struct Control {
     uint32_t sort_overflow;   // bucket sort gave up (1 bucket over capacity, 2 too many equal keys): re-run with onesweep
     uint32_t bucket_max;      // fullest bucket (stats)
     uint32_t strip_tiles;     // tiles this frame's rasteriser drew with four strip waves (the consumed heavy-tile list; stats)
-    uint32_t pad0[21];        // the read-mostly header owns its 128-byte line (see ticket)
+    // (host copy only) from the cost plane the lane's tile order was last made of (tile_order_kernel, TileCost bit 15): the share
+    // of the frame's tile work that was in tiles which ended saturated, x 0x7FFF; 0xFFFFFFFF = no order
+    uint32_t saturated_tiles_prev;
+    uint32_t pad0[20];        // the read-mostly header owns its 128-byte line (see ticket)
     // dynamic tile ids, one word per kernel launch of the frame, each in its OWN 128-byte line: every
     // block of a launch does a returning atomic on its ticket and the L2 retires same-line atomics one
     // at a time (~8 ns), so a load of draw_count queued behind them on a shared line waited for all.
@@ -167,7 +170,7 @@ struct Control {
                                          // FrameCleanup::split_sub): the host hands them to later frames' keygen (SplitterTable)
     uint32_t bucket_count[BUCKET_MAX];   // bucket sort: pairs in each bucket (keygen's returning atomics); the frame's 256 * sub first
 };
-constexpr uint32_t CONTROL_HEADER_WORDS = 11;  // draw_count .. strip_tiles: what a frame reports to the host
+constexpr uint32_t CONTROL_HEADER_WORDS = 12;  // draw_count .. saturated_tiles_prev: what a frame reports to the host
 
 
 // packed tile rectangle x0 | x1 << 8 | y0 << 16 | y1 << 24 (inclusive); x0 > x1 = touches no tile

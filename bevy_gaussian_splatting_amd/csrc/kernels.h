@@ -58,6 +58,10 @@ struct FrameCleanup {
     const uint2* sorted;
     uint32_t key_xor;
     uint32_t split_sub;       // the table this frame leaves has 256 * split_sub - 1 quantile keys (1 .. BUCKET_SUB_MAX)
+    // what tile_order_kernel counted in the completed frame's cost plane the lane's order was made of (tile_order_stats_offset;
+    // null: no order): the clean-up block hands the sums to the host — what decides whether frames of this kind run the
+    // mid-round-exit rasteriser
+    const uint32_t* order_stats;
 };
 
 // Onesweep geometry: 256 threads x KPT keys per tile.
@@ -183,7 +187,10 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
 // frame only (the kernel is a chain of ~40 barriers, ~7 us).
 constexpr uint32_t TILE_ORDER_REFRESH = 8u;
 inline size_t tile_cost_bytes(uint32_t tiles) { return ((size_t)tiles + 4u) * 2u; }
-inline size_t tile_order_bytes(uint32_t tiles) { return (((size_t)tiles + 3u) / 4u + 8u) * 2u; }
+// the order (u16 per workgroup) and, behind it, what tile_order_kernel summed over the cost plane it read: per XCD share x
+// the pair (work of all tiles, work of the tiles that ended saturated) at stats[2 x], stats[2 x + 1] (TileCost units)
+__host__ __device__ inline size_t tile_order_stats_offset(uint32_t tiles) { return (((((size_t)tiles + 3u) / 4u + 8u) * 2u + 63u) / 64u) * 64u; }
+inline size_t tile_order_bytes(uint32_t tiles) { return tile_order_stats_offset(tiles) + 16u * sizeof(uint32_t); }
 void launch_tile_order(hipStream_t stream, const uint16_t* cost, uint16_t* order, uint32_t ntiles, const FrameParams& fp,
                        bool midround_exit);
 // the same with the runs per XCD given (1, 2 or 4; bgs_selftest_tile_order)

@@ -1613,6 +1613,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     // group of 64 candidates — 17 gathers per tile on the scene-like workload before, 3 now. A dense
     // list fills the queue with its first group, so nothing changes there.
     constexpr uint32_t FLUSH_AT = 32u;
+    bool tile_saturated = false;   // the tile stopped because every pixel was saturated (not because its lists ended)
     uint32_t qn = 0u;  // ranks waiting in s_queue (wave-uniform)
     uint32_t rounds = 0u;  // staging rounds blended so far (a dense frame's heavy tiles: more than one)
     uint32_t base = 0u;
@@ -1820,7 +1821,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             saturated = __all(all_saturated(T, t_eps));
             ++rounds;
             }
-            if (saturated) break;
+            if (saturated) { tile_saturated = true; break; }
             __builtin_amdgcn_wave_barrier();  // blend reads of s_rec / s_queue done before they are rewritten
         }
         if constexpr (ABLATE) if (fp.debug & 32u) qn = 0u;
@@ -1865,7 +1866,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             }
         }
     }
-    return rounds;
+    return rounds | (tile_saturated ? 0x80000000u : 0u);   // (bit 31: the tile ended saturated)
 }
 
 // Waves per SIMD: 8 for the single-sampled ellipse variants (<= 64 VGPRs), 6 for the surfel variant; the multisampled
@@ -1954,12 +1955,19 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
             constexpr uint32_t HEADER_WORDS = CONTROL_HEADER_WORDS;  // draw_count .. strip_tiles
             constexpr uint32_t COARSE_OFF = (uint32_t)(offsetof(Control, coarse_total) / 4u);
             constexpr uint32_t SPLIT_OFF = (uint32_t)(offsetof(Control, splitters) / 4u);
-            static_assert(offsetof(Control, strip_tiles) / 4u == HEADER_WORDS - 1u, "strip_tiles is the header's last word");
-            if ((uint32_t)tid < HEADER_WORDS - 1u) host[tid] = src[tid];
-            if ((uint32_t)tid == HEADER_WORDS - 1u) {   // how many tiles this launch draws with strip workgroups (known at its start)
+            static_assert(offsetof(Control, strip_tiles) / 4u == HEADER_WORDS - 2u && offsetof(Control, saturated_tiles_prev) / 4u == HEADER_WORDS - 1u,
+                          "strip_tiles and saturated_tiles_prev are the header's last words");
+            if ((uint32_t)tid < HEADER_WORDS - 2u) host[tid] = src[tid];
+            if ((uint32_t)tid == HEADER_WORDS - 2u) {   // how many tiles this launch draws with strip workgroups (known at its start)
                 uint32_t strips = 0u;
                 if constexpr (MIDROUND_EXIT) strips = heavy_in ? min(*reinterpret_cast<const uint32_t*>(heavy_in), HEAVY_CAP) : 0u;
                 host[tid] = strips;
+            }
+            if ((uint32_t)tid == HEADER_WORDS - 1u) {   // what the order's cost plane said about saturation (tile_order_kernel's eight pairs)
+                uint32_t work = 0u, sat = 0u;
+                if (cl.order_stats)
+                    for (uint32_t x = 0u; x < 8u; ++x) { work += cl.order_stats[2u * x]; sat += cl.order_stats[2u * x + 1u]; }
+                host[tid] = (cl.order_stats && work) ? (uint32_t)(((uint64_t)sat * 0x7FFFu) / work) : 0xFFFFFFFFu;
             }
             host[COARSE_OFF + (uint32_t)tid] = src[COARSE_OFF + (uint32_t)tid];
             // the 1 / (256 sub)-quantile keys of this frame's sorted list: later frames' bucket splitters
@@ -2001,7 +2009,10 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
         // its regular wave, or the first strip's wave for all four (it scanned and staged what the tile's wave would
         // have; a regular wave that stepped aside writes nothing, so the tile keeps a cost worth its place in the order
         // should the next frame draw it whole again)
-        if (cost_out && reports && lane == 0) cost_out[tile] = (uint16_t)min(0xFFFFu, work);
+        // (bit 15: the tile ended saturated, not at the end of its lists — what the host's choice of the mid-round-exit
+        // instantiation for frames of this kind follows; the work count keeps 15 bits)
+        if (cost_out && reports && lane == 0) cost_out[tile] = (uint16_t)(min(0x7FFFu, work) | ((rounds >> 31) << 15));
+        rounds &= 0x7FFFFFFFu;
         if constexpr (MIDROUND_EXIT) {
             // feedback for the frames behind this one: a tile that did not saturate inside its first staging round is
             // heavy (parameter-free: the median tile of a dense frame saturates after ~35 of the round's <= 64 records)
@@ -2049,17 +2060,32 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint16_t* __restr
     const uint32_t len = nblocks > x ? (nblocks - x + 7u) / 8u : 0u;
     uint32_t n2 = 2u;
     while (n2 < len) n2 <<= 1;
+    // what this XCD share's tiles say about saturation (kernels.h tile_order_stats_offset): how much of the frame's work was in
+    // tiles that ended saturated — the host's choice of the mid-round-exit rasteriser for frames of this kind
+    __shared__ uint32_t s_stats[2];
+    if (tid < 2u) s_stats[tid] = 0u;
+    uint32_t my_worked = 0u, my_sat = 0u;
+    __syncthreads();
     for (uint32_t i = tid; i < n2; i += 256u) {
         uint32_t key = 0xFFFFFFFFu;
         if (i < len) {
             const uint32_t t0 = raster_block_item<RUNS>(8u * i + x, nblocks) * 4u;
             uint32_t c = 0u;
-            for (uint32_t k = 0u; k < 4u; ++k) if (t0 + k < ntiles) c = max(c, (uint32_t)cost[t0 + k]);
+            for (uint32_t k = 0u; k < 4u; ++k)
+                if (t0 + k < ntiles) {
+                    const uint32_t w = (uint32_t)cost[t0 + k];
+                    c = max(c, w & 0x7FFFu);                       // (bit 15: ended saturated)
+                    my_worked += w & 0x7FFFu;
+                    my_sat += (w >> 15) ? (w & 0x7FFFu) : 0u;
+                }
             key = ((0xFFFFu - c) << 16) | i;
         }
         s_key[i] = key;
     }
+    if (my_worked) atomicAdd(&s_stats[0], my_worked);
+    if (my_sat) atomicAdd(&s_stats[1], my_sat);
     __syncthreads();
+    if (tid < 2u) reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(order) + tile_order_stats_offset(ntiles))[2u * x + tid] = s_stats[tid];
     for (uint32_t k = 2u; k <= n2; k <<= 1)
         for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
             for (uint32_t p = tid; p < n2 / 2u; p += 256u) {

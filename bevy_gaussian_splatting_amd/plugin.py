@@ -287,14 +287,15 @@ class GaussianSplattingPlugin:
         self._check(self._lib.bgs_tile_order_counters(self._ctx, ctypes.byref(c), ctypes.byref(r), ctypes.byref(n)))
         return int(c.value), int(r.value), int(n.value)
 
-    def selftest_tile_order(self, cost: np.ndarray, runs: int = 1) -> np.ndarray:
+    def selftest_tile_order(self, cost: np.ndarray, runs: int = 1, sums: bool = False):
         """`bgs_selftest_tile_order`: the raster workgroups' order tile_order_kernel makes of per-tile costs (uint16,
-        one per tile): uint16[(tiles + 3) // 4]."""
+        one per tile): uint16[(tiles + 3) // 4] — with `sums` also (work of all tiles, work of the tiles with bit 15 set)."""
         c = np.ascontiguousarray(cost, dtype=np.uint16)
         out = np.empty((c.size + 3) // 4, np.uint16)
+        two = np.zeros(2, np.uint32)
         self._check(self._lib.bgs_selftest_tile_order(self._ctx, c.ctypes.data_as(ctypes.c_void_p), c.size, runs,
-                                                      out.ctypes.data_as(ctypes.c_void_p)))
-        return out
+                                                      out.ctypes.data_as(ctypes.c_void_p), two.ctypes.data_as(ctypes.c_void_p)))
+        return (out, (int(two[0]), int(two[1]))) if sums else out
 
     # -- interop / introspection -----------------------------------------------------
     def synchronize(self) -> None:
@@ -502,6 +503,8 @@ class GaussianSplattingPlugin:
             "instance_capacity": int(st.instance_capacity),
             "list_entries_allocated": int(st.list_entries_allocated),
             "strip_tiles": int(st.strip_tiles),
+            "tile_saturation": {"known": bool((int(st.tile_saturation) >> 16) & 1), "work_share": (int(st.tile_saturation) & 0x7FFF) / 0x7FFF,
+                                "midround_exit": bool(int(st.tile_saturation) >> 31)},
             "tiles": (int(st.tiles_x), int(st.tiles_y)),
             "depth_passes": int(st.depth_passes),
             "tile_passes": int(st.tile_passes),

@@ -188,7 +188,10 @@ typedef struct bgs_stats {
                                     lists together); instance_count is how many of them the frame filled */
     uint32_t strip_tiles;        /* tiles of the frame that were drawn by four strip waves instead of one wave (dense
                                     frames: the tiles a completed frame found heavy); 0 otherwise */
-    uint32_t reserved_stats;
+    uint32_t tile_saturation;    /* BGS_BINNING_SCAN frames drawn in cost order: bit 16 = known, bits 0-14 = share (x 0x7FFF) of
+                                    the tile work of the completed frame the order was made of that was in tiles whose
+                                    every pixel went opaque before their list ended — what selects the mid-round-exit
+                                    rasteriser for a kind of frame; bit 31: this frame ran it. 0 otherwise */
 } bgs_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */

@@ -90,10 +90,13 @@ int bgs_graph_counters(bgs_ctx* ctx, uint64_t* captures, uint64_t* replays);
  * made that order anew (tile_order_kernel launches). */
 int bgs_tile_order_counters(bgs_ctx* ctx, uint64_t* cost_frames, uint64_t* ordered_frames, uint64_t* refreshes);
 
-/* tile_order_kernel on caller-supplied per-tile costs (host_cost[ntiles], u16; 1 <= ntiles <= 65535; runs per XCD 1, 2 or
- * 4): host_order[(ntiles + 3) / 4] receives the raster workgroups' order — a permutation of 0 .. (ntiles + 3) / 4 - 1
- * whatever the costs hold, heaviest workgroup (its heaviest tile) first inside every XCD's share. Test hook. */
-int bgs_selftest_tile_order(bgs_ctx* ctx, const uint16_t* host_cost, uint32_t ntiles, uint32_t runs, uint16_t* host_order);
+/* tile_order_kernel on caller-supplied per-tile costs (host_cost[ntiles], u16: work in bits 0-14, bit 15 = the tile ended
+ * saturated; 1 <= ntiles <= 65535; runs per XCD 1, 2 or 4): host_order[(ntiles + 3) / 4] receives the raster workgroups'
+ * order — a permutation of 0 .. (ntiles + 3) / 4 - 1 whatever the costs hold, heaviest workgroup (its heaviest tile) first
+ * inside every XCD's share — and host_sums[2] (may be NULL) the kernel's sums: the work of all tiles, the work of the tiles
+ * that ended saturated. Test hook. */
+int bgs_selftest_tile_order(bgs_ctx* ctx, const uint16_t* host_cost, uint32_t ntiles, uint32_t runs, uint16_t* host_order,
+                            uint32_t* host_sums);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,9 @@ def run(p, h, v, s, steps, warm=40, depth=8):
     stages = {k: round(1e3 * x, 1) for k, x in st1["stage_ms"].items() if x}
     if st1.get("strip_tiles"):
         stages["feedback_tiles"] = st1["strip_tiles"]
+    if st1.get("tile_saturation", {}).get("known"):
+        ts = st1["tile_saturation"]
+        stages["saturated_work"] = "%.2f%s" % (ts["work_share"], " midround" if ts["midround_exit"] else "")
     return best, steps / dt1, stages
 
 

@@ -1509,7 +1509,9 @@ def test_tile_order_is_a_permutation_whatever_the_costs_hold(plugin, runs):
     equal, all 0xFFFF, random, a completed frame's shape) the order is a permutation of the workgroups (a workgroup
     nobody draws would be a hole in the image, one drawn twice a race), XCD b % 8 keeps exactly the workgroups the
     static order gives it (splat_math.h xcd_runs_item, the host build of the same function), and inside a share the
-    workgroups' heaviest tiles are non-increasing with ties in the share's own order."""
+    workgroups' heaviest tiles are non-increasing with ties in the share's own order. Round 6: bit 15 of a cost word says the
+    tile ended saturated; the kernel's two sums (all work, work of those tiles) are what the host picks the mid-round-exit
+    rasteriser by."""
     import ctypes
     l = H.shim()
     rng = np.random.default_rng(1234 + runs)
@@ -1523,10 +1525,13 @@ def test_tile_order_is_a_permutation_whatever_the_costs_hold(plugin, runs):
                     "random": rng.integers(0, 65536, ntiles).astype(np.uint16),
                     "few_levels": (rng.integers(0, 4, ntiles) * 100).astype(np.uint16),
                     "ramp": (np.arange(ntiles) % 65536).astype(np.uint16)}[kind]
-            order = plugin.selftest_tile_order(cost, runs).astype(np.int64)
+            order, sums = plugin.selftest_tile_order(cost, runs, sums=True)
+            order = order.astype(np.int64)
             assert np.array_equal(np.sort(order), np.arange(nb)), (ntiles, runs, kind)
+            work = cost.astype(np.int64) & 0x7FFF                      # (bit 15: the tile ended saturated — no part of its cost)
+            assert sums == (int(work.sum()), int(work[cost >= 0x8000].sum())), (ntiles, runs, kind)
             group = np.zeros(nb * 4, np.int64)
-            group[:ntiles] = cost
+            group[:ntiles] = work
             group = group.reshape(nb, 4).max(axis=1)                  # a workgroup costs what its heaviest tile costs
             for x in range(min(8, nb)):
                 mine, share = order[x::8], static[x::8].astype(np.int64)
@@ -1861,6 +1866,53 @@ def test_two_alternating_kinds_that_never_run_clean_are_settled_on_too(plugin):
         plugin.set_pipeline_depth(1)
         plugin.reset_adaptive_state()
     h.free()
+
+
+def test_a_kind_whose_saturating_tiles_hold_the_work_runs_the_midround_exit_rasteriser(plugin):
+    """Round 6: tiles leave bit 15 in their cost word when every pixel went opaque before their list ended; tile_order_kernel
+    sums the work of those tiles and of all tiles while it makes the order, the next frame's clean-up block hands the share
+    to the host, and kinds at >= 30 % (trained-like 1 M: 36 %) run the rasteriser instantiation that looks for saturation
+    inside a staging round — with frames in flight only (alone on the chip the launch ends with its longest lists, which do
+    not saturate). Leaving early changes no bit: the frame equals the one with that instantiation switched off (debug flag
+    0x1000000). The scene-like frame (no tile saturates) stays on the plain instantiation."""
+    from bevy_gaussian_splatting_amd import trained_like_gaussians_3d_seeded
+    v = View.headless(1920, 1080)
+    for what in ("trained", "scene"):
+        c = trained_like_gaussians_3d_seeded(1_000_000, 7) if what == "trained" else random_gaussians_3d_seeded(1_000_000, 2)
+        s = CloudSettings() if what == "trained" else CloudSettings(global_scale=0.05)
+        h = plugin.upload(c)
+        try:
+            plugin.reset_adaptive_state()
+            plugin.set_debug_flags(0x1000000)
+            want = plugin.render(h, v, s)
+            plugin.set_debug_flags(0)
+            plugin.reset_adaptive_state()
+            plugin.set_async(True)
+            plugin.set_pipeline_depth(4)
+            for i in range(40):
+                plugin.render(h, v, s, download=False)
+                if plugin.frames_in_flight() >= 4:
+                    plugin.pipeline_pop()
+            got = plugin.render(h, v, s)
+            ts = plugin.stats()["tile_saturation"]
+            assert ts["known"], what
+            if what == "trained":
+                assert ts["work_share"] >= 0.30 and ts["midround_exit"], ts
+            else:
+                assert ts["work_share"] <= 0.15 and not ts["midround_exit"], ts
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), what
+            plugin.synchronize()
+            plugin.set_pipeline_depth(1)           # one frame at a time: the plain instantiation, whatever the share
+            for i in range(3):
+                got = plugin.render(h, v, s)
+            assert not plugin.stats()["tile_saturation"]["midround_exit"], what
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), what
+        finally:
+            plugin.set_debug_flags(0)
+            plugin.set_async(False)
+            plugin.set_pipeline_depth(1)
+            plugin.reset_adaptive_state()
+            h.free()
 
 
 def test_rerun_keeps_the_output_state_the_frame_was_enqueued_with(plugin):
