@@ -124,16 +124,20 @@ constexpr uint32_t BUCKET_SUB_MAX = 16;
 constexpr uint32_t BUCKET_SUB_KERNARG = 3;
 constexpr uint32_t BUCKET_MAX = BUCKET_COUNT * BUCKET_SUB_MAX;
 constexpr uint32_t BUCKET_TARGET = 2048;     // pairs per bucket the host aims at when it picks `sub`
+// Lists the narrow buckets would need more than BUCKET_SUB_KERNARG x 256 of (round 6): WIDE buckets, a quarter as many
+constexpr uint32_t BUCKET_CAP_WIDE = 16384;  // 128 KB of a CU's 160 KB of LDS
+#ifndef BGS_BUCKET_FINE_WIDE
+#define BGS_BUCKET_FINE_WIDE 8192            // (half a word each: sort_kernels.hip; 4096: a word each, A/B)
+#endif
+constexpr uint32_t BUCKET_FINE_WIDE = BGS_BUCKET_FINE_WIDE;
+constexpr uint32_t BUCKET_TARGET_WIDE = 10240;
 struct SplitterTable {
     uint32_t key[BUCKET_COUNT * BUCKET_SUB_KERNARG];   // sub <= BUCKET_SUB_KERNARG: key[0 .. 256 * sub - 2] ascending quantile keys
     const uint32_t* device_keys;                       // sub > BUCKET_SUB_KERNARG: the same, in device memory
     uint32_t sub;                                      // 1 .. BUCKET_SUB_MAX: the table defines 256 * sub buckets
-    // TWO-LEVEL placement (round 6; tables in device memory, sub > BUCKET_SUB_KERNARG): keygen places a pair into one of the
-    // 256 COARSE buckets (bucket / sub; slot regions of BUCKET_CAP * sub pairs) — a tile's pairs of a coarse bucket are a
-    // coalesced run of ~16 where the one-level scatter into 256 * sub buckets left ~1.5 pairs per (tile, bucket), every
-    // 8-byte pair its own partial line — and bucket_sort_kernel's workgroup f picks the pairs of fine bucket f out of its
-    // coarse bucket's region (it lies in the L2 by then) while it loads them.
-    uint32_t coarse;
+    // WIDE buckets (round 6; lists past BUCKET_COUNT * BUCKET_SUB_KERNARG * BUCKET_TARGET pairs): slot regions of BUCKET_CAP_WIDE
+    // pairs, sorted by bucket_sort_kernel's 1024-thread instantiation in 128 KB of LDS
+    uint32_t wide;
 };
 // what the host keeps per view slot (a completed frame's quantile keys, any sub)
 struct SplitterKeys { uint32_t key[BUCKET_MAX]; uint32_t sub; };
@@ -148,7 +152,7 @@ struct Control {
     uint32_t visible_count;   // splats that pass the vertex-stage cull (stats)
     uint32_t splat_count;     // N, parked on the device so the sort kernels read every size the same way
     uint32_t sort_overflow;   // bucket sort gave up (1 bucket over capacity, 2 too many equal keys): re-run with onesweep
-    uint32_t bucket_max;      // fullest bucket (stats)
+    uint32_t bucket_max;      // fullest bucket (stats; one-level placement only)
     uint32_t strip_tiles;     // tiles this frame's rasteriser drew with four strip waves (the consumed heavy-tile list; stats)
     // (host copy only) from the cost plane the lane's tile order was last made of (tile_order_kernel, TileCost bit 15): the share
     // of the frame's tile work that was in tiles which ended saturated, x 0x7FFF; 0xFFFFFFFF = no order

@@ -137,10 +137,9 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
 // to out[] at its offset; out[0 .. draw_count) is then bit-identical to what the stable LSD passes
 // produce. Sets ctl->sort_overflow instead when a bucket holds more than BUCKET_CAP pairs or one key value
 // repeats more than BUCKET_FINE_MAX times (the host re-runs the frame with the onesweep passes).
-// two_level_keys (round 6, SplitterTable::coarse): the frame's 256 * sub - 1 splitter keys in device memory when keygen
-// placed the pairs into the 256 COARSE buckets — workgroup f then collects fine bucket f's pairs out of its coarse region.
-void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor,
-                        uint32_t buckets = BUCKET_COUNT /* 256 * sub */, const uint32_t* two_level_keys = nullptr);
+// wide (round 6, SplitterTable::wide): the buckets are slot regions of BUCKET_CAP_WIDE pairs (1024-thread workgroups, 128 KB of LDS).
+hipError_t launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor,
+                              uint32_t buckets = BUCKET_COUNT /* 256 * sub */, bool wide = false);
 // ctl->splitters = the 255 quantile keys of the sorted draw list (for frames without a cleaning rasteriser).
 void launch_splitters(hipStream_t stream, const uint2* sorted, Control* ctl, uint32_t key_xor, uint32_t sub = 1u);
 

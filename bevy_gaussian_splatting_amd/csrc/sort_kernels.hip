@@ -116,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_bcnt = s_dyn;     // pairs of this tile per bucket; then, IN PLACE, the bucket's pairs of earlier tiles
     uint32_t* const s_bexcl = s_dyn;    // (thread f reads its count and leaves the returning atomic's value in the same word)
-    uint32_t* const s_split = s_dyn + (BUCKET ? BUCKET_COUNT * (split.coarse ? 1u : split.sub) : 0u);
+    uint32_t* const s_split = s_dyn + (BUCKET ? BUCKET_COUNT * split.sub : 0u);
     __shared__ uint16_t s_at[BUCKET ? THREADS * KG_ITEMS : 1];  // arrival slot of compacted pair j inside its bucket (this tile)
     __shared__ uint16_t s_bk[BUCKET ? THREADS * KG_ITEMS : 1];  // its bucket
     __shared__ uint32_t s_total;
@@ -129,17 +129,15 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
     if (fp_out && blockIdx.x == 0 && (uint32_t)tid < (uint32_t)(sizeof(FrameParams) / 4u))
         reinterpret_cast<uint32_t*>(fp_out)[tid] = reinterpret_cast<const uint32_t*>(&fp)[tid];
     if (zero_word && blockIdx.x == 0 && tid == 0) *zero_word = 0u;
-    // two-level placement (SplitterTable::coarse): the 256 coarse buckets, whose splitters are every sub-th key of the table
-    const uint32_t fsub = BUCKET ? split.sub : 1u;                                  // fine buckets per coarse one
-    const bool two_level = BUCKET && split.coarse != 0u;
-    const uint32_t nsub = two_level ? 1u : fsub, nb = BUCKET_COUNT * nsub;          // buckets keygen places into
-    const uint32_t bucket_cap = two_level ? BUCKET_CAP * fsub : BUCKET_CAP;         // pairs per slot region
+    // nb = 256 * sub buckets of BUCKET_CAP pairs — or, for the long lists (SplitterTable::wide), of BUCKET_CAP_WIDE
+    const uint32_t nsub = BUCKET ? split.sub : 1u, nb = BUCKET_COUNT * nsub;
+    const uint32_t bucket_cap = (BUCKET && split.wide != 0u) ? BUCKET_CAP_WIDE : BUCKET_CAP;   // pairs per slot region
     uint32_t p2 = 256u;                 // the splitter table's padded length: the power of two >= nb
     while (p2 < nb) p2 <<= 1;
     if constexpr (BUCKET) {
-        const uint32_t* __restrict__ keys = fsub <= BUCKET_SUB_KERNARG ? split.key : split.device_keys;
+        const uint32_t* __restrict__ keys = nsub <= BUCKET_SUB_KERNARG ? split.key : split.device_keys;
         for (uint32_t t = (uint32_t)tid; t < p2; t += (uint32_t)THREADS)
-            s_split[t] = t < nb - 1u ? keys[two_level ? (t + 1u) * fsub - 1u : t] : 0xFFFFFFFFu;
+            s_split[t] = t < nb - 1u ? keys[t] : 0xFFFFFFFFu;
     } else if (tid < 256) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) s_hist[p][tid] = 0u;
@@ -364,7 +362,9 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
                 uint32_t excl = 0u;
                 if (tile > 0u) {
                     if (lane == 0) st_agent(my_status, STATUS_AGGREGATE | total);
-                    excl = lookback_wave(part_status, tile, lane, &ctl->error, 8u);
+                    // (a sort mode that draws every splat — Rayon / Std / None — has full tiles before this one: no chain to
+                    // walk, 12 of the 83 us of a 5 M-splat keygen; the status words are written all the same)
+                    excl = all_draw ? tile * per_tile : lookback_wave(part_status, tile, lane, &ctl->error, 8u);
                 }
                 if (lane == 0) {
                     st_agent(my_status, STATUS_PREFIX | ((excl + total) & STATUS_VALUE_MASK));
@@ -466,9 +466,11 @@ bool KeygenLaunch::prepare(int max_blocks) {
     // every thread's chain (keygen 17.6 -> 12.5 us at 1 M). With frames in flight the narrow tile wins (21.0 vs 20.2 k
     // frames/s: a 16-wave workgroup needs a CU's worth of free slots at once, and there the other frames' kernels are
     // what hides a tile's latency) — the same trade as in round 2, now decided per frame.
-    if (unordered && wide && per_block == 4096u) {
+    // (round 6: the tiles with a chain — bgs_sort's bucket frames — likewise)
+    if (bucket && wide && per_block == 4096u) {
         threads = 1024u;
-        func = reinterpret_cast<const void*>(&keygen_kernel<4, true, 1024, false>);
+        func = unordered ? reinterpret_cast<const void*>(&keygen_kernel<4, true, 1024, false>)
+                         : reinterpret_cast<const void*>(&keygen_kernel<4, true, 1024, true>);
     }
 #undef BGS_KG_PICK
     blocks = (fp.n + per_block - 1) / per_block;
@@ -479,7 +481,7 @@ bool KeygenLaunch::prepare(int max_blocks) {
     argv[10] = &bucket_status; argv[11] = &split; argv[12] = &zero_word;
     if (split.sub < 1u || split.sub > BUCKET_SUB_MAX) split.sub = 1u;
     {   // the per-bucket counters + the padded splitter table
-        uint32_t nbk = BUCKET_COUNT * (split.coarse ? 1u : split.sub), pad2 = 256u;   // (two-level placement: the 256 coarse buckets)
+        uint32_t nbk = BUCKET_COUNT * split.sub, pad2 = 256u;
         while (pad2 < nbk) pad2 <<= 1;
         lds_bytes = bucket ? (nbk + pad2) * (uint32_t)sizeof(uint32_t) : 0u;
     }
@@ -727,49 +729,40 @@ void launch_onesweep_pass(hipStream_t stream, const uint2* in, uint2* out, const
 // 16 waves on every CU instead of 4 and is faster alone (600 k pairs of a 5 M-splat cloud 27.9 -> 15.3 us,
 // 120 k pairs 9.9 -> 9.5 us), but slower where it matters, with other frames' kernels sharing the chip
 // (kernels.h, BGS_KEYGEN_WIDE_THREADS): 256 is the default.
+// WIDE buckets (round 6, lists past ~1.5 M pairs; bgs_device.h BUCKET_CAP_WIDE): 16 384 pairs = 128 KB of the CU's 160 KB
+// of LDS, 1024 threads x 16 pairs, 4096 fine ranges. A 5 M-pair list is 768 of them instead of 2816 narrow ones: keygen's
+// scatter leaves runs of ~5 pairs per (tile, bucket) instead of 1.5, and a quarter of the workgroups start up.
 #ifndef BGS_BUCKET_SORT_THREADS
 #define BGS_BUCKET_SORT_THREADS 256
 #endif
 constexpr uint32_t BUCKET_SORT_THREADS = BGS_BUCKET_SORT_THREADS;
-template <uint32_t THREADS, bool TWO = false>  // 256 or 1024; TWO: two-level placement (SplitterTable::coarse)
+template <uint32_t THREADS, uint32_t CAP, uint32_t NF>  // 256 or 1024 threads; pairs a bucket holds; fine ranges
 __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __restrict__ slots,
                                                               uint2* __restrict__ out, Control* ctl,
-                                                              uint32_t key_xor, uint32_t nb /* buckets of the frame: 256 * sub */,
-                                                              [[maybe_unused]] uint32_t sub, [[maybe_unused]] const uint32_t* __restrict__ fine_keys) {
+                                                              uint32_t key_xor, uint32_t nb /* buckets of the frame: 256 * sub */) {
     constexpr uint32_t WAVES = THREADS / 64u;
-    constexpr uint32_t EPT = BUCKET_CAP / THREADS;              // pairs per thread (strided)
-    constexpr uint32_t NF = BUCKET_FINE, FPT = NF / THREADS;    // fine ranges per thread (contiguous)
-    static_assert(NF == 2048u && BUCKET_COUNT == 256u && (THREADS == 256u || THREADS == 1024u), "bucket geometry");
-    __shared__ uint2 s_el[BUCKET_CAP];
-    __shared__ uint32_t s_f[NF + 1];
+    constexpr uint32_t EPT = CAP / THREADS;                     // pairs per thread (strided)
+    constexpr uint32_t FPT = NF / THREADS;                      // fine ranges per thread (contiguous)
+    // the fine ranges' counts, then offsets: a word each — or, for the wide buckets, HALF a word (PACK: 8192 ranges in the 16 KB
+    // that 128 KB of pairs leave; counts and offsets are <= CAP = 2^14, and a count that would carry into its neighbour is
+    // impossible for the same reason)
+    constexpr bool PACK = NF > 4096u;
+    constexpr uint32_t FWORDS = PACK ? NF / 2u + 1u : NF + 1u;
+    static_assert((NF == 2048u || NF == 4096u || NF == 8192u) && BUCKET_COUNT == 256u && (THREADS == 256u || THREADS == 1024u) &&
+                  EPT >= 1u && FPT >= 2u && FPT % 2u == 0u && CAP <= 65535u, "bucket geometry");
+    extern __shared__ uint2 s_el[];                              // CAP pairs (dynamic: a wide bucket's 128 KB are past the 64 KB default)
+    __shared__ uint32_t s_f[FWORDS];
     __shared__ uint32_t s_tot[WAVES];
     __shared__ uint32_t s_red[WAVES][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // TWO: this workgroup sorts fine bucket b = the keys in [lo, hi) of coarse bucket cb (hi open; the last bucket takes ~0 too).
-    // The `sub` workgroups of a coarse bucket all read its whole region: they are given to ONE XCD (workgroup w runs on XCD
-    // w % 8, an assumption about speed only), back to back in its dispatch order, so that the region comes out of HBM once
-    // and out of that XCD's L2 sub - 1 times (110 -> ? us at 5 M pairs with the buckets dealt round-robin over the XCDs).
-    uint32_t b = blockIdx.x;
-    if constexpr (TWO) {
-        const uint32_t x = b & 7u, i = b >> 3;           // BUCKET_COUNT % 8 == 0: 32 coarse buckets per XCD
-        b = (x + 8u * (i / sub)) * sub + i % sub;
-    }
-    const uint32_t cb = TWO ? b / sub : b, ncount = TWO ? BUCKET_COUNT : nb;
-    const uint32_t cap = TWO ? BUCKET_CAP * sub : BUCKET_CAP;
-    [[maybe_unused]] uint32_t lo = 0u, hi = 0xFFFFFFFFu;
-    if constexpr (TWO) {
-        if (b > 0u) lo = fine_keys[b - 1u];
-        if (b < nb - 1u) hi = fine_keys[b];
-    }
-    __shared__ uint32_t s_fill;
-    if constexpr (TWO) { if (tid == 0) s_fill = 0u; }
+    const uint32_t b = blockIdx.x;
     // offset of this bucket in the sorted list, its own count, the fullest bucket (every thread takes a stride of the counts)
     uint32_t before = 0u, mine = 0u, mx = 0u;
-    for (uint32_t i = (uint32_t)tid; i < ncount; i += THREADS) {
+    for (uint32_t i = (uint32_t)tid; i < nb; i += THREADS) {
         const uint32_t cnt = ctl->bucket_count[i];
-        before += i < cb ? cnt : 0u;
-        mine += i == cb ? cnt : 0u;
+        before += i < b ? cnt : 0u;
+        mine += i == b ? cnt : 0u;
         mx = max(mx, cnt);
     }
 #pragma unroll
@@ -779,72 +772,29 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
     }
     if (lane == 0) { s_red[wave][0] = before; s_red[wave][1] = mine; s_tot[wave] = mx; }
-#pragma unroll
-    for (uint32_t j = 0; j < FPT; ++j) s_f[j * THREADS + (uint32_t)tid] = 0u;
+    for (uint32_t j = (uint32_t)tid; j < FWORDS; j += THREADS) s_f[j] = 0u;
     __syncthreads();
     uint32_t base = 0u, m = 0u;
     mx = 0u;
 #pragma unroll
     for (uint32_t w = 0; w < WAVES; ++w) { base += s_red[w][0]; m += s_red[w][1]; mx = max(mx, s_tot[w]); }
     if (b == 0u && tid == 0) {
-        if constexpr (!TWO) ctl->bucket_max = mx;
-        if (mx > cap) {
+        ctl->bucket_max = mx;
+        if (mx > CAP) {
             // some bucket lost pairs: the list is void. draw_count = 0 keeps the kernels behind this one
             // (project, raster) away from the unwritten entries; the host re-runs the frame.
             ctl->sort_overflow = 1u;
             ctl->draw_count = 0u;
         }
     }
-    if constexpr (!TWO) {
-        // the length of the list: the last bucket's offset + its pairs (a keygen without chains leaves only the per-bucket
-        // counts; one with chains has written the same number already)
-        if (b == nb - 1u && tid == 0 && mx <= BUCKET_CAP) ctl->draw_count = base + m;
-        if (m == 0u) return;
-    }
-    if (mx > cap) return;
+    // the length of the list: the last bucket's offset + its pairs (a keygen without chains leaves only the per-bucket
+    // counts; one with chains has written the same number already)
+    if (b == nb - 1u && tid == 0 && mx <= CAP) ctl->draw_count = base + m;
+    if (m == 0u || mx > CAP) return;
     __syncthreads();  // s_red / s_tot are reused below
 
     // ---- 2. load ----
-    const uint2* __restrict__ src = slots + (size_t)cb * cap;
-    if constexpr (TWO) {
-        // the coarse bucket's m pairs (out of the L2: sub workgroups read the same region): those below this fine bucket's
-        // range only count towards its place in the list, those inside it are collected in s_el (any order)
-        uint32_t below = 0u;
-        for (uint32_t e0 = (uint32_t)tid; e0 < m; e0 += 8u * THREADS) {
-            uint2 in[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8u; ++k) { const uint32_t e = e0 + k * THREADS; in[k] = e < m ? src[e] : make_uint2(0xFFFFFFFFu, 0u); }
-#pragma unroll
-            for (uint32_t k = 0; k < 8u; ++k) {
-                const uint32_t e = e0 + k * THREADS;
-                if (e < m) {
-                    const uint32_t key = in[k].x;
-                    if (key < lo) below += 1u;
-                    else if (key < hi || b == nb - 1u) {
-                        const uint32_t at = atomicAdd(&s_fill, 1u);
-                        if (at < BUCKET_CAP) s_el[at] = in[k];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) below += (uint32_t)__shfl_xor((int)below, off, 64);
-        if (lane == 0) s_red[wave][0] = below;
-        __syncthreads();
-        m = s_fill;
-        below = 0u;
-#pragma unroll
-        for (uint32_t w = 0; w < WAVES; ++w) below += s_red[w][0];
-        base += below;
-        if (tid == 0) {
-            atomicMax(&ctl->bucket_max, m);
-            if (m > BUCKET_CAP) { ctl->sort_overflow = 1u; ctl->draw_count = 0u; }   // (sticky: see above)
-            else if (b == nb - 1u) ctl->draw_count = base + m;
-        }
-        if (m == 0u || m > BUCKET_CAP) return;
-        __syncthreads();  // s_red is reused below
-        src = s_el;       // (generic pointer into LDS: the loads below read the collected pairs)
-    }
+    const uint2* __restrict__ src = slots + (size_t)b * CAP;
     uint2 kv[EPT];
     uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
 #pragma unroll
@@ -852,7 +802,7 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
         const uint32_t e = k * THREADS + (uint32_t)tid;
         kv[k] = make_uint2(0u, 0u);
         if (e < m) {
-            kv[k] = TWO ? s_el[e] : src[e];
+            kv[k] = src[e];
             kmn = min(kmn, kv[k].x);
             kmx = max(kmx, kv[k].x);
         }
@@ -867,22 +817,31 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     kmn = 0xFFFFFFFFu; kmx = 0u;
 #pragma unroll
     for (uint32_t w = 0; w < WAVES; ++w) { kmn = min(kmn, s_red[w][0]); kmx = max(kmx, s_red[w][1]); }
+    // fine range of a key: floor((key - kmn) * NF / (span + 1)) — monotone in the key and ALL NF ranges in use whatever the
+    // span (a shift — round 5 — left between NF / 2 and NF of them in use: up to twice the pairs per range, four times the
+    // compares of step 4, which is 17 of a 5 M-pair sort's 51 us). As a multiplication by floor(2^32 NF / (span + 1)) < 2^32.
     const uint32_t span = kmx - kmn;
-    const uint32_t bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
-    const uint32_t fshift = bits > 11u ? bits - 11u : 0u;  // (span >> fshift) < NF = 2^11
+    const bool direct = span < NF;   // (every key value its own range)
+    const uint32_t scale = direct ? 0u : (uint32_t)(((unsigned long long)NF << 32) / ((unsigned long long)span + 1ull));
+    auto fine_of = [&](const uint32_t key) -> uint32_t { const uint32_t d = key - kmn; return direct ? d : __umulhi(d, scale); };
 
     // ---- 3. counting sort on the fine ranges ----
     uint32_t slot[EPT];
 #pragma unroll
     for (uint32_t k = 0; k < EPT; ++k) {
         const uint32_t e = k * THREADS + (uint32_t)tid;
-        if (e < m) slot[k] = atomicAdd(&s_f[(kv[k].x - kmn) >> fshift], 1u);
+        if (e < m) {   // (slot: the fine range in the low half, the arrival order inside it in the high half)
+            const uint32_t fb = fine_of(kv[k].x);
+            if constexpr (PACK) slot[k] = fb | (((atomicAdd(&s_f[fb >> 1], 1u << ((fb & 1u) << 4)) >> ((fb & 1u) << 4)) & 0xFFFFu) << 16);
+            else slot[k] = fb | (atomicAdd(&s_f[fb], 1u) << 16);
+        }
     }
     __syncthreads();
     uint32_t f[FPT], fsum = 0u, fmax = 0u;
 #pragma unroll
     for (uint32_t j = 0; j < FPT; ++j) {
-        f[j] = s_f[(uint32_t)tid * FPT + j];
+        if constexpr (PACK) f[j] = (s_f[((uint32_t)tid * FPT + j) >> 1] >> ((j & 1u) << 4)) & 0xFFFFu;   // (FPT is even)
+        else f[j] = s_f[(uint32_t)tid * FPT + j];
         fmax = max(fmax, f[j]);
         fsum += f[j];
     }
@@ -893,12 +852,26 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
     uint32_t fexcl = finc - fsum;
 #pragma unroll
     for (uint32_t w = 0; w < WAVES; ++w) fexcl += w < (uint32_t)wave ? s_tot[w] : 0u;
+    if constexpr (PACK) {
 #pragma unroll
-    for (uint32_t j = 0; j < FPT; ++j) {
-        s_f[(uint32_t)tid * FPT + j] = fexcl;
-        fexcl += f[j];
+        for (uint32_t j = 0; j < FPT; j += 2u) {
+            s_f[((uint32_t)tid * FPT + j) >> 1] = fexcl | ((fexcl + f[j]) << 16);
+            fexcl += f[j] + f[j + 1u];
+        }
+        if (tid == 0) s_f[NF / 2u] = m;
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < FPT; ++j) {
+            s_f[(uint32_t)tid * FPT + j] = fexcl;
+            fexcl += f[j];
+        }
+        if (tid == 0) s_f[NF] = m;
     }
-    if (tid == 0) s_f[NF] = m;
+    // first pair of fine range fb in s_el (fb = NF: the bucket's pair count)
+    auto fine_start = [&](const uint32_t fb) -> uint32_t {
+        if constexpr (PACK) return (uint32_t)reinterpret_cast<const uint16_t*>(s_f)[fb];   // (ds_read_u16)
+        else return s_f[fb];
+    };
     if (__syncthreads_or(fmax > BUCKET_FINE_MAX ? 1 : 0)) {  // step 4 is quadratic in equal keys: give up
         if (tid == 0) {
             atomicOr(&ctl->sort_overflow, 2u);
@@ -911,38 +884,57 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(const uint2* __res
 #pragma unroll
     for (uint32_t k = 0; k < EPT; ++k) {
         const uint32_t e = k * THREADS + (uint32_t)tid;
-        if (e < m) s_el[s_f[(kv[k].x - kmn) >> fshift] + slot[k]] = kv[k];
+        if (e < m) s_el[fine_start(slot[k] & 0xFFFFu) + (slot[k] >> 16)] = make_uint2(kv[k].y, kv[k].x);   // (index, key): as ONE 64-bit number key-major
     }
     __syncthreads();
 
     // ---- 4. rank among the fine range's pairs by (key, index), write out ----
-#pragma unroll 4
-    for (uint32_t k = 0; k < EPT; ++k) {
-        const uint32_t p = k * THREADS + (uint32_t)tid;
-        if (p < m) {
-            const uint2 el = s_el[p];
-            const uint32_t fb = (el.x - kmn) >> fshift;
-            const uint32_t fs = s_f[fb], fe = s_f[fb + 1u];
-            uint32_t r = 0u;
-            for (uint32_t j = fs; j < fe; ++j) {
-                const uint2 o = s_el[j];
-                r += (o.x < el.x || (o.x == el.x && o.y < el.y)) ? 1u : 0u;
+    // Eight pairs at a time, their reads issued together (pair -> fine range -> the range's bounds -> the range's pairs is a
+    // chain of dependent LDS round trips). What this step costs is its instruction count (16 waves on 4 SIMDs, ~16 pairs a
+    // thread): a pair is ONE 64-bit number in LDS (key in the high word), a compare is v_cmp_lt_u64 + an add with carry.
+    const unsigned long long* const s_el64 = reinterpret_cast<const unsigned long long*>(s_el);
+    constexpr uint32_t G = EPT >= 8u ? 8u : EPT;
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < EPT; k0 += G) {
+        if (k0 * THREADS >= m) break;   // (uniform)
+        unsigned long long el[G];
+        uint32_t fs[G], fe[G];
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) {
+            const uint32_t p = (k0 + k) * THREADS + (uint32_t)tid;
+            el[k] = s_el64[min(p, m - 1u)];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) {
+            const uint32_t fb = fine_of((uint32_t)(el[k] >> 32));
+            fs[k] = fine_start(fb);
+            fe[k] = fine_start(fb + 1u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) {
+            const uint32_t p = (k0 + k) * THREADS + (uint32_t)tid;
+            if (p < m) {
+                uint32_t r = 0u;
+                for (uint32_t j = fs[k]; j < fe[k]; ++j) r += s_el64[j] < el[k] ? 1u : 0u;
+                out[base + fs[k] + r] = make_uint2((uint32_t)(el[k] >> 32) ^ key_xor, (uint32_t)el[k]);
             }
-            out[base + fs + r] = make_uint2(el.x ^ key_xor, el.y);
         }
     }
 }
 
-void launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor, uint32_t buckets,
-                        const uint32_t* two_level_keys) {
-    if (two_level_keys)   // two-level placement: the pairs lie in 256 coarse regions, the table's keys say which are workgroup f's
-        // (1024 threads: a workgroup walks its whole coarse region — sub times the pairs it sorts —, a chain of dependent
-        // loads per thread that is four times shorter than with 256)
-        hipLaunchKernelGGL((bucket_sort_kernel<1024u, true>), dim3(buckets), dim3(1024), 0, stream,
-                           bucket_slots, out, ctl, key_xor, buckets, buckets / BUCKET_COUNT, two_level_keys);
-    else
-        hipLaunchKernelGGL((bucket_sort_kernel<BUCKET_SORT_THREADS, false>), dim3(buckets), dim3(BUCKET_SORT_THREADS), 0, stream,
-                           bucket_slots, out, ctl, key_xor, buckets, 1u, (const uint32_t*)nullptr);
+hipError_t launch_bucket_sort(hipStream_t stream, const uint2* bucket_slots, uint2* out, Control* ctl, uint32_t key_xor, uint32_t buckets,
+                              bool wide) {
+    if (wide) {
+        const auto k = &bucket_sort_kernel<1024u, BUCKET_CAP_WIDE, BUCKET_FINE_WIDE>;
+        constexpr int lds = (int)(BUCKET_CAP_WIDE * sizeof(uint2));
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(buckets), dim3(1024), lds, stream, bucket_slots, out, ctl, key_xor, buckets);
+    } else {
+        hipLaunchKernelGGL((bucket_sort_kernel<BUCKET_SORT_THREADS, BUCKET_CAP, BUCKET_FINE>), dim3(buckets), dim3(BUCKET_SORT_THREADS),
+                           BUCKET_CAP * sizeof(uint2), stream, bucket_slots, out, ctl, key_xor, buckets);
+    }
+    return hipSuccess;
 }
 
 // The 255 keys at the 1/256-quantiles of a sorted draw list, in keygen's key space (key ^ key_xor): the

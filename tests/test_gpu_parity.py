@@ -1721,14 +1721,16 @@ def test_fine_buckets_on_small_lists_give_the_same_frames(plugin, oracle):
     """Debug flags 0x200 / 0x400: at least 768 buckets (767 quantile keys in keygen's arguments) / at least 1280 (1279 keys in
     the lane's device table) whatever the list's length — headline-sized lists normally take 256 buckets: rendered frames
     (chainless keygen) and bgs_sort (ordered keygen, culled tail) give the bits of the 256-bucket path and of the digit
-    passes."""
+    passes. Flag 0x800 (round 6): the WIDE buckets of the long lists (16 384 pairs, 1024-thread workgroups, 128 KB of LDS) on
+    this short one, with each of the three tables."""
     c = random_gaussians_3d_seeded(250_000, 71)
     v, s = View.headless(1280, 720), CloudSettings()
     h = plugin.upload(c)
     ref_entries = oracle.sort(c, v, s)
     try:
         out = {}
-        for name, flags in (("passes", 0x80000), ("coarse", 0), ("fine", 0x200), ("device_table", 0x400)):
+        for name, flags in (("passes", 0x80000), ("coarse", 0), ("fine", 0x200), ("device_table", 0x400),
+                            ("wide", 0x800), ("wide_fine", 0xA00), ("wide_device_table", 0xC00)):
             plugin.reset_adaptive_state()
             plugin.set_debug_flags(flags)
             for _ in range(3):
@@ -1739,7 +1741,7 @@ def test_fine_buckets_on_small_lists_give_the_same_frames(plugin, oracle):
                 e = plugin.sort(h, v, s)
             assert plugin.stats()["sort_path"] == ("onesweep" if name == "passes" else "bucket")
             out[name] = (img, e)
-        for name in ("coarse", "fine", "device_table"):
+        for name in ("coarse", "fine", "device_table", "wide", "wide_fine", "wide_device_table"):
             assert np.array_equal(out[name][0], out["passes"][0]), name
             assert np.array_equal(out[name][1]["key"], ref_entries["key"]) and np.array_equal(out[name][1]["index"], ref_entries["index"]), name
     finally:
