@@ -22,7 +22,7 @@ for n, seed in ((1_000_000, 2), (2_000_000, 5), (5_000_000, 3)):
     far = View.perspective(transform_from((0.0, 0.0, 120.0), (0.0, 0.0, 0.0, 1.0)), 1920, 1080)
     for name, v, s in (("rayon", View.headless(1920, 1080), CloudSettings(sort_mode=SortMode.Rayon)), ("radix_far", far, CloudSettings()),
                        ("radix_headline", View.headless(1920, 1080), CloudSettings())):
-        for flags in (0x80000, 0, 0x100):   # 0x80000: never the bucket path; 0x100: the bucket path with narrow buckets whatever the length (round 5's geometry)
+        for flags in (0x80000, 0, 0x100, 0x800):   # 0x80000: never the bucket path; 0x100 / 0x800: the bucket path with narrow / wide buckets whatever the length
             if only and (name, flags) != only[1:]:
                 continue
             p.set_debug_flags(flags); p.reset_adaptive_state(); p.set_profiling_stride(1)
