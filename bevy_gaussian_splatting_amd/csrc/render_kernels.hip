@@ -1536,6 +1536,10 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     // (every sample count; under a depth buffer too: a record the tile's depths leave whole — in front of everything the tile
     // holds — is interior like any other, one they split goes through the per-sample path with the others)
     constexpr bool FAST = BGS_INTERIOR_PATH != 0 && !ABLATE && (VARIANT == RV_OBB || VARIANT == RV_SURFEL) && !BBOX && ROWS == 4;
+    // ... and their strips' reach masks (below) where frames are not dense: on a dense frame nearly every strip is reached and the
+    // three scalar instructions per strip only cost (dense 1 M -6 % frames/s; scene-like +1.4 %, 5 M scene-like +2 %, dense
+    // surfels +4 %: profiles/r6_experiments/strip_reach_ab.txt)
+    constexpr bool STRIPS = FAST && !MIDROUND_EXIT;
     // half extent of the box the tile's sample positions span around the tile centre (the exact quad-vs-tile test)
     constexpr float HALF = 7.5f + ms_reach(MSAA);
 
@@ -1650,6 +1654,11 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             work += WORK_ROUND + ccnt * WORK_STAGED;
             __builtin_amdgcn_wave_barrier();
             [[maybe_unused]] bool keep_lane = false, interior_lane = false;   // this lane's record: blended at all / INTERIOR (FAST)
+            // ... and which of the tile's four 16 x 4 strips it can reach at all (FAST, round 6): a strip none of whose pixels'
+            // samples the quad covers costs ~8 vector + 3 scalar instructions to find that out pixel by pixel — on the scene-like
+            // and trained-like frames that is one or two of a pair's four strips. The same separating-axis test as `keep`, on the
+            // strip's box of pixel centres (x 0..15, y 4r..4r+3) against the reach blend_px_ms / blend_px give a pixel (lim + m)
+            [[maybe_unused]] bool strip_lane[4] = {false, false, false, false};
             if ((uint32_t)lane < ccnt) {
                 const float4* src = records + (size_t)s_queue[c0 + (uint32_t)lane] * REC_V4;
                 float4 r0 = src[0], r1 = src[1];
@@ -1685,6 +1694,16 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         keep_lane = keep && (!DEPTH || r2.w >= tile_dmin);
                         interior_lane = keep && (!DEPTH || r2.w >= tile_dmax) &&
                                         (fabsf(ucc) + su + r1.z <= 0.9999f * OBB_C) && (fabsf(vcc) + sv + r1.z <= 0.9999f * OBB_C);
+                        if constexpr (STRIPS) {
+                        const float eus = fmaf(7.5f, fabsf(r0.z), 1.5f * fabsf(r0.w)), evs = fmaf(7.5f, fabsf(r1.x), 1.5f * fabsf(r1.y));
+                        const float ub = fmaf(r0.z, 7.5f, r0.x), vb = fmaf(r1.x, 7.5f, r0.y);
+                        const float reach = 1.0001f * (OBB_C + r1.z);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {   // (a NaN keeps the strip)
+                            const float yc = 4.0f * (float)r + 1.5f;
+                            strip_lane[r] = keep_lane && !(fabsf(fmaf(r0.w, yc, ub)) - eus > reach) && !(fabsf(fmaf(r1.y, yc, vb)) - evs > reach);
+                        }
+                        }
                     }
                     r2.w = keepz_of(keep && (!DEPTH || r2.w >= tile_dmin), r2.w);
                     s_rec[lane * REC_V4 + 0] = r0;
@@ -1710,6 +1729,12 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         const float mg = MSAA == 1 ? 0.0f : ms_reach(MSAA) * fmaxf(fabsf(st[0].y), fabsf(st[0].w));
                         keep_lane = keep && (!DEPTH || z >= tile_dmin);
                         interior_lane = keep && (!DEPTH || z >= tile_dmax) && (fmaxf(um, vm) + mg <= 0.9999f);
+                        if constexpr (STRIPS) {
+                            const float evs = 1.5f * fabsf(st[0].w), reach = 1.0001f * (1.0f + mg);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)   // (u does not depend on the row: `keep` has looked at it)
+                                strip_lane[r] = keep_lane && !(fabsf(fmaf(st[0].w, 4.0f * (float)r + 1.5f, st[0].z)) - evs > reach);
+                        }
                     }
 #pragma unroll
                     for (int v = 0; v < 6; ++v) s_rec[lane * REC_V4 + v] = st[v];
@@ -1725,6 +1750,11 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                 // the round's records as two bit masks in scalar registers: which to blend, which of those are interior
                 unsigned long long todo = __builtin_amdgcn_ballot_w64(keep_lane);
                 const unsigned long long inter = __builtin_amdgcn_ballot_w64(interior_lane);
+                [[maybe_unused]] unsigned long long reach_mask[4];   // bit k: record k reaches strip r (STRIPS)
+                if constexpr (STRIPS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) reach_mask[r] = __builtin_amdgcn_ballot_w64(strip_lane[r]);
+                }
                 if constexpr (TRACE) trace_staged += ccnt;
                 uint32_t since = 0u;   // records since the last look at the tile's saturation
                 bool out = false;
@@ -1775,6 +1805,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         const bool zmixed = DEPTH && zr < tile_dmax;
 #pragma unroll
                         for (int r = 0; r < ROWS; ++r) {
+                            if constexpr (STRIPS) if (((reach_mask[r] >> k) & 1ull) == 0ull) continue;   // (scalar: the record cannot reach this strip)
                             if constexpr (MSAA == 4) {
                                 float4 d4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                                 if constexpr (DEPTH) if (zmixed) d4 = s_depth[r * 64 + lane];
