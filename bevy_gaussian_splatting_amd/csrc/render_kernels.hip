@@ -857,6 +857,10 @@ __device__ __forceinline__ float ms_inside(const float x, const float big, const
     asm("v_fma_f32 %0, -|%1|, %2, %3 clamp" : "=v"(r) : "v"(x), "v"(big), "v"(limbig));
     return r;
 }
+// acc = fma(-a, b, acc), the result in acc's own register
+__device__ __forceinline__ void ms_fnma_in_place(float& acc, const float a, const float b) {
+    asm("v_fma_f32 %0, -%1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
 template <int VARIANT, bool DEPTH, bool BBOX = false>
 __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, const float qx, const float qy,
                                             const float aspect, const float t_eps, PxMs& t, v2f& crg, float& cb,
@@ -917,11 +921,14 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
     if ((gmax <= lim + m) & ok & (t.S * t.rb >= t_eps)) {
         asm volatile("");  // keeps this a branch (see blend_px)
         const bool full = gmax <= lim - m;
-        float w;
-        if (!(DEPTH && zmixed) && __builtin_amdgcn_ballot_w64(!full) == 0ull) {
-            w = (t.S * t.rb) * alpha;
-            t.S = fmaf(-alpha, t.S, t.S);
-        } else {
+        // TWO one-armed regions, not an if / else: as one region the compiler gives the per-sample arm an edge into the
+        // other one (its lowering of a branch on a ballot inside an exec-masked region) and keeps the old r0 .. r3, rb alive
+        // along it — five v_mov per visited strip, ten with the updates forced in place. A one-armed region updates in place.
+        const bool all_full = !(DEPTH && zmixed) && __builtin_amdgcn_ballot_w64(!full) == 0ull;
+        float w = (t.S * t.rb) * alpha;
+        if (all_full) t.S = fmaf(-alpha, t.S, t.S);   // (the compiler makes it a select; as a branch: the same within noise)
+        asm volatile("");   // (keeps the two regions apart)
+        if (!all_full) {
             // Coverage of a sample as a 0 / 1 factor out of multiplications, additions and the clamp output modifier:
             // min / max, compares and selects issue at half the rate of those on this chip (wave64: 4 clocks against 2;
             // profiles/r4_micro/valu_issue.txt). clamp((lim - |x|) * 2^60) is 1 for |x| <= lim - 2^-60, 0 for |x| >= lim —
@@ -937,9 +944,9 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
             }
             const float sum = (t0 + t1) + (t2 + t3), aq = 0.25f * alpha;
             w = (t.S * aq) * sum;
-            t.r0 = fmaf(-alpha, t0, t.r0); t.r1 = fmaf(-alpha, t1, t.r1);
-            t.r2 = fmaf(-alpha, t2, t.r2); t.r3 = fmaf(-alpha, t3, t.r3);
-            t.rb = fmaf(-aq, sum, t.rb);
+            ms_fnma_in_place(t.r0, alpha, t0); ms_fnma_in_place(t.r1, alpha, t1);
+            ms_fnma_in_place(t.r2, alpha, t2); ms_fnma_in_place(t.r3, alpha, t3);
+            ms_fnma_in_place(t.rb, aq, sum);
         }
         crg = __builtin_elementwise_fma((v2f){w, w}, (v2f){r, g}, crg);
         cb = fmaf(w, b, cb);
@@ -1025,11 +1032,11 @@ __device__ __forceinline__ void blend_px_msn(const StagedRecord<VARIANT>& s, con
     if ((gmax <= lim + m) & ok & (t.S * t.rb >= t_eps)) {   // (one exec-mask region: see blend_px_ms)
         asm volatile("");  // keeps this a branch (see blend_px)
         const bool full = gmax <= lim - m;
-        float w;
-        if (!(DEPTH && zmixed) && __builtin_amdgcn_ballot_w64(!full) == 0ull) {
-            w = (t.S * t.rb) * alpha;
-            t.S = fmaf(-alpha, t.S, t.S);
-        } else {
+        const bool all_full = !(DEPTH && zmixed) && __builtin_amdgcn_ballot_w64(!full) == 0ull;   // (two one-armed regions: see blend_px_ms)
+        float w = (t.S * t.rb) * alpha;
+        if (all_full) t.S = fmaf(-alpha, t.S, t.S);
+        asm volatile("");
+        if (!all_full) {
             const float big = 1.152921504606846976e18f, limbig = lim * 1.152921504606846976e18f;   // 2^60
             float ts[NS];
 #pragma unroll
@@ -1045,8 +1052,8 @@ __device__ __forceinline__ void blend_px_msn(const StagedRecord<VARIANT>& s, con
             const float aq = (1.0f / (float)NS) * alpha;
             w = (t.S * aq) * sum;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) t.r[k] = fmaf(-alpha, ts[k], t.r[k]);
-            t.rb = fmaf(-aq, sum, t.rb);
+            for (int k = 0; k < NS; ++k) ms_fnma_in_place(t.r[k], alpha, ts[k]);
+            ms_fnma_in_place(t.rb, aq, sum);
         }
         crg = __builtin_elementwise_fma((v2f){w, w}, (v2f){r, g}, crg);
         cb = fmaf(w, b, cb);
