@@ -857,11 +857,21 @@ __device__ __forceinline__ float ms_inside(const float x, const float big, const
     asm("v_fma_f32 %0, -|%1|, %2, %3 clamp" : "=v"(r) : "v"(x), "v"(big), "v"(limbig));
     return r;
 }
+// float4 per STAGED record in the wave-per-tile rasteriser's LDS: the 4x OBB record carries a fourth one, the four sample
+// offsets of (u, v) — wave-uniform values every pixel's per-sample update needs, formed once by the staging lane instead of
+// with eight vector instructions per (record, tile) in the record loop (round 6)
+// (not under a depth buffer: with the tile's 16 KB of depth samples a fifth workgroup would no longer fit a CU's LDS)
+// ... and not in the dense frames' instantiation (mid-round exit): their strips rarely take the per-sample update, the compiler
+// had sunk the eight instructions into it, and the fourth LDS read per record only costs (dense 1 M -3.5 % frames/s; scene-like
+// +1.5 %, trained-like +2.5 %, 5 M scene-like +2.1 %: profiles/r6_experiments/staged_sample_offsets_ab.txt)
+__host__ __device__ constexpr int staged_v4(const int variant, const int msaa, const bool depth, const bool midround_exit) {
+    return variant == 2 ? 6 : (variant == 0 && msaa == 4 && !depth && !midround_exit ? 4 : 3);
+}
 // acc = fma(-a, b, acc), the result in acc's own register
 __device__ __forceinline__ void ms_fnma_in_place(float& acc, const float a, const float b) {
     asm("v_fma_f32 %0, -%1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
-template <int VARIANT, bool DEPTH, bool BBOX = false>
+template <int VARIANT, bool DEPTH, bool BBOX = false, bool PRE = false>   // PRE: s.a3 = (du0, du1, dv0, dv1), staged
 __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, const float qx, const float qy,
                                             const float aspect, const float t_eps, PxMs& t, v2f& crg, float& cb,
                                             const float z, const bool zmixed, const float4 dpx) {
@@ -880,8 +890,11 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
         // or not is the same image — except under the overlay, which would paint it opaque
         if constexpr (BBOX) ok = !(fmaf(u, u, v * v) > 9.0f * OBB_C * OBB_C);
         r = s.a1.w; g = s.a2.x; b = s.a2.y;
-        du0 = fmaf(s.a0.w, MS_OY0, s.a0.z * MS_OX0); du1 = fmaf(s.a0.w, MS_OY1, s.a0.z * MS_OX1);
-        dv0 = fmaf(s.a1.y, MS_OY0, s.a1.x * MS_OX0); dv1 = fmaf(s.a1.y, MS_OY1, s.a1.x * MS_OX1);
+        if constexpr (PRE) { du0 = s.a3.x; du1 = s.a3.y; dv0 = s.a3.z; dv1 = s.a3.w; }
+        else {
+            du0 = fmaf(s.a0.w, MS_OY0, s.a0.z * MS_OX0); du1 = fmaf(s.a0.w, MS_OY1, s.a0.z * MS_OX1);
+            dv0 = fmaf(s.a1.y, MS_OY0, s.a1.x * MS_OX0); dv1 = fmaf(s.a1.y, MS_OY1, s.a1.x * MS_OX1);
+        }
     } else if constexpr (VARIANT == RV_AABB3D) {
         const float dx = qx - s.a0.x, dy = qy - s.a0.y;
         u = s.a0.z * dx; v = s.a0.w * dy;
@@ -1536,7 +1549,8 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                                                uint32_t& trace_blended, uint32_t& trace_staged, uint32_t& work,
                                                [[maybe_unused]] uint32_t (&phase)[4]) {
     BGS_PHASE(0);
-    constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
+    constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;   // float4 per record in `records`
+    constexpr int ST_V4 = staged_v4(VARIANT, MSAA, DEPTH, MIDROUND_EXIT);           // ... and per staged record in s_rec
     constexpr uint32_t STAGE = 64u;
     constexpr bool ABLATE = BGS_ABLATION != 0;
     // the interior-record loop (blend_interior_ms): whole tiles of OBB quads without overlay or depth buffer, 1 or 4 samples
@@ -1713,15 +1727,18 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         }
                     }
                     r2.w = keepz_of(keep && (!DEPTH || r2.w >= tile_dmin), r2.w);
-                    s_rec[lane * REC_V4 + 0] = r0;
-                    s_rec[lane * REC_V4 + 1] = r1;
-                    s_rec[lane * REC_V4 + 2] = r2;
+                    s_rec[lane * ST_V4 + 0] = r0;
+                    s_rec[lane * ST_V4 + 1] = r1;
+                    s_rec[lane * ST_V4 + 2] = r2;
+                    if constexpr (ST_V4 == 4)   // (blend_px_ms's own expressions: the instance-sort rasteriser forms them per pixel)
+                        s_rec[lane * ST_V4 + 3] = make_float4(fmaf(r0.w, MS_OY0, r0.z * MS_OX0), fmaf(r0.w, MS_OY1, r0.z * MS_OX1),
+                                                              fmaf(r1.y, MS_OY0, r1.x * MS_OX0), fmaf(r1.y, MS_OY1, r1.x * MS_OX1));
                 } else if constexpr (VARIANT == RV_AABB3D) {
-                    s_rec[lane * REC_V4 + 0] = r0;
-                    s_rec[lane * REC_V4 + 1] = r1;
+                    s_rec[lane * ST_V4 + 0] = r0;
+                    s_rec[lane * ST_V4 + 1] = r1;
                     float4 r2 = src[2];
                     r2.w = keepz_of(keep && (!DEPTH || r2.w >= tile_dmin), r2.w);
-                    s_rec[lane * REC_V4 + 2] = r2;
+                    s_rec[lane * ST_V4 + 2] = r2;
                 } else {
                     float4 st[6];
                     stage_surfel(src, tile_ox, tile_oy, aspect, st);
@@ -1744,7 +1761,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         }
                     }
 #pragma unroll
-                    for (int v = 0; v < 6; ++v) s_rec[lane * REC_V4 + v] = st[v];
+                    for (int v = 0; v < 6; ++v) s_rec[lane * ST_V4 + v] = st[v];
                 }
             }
             // make the staged records visible to every lane of this wave before the broadcast reads
@@ -1773,7 +1790,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         if constexpr (TRACE) trace_blended += 1u;
                         work += WORK_BLENDED;
                         if constexpr (VARIANT == RV_OBB) {
-                            const float4 a0 = s_rec[k * REC_V4 + 0], a1 = s_rec[k * REC_V4 + 1], a2 = s_rec[k * REC_V4 + 2];
+                            const float4 a0 = s_rec[k * ST_V4 + 0], a1 = s_rec[k * ST_V4 + 1], a2 = s_rec[k * ST_V4 + 2];
                             const float ux = fmaf(a0.z, qx, a0.x), vx = fmaf(a1.x, qx, a0.y);
                             if constexpr (MSAA != 1) {
                                 blend_interior_ms(ux, vx, a0.w, a1.y, a2.z, a1.w, a2.x, a2.y, t_eps, qy[0], qy[1], T[0], crg[0], cb[0], T[1], crg[1], cb[1]);
@@ -1784,9 +1801,9 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                             }
                         } else {
                             // a1 = P0x P0y P0z Pxx | a2 = Pxy Pxz Pyx Pyy | a3 = Pyz Dx0 dDx Dy0 | a4 = dDy r g b | a5 = opacity ...
-                            const float4 a1 = s_rec[k * REC_V4 + 1], a2 = s_rec[k * REC_V4 + 2], a3 = s_rec[k * REC_V4 + 3],
-                                         a4 = s_rec[k * REC_V4 + 4];
-                            const float opa = s_rec[k * REC_V4 + 5].x;
+                            const float4 a1 = s_rec[k * ST_V4 + 1], a2 = s_rec[k * ST_V4 + 2], a3 = s_rec[k * ST_V4 + 3],
+                                         a4 = s_rec[k * ST_V4 + 4];
+                            const float opa = s_rec[k * ST_V4 + 5].x;
                             const float pxq = fmaf(a1.w, qx, a1.x), pyq = fmaf(a2.x, qx, a1.y), pzq = fmaf(a2.y, qx, a1.z);
                             const float ddx = fmaf(a3.z, qx, a3.y);
 #pragma unroll
@@ -1803,7 +1820,8 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         const uint32_t k = (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
                         StagedRecord<VARIANT> sr;
-                        sr.load(s_rec + k * REC_V4);
+                        sr.load(s_rec + k * ST_V4);
+                        if constexpr (ST_V4 == 4) sr.a3 = s_rec[k * ST_V4 + 3];
                         if constexpr (TRACE) trace_blended += 1u;
                         work += WORK_BLENDED;
                         // the record's depth (a kept record's: > 0), wave-uniform; zmixed: the tile's depths split it
@@ -1816,7 +1834,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                             if constexpr (MSAA == 4) {
                                 float4 d4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                                 if constexpr (DEPTH) if (zmixed) d4 = s_depth[r * 64 + lane];
-                                blend_px_ms<VARIANT, DEPTH, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, zmixed, d4);
+                                blend_px_ms<VARIANT, DEPTH, false, ST_V4 == 4>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, zmixed, d4);
                             } else if constexpr (MSAA == 1) {
                                 blend_px<VARIANT, DEPTH, false>(sr, qx, qy[r], aspect, t_eps, T[r], crg[r], cb[r], zr, dpx[r]);
                             } else {
@@ -1831,7 +1849,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             } else
             for (uint32_t k = 0; k < kend; ++k) {
                 StagedRecord<VARIANT> sr;
-                sr.load(s_rec + k * REC_V4);
+                sr.load(s_rec + k * ST_V4);
                 const float keepz = VARIANT == RV_SURFEL ? sr.a5.y : sr.a2.w;
                 if constexpr (TRACE) trace_staged += 1u;
                 // the record's depth, or the "skip" flag in its sign bit: wave-uniform, a scalar branch
@@ -1938,11 +1956,10 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
     uint32_t trace_scanned = 0u, trace_blended = 0u, trace_staged = 0u, work = 0u;
     if constexpr (TRACE) trace_t0 = __builtin_amdgcn_s_memtime();
     const FrameParams fp = *fpp;  // left in device memory by the frame's keygen
-    constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;
     // records staged per round: the whole queue (24 KB of LDS per workgroup for the 96-byte surfel records, five
     // workgroups per CU at its 5 waves/SIMD; rounds of 32 were 1-5 % slower)
     constexpr uint32_t STAGE = 64u;
-    __shared__ float4 s_rec_all[4][STAGE * REC_V4];
+    __shared__ float4 s_rec_all[4][STAGE * staged_v4(VARIANT, MSAA, DEPTH, MIDROUND_EXIT)];
     __shared__ uint32_t s_queue_all[4][64];
     __shared__ float4 s_depth_all[4][DEPTH && MSAA > 1 ? 64 * MSAA : 1];   // the tile's depth samples (raster_tile): MSAA floats per pixel
 
