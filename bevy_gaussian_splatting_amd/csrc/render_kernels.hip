@@ -937,15 +937,18 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
         // TWO one-armed regions, not an if / else: as one region the compiler gives the per-sample arm an edge into the
         // other one (its lowering of a branch on a ballot inside an exec-masked region) and keeps the old r0 .. r3, rb alive
         // along it — five v_mov per visited strip, ten with the updates forced in place. A one-armed region updates in place.
+        // (The surfel variant takes the first region as a branch, not a select: dense 1 M surfels 3.02 -> 3.06 k frames/s, the
+        // scene-like surfel frame 10.6 k either way, 10.35 k with the if / else — profiles/r6_experiments/surfel_form_ab.txt)
+#ifndef BGS_SURFEL_FORM
+#define BGS_SURFEL_FORM 2
+#endif
+        constexpr int FORM = VARIANT == RV_SURFEL ? BGS_SURFEL_FORM : 1;   // 0: if / else, 1: two regions, 2: two regions, the first a branch
         const bool all_full = !(DEPTH && zmixed) && __builtin_amdgcn_ballot_w64(!full) == 0ull;
-        float w = (t.S * t.rb) * alpha;
-        if (all_full) t.S = fmaf(-alpha, t.S, t.S);   // (the compiler makes it a select; as a branch: the same within noise)
-        asm volatile("");   // (keeps the two regions apart)
-        if (!all_full) {
-            // Coverage of a sample as a 0 / 1 factor out of multiplications, additions and the clamp output modifier:
-            // min / max, compares and selects issue at half the rate of those on this chip (wave64: 4 clocks against 2;
-            // profiles/r4_micro/valu_issue.txt). clamp((lim - |x|) * 2^60) is 1 for |x| <= lim - 2^-60, 0 for |x| >= lim —
-            // and something in between for a sample closer to the quad's edge than any rasteriser's rounding can place it.
+        // Coverage of a sample as a 0 / 1 factor out of multiplications, additions and the clamp output modifier:
+        // min / max, compares and selects issue at half the rate of those on this chip (wave64: 4 clocks against 2;
+        // profiles/r4_micro/valu_issue.txt). clamp((lim - |x|) * 2^60) is 1 for |x| <= lim - 2^-60, 0 for |x| >= lim —
+        // and something in between for a sample closer to the quad's edge than any rasteriser's rounding can place it.
+        auto per_sample = [&](float& w) {
             const float big = 1.152921504606846976e18f, limbig = lim * 1.152921504606846976e18f;   // 2^60
             float t0 = ms_inside(u + du0, big, limbig) * ms_inside(v + dv0, big, limbig) * t.r0;
             float t1 = ms_inside(u + du1, big, limbig) * ms_inside(v + dv1, big, limbig) * t.r1;
@@ -957,9 +960,30 @@ __device__ __forceinline__ void blend_px_ms(const StagedRecord<VARIANT>& s, cons
             }
             const float sum = (t0 + t1) + (t2 + t3), aq = 0.25f * alpha;
             w = (t.S * aq) * sum;
-            ms_fnma_in_place(t.r0, alpha, t0); ms_fnma_in_place(t.r1, alpha, t1);
-            ms_fnma_in_place(t.r2, alpha, t2); ms_fnma_in_place(t.r3, alpha, t3);
-            ms_fnma_in_place(t.rb, aq, sum);
+            if constexpr (FORM == 0) {
+                t.r0 = fmaf(-alpha, t0, t.r0); t.r1 = fmaf(-alpha, t1, t.r1);
+                t.r2 = fmaf(-alpha, t2, t.r2); t.r3 = fmaf(-alpha, t3, t.r3);
+                t.rb = fmaf(-aq, sum, t.rb);
+            } else {
+                ms_fnma_in_place(t.r0, alpha, t0); ms_fnma_in_place(t.r1, alpha, t1);
+                ms_fnma_in_place(t.r2, alpha, t2); ms_fnma_in_place(t.r3, alpha, t3);
+                ms_fnma_in_place(t.rb, aq, sum);
+            }
+        };
+        float w;
+        if constexpr (FORM == 0) {
+            if (all_full) {
+                w = (t.S * t.rb) * alpha;
+                t.S = fmaf(-alpha, t.S, t.S);
+            } else {
+                per_sample(w);
+            }
+        } else {
+            w = (t.S * t.rb) * alpha;
+            if constexpr (FORM == 1) { if (all_full) t.S = fmaf(-alpha, t.S, t.S); }   // (the compiler makes it a select; as a branch: the same within noise)
+            else { if (all_full) { asm volatile(""); t.S = fmaf(-alpha, t.S, t.S); } }
+            asm volatile("");   // (keeps the two regions apart)
+            if (!all_full) per_sample(w);
         }
         crg = __builtin_elementwise_fma((v2f){w, w}, (v2f){r, g}, crg);
         cb = fmaf(w, b, cb);
@@ -1782,11 +1806,18 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                 if constexpr (TRACE) trace_staged += ccnt;
                 uint32_t since = 0u;   // records since the last look at the tile's saturation
                 bool out = false;
-                while (todo != 0ull && !out) {
+                // Runs of a kind, each taken out of `todo` as a bit mask of its own (the records below the first one of the other
+                // kind): the loop over a run then turns on ONE scalar compare — asking every record for its kind cost eight
+                // scalar instructions per record in the compiler's hands (a shift, a bit test, a select into a lane mask, an
+                // and with exec, ...), and scalar instructions count here like vector ones
+                while (todo != 0ull) {
                     // a run of interior records
-                    while (todo != 0ull && ((inter >> (uint32_t)__builtin_ctzll(todo)) & 1ull) != 0ull) {
-                        const uint32_t k = (uint32_t)__builtin_ctzll(todo);
-                        todo &= todo - 1ull;
+                    const unsigned long long first_other = todo & ~inter;
+                    unsigned long long run = first_other != 0ull ? (todo & ((first_other & (0ull - first_other)) - 1ull)) : todo;
+                    todo ^= run;
+                    while (run != 0ull) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(run);
+                        run &= run - 1ull;
                         if constexpr (TRACE) trace_blended += 1u;
                         work += WORK_BLENDED;
                         if constexpr (VARIANT == RV_OBB) {
@@ -1815,10 +1846,14 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         if constexpr (MIDROUND_EXIT)
                             if (++since == BGS_MIDROUND_PERIOD) { since = 0u; if (__all(all_saturated(T, t_eps))) { out = true; break; } }
                     }
+                    if (out) break;
                     // a run of the others: strip by strip through blend_px_ms / blend_px
-                    while (!out && todo != 0ull && ((inter >> (uint32_t)__builtin_ctzll(todo)) & 1ull) == 0ull) {
-                        const uint32_t k = (uint32_t)__builtin_ctzll(todo);
-                        todo &= todo - 1ull;
+                    const unsigned long long first_inter = todo & inter;
+                    run = first_inter != 0ull ? (todo & ((first_inter & (0ull - first_inter)) - 1ull)) : todo;
+                    todo ^= run;
+                    while (run != 0ull) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(run);
+                        run &= run - 1ull;
                         StagedRecord<VARIANT> sr;
                         sr.load(s_rec + k * ST_V4);
                         if constexpr (ST_V4 == 4) sr.a3 = s_rec[k * ST_V4 + 3];
@@ -1845,6 +1880,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         if constexpr (MIDROUND_EXIT)
                             if (++since == BGS_MIDROUND_PERIOD) { since = 0u; if (__all(all_saturated(T, t_eps))) { out = true; break; } }
                     }
+                    if (out) break;
                 }
             } else
             for (uint32_t k = 0; k < kend; ++k) {
