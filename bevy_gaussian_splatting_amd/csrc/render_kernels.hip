@@ -1815,11 +1815,10 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                     const unsigned long long first_other = todo & ~inter;
                     unsigned long long run = first_other != 0ull ? (todo & ((first_other & (0ull - first_other)) - 1ull)) : todo;
                     todo ^= run;
+                    unsigned long long run0 = run;   // (the records blended are counted after the run: a scalar addition per record less)
                     while (run != 0ull) {
                         const uint32_t k = (uint32_t)__builtin_ctzll(run);
                         run &= run - 1ull;
-                        if constexpr (TRACE) trace_blended += 1u;
-                        work += WORK_BLENDED;
                         if constexpr (VARIANT == RV_OBB) {
                             const float4 a0 = s_rec[k * ST_V4 + 0], a1 = s_rec[k * ST_V4 + 1], a2 = s_rec[k * ST_V4 + 2];
                             const float ux = fmaf(a0.z, qx, a0.x), vx = fmaf(a1.x, qx, a0.y);
@@ -1846,19 +1845,20 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         if constexpr (MIDROUND_EXIT)
                             if (++since == BGS_MIDROUND_PERIOD) { since = 0u; if (__all(all_saturated(T, t_eps))) { out = true; break; } }
                     }
+                    work += WORK_BLENDED * (uint32_t)__builtin_popcountll(run0 ^ run);
+                    if constexpr (TRACE) trace_blended += (uint32_t)__builtin_popcountll(run0 ^ run);
                     if (out) break;
                     // a run of the others: strip by strip through blend_px_ms / blend_px
                     const unsigned long long first_inter = todo & inter;
                     run = first_inter != 0ull ? (todo & ((first_inter & (0ull - first_inter)) - 1ull)) : todo;
                     todo ^= run;
+                    run0 = run;
                     while (run != 0ull) {
                         const uint32_t k = (uint32_t)__builtin_ctzll(run);
                         run &= run - 1ull;
                         StagedRecord<VARIANT> sr;
                         sr.load(s_rec + k * ST_V4);
                         if constexpr (ST_V4 == 4) sr.a3 = s_rec[k * ST_V4 + 3];
-                        if constexpr (TRACE) trace_blended += 1u;
-                        work += WORK_BLENDED;
                         // the record's depth (a kept record's: > 0), wave-uniform; zmixed: the tile's depths split it
                         [[maybe_unused]] float zr = 0.0f;
                         if constexpr (DEPTH) zr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(VARIANT == RV_SURFEL ? sr.a5.y : sr.a2.w)));
@@ -1880,6 +1880,8 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                         if constexpr (MIDROUND_EXIT)
                             if (++since == BGS_MIDROUND_PERIOD) { since = 0u; if (__all(all_saturated(T, t_eps))) { out = true; break; } }
                     }
+                    work += WORK_BLENDED * (uint32_t)__builtin_popcountll(run0 ^ run);
+                    if constexpr (TRACE) trace_blended += (uint32_t)__builtin_popcountll(run0 ^ run);
                     if (out) break;
                 }
             } else
