@@ -650,8 +650,10 @@ def test_bucket_sort_is_bit_exact(plugin, oracle, mode, n):
     h.free()
 
 
-def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
-    """Keys the buckets cannot split: (a) 2000 splats at exactly one distance (one key value beyond the
+@pytest.mark.parametrize("wide", [0, 0x800], ids=["narrow", "wide"])
+def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle, wide):
+    """(wide: the 16 384-pair buckets of the long lists, debug flag 0x800, on the same keys.)
+    Keys the buckets cannot split: (a) 2000 splats at exactly one distance (one key value beyond the
     tie limit of the in-bucket ranking), (b) 40 000 splats inside a key range of a few ulps (one bucket over
     capacity, whatever the splitters). Forced onto the bucket path with a guessed table (debug flag 0x200000)
     and then with the table their own sorted list yields, the frame is re-run with the digit passes before
@@ -669,7 +671,7 @@ def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
         ref = oracle.sort(c, v, s)
         h = plugin.upload(c)
         plugin.reset_adaptive_state()
-        plugin.set_debug_flags(0x200000)
+        plugin.set_debug_flags(0x200000 | wide)
         try:
             got = plugin.sort(h, v, s)
             st = plugin.stats()
@@ -683,7 +685,7 @@ def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
             refimg, amb = oracle.render(c, ref, v, s, with_ambiguity=True)
             _assert_image(refimg, img, amb, frac_slack=0.01, what=f"render with bucket overflow ({case})")
         finally:
-            plugin.set_debug_flags(0)
+            plugin.set_debug_flags(wide)
         # without the flag: the table this view's own sorted list yields cannot split these keys either
         plugin.reset_adaptive_state()
         before = plugin.adaptive_counters()["reruns_sort"]
@@ -692,6 +694,7 @@ def test_bucket_sort_overflow_reruns_with_onesweep(plugin, oracle):
         after = plugin.adaptive_counters()
         assert after["reruns_sort"] > before               # it was tried, it failed, the frame was re-run ...
         assert plugin.stats()["sort_path"] == "onesweep"   # ... and the context has backed off by now
+        plugin.set_debug_flags(0)
         h.free()
     plugin.reset_adaptive_state()
 
