@@ -950,8 +950,11 @@ def test_frame_graphs_follow_changing_inputs(plugin):
         h.free()
 
 
-def test_frame_graphs_are_captured_anew_when_the_splitter_table_grows(plugin):
-    """Round 5's advisor (medium): the number of quantile keys a frame's clean-up leaves (FrameCleanup::split_sub, 256 * sub
+@pytest.mark.parametrize("wide", [0, 0x800], ids=["narrow", "wide"])
+def test_frame_graphs_are_captured_anew_when_the_splitter_table_grows(plugin, wide):
+    """(wide: the same under debug flag 0x800 — the wide buckets' 1024-thread sort launch, whose 128 KB of dynamic LDS need
+    a function attribute, inside a stream capture.)
+    Round 5's advisor (medium): the number of quantile keys a frame's clean-up leaves (FrameCleanup::split_sub, 256 * sub
     - 1 keys) is a rasteriser argument baked into a captured frame graph, but the graph's key did not hold it — when the
     draw-count hint crossed a 524 288-pair step under bgs_set_graphs, replays kept writing the CAPTURED sub's table under
     the new sub's label: a badly balanced (yet ascending) table, a bucket overflow and an onesweep re-run on every frame,
@@ -966,6 +969,7 @@ def test_frame_graphs_are_captured_anew_when_the_splitter_table_grows(plugin):
     direct_far = plugin.render(h, far, s)
     assert plugin.stats()["draw_count"] > 600_000
     plugin.reset_adaptive_state()
+    plugin.set_debug_flags(wide)
     plugin.set_profiling(0)
     plugin.set_async(True)
     plugin.set_graphs(True)
@@ -987,7 +991,7 @@ def test_frame_graphs_are_captured_anew_when_the_splitter_table_grows(plugin):
             plugin.render(h, far, s, download=False)
         plugin.synchronize()
         a1 = plugin.adaptive_counters()
-        assert a1["reruns_sort"] == a0["reruns_sort"]           # the table under the label sub = 2 IS a sub = 2 table
+        assert a1["reruns_sort"] == a0["reruns_sort"]           # the table under the label sub = 2 IS a sub = 2 table (wide: sub stays 1)
         assert a1["bucket_frames"] - a0["bucket_frames"] >= 20
         assert np.array_equal(framebuffer_as_tensor(plugin, 270, 480).cpu().numpy(), direct_far)
     finally:
@@ -995,6 +999,7 @@ def test_frame_graphs_are_captured_anew_when_the_splitter_table_grows(plugin):
         plugin.set_async(False)
         plugin.set_pipeline_depth(1)
         plugin.set_profiling(2)
+        plugin.set_debug_flags(0)
         plugin.reset_adaptive_state()
     h.free()
 
