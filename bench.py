@@ -407,7 +407,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device(f"cuda:{local_rank}"))
         # RCCL's own (idle) streams already hold the HIP runtime's four hardware queues, which is what the
-        # library's queue-holder streams are for in a process without them (csrc/bgs_api.hip, assign_streams)
+        # library's queue-holder streams are for in a process without them (csrc/bgs_frame.hip, assign_streams)
         os.environ.setdefault("BGS_QUEUE_HOLDERS", "0")
         from bevy_gaussian_splatting_amd import _native
         _native.load().bgs_set_queue_holders(0)   # the same switch through the API (process-global)

@@ -1,5 +1,5 @@
 // frame_params.h — bgs_view + bgs_settings -> FrameParams (host, plain C++).
-// Shared by bgs_api.hip and the CPU pre-flight shim (tests/host_shim) so both feed the
+// Shared by bgs_frame.hip and the CPU pre-flight shim (tests/host_shim) so both feed the
 // per-splat arithmetic exactly the same constants.
 #pragma once
 #include <string.h>
@@ -48,7 +48,7 @@ inline void fill_frame_params(uint32_t n, const bgs_view* view, const bgs_settin
     fp.delta_time = view->delta_time;
     memcpy(fp.clear, view->clear_color, sizeof fp.clear);
     fp.srgb8_target = 0;
-    fp.sort_path = 0;  // chosen per frame by the host (bgs_api.hip)
+    fp.sort_path = 0;  // chosen per frame by the host (bgs_frame.hip)
     fp.sample_count = view->sample_count ? view->sample_count : 4u;   // 0 = not set = Msaa::default() = Sample4
     fp.depth_ptr = view->depth_device_ptr;
     // uniform parts of world_to_local_direction (gaussian.wgsl:166-176: normalize(basis[k]) = v / length(v),
@@ -77,7 +77,7 @@ inline uint32_t pow2_ceil_u32(uint64_t v) {
     return (uint32_t)(p < (1ull << 31) ? p : (1ull << 31));
 }
 
-// Supertile level of the next frames from a completed frame's statistics (bgs_api.hip, finish_lane).
+// Supertile level of the next frames from a completed frame's statistics (bgs_frame.hip, finish_lane).
 // `ratio` = list entries per visible splat of a frame that ran at level `lv`; `edges` = supertile edge in
 // tiles of levels 0..3. Inside [1.6, 4] the level stays. Outside it moves straight to the level the frame's
 // own geometry asks for: a splat of s supertile edges overlaps (s + 1)^2 supertiles on average, so

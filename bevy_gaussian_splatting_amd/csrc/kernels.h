@@ -200,7 +200,7 @@ int raster_scan_waves_per_simd(const FrameParams& fp);
 // did not saturate inside their first staging round, as a list (for the strip workgroups) and as a flag per tile (for the
 // regular waves, which step aside). One buffer: [count (own 128-byte line) | list u16[HEAVY_CAP] | flag u8[tiles]].
 // The count is zeroed by the producing frame's keygen; a frame only ever reads the buffer of a COMPLETED frame
-// (bgs_api.hip hands out the pointer in finish_lane), so list, flags and count are consistent by construction.
+// (bgs_frame.hip hands out the pointer in finish_lane), so list, flags and count are consistent by construction.
 constexpr uint32_t HEAVY_CAP = 256u, HEAVY_LIST_OFFSET = 128u, HEAVY_FLAGS_OFFSET = HEAVY_LIST_OFFSET + 2u * HEAVY_CAP;
 inline size_t heavy_feedback_bytes(uint32_t tiles) { return (size_t)HEAVY_FLAGS_OFFSET + tiles; }
 // out_format bits: which packed image the rasteriser writes next to (or instead of) the f32 target

@@ -9,7 +9,7 @@
 // Output contract is the reference's: ascending key, ties by ascending input position
 // (stable LSD, 8-bit digits), so the final order is bit-identical to radix.wgsl's.
 //
-// Two paths produce that order (the host picks one per frame, bgs_api.hip):
+// Two paths produce that order (the host picks one per frame, bgs_frame.hip):
 //   onesweep   keygen (partition + digit histograms) + one onesweep_kernel per digit place — any key width,
 //              any key distribution, any size; ~11 us per place at 10^5 pairs (a chain of L2 round trips)
 //   bucket     keygen places the drawable pairs into 256 key-range buckets (splitters = quantile keys of a

@@ -10,10 +10,10 @@ T=$(mktemp -d)
 mkdir -p $R/gpurun_variants
 cd $R/bevy_gaussian_splatting_amd/csrc
 make -s build_id.inc
-for f in sort_kernels render_kernels bgs_api; do
+for f in $(ls *.hip | sed 's/\.hip$//'); do   # (every translation unit of the revision: one file up to round 6's split)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function "$@" -c $f.hip -o $T/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/gpurun_variants/$NAME.so $T/sort_kernels.o $T/render_kernels.o $T/bgs_api.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/gpurun_variants/$NAME.so $T/*.o
 rm -rf $T
 echo "built gpurun_variants/$NAME.so ($*)"
