@@ -49,6 +49,19 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert lib.bgs_version() == (0 << 16) | 4 == _native.ABI_VERSION
 
 
+def test_the_library_exports_the_c_abi_and_nothing_else():
+    """The host side is several translation units (round 6) whose shared C++ functions must stay inside the library: its
+    dynamic symbol table defines exactly the entry points the two headers declare (csrc/libbgs.map)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    lib = os.path.join(ROOT, "bevy_gaussian_splatting_amd", "csrc", "libbgs.so")
+    _native.load()   # (builds it if it is stale)
+    out = subprocess.run([nm, "-D", "--defined-only", lib], check=True, capture_output=True, text=True).stdout
+    defined = {line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()}
+    assert defined == set(_declared()), sorted(defined ^ set(_declared()))
+
+
 def test_integration_doc_binds_every_exported_symbol():
     """INTEGRATION.md shows the reference-side binding (the `extern "C"` block a maintainer would add): it
     has to name every entry point the header declares, and nothing the library does not have."""
