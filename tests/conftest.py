@@ -66,7 +66,8 @@ def pytest_sessionfinish(session, exitstatus):
         with open(os.path.join(outdir, f"tolerance_accounting_band_{band}.json"), "w") as f:
             json.dump({"edge_band_px": float(band), "values_compared": t["checked"], "beyond_strict_tolerance": t["values"],
                        "max_excess_over_strict": t["max_excess"], "max_excess_over_strict_randomized_configurations": t["max_excess_randomized"],
-                       "max_excess_over_strict_bounding_box_overlay_frames": t["max_excess_overlay"], "exit_status": int(exitstatus),
+                       "max_excess_over_strict_bounding_box_overlay_frames": t["max_excess_overlay"],
+                       "max_excess_overlay_frames_relative_to_max_1_and_frame_max": t.get("max_excess_overlay_rel", 0.0), "exit_status": int(exitstatus),
                        "comparisons": sorted(t["comparisons"], key=lambda r: -r["max_excess"])}, f, indent=1)
     except Exception:  # noqa: BLE001 - reporting must never turn a green run red
         pass

@@ -2085,13 +2085,15 @@ def test_zz_report_ambiguity_slack_use(oracle):
     of alpha exp(-4.5) * 0.8 and a colour of magnitude 15, the brightest the synthetic clouds hold, is 0.033; on the
     RANDOMIZED configurations (Msaa::Off on a third of the seeds: a flip is a whole fragment; global_opacity up to 2;
     every raster mode) none more than 0.24 (largest seen in 41 000 configurations: 0.19); under the bounding-box overlay,
-    where a flip is one sample's share of a whole opaque fragment, none more than that fragment (largest seen: 0.62)."""
+    where a flip is one sample's share of a whole opaque fragment and of what it hides, none more than
+    max(1, the frame's largest value) (largest seen: 1.45 on a frame that reaches 4.76)."""
     t = H.TOLERANCE
     v, n = t["values"], t["checked"]
     print(f"[tolerance accounting] edge band {oracle.lib().oracle_edge_band_px():g} px: {v} of {n} compared values "
           f"({100.0 * v / max(n, 1):.5f} %) beyond 1e-3 + 1e-4 |ref|, largest excess {t['max_excess']:.3e} on the fixed "
           f"configurations, {t['max_excess_randomized']:.3e} on the randomized ones "
-          f"(frames with the bounding-box overlay, where a flip is a whole opaque fragment: {t['max_excess_overlay']:.3e})")
+          f"(frames with the bounding-box overlay, where a flip is a whole opaque fragment: {t['max_excess_overlay']:.3e}, "
+          f"{t['max_excess_overlay_rel']:.3f} of max(1, the frame's largest value))")
     for rec in sorted(t["comparisons"], key=lambda r: -r["max_excess"])[:12]:
         print(f"    {rec['what'][:60]}: {rec['beyond_strict']} of {rec['values']}, excess {rec['max_excess']:.2e}, max |err| {rec['max_err']:.2e}, "
               f"max |ref| {rec['ref_absmax']:.2f}")
@@ -2100,10 +2102,13 @@ def test_zz_report_ambiguity_slack_use(oracle):
     assert v <= 2e-5 * max(n, 1) + 50
     assert t["max_excess"] <= 0.025
     assert t["max_excess_randomized"] <= 0.24
-    # under the overlay a flip swaps a splat's fragment for the frame's opaque (0.3, 1, 0.1, 1): one sample's share of a whole
-    # unit — 0.25 at four samples per pixel, 0.5 at two, 1 at Msaa::Off (seen: 0.25 / 0.45 / 0.50 / 0.62 in 300 forced-surfel
-    # configurations never run before, identical with and without round 6's kernels); the bound is the fragment itself
-    assert t["max_excess_overlay"] <= 1.0
+    # under the overlay a flip swaps a splat's fragment for the frame's opaque (0.3, 1, 0.1, 1) — which also hides, or reveals,
+    # everything behind it: one sample's share (0.25 at four samples per pixel, 0.5 at two, 1 at Msaa::Off) of
+    # max(1, the frame's largest value). Seen: 0.25 / 0.45 / 0.50 / 0.62 in 300 forced-surfel configurations never run
+    # before, identical with and without round 6's kernels; 1.45 on a frame whose colours reach 4.76 (medium seed 501815,
+    # 4 samples: 0.30 of that bound) and 0.9-1.0 on Msaa::Off frames with colours <= 1 among 2000 + 800 further ones
+    # (profiles/r6_v3/explore_500000). The bound is that product, with the share left at 1
+    assert t["max_excess_overlay_rel"] <= 1.0
 
 
 # ---------------------------------------------------------------------------------------------
