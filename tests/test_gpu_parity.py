@@ -1758,6 +1758,39 @@ def test_fine_buckets_on_small_lists_give_the_same_frames(plugin, oracle):
     h.free()
 
 
+def test_rendered_frames_with_a_long_draw_list_take_the_wide_buckets(plugin, oracle):
+    """Round 6: a camera that sees 1.8 M splats (past the 1.57 M pairs the narrow geometry holds in 768 buckets) sorts its RENDERED
+    frames — the chainless keygen — into wide buckets (16 384 pairs, 1024-thread workgroups). Same frame, bit for bit, as
+    with the digit passes (debug flag 0x80000) and with narrow buckets only (0x100); the draw list is the oracle's."""
+    from bevy_gaussian_splatting_amd import transform_from
+    c = random_gaussians_3d_seeded(1_800_000, 61)
+    far = View.perspective(transform_from((0.0, 0.0, 120.0)), 480, 270)   # the whole cloud inside the frustum
+    s = CloudSettings(global_scale=0.05)
+    h = plugin.upload(c)
+    try:
+        out = {}
+        for name, flags in (("passes", 0x80000), ("wide", 0), ("narrow", 0x100)):
+            plugin.reset_adaptive_state()
+            plugin.set_debug_flags(flags)
+            for _ in range(3):
+                img = plugin.render(h, far, s)
+            st = plugin.stats()
+            assert st["draw_count"] == 1_800_000
+            assert st["sort_path"] == ("onesweep" if name == "passes" else "bucket"), (name, st)
+            out[name] = img
+        assert np.array_equal(out["wide"], out["passes"]) and np.array_equal(out["narrow"], out["passes"])
+        plugin.set_debug_flags(0)
+        for _ in range(2):
+            e = plugin.sort(h, far, s)
+        assert plugin.stats()["sort_path"] == "bucket"
+        ref = oracle.sort(c, far, s)
+        assert np.array_equal(e["key"], ref["key"]) and np.array_equal(e["index"], ref["index"])
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.reset_adaptive_state()
+        h.free()
+
+
 def test_forty_kinds_of_frame_stay_pipelined_after_their_first_visit(plugin):
     """Round 4 remembered the last 16 kinds of frame (FIFO) and hashed the cloud's address and the raw global_scale bits into
     the kind: a host cycling through more than 16 (cloud, viewport, mode) combinations, uploading a cloud per frame or
