@@ -97,7 +97,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
                          // 1 M keygen 20.6 / 21.2 / 22.2 / 23.5 us, 5 M 51 / 53 / 64 / 88 us (registers: 153 / 164 / 206 / 256)
 #endif
 template <int KG_ITEMS, bool BUCKET, int THREADS, bool ORDERED = true>  // splats per thread; 256 or 1024 threads per block
-__global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
+// (the ordered 1024-thread tile is held to 64 registers — 8 waves per SIMD, two tiles per CU —: with the all-drawable path it came
+// to 65 and one tile per CU; the chainless one has 61 of its own accord and is left alone)
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 && ORDERED) ? 8 : 1) void keygen_kernel(FrameParams fp, const float4* __restrict__ pos,
                                                          uint2* __restrict__ entries,
                                                          uint2* __restrict__ culled, Control* ctl,
                                                          uint32_t* part_status, uint32_t places,
@@ -320,6 +322,32 @@ __global__ __launch_bounds__(THREADS) void keygen_kernel(FrameParams fp, const f
         else if (fp.sort_mode == SORT_NONE) { BGS_KG_KEYS(0) }
         else { BGS_KG_KEYS(2) }
 #undef BGS_KG_KEYS
+        if constexpr (BUCKET && KG_ITEMS <= 8) {
+            // A FULL tile of a sort mode that draws every splat (Rayon / Std / None; round 6): nothing to compact and no
+            // order to keep — the keys go from the registers straight to their buckets, without the row counts, their scan,
+            // the compacted LDS arrays and two of the barriers (5 M splats, SortMode::Rayon: keygen 76.7 -> 60.3 us)
+            if (all_draw && base + per_tile <= fp.n) {
+                uint32_t bkat[KG_ITEMS];   // bucket (< 4096) | arrival order in it (< tile) << 16: one register per splat
+#pragma unroll
+                for (int k = 0; k < KG_ITEMS; ++k) {
+                    const uint32_t bkt = bucket_of(key[k]);
+                    bkat[k] = bkt | (atomicAdd(&s_bcnt[bkt], 1u) << 16);
+                }
+                if (tid == 0 && tile == num_tiles - 1u) { ctl->draw_count = fp.n; ctl->splat_count = fp.n; }
+                __syncthreads();
+                claim_bucket_slots();
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < KG_ITEMS; ++k) {
+                    const uint32_t bkt = bkat[k] & 0xFFFFu, slot = s_bexcl[bkt] + (bkat[k] >> 16);
+                    if (slot < bucket_cap)  // a bucket over capacity is seen by bucket_sort_kernel (count > cap)
+                        bucket_slots[(size_t)bkt * bucket_cap + slot] = make_uint2(key[k], base + (uint32_t)(k * THREADS) + (uint32_t)tid);
+                }
+                if (single_shot) break;
+                __syncthreads();
+                continue;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < KG_ITEMS; ++k) {
             const unsigned long long b = __ballot(BGS_KG_DRAWN(k));
