@@ -1958,6 +1958,52 @@ def test_a_kind_whose_saturating_tiles_hold_the_work_runs_the_midround_exit_rast
             h.free()
 
 
+def test_alternating_kinds_keep_their_own_rasteriser_choice(plugin):
+    """Two kinds of frame of ONE cloud alternate on the same lanes (a host with two cameras): the trained-like cloud at its own
+    splat sizes (saturating tiles hold a third of the work: mid-round exit) and at global_scale 0.05 (nothing saturates:
+    the plain instantiation). A lane's tile order is made of the costs of its previous frame — of the OTHER kind here —, so
+    the saturation share a frame reports belongs to that frame's kind, not to its own: each kind must settle on its own
+    choice, and every frame must equal the blocking frame of its inputs bit for bit."""
+    from bevy_gaussian_splatting_amd import trained_like_gaussians_3d_seeded
+    from bevy_gaussian_splatting_amd.multiview import device_ptr_as_tensor
+    c = trained_like_gaussians_3d_seeded(1_000_000, 7)
+    h = plugin.upload(c)
+    v = View.headless(1920, 1080)
+    kinds = [CloudSettings(), CloudSettings(global_scale=0.05)]
+    try:
+        plugin.reset_adaptive_state()
+        refs = [plugin.render(h, v, s) for s in kinds]
+        plugin.reset_adaptive_state()
+        plugin.set_async(True)
+        plugin.set_pipeline_depth(3)       # (odd: every lane sees both kinds in turn)
+        for i in range(72):
+            k = i % 2
+            plugin.render(h, v, kinds[k], download=False)
+            while plugin.frames_in_flight() > 2:
+                plugin.pipeline_pop()
+        # drain, comparing the last frame of each kind
+        last = {}
+        order = [(72 - plugin.frames_in_flight() + j) % 2 for j in range(plugin.frames_in_flight())]
+        for k in order:
+            f32, _ = plugin.pipeline_pop()
+            last[k] = device_ptr_as_tensor(f32, (1080, 1920, 4), "<f4", "cuda:0").cpu().numpy().copy()
+        for k in (0, 1):
+            assert k in last and np.array_equal(last[k].view(np.uint32), refs[k].view(np.uint32)), k
+        # the steady state, three more pairs of frames completed one by one: each kind on its own rasteriser
+        for rep in range(3):
+            for k in (0, 1):
+                got = plugin.render(h, v, kinds[k])
+                assert np.array_equal(got.view(np.uint32), refs[k].view(np.uint32)), (rep, k)
+                ts = plugin.stats()["tile_saturation"]
+                if ts["known"]:
+                    assert ts["midround_exit"] == (k == 0), (rep, k, ts)
+    finally:
+        plugin.set_async(False)
+        plugin.set_pipeline_depth(1)
+        plugin.reset_adaptive_state()
+        h.free()
+
+
 def test_rerun_keeps_the_output_state_the_frame_was_enqueued_with(plugin):
     """A frame whose supertile lists overflow is re-run when its lane completes (here: forced). If the caller changed the packed
     output format in between (bgs_set_output_rgba16f / _srgb8 / _packed_only complete nothing), the re-run must still
