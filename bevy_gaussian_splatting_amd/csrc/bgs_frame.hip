@@ -1069,7 +1069,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
             mark(3);
             launch_raster_scan(st, fp, L.d_fp, L.records, L.coarse, coarse_cap, sup_edge, ctl, L.fb, L.fb8,
                                (ctx->debug_flags & 0x40000u) ? 0u : out_format, cl, ctx->tile_trace,
-                               midround_exit, heavy_in, heavy_out, tile_order, cost_out);
+                               midround_exit ? (level >= 2u ? 1 : 2) : 0, heavy_in, heavy_out, tile_order, cost_out);
             mark(6);
         } else if (render) {
             const uint32_t capacity = (uint32_t)std::min<uint64_t>(L.inst_cap, MAX_INSTANCE_CAPACITY);
@@ -1127,7 +1127,7 @@ int enqueue_frame(bgs_ctx* ctx, Lane& L, const bgs_cloud* cloud, const bgs_view*
         key.keygen_func = kg.func;
         key.keygen_threads = kg.threads;
         key.wide_bin = ctx->depth == 1 ? 1u : 0u;
-        key.raster_variant = fp.sample_count | (fp.depth_ptr ? 0x100u : 0u) | (fp.visualize_bbox ? 0x200u : 0u) | (midround_exit ? 0x400u : 0u);
+        key.raster_variant = fp.sample_count | (fp.depth_ptr ? 0x100u : 0u) | (fp.visualize_bbox ? 0x200u : 0u) | (midround_exit ? (level >= 2u ? 0x400u : 0x800u) : 0u);
         key.split_sub = split_sub_out;   // (round 5's advisor: a replay across a 524 k-pair step of the hint left a table of the captured sub under the new sub's label)
         key.sup_edge = sup_edge;
         key.scratch_bytes = L.scratch_bytes;

@@ -169,7 +169,8 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
                         uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace = nullptr,
-                        bool midround_exit = false, const uint8_t* heavy_in = nullptr, uint8_t* heavy_out = nullptr,
+                        int mode = 0 /* raster_scan_kernel's MODE: 0 plain, 1 dense + mid-round exit, 2 sparse + mid-round exit */,
+                        const uint8_t* heavy_in = nullptr, uint8_t* heavy_out = nullptr,
                         const uint16_t* order = nullptr, uint16_t* cost_out = nullptr);
 // TileCost: what every tile of a frame cost its wave — records blended, records staged, staging rounds and candidate
 // groups scanned, weighted into eighths of a blended record (render_kernels.hip WORK_*; u16 per tile) — left by the

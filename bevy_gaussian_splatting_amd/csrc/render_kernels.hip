@@ -864,8 +864,8 @@ __device__ __forceinline__ float ms_inside(const float x, const float big, const
 // ... and not in the dense frames' instantiation (mid-round exit): their strips rarely take the per-sample update, the compiler
 // had sunk the eight instructions into it, and the fourth LDS read per record only costs (dense 1 M -3.5 % frames/s; scene-like
 // +1.5 %, trained-like +2.5 %, 5 M scene-like +2.1 %: profiles/r6_experiments/staged_sample_offsets_ab.txt)
-__host__ __device__ constexpr int staged_v4(const int variant, const int msaa, const bool depth, const bool midround_exit) {
-    return variant == 2 ? 6 : (variant == 0 && msaa == 4 && !depth && !midround_exit ? 4 : 3);
+__host__ __device__ constexpr int staged_v4(const int variant, const int msaa, const bool depth, const bool dense) {
+    return variant == 2 ? 6 : (variant == 0 && msaa == 4 && !depth && !dense ? 4 : 3);
 }
 // acc = fma(-a, b, acc), the result in acc's own register
 __device__ __forceinline__ void ms_fnma_in_place(float& acc, const float a, const float b) {
@@ -1562,7 +1562,7 @@ __device__ __forceinline__ bool all_saturated(const PxMsN<NS> (&T)[ROWS], const 
     for (int r = 0; r < ROWS; ++r) s = s && T[r].S * T[r].rb < t_eps;
     return s;
 }
-template <int VARIANT, bool TRACE, bool MIDROUND_EXIT, int ROWS, int MSAA, bool DEPTH, bool BBOX>
+template <int VARIANT, bool TRACE, int MODE, int ROWS, int MSAA, bool DEPTH, bool BBOX>   // MODE: raster_scan_kernel
 __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const float4* __restrict__ records,
                                                const uint32_t* __restrict__ coarse, const uint32_t coarse_cap,
                                                const uint32_t sup_mul, const uint32_t sup_x, Control* ctl,
@@ -1574,7 +1574,8 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
                                                [[maybe_unused]] uint32_t (&phase)[4]) {
     BGS_PHASE(0);
     constexpr int REC_V4 = VARIANT == RV_SURFEL ? 6 : 3;   // float4 per record in `records`
-    constexpr int ST_V4 = staged_v4(VARIANT, MSAA, DEPTH, MIDROUND_EXIT);           // ... and per staged record in s_rec
+    constexpr bool MIDROUND_EXIT = MODE != 0, DENSE = MODE == 1;
+    constexpr int ST_V4 = staged_v4(VARIANT, MSAA, DEPTH, DENSE);                   // ... and per staged record in s_rec
     constexpr uint32_t STAGE = 64u;
     constexpr bool ABLATE = BGS_ABLATION != 0;
     // the interior-record loop (blend_interior_ms): whole tiles of OBB quads without overlay or depth buffer, 1 or 4 samples
@@ -1584,7 +1585,7 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
     // ... and their strips' reach masks (below) where frames are not dense: on a dense frame nearly every strip is reached and the
     // three scalar instructions per strip only cost (dense 1 M -6 % frames/s; scene-like +1.4 %, 5 M scene-like +2 %, dense
     // surfels +4 %: profiles/r6_experiments/strip_reach_ab.txt)
-    constexpr bool STRIPS = FAST && !MIDROUND_EXIT;
+    constexpr bool STRIPS = FAST && !DENSE;
     // half extent of the box the tile's sample positions span around the tile centre (the exact quad-vs-tile test)
     constexpr float HALF = 7.5f + ms_reach(MSAA);
 
@@ -1980,7 +1981,10 @@ int raster_scan_waves_per_simd(const FrameParams& fp) {
     const int variant = fp.aabb == 0u ? RV_OBB : (fp.gaussian_mode != 0u ? RV_AABB3D : RV_SURFEL);
     return raster_waves_per_simd(variant, (int)fp.sample_count, fp.depth_ptr != 0ull);
 }
-template <int VARIANT, bool TRACE = false, bool MIDROUND_EXIT = false, int MSAA = 1, bool DEPTH = false, bool BBOX = false>
+// MODE (round 6; a bool until then): 0 the plain instantiation; 1 mid-round exit for DENSE frames (supertile level >= 2: heavy-tile
+// strips, no strip reach masks, no staged sample offsets — each of them only costs there); 2 mid-round exit for frames of a kind
+// whose saturating tiles hold the work at a lower level (trained-like): the sparse frames' machinery plus the exit
+template <int VARIANT, bool TRACE = false, int MODE = 0, int MSAA = 1, bool DEPTH = false, bool BBOX = false>
 __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) void raster_scan_kernel(const FrameParams* __restrict__ fpp, const float4* __restrict__ records,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint32_t coarse_cap, uint32_t sup_mul,
@@ -1997,7 +2001,8 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
     // records staged per round: the whole queue (24 KB of LDS per workgroup for the 96-byte surfel records, five
     // workgroups per CU at its 5 waves/SIMD; rounds of 32 were 1-5 % slower)
     constexpr uint32_t STAGE = 64u;
-    __shared__ float4 s_rec_all[4][STAGE * staged_v4(VARIANT, MSAA, DEPTH, MIDROUND_EXIT)];
+    constexpr bool MIDROUND_EXIT = MODE != 0;
+    __shared__ float4 s_rec_all[4][STAGE * staged_v4(VARIANT, MSAA, DEPTH, MODE == 1)];
     __shared__ uint32_t s_queue_all[4][64];
     __shared__ float4 s_depth_all[4][DEPTH && MSAA > 1 ? 64 * MSAA : 1];   // the tile's depth samples (raster_tile): MSAA floats per pixel
 
@@ -2088,12 +2093,12 @@ __global__ __launch_bounds__(256, raster_waves_per_simd(VARIANT, MSAA, DEPTH)) v
         uint32_t rounds;
         bool reports = true;   // which wave speaks for the tile in the feedback
         if (MIDROUND_EXIT && strip_block) {
-            rounds = raster_tile<VARIANT, false, MIDROUND_EXIT, 1, MSAA, DEPTH, BBOX>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
+            rounds = raster_tile<VARIANT, false, MODE, 1, MSAA, DEPTH, BBOX>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
                                                                    t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 4 * wave,
                                                                    trace_scanned, trace_blended, trace_staged, work, phase);
             reports = wave == 0;
         } else {
-            rounds = raster_tile<VARIANT, TRACE, MIDROUND_EXIT, 4, MSAA, DEPTH, BBOX>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
+            rounds = raster_tile<VARIANT, TRACE, MODE, 4, MSAA, DEPTH, BBOX>(fp, records, coarse, coarse_cap, sup_mul, sup_x, ctl, fb, fb8_default, want_srgb8,
                                                                    t_eps, surfel_limit, s_rec_all[wave], s_queue_all[wave], s_depth_all[wave], lane, tile, 0,
                                                                    trace_scanned, trace_blended, trace_staged, work, phase);
             tile_done = tile;
@@ -2210,7 +2215,7 @@ void launch_tile_order_runs(hipStream_t stream, const uint16_t* cost, uint16_t* 
 void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FrameParams* d_fp, const void* records,
                         const uint32_t* coarse, uint32_t coarse_cap,
                         uint32_t sup_edge, Control* ctl, float4* framebuffer, uint32_t* srgb8_default,
-                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace, bool midround_exit,
+                        uint32_t out_format, const FrameCleanup& cleanup, uint4* tile_trace, int mode,
                         const uint8_t* heavy_in, uint8_t* heavy_out, const uint16_t* order, uint16_t* cost_out) {
     const uint32_t ntiles = (uint32_t)(fp.tiles_x * fp.tiles_y);
     if (ntiles == 0) return;
@@ -2224,8 +2229,8 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
     const bool depth = fp.depth_ptr != 0ull, bbox = fp.visualize_bbox != 0u;
     const uint32_t ms = fp.sample_count;
     const bool plain = (ms == 1u || ms == 4u) && !bbox;
-    if (!plain) midround_exit = false;
-    if (!midround_exit) { heavy_in = nullptr; heavy_out = nullptr; }
+    if (!plain) mode = 0;
+    if (mode != 1) { heavy_in = nullptr; heavy_out = nullptr; }   // (the strips are the dense frames')
 #define BGS_LAUNCH_RS4(V, X, TR, MS, DP, BB)                                                      \
     hipLaunchKernelGGL((raster_scan_kernel<V, TR, X, MS, DP, BB>), dim3(grid), dim3(256), 0, stream, d_fp, rec, coarse,      \
                        coarse_cap, sup_mul, sup_x, ctl, framebuffer, srgb8_default, out_format, cleanup, (TR) ? tile_trace : (uint4*)nullptr, heavy_in, heavy_out, order, cost_out)
@@ -2256,9 +2261,9 @@ void launch_raster_scan(hipStream_t stream, const FrameParams& fp, const FramePa
         else if (fp.gaussian_mode != 0u) BGS_LAUNCH_RSX(RV_AABB3D);
         else BGS_LAUNCH_RSX(RV_SURFEL);
     }
-    else if (fp.aabb == 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_OBB, true); else BGS_LAUNCH_RS(RV_OBB, false); }
-    else if (fp.gaussian_mode != 0u) { if (midround_exit) BGS_LAUNCH_RS(RV_AABB3D, true); else BGS_LAUNCH_RS(RV_AABB3D, false); }
-    else BGS_LAUNCH_RS(RV_SURFEL, false);
+    else if (fp.aabb == 0u) { if (mode == 1) BGS_LAUNCH_RS(RV_OBB, 1); else if (mode == 2) BGS_LAUNCH_RS(RV_OBB, 2); else BGS_LAUNCH_RS(RV_OBB, 0); }
+    else if (fp.gaussian_mode != 0u) { if (mode != 0) BGS_LAUNCH_RS(RV_AABB3D, 1); else BGS_LAUNCH_RS(RV_AABB3D, 0); }   // (no interior path: one exit instantiation)
+    else BGS_LAUNCH_RS(RV_SURFEL, 0);
 #undef BGS_LAUNCH_RSX
 #undef BGS_LAUNCH_RS
 #undef BGS_LAUNCH_RS4
