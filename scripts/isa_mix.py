@@ -1,7 +1,7 @@
 """Static instruction mix of a kernel from the gfx950 assembly hipcc emits: by class, for the whole kernel and for
 its hottest loop (the innermost backward-branch region with the most vector instructions).
 python scripts/isa_mix.py [source.hip] [kernel-name-substring]
-default: render_kernels.hip raster_scan_kernelILi0ELb0ELb1ELi4ELb0E (OBB, no trace, mid-round exit, 4 samples, no depth: the
+default: render_kernels.hip raster_scan_kernelILi0ELb0ELi1ELi4ELb0E (OBB, no trace, mode 1 = the dense frames' mid-round exit, 4 samples, no depth: the
 headline frame's instantiation). Compiled with the Makefile's flags; instruction classes priced as measured on the chip
 (profiles/r4_micro/valu_issue.txt): f32 fma / mul / add / mov / logic / integer add 2 clocks, min / max / compare / select /
 convert / shift / packed 4, transcendental 8."""
@@ -13,7 +13,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bevy_gaussian_splatting_amd", "csrc")
 src = os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else os.path.join(CSRC, "render_kernels.hip")
-want = sys.argv[2] if len(sys.argv) > 2 else "raster_scan_kernelILi0ELb0ELb1ELi4ELb0E"
+want = sys.argv[2] if len(sys.argv) > 2 else "raster_scan_kernelILi0ELb0ELi1ELi4ELb0E"
 asm = "/tmp/isa_mix.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                 "-fPIC", "--offload-device-only", "-S", src, "-o", asm], check=True, capture_output=True, cwd=CSRC)

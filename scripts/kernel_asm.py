@@ -6,7 +6,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(R, "bevy_gaussian_splatting_amd", "csrc")
 args = [a for a in sys.argv[1:] if not a.startswith("-D")]
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
-want = args[0] if args and args[0] else r"_ZN3bgs18raster_scan_kernelILi0ELb0ELb1ELi4ELb0ELb0E"
+want = args[0] if args and args[0] else r"_ZN3bgs18raster_scan_kernelILi0ELb0ELi1ELi4ELb0ELb0E"
 out = args[1] if len(args) > 1 else "/tmp/kernel.s"
 src = "sort_kernels.hip" if "sort" in want or "keygen" in want or "onesweep" in want else "render_kernels.hip"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
