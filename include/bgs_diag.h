@@ -29,6 +29,10 @@ extern "C" {
  * 0x8000000: every BINNING_SCAN frame is run twice, as if a data-dependent capacity had been too small (exercises the
  * re-run path). 0x10000000: no tile-cost feedback / cost-ordered raster workgroups; 0x20000000: none at pipeline
  * depths > 1; 0x40000000: the order is made anew with every frame (default: every 8th).
+ * 0x100 / 0x800: the bucket sort with narrow (4096-pair) / wide (16 384-pair) buckets whatever the list's length (default: wide
+ * past 1.57 M drawable pairs). 0x1000000: never the rasteriser's mid-round-exit instantiations; 0x20000: always one of them,
+ * whatever the supertile level and the kind's saturation share (the dense frames' at level >= 2, the sparse frames' below);
+ * 0x2000000 / 0x4000000: the heavy-tile strip workgroups never / at any pipeline depth (default: depth 1 only).
  * Bits 1..64 exist only in libraries built with -DBGS_ABLATION=1 (scripts/build_variant.sh); the production library
  * ignores them. Production code leaves this at 0. */
 int bgs_set_debug_flags(bgs_ctx* ctx, uint32_t flags);
