@@ -1640,7 +1640,22 @@ __device__ __forceinline__ uint32_t raster_tile(const FrameParams& fp, const flo
             }
         }
         if constexpr (DEPTH) {
-            // (a ROWS == 1 strip wave sees its strip's range only: a tighter, equally valid pre-test)
+            // A ROWS == 1 strip wave takes the range of the WHOLE tile too (three more rows of depths per lane, once per heavy
+            // tile): its own strip's range would be a tighter, equally valid pre-test — but which update a record takes
+            // (all samples / per sample, which differ in the last bit) follows from it, and a tile must come out the same
+            // whichever shape of wave draws it (found in round 6's last exploration: 1 ulp on ~270 pixels of a frame with a
+            // depth buffer whose heavy tiles went to strip waves from the second frame on).
+            if constexpr (ROWS == 1) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int pyt = (int)ty * TILE_PX + (lane >> 4) + 4 * rr;
+                    if (px < fp.width && pyt < fp.height) {
+                        const float* dsrc = reinterpret_cast<const float*>(fp.depth_ptr) + ((size_t)pyt * (size_t)fp.width + (size_t)px) * MSAA;
+#pragma unroll
+                        for (int k = 0; k < MSAA; ++k) { const float d = dsrc[k]; lo = fminf(lo, d); hi = fmaxf(hi, d); }
+                    }
+                }
+            }
             tile_dmin = wave_min(lo);
             tile_dmax = wave_max(hi);
         }

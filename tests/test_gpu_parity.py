@@ -1429,6 +1429,47 @@ def test_whole_frame_parity_1m_2dgs(plugin, oracle, cloud_1m, aabb):
 
 
 
+@pytest.mark.parametrize("what", ["seed_900850", "obb_x4", "aabb3d_x4", "obb_x1"])
+def test_heavy_tiles_under_a_depth_buffer_give_the_same_bits(plugin, cloud_1m, what):
+    """Round 6's last exploration found it (medium seed 900850 in a sequence of frames on one context: 48 k large splats, AABB
+    quads, 4 samples, a depth buffer): with a depth buffer bound, a heavy tile drawn by four strip waves came out 1 ulp off
+    on ~270 pixels — a strip wave took the depth range of its own strip for the pre-test that picks the all-samples or the
+    per-sample update (they differ in the last bit), a tile wave the whole tile's. Both take the tile's now. That
+    configuration at the supertile level the sequence had brought it to (debug flag 0x400000: level 2, strips from the
+    second frame on), and dense 1 M frames under a jittered, tilted depth plane: every repetition equals the frame without
+    strip workgroups (0x2000000)."""
+    if what == "seed_900850":
+        c, v, s = H.random_case(1000 + 900850, medium=True)
+        assert v.depth_host is not None and v.msaa_samples == 4 and s.aabb
+        level = 0x400000
+    else:
+        c = cloud_1m
+        v = View.headless(1920, 1080, msaa_samples=1 if what.endswith("x1") else 4)
+        s = CloudSettings(aabb=what.startswith("aabb3d"))
+        v.depth_host = H.random_depth_buffer(c, v, s, np.random.default_rng(17))
+        level = 0
+    h = plugin.upload(c)
+    plugin.reset_adaptive_state()
+    try:
+        with _scene_depth(plugin, v):
+            plugin.set_debug_flags(level | 0x2000000)
+            for _ in range(4):
+                plain = plugin.render(h, v, s)
+            assert plugin.stats()["strip_tiles"] == 0
+            plugin.set_debug_flags(level)
+            plugin.reset_adaptive_state()
+            strips = []
+            for k in range(8):
+                img = plugin.render(h, v, s)
+                strips.append(plugin.stats()["strip_tiles"])
+                assert np.array_equal(img.view(np.uint32), plain.view(np.uint32)), (what, k, strips)
+            assert strips[-1] > 0, strips
+    finally:
+        plugin.set_debug_flags(0)
+        plugin.reset_adaptive_state()
+        h.free()
+
+
 @pytest.mark.parametrize("what", ["1m_f32", "2dgs_obb", "aabb3d"])
 def test_heavy_tiles_drawn_by_strip_waves_give_the_same_bits(plugin, oracle, cloud_1m, what):
     """Dense frames (supertile level >= 2) run the rasteriser's mid-round-exit instantiation, and the tiles a completed
